@@ -1,0 +1,117 @@
+/*
+ * artn.h -- C ABI of libartn_hip.so, the MI355X (gfx950) numerical contraction engine
+ * behind artensor's executor entry points.
+ *
+ * The reference (Fanerst/artensor) has no FFI: its executor is Python calling
+ * torch.einsum.  Each entry point below replaces one such call site; the reference
+ * file:line it stands in for is cited on the declaration.  All pointers are raw device
+ * pointers (hipMalloc'ed / torch `Tensor.data_ptr()`), sizes are in elements unless a
+ * name says bytes, `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Every function returns 0 on success and a negative ARTN_E_* code on failure;
+ * artn_last_error() then holds a message.  No function allocates or frees device
+ * memory, synchronises the device or calls a CPU fallback: work is enqueued on `stream`
+ * and the caller owns every buffer (graph-capture safe).
+ */
+#ifndef ARTN_H
+#define ARTN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARTN_ABI_VERSION 1
+#define ARTN_MAX_LABELS 96
+
+/* error codes */
+#define ARTN_OK 0
+#define ARTN_E_INVALID (-1)     /* malformed descriptor / argument            */
+#define ARTN_E_UNSUPPORTED (-2) /* valid but not implemented (e.g. dtype)     */
+#define ARTN_E_LAUNCH (-3)      /* HIP launch / runtime error                 */
+#define ARTN_E_NODEVICE (-4)    /* no gfx950 device visible                   */
+
+/* dtypes (arithmetic type of the contraction) */
+#define ARTN_C64 0  /* interleaved (re,im) float32 pairs  -- torch.complex64  */
+#define ARTN_C128 1 /* interleaved (re,im) float64 pairs  -- torch.complex128 */
+
+/*
+ * One pairwise contraction step  C[out labels] = sum_{labels not in C} A[...] * B[...]
+ * i.e. one `torch.einsum(eq, tensors[i], tensors[j])` of
+ *   artensor/contraction.py:70 (dense executor) and
+ *   artensor/contraction.py:147,156,163,169,179,181,190 (sparse executor).
+ * The einsum string is replaced by label lists so unions of more than 50 labels
+ * (the reference's alphabet, contraction.py:9-10) are representable.
+ *
+ * Label l (0 <= l < n_labels) has `extent[l]` and an element stride in each operand,
+ * or -1 where the operand does not carry the label.  A label carried by A and B but
+ * not C is contracted; by A (or B) and C only is free; by all three is a batch label
+ * (the sparse path's shared label -3, contraction.py:306-308); by A or B alone is
+ * summed out (einsum semantics).  C must be dense row-major over its labels in the
+ * order implied by stride_c; A and B may be arbitrary non-overlapping strided views.
+ */
+typedef struct ArtnStepDesc {
+  int32_t dtype;
+  int32_t n_labels;
+  int64_t extent[ARTN_MAX_LABELS];
+  int64_t stride_a[ARTN_MAX_LABELS];
+  int64_t stride_b[ARTN_MAX_LABELS];
+  int64_t stride_c[ARTN_MAX_LABELS];
+} ArtnStepDesc;
+
+/* What the planner decided for a step (filled on the host, no GPU needed). */
+#define ARTN_KERNEL_GENERIC 0 /* one thread per output element, strided loops       */
+#define ARTN_KERNEL_BITS_MFMA 1 /* LDS-tiled bit-permuted complex GEMM on fp32 MFMA */
+typedef struct ArtnStepInfo {
+  int32_t kernel;       /* ARTN_KERNEL_*                                        */
+  int32_t k_bits;       /* contracted bits handled inside a tile                */
+  int32_t m_tile_bits;  /* free A bits inside a tile                            */
+  int32_t n_tile_bits;  /* free B bits inside a tile                            */
+  int32_t tile_in_bits; /* log2 elements of A staged in LDS per tile            */
+  int32_t tile_out_bits;/* log2 elements of C staged in LDS per tile            */
+  int32_t run_in_bits;  /* log2 contiguous elements per global read run         */
+  int32_t run_out_bits; /* log2 contiguous elements per global write run        */
+  int32_t lds_bytes;
+  int32_t grid;
+  int64_t n_tiles;
+  int64_t a_rereads;    /* how many tiles read each A element (outer-N split)   */
+  double flops;         /* 8 * prod(all extents) real FLOP (c64 MAC = 8)        */
+  double bytes;         /* compulsory: 8|16 * (numel A + numel B + numel C)     */
+} ArtnStepInfo;
+
+int artn_abi_version(void);
+const char *artn_last_error(void);
+
+/* Number of visible gfx950 devices (0 on a CPU-only box; never fails). */
+int artn_device_count(void);
+
+/* Host-only: run the planner for `d` and report its decision. */
+int artn_contract_query(const ArtnStepDesc *d, ArtnStepInfo *info);
+
+/* Enqueue one pairwise contraction (replaces torch.einsum at contraction.py:70 etc.). */
+int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *stream);
+
+/*
+ * dst[r, :] = src[idx[r], :] for r < nrows, rows of `row_bytes` bytes (multiple of 8).
+ * Replaces the batch-row gathers `tensors[i][batch_i[k]]` of
+ * artensor/contraction.py:149-150,158-159,165-166,171-172,177-178,187.
+ * `idx` is a DEVICE pointer to int64 row indices; src_rows bounds-checks them
+ * (out-of-range rows are written as zeros and flagged in *err_flag if non-NULL).
+ */
+int artn_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t nrows,
+                     int64_t row_bytes, int64_t src_rows, int32_t *err_flag, void *stream);
+
+/* acc[i] += x[i], i < n complex64 elements: the slice accumulation
+ * `collect_tensor += ...` of artensor/simulation.py:114 and :210. */
+int artn_axpy_c64(void *acc, const void *x, int64_t n, void *stream);
+
+/* out[0] = max_i |x[i]| over n complex64 elements (float32, device pointer), then
+ * x[i] /= out[0]: the running renormalisation of artensor/contraction.py:197-200
+ * (`norm_factor = tensors[i].abs().max(); tensors[i] /= norm_factor`).
+ * `scratch` is a device buffer of at least 4 bytes that the call zeroes itself. */
+int artn_absmax_normalize_c64(void *x, int64_t n, float *out_absmax, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTN_H */

@@ -1,0 +1,429 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONHASHSEED=0 PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [case ...]
+
+Every fixture is data: leaf tensors, the compiled scheme (the step tuples produced by
+/root/reference/artensor/contraction.py:23-59 and :208-341), slicing indices
+(/root/reference/artensor/simulation.py:60-65) and the outputs the reference's own
+executors (/root/reference/artensor/contraction.py:62-76, :132-205, the slice loop
+simulation.py:107-114) returned here on torch-CPU.  No reference source is stored.
+
+PYTHONHASHSEED must be 0: bond labels are strings that pass through set()
+(contraction.py:17,:49), so schemes depend on the hash seed.
+"""
+import os
+import sys
+import time
+import types
+from copy import deepcopy
+
+if os.environ.get("PYTHONHASHSEED") != "0":
+    sys.exit("run with PYTHONHASHSEED=0 (schemes depend on the str hash seed)")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+import artensor  # the reference  # noqa: E402
+from artensor import (  # noqa: E402
+    TensorNetworkCircuit, TensorNetworkSimulation, AbstractTensorNetwork, ContractionTree,
+    find_order, contraction_scheme, tensor_contraction, contraction_scheme_sparse,
+    tensor_contraction_sparse,
+)
+from artensor_amd.fixtures import save_case  # noqa: E402
+
+PLAN = dict(trials=5, iters=10, slicing_repeat=1)
+N12_QSIM = os.path.join(REF, "tests", "circuit_n12_m14_s0_e0_pEFGH.qsim")
+N30_PY = os.path.join(REF, "examples", "circuit_n30_m14_s0_e0_pEFGH.py")
+N30_AMPS = os.path.join(REF, "examples", "amplitudes_n30_m14_s0_e0_pEFGH_10000.txt")
+N30_QSIM = "/tmp/circuit_n30_m14_s0_e0_pEFGH.qsim"
+
+# known-answer table of the reference's own test (tests/test_circuits.py:25-31)
+N12_TABLE = {
+    "100001000001": 0.0198028199 + 1j * (0.0106442748),
+    "000101111011": 0.00497586094 + 1j * (-0.0245072283),
+    "011000101100": -0.00853562169 + 1j * (-0.00701293815),
+    "111001100001": -0.0100137182 + 1j * (0.0147468708),
+    "001110110000": 0.00681955926 + 1j * (0.0106616206),
+}
+
+
+# --------------------------------------------------------------------------------------
+# n30 circuit: the reference only ships it as a cirq program; cirq is absent here.  The
+# program uses five gate constructors only, each of which maps 1:1 onto a qsim text gate
+# understood by artensor/circuit.py:5-15.  Evaluate the program against a recording
+# stand-in and emit qsim text to /tmp (an input-format conversion; nothing is stored).
+# --------------------------------------------------------------------------------------
+def n30_qsim():
+    if os.path.exists(N30_QSIM):
+        return N30_QSIM
+
+    class Q:
+        def __init__(s, r, c): s.rc = (r, c)
+        def __eq__(s, o): return s.rc == o.rc
+        def __hash__(s): return hash(s.rc)
+
+    class Op:
+        def __init__(s, name, params=()): s.name, s.params = name, params
+        def on(s, *qs): return (s.name, qs, s.params)
+
+    class Pow:
+        def __init__(s, name): s.name = name
+        def __pow__(s, e):
+            assert e == 0.5
+            return Op(s.name)
+
+    def phasedx(phase_exponent, exponent):
+        assert (phase_exponent, exponent) == (0.25, 0.5)
+        return Op("hz_1_2")
+
+    cirq = types.ModuleType("cirq")
+    cirq.GridQubit = Q
+    cirq.X, cirq.Y = Pow("x_1_2"), Pow("y_1_2")
+    cirq.PhasedXPowGate = phasedx
+    cirq.Rz = lambda rads: Op("rz", (rads,))
+    cirq.FSimGate = lambda theta, phi: Op("fs", (theta, phi))
+    cirq.Moment = lambda operations: list(operations)
+    cirq.Circuit = lambda moments: list(moments)
+    sys.modules["cirq"] = cirq
+    ns = {}
+    exec(compile(open(N30_PY).read(), N30_PY, "exec"), ns)
+    del sys.modules["cirq"]
+    order = {q.rc: i for i, q in enumerate(ns["QUBIT_ORDER"])}
+    lines = [str(len(order))]
+    for layer, moment in enumerate(ns["CIRCUIT"]):
+        for name, qs, params in moment:
+            lines.append(" ".join([str(layer), name] + [str(order[q.rc]) for q in qs]
+                                  + [repr(float(p)) for p in params]))
+    with open(N30_QSIM, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return N30_QSIM
+
+
+def read_google(n):
+    bits, amps = [], []
+    with open(N30_AMPS) as f:
+        for line in f:
+            b, re, im = line.split()
+            bits.append(b)
+            amps.append(float(re) + 1j * float(im))
+            if len(bits) == n:
+                break
+    return bits, np.array(amps)
+
+
+def plan(qsim, bitstrings, sc_target):
+    sim = TensorNetworkSimulation.from_circuit_file(qsim, bitstrings)
+    t0 = time.time()
+    sim.prepare_contraction(sc_target=sc_target, **PLAN)
+    tc, sc, mc = sim.ctree.tree_complexity()[:3]
+    meta = dict(sc_target=sc_target, plan=PLAN, log10_tc=float(tc), sc=float(sc),
+                plan_seconds=time.time() - t0, output_bonds=[str(b) for b in sim.output_bonds],
+                pattern=sim.pattern, hashseed=0, torch=torch.__version__)
+    if hasattr(sim, "permute_dims"):
+        meta["permute_dims"] = [int(x) for x in sim.permute_dims]
+    if sim.pattern == "sparse":
+        meta["bitstrings_sorted"] = list(sim.bitstrings_sorted)
+    return sim, meta
+
+
+def slicing_ok(sim):
+    """True when the reference slice loop is well defined (a tensor
+    carrying two sliced bonds makes the second select() use a stale dim index)."""
+    seen = {}
+    for bond, lst in sim.slicing_indices.items():
+        for tid, ind in lst:
+            seen.setdefault(tid, []).append(ind)
+    for tid, inds in seen.items():
+        for a in range(len(inds)):
+            for b in range(a + 1, len(inds)):
+                if inds[a] < inds[b]:
+                    return False
+    return True
+
+
+# --------------------------------------------------------------------------------------
+def case_n12_dense():
+    sim, meta = plan(N12_QSIM, [], 30)
+    assert len(sim.slicing_indices) == 0
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    raw = tensor_contraction(dict(tensors), sim.scheme)
+    final = sim.contraction().reshape(-1)
+    assert torch.equal(raw.permute(sim.permute_dims).reshape(-1), final)
+    sv = TensorNetworkCircuit(N12_QSIM).state_vec().reshape(-1)
+    meta["table"] = {b: [v.real, v.imag] for b, v in N12_TABLE.items()}
+    save_case(os.path.join(HERE, "n12_dense.npz"), tensors, sim.scheme, meta,
+              arrays=dict(raw=raw, final=final, state_vec=sv))
+    print("n12_dense", len(sim.scheme), "steps; max|tn-sv| =", (final - sv).abs().max().item())
+
+
+def case_n12_sparse5():
+    bits = list(N12_TABLE.keys())
+    sim, meta = plan(N12_QSIM, bits, 30)
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    out = sim.contraction()
+    meta["table"] = {b: [v.real, v.imag] for b, v in N12_TABLE.items()}
+    save_case(os.path.join(HERE, "n12_sparse5.npz"), tensors, sim.scheme, meta,
+              arrays=dict(final=out), slicing_indices=sim.slicing_indices)
+    ref = np.array([N12_TABLE[b] for b in sim.bitstrings_sorted])
+    print("n12_sparse5 rel err vs table", np.abs(out.numpy() - ref).max() / np.abs(ref).max())
+
+
+def case_n12_sparse_sliced():
+    rng = np.random.RandomState(7)
+    bits = sorted({np.binary_repr(x, 12) for x in rng.randint(0, 4096, size=24)})[:20]
+    for sc_target in (10, 9, 11, 8):
+        sim, meta = plan(N12_QSIM, bits, sc_target)
+        if len(sim.slicing_indices) >= 2 and slicing_ok(sim):
+            break
+    else:
+        raise SystemExit("no well-defined sliced n12 sparse case found")
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    out = sim.contraction()
+    sv = TensorNetworkCircuit(N12_QSIM).state_vec().reshape(-1)
+    want = np.array([sv[int(b, 2)].item() for b in sim.bitstrings_sorted])
+    # per-slice outputs too, so the slice loop can be checked term by term
+    save_case(os.path.join(HERE, "n12_sparse_sliced.npz"), tensors, sim.scheme, meta,
+              arrays=dict(final=out, state_vec_at=want), slicing_indices=sim.slicing_indices)
+    print("n12_sparse_sliced", len(sim.slicing_indices), "bonds, sc", sc_target,
+          "err vs sv", np.abs(out.numpy() - want).max())
+
+
+def case_n12_scinot():
+    """scientific_notation=True branch (contraction.py:197-204)."""
+    bits = list(N12_TABLE.keys())
+    sim, meta = plan(N12_QSIM, bits, 30)
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    factor, out = tensor_contraction_sparse(dict(tensors), sim.scheme, scientific_notation=True)
+    save_case(os.path.join(HERE, "n12_sparse5_scinot.npz"), tensors, sim.scheme, meta,
+              arrays=dict(final=out, factor=factor))
+    print("n12_scinot factor", factor)
+
+
+def _rand_tn(nv, D, seed, n_open):
+    """3-regular random graph TN (SURVEY 8d input 2).  Bonds are ints; n_open extra
+    dangling bonds on the first tensors make it an open network."""
+    import networkx as nx
+    g = nx.random_regular_graph(3, nv, seed=seed)
+    edges = sorted((min(a, b), max(a, b)) for a, b in g.edges())
+    tensor_bonds = {i: [] for i in range(nv)}
+    for e, (a, b) in enumerate(edges):
+        tensor_bonds[a].append(e)
+        tensor_bonds[b].append(e)
+    nb = len(edges)
+    for k in range(n_open):
+        tensor_bonds[k].append(nb + k)
+    bond_dims = {b: float(D) for b in range(nb + n_open)}
+    gen = torch.Generator().manual_seed(seed)
+    tensors = {}
+    for i in range(nv):
+        shape = [D] * len(tensor_bonds[i])
+        tensors[i] = torch.complex(torch.randn(shape, generator=gen),
+                                   torch.randn(shape, generator=gen)) / D ** 1.5
+    return tensors, tensor_bonds, bond_dims
+
+
+def case_random_tns():
+    try:
+        import networkx  # noqa: F401
+    except ImportError:
+        print("networkx missing: random TN cases skipped")
+        return
+    for nv, D, n_open, sc_target, name in [
+        (16, 2, 0, 30, "rand_D2_closed"),
+        (14, 3, 2, 30, "rand_D3_open"),
+        (12, 4, 0, 30, "rand_D4_closed"),
+        (16, 2, 3, 4, "rand_D2_open_sliced"),
+        (24, 2, 0, 3, "rand_D2_closed_sliced"),
+    ]:
+        tensors, tensor_bonds, bond_dims = _rand_tn(nv, D, 0, n_open)
+        order, slicing_bonds, ctree = find_order(
+            deepcopy(tensor_bonds), deepcopy(bond_dims), [], 0, 1, sc_target=sc_target,
+            trials=4, iters=5, betas=np.linspace(3.0, 21.0, 61), start_seed=0, slicing_repeat=1)
+        scheme, output_bonds = contraction_scheme(deepcopy(ctree))
+        # slice loop restated as simulation.py:198-213 does it
+        slicing_indices = {}
+        for bond in slicing_bonds:
+            slicing_indices[bond] = [(tid, tensor_bonds[tid].index(bond))
+                                     for tid in tensor_bonds if bond in tensor_bonds[tid]]
+        ok = True
+        seen = {}
+        for bond, lst in slicing_indices.items():
+            for tid, ind in lst:
+                if any(prev < ind for prev in seen.get(tid, [])):
+                    ok = False
+                seen.setdefault(tid, []).append(ind)
+        if not ok:
+            print(name, "skipped: reference slice loop ill-defined for this plan")
+            continue
+        shape = [int(bond_dims[b]) for b in output_bonds]
+        collect = torch.zeros(shape, dtype=torch.complex64)
+        for s in range(2 ** len(slicing_bonds)):
+            cfg = list(map(int, np.binary_repr(s, len(slicing_bonds)))) if slicing_bonds else []
+            sliced = dict(tensors)
+            for x, bond in enumerate(slicing_bonds):
+                for tid, ind in slicing_indices[bond]:
+                    sliced[tid] = sliced[tid].select(ind, cfg[x]).clone()
+            collect += tensor_contraction(sliced, scheme)
+        # independent one-shot complex128 einsum over the whole network
+        labels = sorted(bond_dims.keys())
+        sub = []
+        for i in range(nv):
+            sub += [tensors[i].to(torch.complex128), list(tensor_bonds[i])]
+        exact = torch.einsum(*sub, list(output_bonds))
+        err = (collect.to(torch.complex128) - exact).abs().max() / exact.abs().max()
+        tc = ctree.tree_complexity()[0]
+        meta = dict(D=D, nv=nv, n_open=n_open, sc_target=sc_target, log10_tc=float(tc),
+                    output_bonds=[int(b) for b in output_bonds], bond_dim=D,
+                    n_slicing=len(slicing_bonds))
+        save_case(os.path.join(HERE, name + ".npz"), tensors, scheme, meta,
+                  arrays=dict(final=collect, exact128=exact), slicing_indices=slicing_indices)
+        print(name, "steps", len(scheme), "slices", 2 ** len(slicing_bonds), "rel err vs c128", err.item())
+
+
+def case_n30_plan():
+    """n30 m14 full amplitude: leaf tensors + 180-step scheme only (fast)."""
+    sim, meta = plan(n30_qsim(), [], 30)
+    assert len(sim.slicing_indices) == 0
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    bits, amps = read_google(10000)
+    meta["google_bitstrings"] = bits
+    save_case(os.path.join(HERE, "n30_dense.npz"), tensors, sim.scheme, meta,
+              arrays=dict(google=amps))
+    print("n30_dense plan", len(sim.scheme), "steps log10 tc", meta["log10_tc"])
+    return sim, meta
+
+
+def case_n30_run():
+    """Run the reference dense executor on n30 (minutes, ~25 GB) and append statistics."""
+    from artensor_amd.fixtures import load_case
+    path = os.path.join(HERE, "n30_dense.npz")
+    case = load_case(path)
+    tensors = case.fresh_tensors()
+    t0 = time.time()
+    raw = tensor_contraction(tensors, case.scheme)
+    wall = time.time() - t0
+    final = raw.permute(case.meta["permute_dims"]).reshape(-1)
+    bits = case.meta["google_bitstrings"]
+    pos = torch.tensor([int(b, 2) for b in bits])
+    at = final[pos].clone()
+    blocks = final.reshape(1024, -1).sum(dim=1).to(torch.complex128)
+    norm2 = float((final.real.double() ** 2 + final.imag.double() ** 2).sum())
+    stride = final[:: 2 ** 14 + 1][:65536].clone()   # 65536-point strided probe
+    meta = case.meta
+    meta["reference_cpu_seconds"] = wall
+    meta["reference_cpu_threads"] = torch.get_num_threads()
+    meta["norm2"] = norm2
+    for k in ("tensor_ids", "steps"):
+        meta.pop(k, None)
+    arrays = dict(case.arrays)
+    arrays.update(amps_at_google=at, block_sums=blocks, strided=stride)
+    save_case(path, case.tensors, case.scheme, meta, arrays=arrays)
+    g = case.arrays["google"]
+    print("n30 run", wall, "s; norm2", norm2, "max rel err vs google",
+          (np.abs(at.numpy() - g) / np.abs(g)).max())
+
+
+def case_n30_sparse(nbits):
+    bits, amps = read_google(nbits)
+    sim, meta = plan(n30_qsim(), bits, 30)
+    assert len(sim.slicing_indices) == 0
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    t0 = time.time()
+    out = sim.contraction()
+    meta["reference_cpu_seconds"] = time.time() - t0
+    g = np.array([amps[bits.index(b)] for b in sim.bitstrings_sorted])
+    save_case(os.path.join(HERE, f"n30_sparse{nbits}.npz"), tensors, sim.scheme, meta,
+              arrays=dict(final=out, google=g))
+    print("n30_sparse", nbits, meta["reference_cpu_seconds"], "s  max rel err vs google",
+          (np.abs(out.numpy() - g) / np.abs(g)).max())
+
+
+def case_n30_sliced(k=3):
+    """n30 full amplitude with k manually sliced inner bonds, the way the reference's
+    notebook does it (examples/sycamore.ipynb cell 7: AbstractTensorNetwork.slicing +
+    ContractionTree(tn, order) + contraction_scheme).  Plan + leaf tensors only; the sum of
+    the 2**k slices equals the unsliced n30 result, which n30_dense.npz pins."""
+    from artensor.simulation import get_bond_tensors
+    sim = TensorNetworkSimulation.from_circuit_file(n30_qsim(), [])
+    betas = np.linspace(3.0, 21.0, 61)
+    order, slicing_bonds, ctree = find_order(
+        sim.tensor_bonds, sim.bond_dims, sim.final_qubits, 0, 1, sc_target=30,
+        betas=betas, start_seed=0, alpha=32.0, **PLAN)
+    assert not slicing_bonds
+    bond_tensors = get_bond_tensors(sim.tensor_bonds)
+    scheme0, out0 = contraction_scheme(deepcopy(ctree))
+    # choose inner bonds (shared by two tensors, not output bonds) that live longest in
+    # the big "state" tensor: here simply the k bonds contracted by the last big steps
+    # that are leaf-leaf bonds, greedily keeping the slice loop well defined.
+    tn = AbstractTensorNetwork(deepcopy(sim.tensor_bonds), deepcopy(sim.bond_dims),
+                               sim.final_qubits, 1)
+    cand = [b for b, ts in bond_tensors.items() if len(ts) == 2 and b not in out0]
+    # rank candidates by how much slicing them lowers tc of the tree
+    scored = []
+    for b in cand:
+        t2 = deepcopy(tn)
+        t2.slicing(b)
+        ct = ContractionTree(t2, order, 0)
+        scored.append((ct.tree_complexity()[0], b))
+    scored.sort()
+    chosen, used = [], {}
+    for _, b in scored:
+        inds = [(tid, sim.tensor_bonds[tid].index(b)) for tid in bond_tensors[b]]
+        if any(tid in used for tid, _ in inds):
+            continue
+        chosen.append(b)
+        for tid, _ in inds:
+            used[tid] = True
+        if len(chosen) == k:
+            break
+    for b in chosen:
+        tn.slicing(b)
+    ctree_s = ContractionTree(tn, order, 0)
+    scheme, output_bonds = contraction_scheme(deepcopy(ctree_s))
+    assert list(output_bonds) == list(out0) or sorted(output_bonds) == sorted(out0)
+    slicing_indices = {b: [(tid, sim.tensor_bonds[tid].index(b)) for tid in bond_tensors[b]]
+                       for b in chosen}
+    bond_inds = []
+    bt = get_bond_tensors(sim.tensor_bonds)
+    for x in range(len(output_bonds)):
+        tid = list(bt[output_bonds[x]])[0]
+        bond_inds.append(list(sim.final_qubits).index(tid))
+    tc = ctree_s.tree_complexity()[0]
+    meta = dict(sc_target=30, plan=PLAN, log10_tc_per_slice=float(tc), n_slicing=k,
+                permute_dims=[int(x) for x in np.argsort(bond_inds)],
+                output_bonds=[str(b) for b in output_bonds], hashseed=0)
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    save_case(os.path.join(HERE, f"n30_dense_sliced{k}.npz"), tensors, scheme, meta,
+              slicing_indices=slicing_indices)
+    print("n30_sliced", k, "bonds", chosen, "log10 tc/slice", tc)
+
+
+CASES = {
+    "n12_dense": case_n12_dense,
+    "n12_sparse5": case_n12_sparse5,
+    "n12_sparse_sliced": case_n12_sparse_sliced,
+    "n12_scinot": case_n12_scinot,
+    "random": case_random_tns,
+    "n30_plan": case_n30_plan,
+    "n30_run": case_n30_run,
+    "n30_sparse100": lambda: case_n30_sparse(100),
+    "n30_sparse10000": lambda: case_n30_sparse(10000),
+    "n30_sliced3": lambda: case_n30_sliced(3),
+}
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or ["n12_dense", "n12_sparse5", "n12_sparse_sliced", "n12_scinot", "random"]
+    for name in todo:
+        t0 = time.time()
+        CASES[name]()
+        print(f"[{name}] {time.time() - t0:.1f} s", flush=True)
