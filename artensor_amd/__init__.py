@@ -1,1 +1,31 @@
-"""artensor_amd: MI355X-native numerical contraction engine behind artensor's executor API."""
+"""artensor_amd: MI355X-native numerical contraction engine behind artensor's executor API.
+
+Drop-in for the hot path of Fanerst/artensor:
+
+    from artensor_amd import tensor_contraction, tensor_contraction_sparse   # executors
+    from artensor_amd import contraction_scheme, contraction_scheme_sparse   # scheme compilers
+    from artensor_amd import TensorNetworkSimulation, sliced_contraction     # slice loop, multi-GPU
+
+Planning (AbstractTensorNetwork / ContractionTree / find_order / GreedyOrderFinder) is not
+part of this package: the engine consumes the planner's products unchanged.
+"""
+from .contraction import (  # noqa: F401
+    contract,
+    contraction_scheme,
+    contraction_scheme_sparse,
+    einsum_eq_convert,
+    step_info,
+    tensor_contraction,
+    tensor_contraction_sparse,
+)
+from .fixtures import load_case, save_case  # noqa: F401
+from .simulation import (  # noqa: F401
+    TensorNetworkSimulation,
+    accumulate,
+    apply_slice,
+    rank_slices,
+    slice_assignments,
+    sliced_contraction,
+)
+
+__version__ = "0.1.0"

@@ -1,0 +1,467 @@
+"""Host-side mirror of the reference's executor module (artensor/contraction.py).
+
+Same entry points, same argument meaning, same step formats:
+
+    contraction_scheme(ctree)                      -> (scheme, output_bonds)   ref :23-59
+    tensor_contraction(tensors, scheme)            -> Tensor                   ref :62-76
+    contraction_scheme_sparse(ctree, bitstrings, sc_target)                    ref :208-341
+    tensor_contraction_sparse(tensors, scheme, scientific_notation=False)      ref :132-205
+
+but every `torch.einsum`, row gather, `torch.cat` and renormalisation of the reference is
+one call through the C ABI of libartn_hip.so (include/artn.h) into hand-written gfx950
+kernels.  Tree traversal stays in Python on PyTorch-ROCm tensors.  Errors raise
+RuntimeError (the reference prints and sys.exit(1)s, contraction.py:71-74).
+"""
+import ctypes
+from math import ceil
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+__all__ = [
+    "einsum_eq_convert", "contraction_scheme", "tensor_contraction",
+    "contraction_scheme_sparse", "tensor_contraction_sparse", "contract", "step_info",
+]
+
+# the reference's einsum alphabet (contraction.py:9-10): A-Y, a-y  (Z/z excluded)
+letters = [chr(c) for c in list(range(65, 90)) + list(range(97, 122))]
+
+
+# ----------------------------------------------------------------------------------------
+# one pairwise step through the C ABI
+# ----------------------------------------------------------------------------------------
+def _parse(eq):
+    try:
+        lhs, out = eq.split("->")
+        a, b = lhs.split(",")
+    except ValueError:
+        raise RuntimeError(f"not a two-operand einsum equation: {eq!r}")
+    for part in (a, b, out):
+        if len(set(part)) != len(part):
+            raise RuntimeError(f"repeated label inside one operand is not supported: {eq!r}")
+    for lab in out:
+        if lab not in a and lab not in b:
+            raise RuntimeError(f"output label {lab!r} not carried by an operand: {eq!r}")
+    return tuple(a), tuple(b), tuple(out)
+
+
+_DTYPES = {torch.complex64: N.ARTN_C64, torch.complex128: N.ARTN_C128}
+_desc_cache = {}
+
+
+def _descriptor(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype):
+    key = (la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype)
+    hit = _desc_cache.get(key)
+    if hit is not None:
+        return hit
+    if len(la) != len(a_shape) or len(lb) != len(b_shape):
+        raise RuntimeError(f"operand rank does not match the equation: {la} {a_shape} / {lb} {b_shape}")
+    labels = list(la) + [x for x in lb if x not in la]
+    if len(labels) > N.ARTN_MAX_LABELS:
+        raise RuntimeError(f"step has {len(labels)} labels; the ABI carries at most {N.ARTN_MAX_LABELS}")
+    ext = {}
+    for lab, n in zip(la, a_shape):
+        ext[lab] = n
+    for lab, n in zip(lb, b_shape):
+        if ext.setdefault(lab, n) != n:
+            raise RuntimeError(f"label {lab!r} has extent {ext[lab]} in one operand and {n} in the other")
+    out_shape = tuple(ext[x] for x in lo)
+    c_stride = {}
+    s = 1
+    for lab in reversed(lo):
+        c_stride[lab] = s
+        s *= ext[lab]
+    d = N.ArtnStepDesc()
+    d.dtype = _DTYPES[dtype]
+    d.n_labels = len(labels)
+    sa, sb = dict(zip(la, a_stride)), dict(zip(lb, b_stride))
+    for n, lab in enumerate(labels):
+        d.extent[n] = ext[lab]
+        d.stride_a[n] = sa.get(lab, -1)
+        d.stride_b[n] = sb.get(lab, -1)
+        d.stride_c[n] = c_stride.get(lab, -1)
+    hit = (d, out_shape)
+    _desc_cache[key] = hit
+    return hit
+
+
+def _as_operand(t):
+    # degenerate strides (expanded views) are materialised; ordinary views pass through
+    if any(st == 0 and n > 1 for st, n in zip(t.stride(), t.shape)):
+        return t.contiguous()
+    return t
+
+
+def contract(eq, a, b, out=None):
+    """C = einsum(eq, a, b) on the GPU through artn_contract (stands in for torch.einsum at
+    reference contraction.py:70,147,156,163,169,179,181,190).  `eq` is an einsum string or
+    a triple of label tuples (labels may then be any hashables: no 50-letter limit)."""
+    la, lb, lo = _parse(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
+    N.require_gpu(a, "contract")
+    N.require_gpu(b, "contract")
+    if a.dtype != b.dtype or a.dtype not in _DTYPES:
+        raise RuntimeError(f"operands must both be complex64 or complex128, got {a.dtype} and {b.dtype}")
+    if a.device != b.device:
+        raise RuntimeError(f"operands live on different devices: {a.device} / {b.device}")
+    a, b = _as_operand(a), _as_operand(b)
+    d, out_shape = _descriptor(la, lb, lo, tuple(a.shape), tuple(a.stride()), tuple(b.shape),
+                               tuple(b.stride()), a.dtype)
+    if out is None:
+        out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
+    else:
+        if tuple(out.shape) != out_shape or not out.is_contiguous() or out.dtype != a.dtype:
+            raise RuntimeError("out= must be a contiguous tensor of the result shape and dtype")
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(a.device):
+        N.check(N.lib().artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                      N.current_stream_ptr(a.device)))
+    return out
+
+
+def step_info(eq, a_shape, b_shape, dtype=torch.complex64, a_stride=None, b_stride=None):
+    """Planner decision for one step (host only, works without a GPU)."""
+    la, lb, lo = _parse(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
+
+    def dense(shape):
+        st, s = [], 1
+        for n in reversed(shape):
+            st.append(s)
+            s *= n
+        return tuple(reversed(st))
+
+    a_shape, b_shape = tuple(a_shape), tuple(b_shape)
+    d, out_shape = _descriptor(la, lb, lo, a_shape, tuple(a_stride or dense(a_shape)), b_shape,
+                               tuple(b_stride or dense(b_shape)), dtype)
+    info = N.ArtnStepInfo()
+    N.check(N.lib().artn_contract_query(ctypes.byref(d), ctypes.byref(info)))
+    res = {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+    res["out_shape"] = out_shape
+    return res
+
+
+# ----------------------------------------------------------------------------------------
+# dense executor
+# ----------------------------------------------------------------------------------------
+def tensor_contraction(tensors, scheme):
+    """Run a dense scheme: for each ((i, j), eq): tensors[i] <- contract(eq, tensors[i],
+    tensors[j]); returns the last tensors[i] (reference contraction.py:62-76; `tensors` is
+    mutated the same way)."""
+    i = None
+    for n, step in enumerate(scheme):
+        i, j = step[0]
+        try:
+            tensors[i] = contract(step[1], tensors[i], tensors[j])
+        except Exception as e:
+            raise RuntimeError(f"tensor_contraction failed at step {n} {step[0]} {step[1]!r}: {e}") from e
+    if i is None:
+        raise RuntimeError("empty contraction scheme")
+    return tensors[i]
+
+
+# ----------------------------------------------------------------------------------------
+# sparse-state executor
+# ----------------------------------------------------------------------------------------
+_index_cache = {}
+
+
+def _device_index(idx, device):
+    """int64 row indices of a scheme step (CPU tensors built at reference
+    contraction.py:249-283) cached on the device: the scheme is reused for every slice."""
+    key = (id(idx), str(device))
+    hit = _index_cache.get(key)
+    if hit is not None and hit[0] is idx:
+        return hit[1]
+    dev = torch.as_tensor(idx, dtype=torch.int64).to(device).contiguous()
+    if len(_index_cache) > 4096:
+        _index_cache.clear()
+    _index_cache[key] = (idx, dev)
+    return dev
+
+
+def gather_rows(t, idx):
+    """t[idx] along dim 0 through artn_gather_rows (reference contraction.py:149-150 etc.)."""
+    N.require_gpu(t, "gather_rows")
+    t = t.contiguous()
+    dev_idx = _device_index(idx, t.device)
+    nrows = dev_idx.numel()
+    out = torch.empty((nrows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if out.numel() == 0:
+        return out
+    row_bytes = (t.numel() // t.shape[0]) * t.element_size()
+    flag = torch.zeros(1, dtype=torch.int32, device=t.device)
+    with torch.cuda.device(t.device):
+        N.check(N.lib().artn_gather_rows(t.data_ptr(), dev_idx.data_ptr(), out.data_ptr(), nrows, row_bytes,
+                                         t.shape[0], flag.data_ptr(), N.current_stream_ptr(t.device)))
+    gather_rows.last_flag = flag  # checked lazily by callers that can afford a sync
+    return out
+
+
+def _normalize_inplace(t):
+    """t /= t.abs().max(); returns the device scalar abs-max (reference contraction.py:197-199)."""
+    if t.dtype != torch.complex64:
+        raise RuntimeError("scientific_notation is implemented for complex64")
+    amax = torch.empty(1, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        N.check(N.lib().artn_absmax_normalize_c64(t.data_ptr(), t.numel(), amax.data_ptr(),
+                                                  N.current_stream_ptr(t.device)))
+    return amax
+
+
+def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=False):
+    """Run a sparse-state scheme (reference contraction.py:132-205); the four branches are
+    keyed exactly like the reference:
+
+    (A) several index chunks: per chunk gather rows of both operands and run the batched
+        contraction straight into its row range of the result (no torch.cat copy)
+    (B) 5-tuple with one index list per operand: gather both, batched contraction
+    (C) other 5-tuples: contraction with both batch labels in the output, merged by a
+        free reshape, then an optional row select
+    (D) 3-tuples: plain contraction.
+    Consumed operands are released (`tensors[j] = []`) as the reference does."""
+    factor = None
+    i = None
+    for n, step in enumerate(contraction_scheme):
+        i, j = step[0]
+        eq = step[1]
+        batch_i, batch_j = step[2]
+        try:
+            if len(batch_i) > 1:
+                src_i, src_j = tensors[i], tensors[j]
+                la, lb, lo = _parse(eq)
+                rows = [len(x) for x in batch_i]
+                first = None
+                r0 = 0
+                for k in range(len(batch_i)):
+                    gi, gj = gather_rows(src_i, batch_i[k]), gather_rows(src_j, batch_j[k])
+                    if first is None:
+                        ext = dict(zip(la, gi.shape))
+                        ext.update(zip(lb, gj.shape))
+                        first = torch.empty((sum(rows),) + tuple(ext[x] for x in lo[1:]),
+                                            dtype=gi.dtype, device=gi.device)
+                    contract(eq, gi, gj, out=first[r0:r0 + rows[k]])
+                    r0 += rows[k]
+                if step[3]:
+                    first = first.reshape((-1,) + tuple(step[3][1:]))
+                tensors[j] = []
+                tensors[i] = first
+            elif len(step) > 3 and len(batch_i) == len(batch_j) == 1:
+                tensors[i] = gather_rows(tensors[i], batch_i[0])
+                tensors[j] = gather_rows(tensors[j], batch_j[0])
+                tensors[i] = contract(eq, tensors[i], tensors[j])
+            elif len(step) > 3:
+                tensors[i] = contract(eq, tensors[i], tensors[j]).reshape(step[3])
+                if len(batch_i) == 1:
+                    tensors[i] = gather_rows(tensors[i], batch_i[0])
+                tensors[j] = []
+            else:
+                tensors[i] = contract(eq, tensors[i], tensors[j])
+                tensors[j] = []
+        except Exception as e:
+            raise RuntimeError(f"tensor_contraction_sparse failed at step {n} {step[0]} {eq!r}: {e}") from e
+        if scientific_notation:
+            amax = _normalize_inplace(tensors[i])
+            lg = torch.log10(amax)
+            factor = lg if factor is None else factor + lg
+    if i is None:
+        raise RuntimeError("empty contraction scheme")
+    if scientific_notation:
+        return factor.reshape(()).to(tensors[i].dtype), tensors[i]
+    return tensors[i]
+
+
+# ----------------------------------------------------------------------------------------
+# scheme compilers (host only; consume the planner's ContractionTree by duck typing)
+# ----------------------------------------------------------------------------------------
+def einsum_eq_convert(ixs, iy):
+    """Bond-label lists -> einsum string over the reference alphabet (contraction.py:13-20).
+    The label -> letter assignment follows set iteration order exactly like the reference
+    so that equations compare equal string for string under the same PYTHONHASHSEED."""
+    unique = list(set(sum(ixs, start=[]) + iy))
+    if len(unique) > len(letters):
+        raise RuntimeError(f"{len(unique)} labels exceed the {len(letters)}-letter einsum alphabet; "
+                           "use contract() with label tuples instead")
+    m = {lab: letters[k] for k, lab in enumerate(unique)}
+    return ",".join("".join(m[x] for x in ix) for ix in ixs) + "->" + "".join(m[x] for x in iy)
+
+
+def contraction_scheme(ctree):
+    """Dense scheme of a contraction tree (reference contraction.py:23-59): depth-first from
+    the root, larger-space child first, emitted in reverse; each step is
+    ((rep, other), equation) where `rep` is the vertex's representative tensor id (always
+    the child with the larger sc, contraction_tree.py:305-314) and the output labels are
+    list(vertex.contain_bonds)."""
+    ctree.mark_rep_tensor()
+    root = ctree.tree[ctree.all_tensors]
+    bonds_of = ctree.tn.tensor_bonds
+    scheme, output_bonds = [], None
+    todo = [root]
+    while todo:
+        v = todo.pop()
+        if not (v.left and v.right):
+            continue
+        child_labels = []
+        for ch in (v.left, v.right):
+            child_labels.append(bonds_of[ch.rep_tensor] if ch.is_leaf() else list(ch.contain_bonds))
+        if v.rep_tensor == v.left.rep_tensor:
+            pair, ixs = (v.left.rep_tensor, v.right.rep_tensor), (child_labels[0], child_labels[1])
+        elif v.rep_tensor == v.right.rep_tensor:
+            pair, ixs = (v.right.rep_tensor, v.left.rep_tensor), (child_labels[1], child_labels[0])
+        else:
+            raise ValueError("Incorrect rep tensor mark process.")
+        iy = list(v.contain_bonds)
+        if v is root:
+            output_bonds = iy
+        scheme.append((pair, einsum_eq_convert(ixs, iy)))
+        todo += [v.left, v.right] if v.left.sc > v.right.sc else [v.right, v.left]
+    scheme.reverse()
+    return scheme, output_bonds
+
+
+def _select_bits(bitstrings, inds):
+    return ["".join(b[k] for k in inds) for b in bitstrings]
+
+
+def _merge_bits(bits_i, bits_j, loc_i, loc_j):
+    n = len(loc_i) + len(loc_j)
+    return "".join(bits_i[loc_i.index(k)] if k in loc_i else bits_j[loc_j.index(k)] for k in range(n))
+
+
+def contraction_scheme_sparse(ctree, bitstrings=None, sc_target=31):
+    """Sparse-state scheme (reference contraction.py:208-341).
+
+    Walks the tree's DFS order keeping, per live tensor, which final qubits it already
+    fixes and the list of partial bitstrings (one batch row each).  Emits
+        (edge, eq, batch_seq)                                   3-tuple, or
+        (edge, eq, batch_seq, rshape_or_None, next_shape)       5-tuple
+    with batch labels -1 (left rows), -2 (right rows), -3 (shared rows of a chunked
+    gather), exactly the reference's step format.  Returns (scheme, bonds of the final
+    tensor, bitstrings in output-row order)."""
+    order = ctree.tree_order_dfs()
+    tensor_bonds = ctree.tn.tensor_bonds
+    final_qubits = ctree.tn.final_qubits
+    if isinstance(final_qubits, (set, frozenset)):
+        final_qubits = sorted(final_qubits)
+    final_qubits = list(final_qubits)
+    # per tensor: (sorted final-qubit positions it fixes, int-encoded partial bitstrings per row)
+    info = {}
+    for tid in tensor_bonds.keys():
+        if tid in final_qubits:
+            info[tid] = ([final_qubits.index(tid)], np.array([0, 1]))
+        else:
+            info[tid] = ([], np.array([-1]))
+    scheme = []
+    out_bits = None
+    for edge in order:
+        i, j = edge
+        bond_i, bond_j = tensor_bonds[i], tensor_bonds[j]
+        shared = sorted(frozenset(bond_i) & frozenset(bond_j))
+        # a shared bond that a third live tensor still carries is a hyper-edge: keep it
+        keep = []
+        for b in shared:
+            for x in tensor_bonds.keys():
+                if x == i or x == j or len(tensor_bonds[x]) == 0:
+                    continue
+                if b in tensor_bonds[x]:
+                    keep.append(b)
+                    break
+        contracted = [b for b in shared if b not in keep]
+        pos_i = [bond_i.index(b) for b in contracted]
+        pos_j = [bond_j.index(b) for b in contracted]
+        new_i = [bond_i[m] for m in range(len(bond_i)) if m not in pos_i]
+        new_i += [bond_j[n] for n in range(len(bond_j)) if n not in pos_j and bond_j[n] not in new_i]
+        tensor_bonds[i] = new_i
+        tensor_bonds[j] = []
+
+        fq_i, rows_i = info[i]
+        fq_j, rows_j = info[j]
+        fq = sorted(fq_i + fq_j)
+        chunked = False
+        if len(fq) == 0:
+            batch_seq = [[torch.tensor([0])], [torch.tensor([0])]]
+            rows = np.array([-1])
+        elif len(fq_i) > 0 and len(fq_j) == 0:
+            batch_seq = [[torch.tensor(list(range(len(rows_i))))], [torch.tensor([0])]]
+            rows = rows_i
+        elif len(fq_j) > 0 and len(fq_i) == 0:
+            batch_seq = [[torch.tensor([0])], [torch.tensor(list(range(len(rows_j))))]]
+            rows = rows_j
+        else:
+            loc_i = [fq.index(q) for q in fq_i]
+            loc_j = [fq.index(q) for q in fq_j]
+            bigger_left = int(len(rows_i) > len(rows_j))
+            wanted = np.unique(_select_bits(bitstrings, fq))
+            if len(wanted) == 2 ** len(fq) or len(fq) + len(new_i) <= sc_target:
+                # outer product of the two row sets, optionally followed by a row select
+                rows = np.array([
+                    int(_merge_bits(np.binary_repr(x, len(fq_i)), np.binary_repr(y, len(fq_j)), loc_i, loc_j), 2)
+                    for x in rows_i for y in rows_j])
+                if len(wanted) != len(rows):
+                    sel = np.sort(np.array([np.argwhere(rows == int(s, 2))[0][0] for s in wanted]))
+                    rows = np.array([rows[k] for k in sel])
+                    batch_seq = [[torch.tensor(sel)], []]
+                else:
+                    batch_seq = [[], []]
+            else:
+                # too big for an outer product: gather matching row pairs, in chunks
+                part = np.stack([
+                    np.array([int(s, 2) for s in _select_bits(wanted, loc_i)]),
+                    np.array([int(s, 2) for s in _select_bits(wanted, loc_j)])])
+                rows = np.array([int(s, 2) if len(s) > 0 else -1 for s in wanted])
+                pairs = np.array([[np.argwhere(rows_i == bi)[0][0], np.argwhere(rows_j == bj)[0][0]]
+                                  for bi, bj in zip(part[0], part[1])])
+                perm = np.argsort(pairs[:, 1 - bigger_left])
+                pairs = pairs[perm].T.reshape(2, -1)
+                batch_seq = [[torch.from_numpy(pairs[0])], [torch.from_numpy(pairs[1])]]
+                assert torch.max(batch_seq[0][0]) < len(rows_i)
+                assert torch.max(batch_seq[1][0]) < len(rows_j)
+                n_chunks = 2 ** ceil(max(0, np.log2(len(rows)) + max(len(bond_i), len(bond_j)) - (sc_target - 2)))
+                if n_chunks > 1:
+                    length = int(len(rows) / n_chunks)
+                    if len(rows) % n_chunks > 0:
+                        n_chunks += 1
+                    batch_seq = [
+                        [batch_seq[0][0][c * length:(c + 1) * length] for c in range(n_chunks)],
+                        [batch_seq[1][0][c * length:(c + 1) * length] for c in range(n_chunks)]]
+                chunked = True
+                rows = rows[perm]
+            assert len(rows) == len(wanted)
+
+        iy = []
+        if len(fq_j):
+            has_j = 1
+            if chunked:
+                ix_right = [-3] + bond_j
+                iy.insert(0, -3)
+            else:
+                ix_right = [-2] + bond_j
+                iy.insert(0, -2)
+        else:
+            has_j = 0
+            ix_right = bond_j
+        if len(fq_i):
+            has_i = 1
+            if chunked:
+                ix_left = [-3] + bond_i
+            else:
+                ix_left = [-1] + bond_i
+                iy.insert(0, -1)
+        else:
+            has_i = 0
+            ix_left = bond_i
+        iy = iy + tensor_bonds[i]
+        eq = einsum_eq_convert((ix_left, ix_right), iy)
+        if has_i and has_j:
+            next_shape = (len(rows),) + (2,) * len(tensor_bonds[i])
+            if chunked:
+                scheme.append((edge, eq, batch_seq, None, next_shape))
+            else:
+                scheme.append((edge, eq, batch_seq, (-1,) + (2,) * len(tensor_bonds[i]), next_shape))
+        else:
+            scheme.append((edge, eq, batch_seq))
+        info[i] = (fq, rows)
+        if edge == order[-1]:
+            out_bits = [np.binary_repr(n, len(final_qubits)) for n in info[i][1]]
+    return scheme, tensor_bonds[i], out_bits

@@ -1,0 +1,152 @@
+"""Driver side of the hot path: the slice loop of the reference's
+`TensorNetworkSimulation.contraction` (artensor/simulation.py:90-117, twin :198-213),
+sharded over the GPUs of one node.
+
+Every slice (one assignment of the sliced bonds) runs the same scheme on leaf tensors
+with those bonds fixed; slices are independent, so rank r takes slices r, r+W, r+2W, ...
+and accumulates a local `collect_tensor` with the HIP axpy kernel.  The only exchange is
+ONE sum of `collect_tensor` across ranks at the end (`torch.distributed` reduce; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests of the sharding logic).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .contraction import tensor_contraction, tensor_contraction_sparse
+
+__all__ = ["slice_assignments", "rank_slices", "apply_slice", "accumulate", "sliced_contraction",
+           "TensorNetworkSimulation"]
+
+
+def slice_assignments(n_bonds, s):
+    """Bits of slice number s, MSB = first sliced bond (reference simulation.py:108)."""
+    return [int(c) for c in np.binary_repr(s, n_bonds)] if n_bonds else []
+
+
+def rank_slices(n_slices, rank, world_size):
+    """Slices of `rank`: round-robin, so every rank gets the same count +-1."""
+    return range(rank, n_slices, world_size)
+
+
+def apply_slice(tensors, slicing_indices, config):
+    """Leaf tensors with the sliced bonds fixed to `config` (one bit per bond, in the
+    mapping's order).  `slicing_indices[bond] = [(tensor_id, dim_index), ...]` with
+    dim indices of the UNSLICED tensors (reference simulation.py:60-65).
+
+    The reference applies `select(dim, bit)` bond after bond with those indices
+    (simulation.py:110-113), which goes stale when one tensor carries two sliced bonds in
+    ascending dim order.  Here all of a tensor's selects are applied
+    in one indexing operation on the unsliced tensor, which equals the reference wherever
+    the reference is well defined and is correct where it is not."""
+    per_tensor = {}
+    for x, (bond, lst) in enumerate(slicing_indices.items()):
+        for tid, dim in lst:
+            per_tensor.setdefault(tid, {})[dim] = config[x]
+    out = dict(tensors) if isinstance(tensors, dict) else list(tensors)
+    for tid, sel in per_tensor.items():
+        t = tensors[tid]
+        index = tuple(sel.get(d, slice(None)) for d in range(t.dim()))
+        out[tid] = t[index].contiguous()
+    return out
+
+
+def accumulate(acc, x):
+    """acc += x through artn_axpy_c64 (reference simulation.py:114 `collect_tensor += ...`)."""
+    N.require_gpu(acc, "accumulate")
+    N.require_gpu(x, "accumulate")
+    if acc.shape != x.shape or acc.dtype != torch.complex64 or x.dtype != torch.complex64:
+        raise RuntimeError(f"accumulate needs equal-shape complex64 tensors, got {acc.shape} {acc.dtype} / {x.shape} {x.dtype}")
+    if not acc.is_contiguous():
+        raise RuntimeError("accumulator must be contiguous")
+    x = x.contiguous()
+    with torch.cuda.device(acc.device):
+        N.check(N.lib().artn_axpy_c64(acc.data_ptr(), x.data_ptr(), acc.numel(),
+                                      N.current_stream_ptr(acc.device)))
+    return acc
+
+
+def sliced_contraction(tensors, scheme, slicing_indices, out_shape, sparse=False, permute_dims=None,
+                       dtype=torch.complex64, device="cuda", group=None, slices=None, reduce="all",
+                       _execute=None, _accumulate=None):
+    """The slice loop (reference simulation.py:101-116) on one rank of `group`.
+
+    tensors         leaf tensors (dict or list) already on `device` or movable to it
+    slices          explicit slice numbers for this rank (default: round-robin shard)
+    reduce          "all" -> every rank returns the full sum (all_reduce);
+                    "root" -> only rank 0 does (reduce to 0); None -> local partial sum
+    _execute/_accumulate   test seams: the world_size-2 gloo tests of the sharding and
+                    reduction logic run on CPU boxes and inject a CPU executor; the
+                    product path never sets them (defaults are the HIP kernels)
+    """
+    import torch.distributed as dist
+    execute = _execute or (tensor_contraction_sparse if sparse else tensor_contraction)
+    add = _accumulate or accumulate
+    distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
+    rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
+    items = tensors.items() if isinstance(tensors, dict) else enumerate(tensors)
+    dev_tensors = {k: (t.to(dtype).to(device) if isinstance(t, torch.Tensor) else t) for k, t in items}
+    bonds = list(slicing_indices.keys()) if slicing_indices else []
+    n_slices = 2 ** len(bonds)
+    if slices is None:
+        slices = rank_slices(n_slices, rank, world)
+    collect = torch.zeros(tuple(out_shape), dtype=dtype, device=device)
+    for s in slices:
+        cfg = slice_assignments(len(bonds), s)
+        sliced = apply_slice(dev_tensors, slicing_indices, cfg) if bonds else dict(dev_tensors)
+        res = execute(sliced, scheme)
+        add(collect, res.reshape(collect.shape))
+    if distributed and reduce is not None:
+        buf = torch.view_as_real(collect)
+        if reduce == "all":
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
+    if permute_dims is not None and len(permute_dims) > 0:
+        collect = collect.permute(tuple(permute_dims))
+    return collect
+
+
+class TensorNetworkSimulation:
+    """Execution half of the reference class of the same name (simulation.py:33-148).
+
+    Planning (`prepare_contraction`, simulation.py:47-77) stays with the reference's
+    planner; this class is built from its products -- either a planned reference object
+    (`from_planned(sim)`, duck-typed) or a saved case (`from_case(case)`) -- and runs
+    `.contraction(...)` with the reference's signature on the MI355X engine."""
+
+    def __init__(self, tensors, scheme, slicing_indices, output_bonds, pattern="normal",
+                 bitstrings_sorted=None, permute_dims=None):
+        self.tensors = tensors
+        self.scheme = scheme
+        self.slicing_indices = slicing_indices or {}
+        self.output_bonds = list(output_bonds)
+        self.pattern = pattern
+        self.bitstrings_sorted = bitstrings_sorted
+        if permute_dims is not None:
+            self.permute_dims = permute_dims
+        self.tensor_contraction_func = tensor_contraction_sparse if pattern == "sparse" else tensor_contraction
+
+    @classmethod
+    def from_planned(cls, sim):
+        """`sim`: a reference TensorNetworkSimulation after prepare_contraction()."""
+        return cls(sim.tensors, sim.scheme, sim.slicing_indices, sim.output_bonds, sim.pattern,
+                   getattr(sim, "bitstrings_sorted", None), getattr(sim, "permute_dims", None))
+
+    @classmethod
+    def from_case(cls, case):
+        m = case.meta
+        return cls(case.tensors, case.scheme, case.slicing_indices, m.get("output_bonds", []),
+                   m.get("pattern", "normal"), m.get("bitstrings_sorted"), m.get("permute_dims"))
+
+    def contraction(self, tensors=None, dtype=torch.complex64, device="cuda", group=None, reduce="all"):
+        src = self.tensors if tensors is None else tensors
+        if self.pattern == "sparse":
+            shape = [len(self.bitstrings_sorted)] + [2] * len(self.output_bonds)
+        else:
+            shape = [2] * len(self.output_bonds)
+        permute = getattr(self, "permute_dims", None) if len(self.output_bonds) > 0 else None
+        return sliced_contraction(src, self.scheme, self.slicing_indices, shape, sparse=self.pattern == "sparse",
+                                  permute_dims=permute, dtype=dtype, device=device, group=group, reduce=reduce)
