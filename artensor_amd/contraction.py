@@ -50,6 +50,17 @@ def _parse(eq):
 _DTYPES = {torch.complex64: N.ARTN_C64, torch.complex128: N.ARTN_C128}
 _desc_cache = {}
 
+# Optional per-launch timing hook (bench.py / profiling only): an object with
+# .record(info_dict, start_event, end_event); events are recorded on the launch stream.
+profiler = None
+_info_cache = {}
+
+
+def _query(d):
+    info = N.ArtnStepInfo()
+    N.check(N.lib().artn_contract_query(ctypes.byref(d), ctypes.byref(info)))
+    return {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+
 
 def _descriptor(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype):
     key = (la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype)
@@ -116,8 +127,19 @@ def contract(eq, a, b, out=None):
     if out.numel() == 0:
         return out
     with torch.cuda.device(a.device):
-        N.check(N.lib().artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                      N.current_stream_ptr(a.device)))
+        if profiler is None:
+            N.check(N.lib().artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                          N.current_stream_ptr(a.device)))
+        else:
+            info = _info_cache.get(id(d))
+            if info is None:
+                info = _info_cache[id(d)] = _query(d)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            N.check(N.lib().artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                          N.current_stream_ptr(a.device)))
+            e1.record()
+            profiler.record(info, e0, e1)
     return out
 
 
@@ -135,9 +157,7 @@ def step_info(eq, a_shape, b_shape, dtype=torch.complex64, a_stride=None, b_stri
     a_shape, b_shape = tuple(a_shape), tuple(b_shape)
     d, out_shape = _descriptor(la, lb, lo, a_shape, tuple(a_stride or dense(a_shape)), b_shape,
                                tuple(b_stride or dense(b_shape)), dtype)
-    info = N.ArtnStepInfo()
-    N.check(N.lib().artn_contract_query(ctypes.byref(d), ctypes.byref(info)))
-    res = {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+    res = dict(_query(d))
     res["out_shape"] = out_shape
     return res
 

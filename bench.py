@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- contracted TFLOP/s of the hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input: one full
+`tensor_contraction` of the Sycamore n30 m14 full-amplitude scheme (BASELINE.json configs[1]:
+180 pairwise steps, 5.3705e12 real FLOP, all 2^30 complex64 amplitudes, no slicing) with the
+181 leaf tensors already resident in HBM.  Leaf tensors and scheme come from the committed
+fixture tests/golden/n30_dense.npz (circuit gate tensors are tiny and fixed: "synthetic"
+here means no dataset is read; amplitudes are checked against the fixture's statistics).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the unsliced n30 contraction
+does not shard (its 8 GiB dense output would need an 8 GiB all-reduce), so
+every rank contracts its own replica -- weak scaling, no data-path collective; the
+barrier + max-over-ranks timing of the contract stays.  The slice-sharded path with its
+single RCCL reduce is `artensor_amd.sliced_contraction` (tests/test_distributed.py).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (spec)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak (spec)
+
+
+class KernelTimes:
+    """Per-launch HIP-event timing of artn_contract calls inside the timed region."""
+
+    def __init__(self):
+        self.rows = []
+
+    def record(self, info, e0, e1):
+        self.rows.append((info, e0, e1))
+
+    def summarize(self):
+        out = {}
+        for info, e0, e1 in self.rows:
+            d = out.setdefault(info["kernel"], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += info["flops"]
+            d["bytes"] += info["bytes"]
+        return out
+
+
+def cpu_baseline(case, budget_log2=25):
+    """The oracle (numpy port of the reference executor) timed on this box's host cores on a
+    bounded sample: the 28 big steps of the same n30 scheme with the state operand truncated
+    to 2^budget_log2 elements (surrogates keep each step's contracted/free bit pattern)."""
+    from oracle import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import dense_scheme_shapes, shrink_step, crandn
+    steps = dense_scheme_shapes(case)
+    big = [s for s in steps if np.prod(s[1]) >= 2 ** 20]
+    rng = np.random.default_rng(0)
+    work = []
+    flops = 0.0
+    for eq, sa, sb in big:
+        eq2, sa2, sb2 = shrink_step(eq, sa, sb, max_log2=budget_log2)
+        a, b = crandn(rng, sa2), crandn(rng, sb2)
+        lhs, _ = eq2.split("->")
+        la, lb = lhs.split(",")
+        flops += 8.0 * float(2 ** len(set(la) | set(lb)))
+        work.append((eq2, a, b))
+    t0 = time.perf_counter()
+    for eq2, a, b in work:
+        oracle.einsum_pair(eq2, a, b)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count()])
+    except Exception:
+        threads = os.cpu_count()
+    return {
+        "value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
+        "sample": f"28 big steps of the n30 m14 scheme, state operand truncated to 2^{budget_log2} "
+                  f"elements ({flops:.3e} FLOP, {dt:.1f} s, numpy oracle)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail", default=None, help="write a per-launch table of the MFMA kernel to this file")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import artensor_amd as A
+    from artensor_amd import contraction as C
+    from artensor_amd.fixtures import load_case
+
+    case = load_case(os.path.join(ROOT, "tests", "golden", "n30_dense.npz"))
+    leaves = case.fresh_tensors(device=dev)  # resident in HBM before the timed region
+    flops_per_step = 8.0 * 10 ** case.meta["log10_tc"]
+    # final = raw.permute(permute_dims) is a view (reference simulation.py:115-116): map the
+    # positions of Google's 10 000 bitstrings in `final` to positions in the raw result
+    perm = case.meta["permute_dims"]
+    fpos = np.array([int(b, 2) for b in case.meta["google_bitstrings"]], dtype=np.int64)
+    rpos = np.zeros_like(fpos)
+    for d in range(30):
+        rpos |= ((fpos >> (29 - d)) & 1) << (29 - perm[d])
+    pos = torch.from_numpy(rpos).to(dev)
+
+    def one_step():
+        return A.tensor_contraction(dict(leaves), case.scheme)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    # result check outside the timed region (amplitudes at Google's 10 000 bitstrings)
+    at = out.reshape(-1)[pos].cpu().numpy()
+    want = case.arrays["amps_at_google"]
+    rel_err = float((np.abs(at - want) / np.maximum(np.abs(want), 2.0 ** -15)).max())
+    del out
+
+    prof = KernelTimes()
+    C.profiler = prof
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    C.profiler = None
+    del out
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0 and args.detail:
+        per = {}
+        order = []
+        n_per_step = len(prof.rows) // max(args.steps, 1)
+        for n, (info, e0, e1) in enumerate(prof.rows):
+            key = n % n_per_step
+            if key not in per:
+                per[key] = [info, 0.0]
+                order.append(key)
+            per[key][1] += e0.elapsed_time(e1) / args.steps
+        with open(args.detail, "w") as f:
+            f.write("launch kernel k mt nt Tin Tout tiles rereads ms GB/s TFLOP/s\n")
+            for key in order:
+                info, ms = per[key]
+                if info["kernel"] != 1 and ms < 0.05:
+                    continue
+                f.write(f"{key} {info['kernel']} {info['k_bits']} {info['m_tile_bits']} {info['n_tile_bits']} "
+                        f"{info['tile_in_bits']} {info['tile_out_bits']} {info['n_tiles']} {info['a_rereads']} "
+                        f"{ms:.3f} {info['bytes'] / ms / 1e6:.0f} {info['flops'] / ms / 1e9:.1f}\n")
+    if rank == 0:
+        ks = prof.summarize()
+        bits = ks.get(1, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        ms_per_step = dt / args.steps * 1e3
+        value = world * args.steps * flops_per_step / dt / 1e12
+        achieved = bits["flops"] / (bits["ms"] * 1e-3) / 1e12 if bits["ms"] else 0.0
+        hbm_gbs = bits["bytes"] / (bits["ms"] * 1e-3) / 1e9 if bits["ms"] else 0.0
+        line = {
+            "metric": "contracted TFLOP/s, Sycamore n30 m14 full-amplitude (8 real FLOP per complex MAC)",
+            "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "c64 (fp32 MFMA)", "data": "synthetic",
+            "config": {"workload": "Sycamore n30 m14 full-amplitude, complex64, no slicing, 180-step scheme "
+                                   "(tests/golden/n30_dense.npz)",
+                       "flops_per_step": flops_per_step, "parallelism": "replicas" if world > 1 else "single",
+                       "frac_mfma_peak": value / world / MFMA_F32_PEAK_TFLOPS,
+                       "max_rel_err_vs_reference": rel_err},
+            "roofline": {
+                "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "kernel": "artn_k_bits", "launches_per_step": bits["launches"] / max(args.steps, 1),
+                "avg_launch_ms": bits["ms"] / max(bits["launches"], 1),
+                "hbm_achieved_GBs": hbm_gbs, "hbm_frac": hbm_gbs / HBM_PEAK_GBS,
+                "kernel_ms_per_step": bits["ms"] / max(args.steps, 1),
+                "other_kernels_ms_per_step": sum(v["ms"] for k, v in ks.items() if k != 1) / max(args.steps, 1),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(case)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
