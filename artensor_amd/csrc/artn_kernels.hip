@@ -58,35 +58,62 @@ static int fail(int code, const std::string &msg) {
 // Accumulator (guide section 3): lane l holds column j = l&31 and rows
 //   i = (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15  =>  n_local = (r&3)/2 + 2*h + 4*(r>>2),
 //   (acc[4q+2b], acc[4q+2b+1]) = (re, im) of n_local = b + 2h + 4q.
-// One group of U 16-byte chunks per thread: issue all global loads, then (after the barrier
-// that retires the previous tile's LDS reads, first group only) write them to LDS.
-template <int U>
-__device__ __forceinline__ void copy_in_group(const float2 *__restrict__ Ag, float2 *lds,
-                                              const ArtnBitsPlan &P, int tid, int i0, bool first) {
-  f32x4 v[U];
+// Register discipline: everything that is the same for all lanes lives in SGPRs and is
+// recomputed from the kernel argument per tile; per-lane state is a handful of 32-bit
+// offsets.  OPAQUE() stops the compiler from hoisting per-chunk address arithmetic out of
+// the tile loop (that hoisting, not the algorithm, is what used to cost >100 VGPRs).
+#define OPAQUE_V(x) asm volatile("" : "+v"(x))
+
+// Tile index -> element offsets of the tile in A, B, C (all wave-uniform: SALU only).
+__device__ __forceinline__ void tile_offsets(const ArtnBitsPlan &P, long tile, long &offA, long &offB, long &offC) {
+  long r = tile;
+  offA = offB = offC = 0;
+  for (int d = 0; d < P.n_outer; ++d) {
+    const long ext = P.outer[d].ext;
+    long x;
+    if (P.outer[d].log2ext >= 0) {
+      x = r & (ext - 1);
+      r >>= P.outer[d].log2ext;
+    } else {
+      x = r % ext;
+      r /= ext;
+    }
+    offA += x * P.outer[d].sA;
+    offB += x * P.outer[d].sB;
+    offC += x * P.outer[d].sC;
+  }
+}
+
+// Copy-in, split in two so the loads of tile t+1 can be in flight while tile t is computed:
+// issue_loads puts 8 x 16 B per thread in flight (uniform 64-bit base in SGPRs + one 32-bit
+// per-lane byte offset); store_lds writes them to LDS linearly.  With fewer than 8 chunks
+// per thread (small tiles) the surplus slots re-load an earlier chunk and are not stored.
+__device__ __forceinline__ void issue_loads(f32x4 (&v)[8], const char *__restrict__ Abase, const ArtnBitsPlan &P,
+                                            unsigned lane_off, int i0, int n_iters) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int i = i0 + u;
+  for (int u = 0; u < 8; ++u) {
+    const int i = (i0 + u) & (n_iters - 1);
     long off = 0;
 #pragma unroll
     for (int b = 9; b < ARTN_TILE_BITS_MAX; ++b)
       if (b < P.T_in && ((i >> (b - 9)) & 1)) off += P.in_stride[b];
-    v[u] = *reinterpret_cast<const f32x4 *>(Ag + off);
+    v[u] = *reinterpret_cast<const f32x4 *>(Abase + off * 8 + lane_off);
   }
-  if (first) __syncthreads();
+}
+__device__ __forceinline__ void store_lds(const f32x4 (&v)[8], char *ldsb, unsigned tid16, int i0, int n_iters) {
 #pragma unroll
-  for (int u = 0; u < U; ++u)
-    *reinterpret_cast<f32x4 *>(lds + 2 * (tid + ARTN_WG_THREADS * (i0 + u))) = v[u];
+  for (int u = 0; u < 8; ++u)
+    if (i0 + u < n_iters) *reinterpret_cast<f32x4 *>(ldsb + tid16 + (i0 + u) * (ARTN_WG_THREADS * 16)) = v[u];
 }
 
 template <int KB, int PM>
-__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_bits(const float2 *__restrict__ A,
+__global__ __launch_bounds__(ARTN_WG_THREADS, (KB <= 5 ? 4 : 3)) void artn_k_bits(const float2 *__restrict__ A,
                                                                const float2 *__restrict__ B,
                                                                float2 *__restrict__ C,
                                                                const ArtnBitsPlan P) {
   constexpr int S = 1 << (KB - 1); // complex K pairs
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2 *lds = reinterpret_cast<float2 *>(smem);
+  char *ldsb = reinterpret_cast<char *>(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,100 +123,68 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_bits(const float2 *__r
   const int wm = wave >> P.wn_log2;
   const int nt_eff = P.nt < 4 ? P.nt : 4;
 
-  // ---- copy phases: thread handles 16-byte chunks c = tid + 256*i (tile-local elements 2c, 2c+1)
-  long in_lane = 0, out_lane = 0;
+  // ---- copy phases: thread handles 16-byte chunks c = tid + 256*i (tile-local elements 2c, 2c+1);
+  //      per-lane byte offsets fit 32 bits (checked by the planner)
+  unsigned in_lane = 0, out_lane = 0;
 #pragma unroll
   for (int b = 1; b <= 8; ++b) {
     if ((tid >> (b - 1)) & 1) {
-      in_lane += P.in_stride[b];
-      out_lane += P.out_stride[b];
+      in_lane += (unsigned)P.in_stride[b] * 8u;
+      out_lane += (unsigned)P.out_stride[b] * 8u;
     }
   }
+  const unsigned tid16 = tid * 16;
   const int n_in_iters = 1 << (P.T_in - 9), n_out_iters = 1 << (P.T_out - 9);
 
-  // ---- MFMA phase: per-lane tile-local offsets (elements)
-  int lane_in = h << P.k_in_pos[0], lane_out = 0;
+  // ---- MFMA phase: per-lane tile-local byte offsets
+  unsigned lane_in = (unsigned)h << (P.k_in_pos[0] + 3), lane_out = 0;
 #pragma unroll
   for (int b = 0; b < 5; ++b) {
     if ((j >> b) & 1) {
-      lane_in += 1 << P.lane_in_pos[b];
-      lane_out += 1 << P.lane_out_pos[b];
+      lane_in += 8u << P.lane_in_pos[b];
+      lane_out += 8u << P.lane_out_pos[b];
     }
   }
-  if (P.nt > 1) lane_out += h << P.n_out_pos[1];
-  int wn_out = 0;
-  long wn_b = 0;
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    if (b < P.wn_log2 && ((wn >> b) & 1)) {
-      wn_out += 1 << P.n_out_pos[4 + b];
-      wn_b += P.n_b_stride[4 + b];
-    }
-  }
-  lane_out += wn_out;
-  const int o0 = P.nt > 0 ? 1 << P.n_out_pos[0] : 0;
-  const int o2 = P.nt > 2 ? 1 << P.n_out_pos[2] : 0;
-  const int o3 = P.nt > 3 ? 1 << P.n_out_pos[3] : 0;
-  int msub_in[PM], msub_out[PM];
-#pragma unroll
-  for (int pm = 0; pm < PM; ++pm) {
-    const int msub = wm * PM + pm;
-    int oi = 0, oo = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if (b < P.mt - 5 && ((msub >> b) & 1)) {
-        oi += 1 << P.msub_in_pos[b];
-        oo += 1 << P.msub_out_pos[b];
-      }
-    }
-    msub_in[pm] = oi;
-    msub_out[pm] = oo;
-  }
-  int kin[KB > 1 ? KB : 2];
-  long kb[KB > 1 ? KB : 2];
-#pragma unroll
-  for (int b = 1; b < KB; ++b) {
-    kin[b] = 1 << P.k_in_pos[b];
-    kb[b] = P.k_b_stride[b];
-  }
+  if (P.nt > 1) lane_out += (unsigned)h << (P.n_out_pos[1] + 3);
 
   // ---- small-operand fragments: lane (i = lane&31, h) needs W[n'=i][(kc = 2s+h, p)]
   const int ro = j & 1, nloc = j >> 1;
   const bool w_valid = (nloc >> nt_eff) == 0;
-  long lane_b = (long)h * P.k_b_stride[0] + wn_b;
+  unsigned lane_b = (unsigned)h * (unsigned)P.k_b_stride[0] * 8u;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
-    if (b < nt_eff && ((nloc >> b) & 1)) lane_b += P.n_b_stride[b];
+    if (b < nt_eff && ((nloc >> b) & 1)) lane_b += (unsigned)P.n_b_stride[b] * 8u;
   float W0[S], W1[S];
   long prev_offB = -1;
 
+  // software pipeline: the loads of the next tile are issued before this tile's MFMA phase
+  f32x4 v[8];
+  const bool prefetch = n_in_iters <= 8;
+  if (prefetch && (long)blockIdx.x < P.n_tiles) {
+    long oa, ob, oc;
+    tile_offsets(P, blockIdx.x, oa, ob, oc);
+    issue_loads(v, reinterpret_cast<const char *>(A + oa), P, in_lane, 0, n_in_iters);
+  }
+
   for (long tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
-    long r = tile, offA = 0, offB = 0, offC = 0;
-    for (int d = 0; d < P.n_outer; ++d) {
-      const long ext = P.outer[d].ext;
-      long x;
-      if (P.outer[d].log2ext >= 0) {
-        x = r & (ext - 1);
-        r >>= P.outer[d].log2ext;
-      } else {
-        x = r % ext;
-        r /= ext;
-      }
-      offA += x * P.outer[d].sA;
-      offB += x * P.outer[d].sB;
-      offC += x * P.outer[d].sC;
-    }
+    long offA, offB, offC;
+    tile_offsets(P, tile, offA, offB, offC);
 
     if (offB != prev_offB) {
       prev_offB = offB;
+      long wn_b = 0;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if (b < P.wn_log2 && ((wn >> b) & 1)) wn_b += P.n_b_stride[4 + b];
+      const char *Bbase = reinterpret_cast<const char *>(B + offB + wn_b);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         long ko = 0;
 #pragma unroll
         for (int b = 1; b < KB; ++b)
-          if ((s >> (b - 1)) & 1) ko += kb[b];
+          if ((s >> (b - 1)) & 1) ko += P.k_b_stride[b];
         float2 bv = make_float2(0.f, 0.f);
-        if (w_valid) bv = B[offB + lane_b + ko];
+        if (w_valid) bv = *reinterpret_cast<const float2 *>(Bbase + ko * 8 + lane_b);
         W0[s] = ro ? bv.y : bv.x;
         W1[s] = ro ? bv.x : -bv.y;
       }
@@ -197,49 +192,90 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_bits(const float2 *__r
 
     // ---- copy-in: global (16 B per lane, runs of 2^run_in elements) -> LDS (linear)
     {
-      const float2 *Ag = A + offA + in_lane;
-      switch (n_in_iters) {
-        case 1: copy_in_group<1>(Ag, lds, P, tid, 0, true); break;
-        case 2: copy_in_group<2>(Ag, lds, P, tid, 0, true); break;
-        case 4: copy_in_group<4>(Ag, lds, P, tid, 0, true); break;
-        default:
-          for (int i0 = 0; i0 < n_in_iters; i0 += 8) copy_in_group<8>(Ag, lds, P, tid, i0, i0 == 0);
+      unsigned lo = in_lane, t16 = tid16;
+      OPAQUE_V(lo);
+      OPAQUE_V(t16);
+      if (prefetch) {
+        __syncthreads(); // previous tile's copy-out has finished reading LDS
+        store_lds(v, ldsb, t16, 0, n_in_iters);
+        __syncthreads();
+        const long next = tile + gridDim.x;
+        if (next < P.n_tiles) {
+          long oa, ob, oc;
+          tile_offsets(P, next, oa, ob, oc);
+          issue_loads(v, reinterpret_cast<const char *>(A + oa), P, lo, 0, n_in_iters);
+        }
+      } else {
+        const char *Abase = reinterpret_cast<const char *>(A + offA);
+        for (int i0 = 0; i0 < n_in_iters; i0 += 8) {
+          issue_loads(v, Abase, P, lo, i0, n_in_iters);
+          if (i0 == 0) __syncthreads();
+          store_lds(v, ldsb, t16, i0, n_in_iters);
+        }
+        __syncthreads();
       }
     }
-    __syncthreads();
 
     // ---- MFMA
     f32x16 acc[PM];
-#pragma unroll
-    for (int pm = 0; pm < PM; ++pm)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[pm][e] = 0.f;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      int ko = 0;
-#pragma unroll
-      for (int b = 1; b < KB; ++b)
-        if ((s >> (b - 1)) & 1) ko += kin[b];
+    unsigned msub_out[PM];
+    {
+      unsigned li = lane_in;
+      OPAQUE_V(li);
+      unsigned msub_in[PM];
 #pragma unroll
       for (int pm = 0; pm < PM; ++pm) {
-        const float2 a = lds[lane_in + msub_in[pm] + ko];
-        acc[pm] = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[s], a.x, acc[pm], 0, 0, 0);
-        acc[pm] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[s], a.y, acc[pm], 0, 0, 0);
+        const int msub = wm * PM + pm;
+        unsigned oi = 0, oo = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (b < P.mt - 5 && ((msub >> b) & 1)) {
+            oi += 8u << P.msub_in_pos[b];
+            oo += 8u << P.msub_out_pos[b];
+          }
+        }
+        msub_in[pm] = oi;
+        msub_out[pm] = oo;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pm][e] = 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        unsigned ko = 0;
+#pragma unroll
+        for (int b = 1; b < KB; ++b)
+          if ((s >> (b - 1)) & 1) ko += 8u << P.k_in_pos[b];
+#pragma unroll
+        for (int pm = 0; pm < PM; ++pm) {
+          const float2 a = *reinterpret_cast<const float2 *>(ldsb + li + msub_in[pm] + ko);
+          acc[pm] = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[s], a.x, acc[pm], 0, 0, 0);
+          acc[pm] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[s], a.y, acc[pm], 0, 0, 0);
+        }
       }
     }
     __syncthreads(); // every wave is done reading the input tile
 
     // ---- accumulators -> LDS in output-tile order (in place over the input tile)
+    {
+      unsigned lo = lane_out;
+      OPAQUE_V(lo);
 #pragma unroll
-    for (int pm = 0; pm < PM; ++pm) {
+      for (int b = 0; b < 2; ++b)
+        if (b < P.wn_log2 && ((wn >> b) & 1)) lo += 8u << P.n_out_pos[4 + b];
+      const unsigned o0 = P.nt > 0 ? 8u << P.n_out_pos[0] : 0;
+      const unsigned o2 = P.nt > 2 ? 8u << P.n_out_pos[2] : 0;
+      const unsigned o3 = P.nt > 3 ? 8u << P.n_out_pos[3] : 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int pm = 0; pm < PM; ++pm) {
 #pragma unroll
-        for (int b0 = 0; b0 < 2; ++b0) {
-          const int nl = b0 + 2 * h + 4 * (q & 1) + 8 * (q >> 1);
-          if ((nl >> nt_eff) == 0) {
-            const int o = lane_out + msub_out[pm] + b0 * o0 + (q & 1) * o2 + (q >> 1) * o3;
-            lds[o] = make_float2(acc[pm][4 * q + 2 * b0], acc[pm][4 * q + 2 * b0 + 1]);
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int b0 = 0; b0 < 2; ++b0) {
+            const int nl = b0 + 2 * h + 4 * (q & 1) + 8 * (q >> 1);
+            if ((nl >> nt_eff) == 0) {
+              const unsigned o = lo + msub_out[pm] + b0 * o0 + (q & 1) * o2 + (q >> 1) * o3;
+              *reinterpret_cast<float2 *>(ldsb + o) = make_float2(acc[pm][4 * q + 2 * b0], acc[pm][4 * q + 2 * b0 + 1]);
+            }
           }
         }
       }
@@ -247,14 +283,19 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_bits(const float2 *__r
     __syncthreads();
 
     // ---- copy-out: LDS (linear) -> global (16 B per lane, runs of 2^run_out elements)
-    float2 *Cg = C + offC + out_lane;
-    for (int i = 0; i < n_out_iters; ++i) {
-      long off = 0;
+    {
+      char *Cbase = reinterpret_cast<char *>(C + offC);
+      unsigned lo = out_lane, t16 = tid16;
+      OPAQUE_V(lo);
+      OPAQUE_V(t16);
+      for (int i = 0; i < n_out_iters; ++i) {
+        long off = 0;
 #pragma unroll
-      for (int b = 9; b < ARTN_TILE_BITS_MAX; ++b)
-        if (b < P.T_out && ((i >> (b - 9)) & 1)) off += P.out_stride[b];
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(lds + 2 * (tid + ARTN_WG_THREADS * i));
-      *reinterpret_cast<f32x4 *>(Cg + off) = v;
+        for (int b = 9; b < ARTN_TILE_BITS_MAX; ++b)
+          if (b < P.T_out && ((i >> (b - 9)) & 1)) off += P.out_stride[b];
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ldsb + t16 + i * (ARTN_WG_THREADS * 16));
+        *reinterpret_cast<f32x4 *>(Cbase + off * 8 + lo) = v;
+      }
     }
   }
 }

@@ -19,6 +19,7 @@
 #define ARTN_PLAN_H
 
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -81,6 +82,24 @@ struct ArtnPlan {
 };
 
 namespace artn {
+
+// Development knobs (environment: ARTN_WG_PER_CU, ARTN_TILE_TARGET, ARTN_RUN_MAX); the
+// defaults are what ships.
+struct Tuning {
+  int wg_per_cu = 4;    // persistent workgroups per CU (grid = CUs * this)
+  int tile_target = ARTN_TILE_BITS_TARGET;
+  int run_max = 4;      // longest contiguous run (log2 elements) the tile is forced to keep
+};
+static inline Tuning &tuning() {
+  static Tuning t = [] {
+    Tuning x;
+    if (const char *e = getenv("ARTN_WG_PER_CU")) x.wg_per_cu = std::max(1, atoi(e));
+    if (const char *e = getenv("ARTN_TILE_TARGET")) x.tile_target = std::min(ARTN_TILE_BITS_MAX, std::max(9, atoi(e)));
+    if (const char *e = getenv("ARTN_RUN_MAX")) x.run_max = std::min(6, std::max(1, atoi(e)));
+    return x;
+  }();
+  return t;
+}
 
 struct Axis {
   int64_t ext, sA, sB, sC; // stride -1 = absent
@@ -217,7 +236,7 @@ static inline bool make_bits(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   // contiguous run at the bottom of A (over K u M bits) and of C (over M u N bits)
   auto run_len = [&](bool in_side) {
     int r = 0;
-    for (; r < 4; ++r) {
+    for (; r < tuning().run_max; ++r) {
       bool found = false;
       for (int i = 0; i < (int)ax.size() && !found; ++i) {
         const Axis &a = ax[i];
@@ -261,7 +280,7 @@ static inline bool make_bits(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
     else { p.why_generic = "forced tile bits exceed the LDS tile"; return false; }
   }
   if (mt_min > mt_max) { p.why_generic = "tile envelope empty"; return false; }
-  int mt_target = std::min(mt_max, std::max(mt_min, ARTN_TILE_BITS_TARGET - k));
+  int mt_target = std::min(mt_max, std::max(mt_min, tuning().tile_target - k));
   for (int i : M) {
     if ((int)Mt.size() >= mt_target) break;
     if (std::find(Mt.begin(), Mt.end(), i) == Mt.end()) Mt.push_back(i);
@@ -343,6 +362,16 @@ static inline bool make_bits(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   for (int i = 1; i < b.T_out; ++i) if (b.out_stride[i] & 1) { p.why_generic = "odd C stride"; return false; }
   for (int i = 0; i < b.n_outer; ++i)
     if ((b.outer[i].sA & 1) || (b.outer[i].sC & 1)) { p.why_generic = "odd outer stride"; return false; }
+  {
+    // per-lane byte offsets inside the kernel are 32-bit: copy chunks span tile bits 1..8,
+    // the small operand is addressed by its N_t / K bits
+    int64_t si = 0, so = 0, sb = 0;
+    for (int i = 1; i <= 8; ++i) { si += b.in_stride[i]; so += b.out_stride[i]; }
+    for (int i = 0; i < nt; ++i) sb += b.n_b_stride[i];
+    for (int i = 0; i < k; ++i) sb += b.k_b_stride[i];
+    const int64_t lim = (int64_t(1) << 28) - 1; // elements: * 8 B < 2^31
+    if (si > lim || so > lim || sb > lim) { p.why_generic = "lane offsets exceed 32 bits"; return false; }
+  }
   if (b.n_tiles < min_tiles) { p.why_generic = "too few tiles to fill the chip"; return false; }
 
   p.kernel = ARTN_KERNEL_BITS_MFMA;
@@ -354,7 +383,7 @@ static inline bool make_bits(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   f.lds_bytes = 8 << std::max(b.T_in, b.T_out);
   f.n_tiles = b.n_tiles;
   f.a_rereads = a_rereads;
-  int wg_per_cu = std::max(1, std::min(4, (160 * 1024) / f.lds_bytes));
+  int wg_per_cu = std::max(1, std::min(tuning().wg_per_cu, (160 * 1024) / f.lds_bytes));
   f.grid = (int32_t)std::min<int64_t>(b.n_tiles, (int64_t)n_cu * wg_per_cu);
   (void)m;
   return true;
