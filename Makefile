@@ -9,6 +9,10 @@ all: $(LIB)
 $(LIB): $(CSRC)/artn_kernels.hip $(CSRC)/artn_plan.h include/artn.h
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Iinclude -I$(CSRC) $< -o $@
 
+# diagnostic build with in-kernel phase stamps (never loaded by the product; tools/stamps.py)
+stamps: $(CSRC)/artn_kernels.hip $(CSRC)/artn_plan.h include/artn.h
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_STAMPS -Iinclude -I$(CSRC) $< -o tools/libartn_hip_stamps.so
+
 clean:
 	rm -f $(LIB)
 .PHONY: all clean

@@ -16,7 +16,7 @@ ARTN_C64, ARTN_C128 = 0, 1
 KERNEL_GENERIC, KERNEL_BITS_MFMA = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libartn_hip.so")
+LIB_PATH = os.environ.get("ARTN_LIB") or os.path.join(_HERE, "libartn_hip.so")  # ARTN_LIB: diagnostic builds
 
 
 class ArtnStepDesc(ctypes.Structure):
@@ -46,6 +46,10 @@ class ArtnStepInfo(ctypes.Structure):
         ("a_rereads", ctypes.c_int64),
         ("flops", ctypes.c_double),
         ("bytes", ctypes.c_double),
+        ("k2_bits", ctypes.c_int32),
+        ("n2_tile_bits", ctypes.c_int32),
+        ("tile_mid_bits", ctypes.c_int32),
+        ("reserved_", ctypes.c_int32),
     ]
 
 
@@ -59,6 +63,10 @@ _EXPORTS = {
     "artn_contract_query": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepInfo)]),
     "artn_contract": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p]),
+    "artn_contract2_query": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepDesc),
+                                            ctypes.POINTER(ArtnStepInfo)]),
+    "artn_contract2": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_axpy_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),

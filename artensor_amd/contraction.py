@@ -143,6 +143,85 @@ def contract(eq, a, b, out=None):
     return out
 
 
+def _dense_strides(shape):
+    st, s = [], 1
+    for n in reversed(shape):
+        st.append(s)
+        s *= n
+    return tuple(reversed(st))
+
+
+_pair_cache = {}
+
+
+def _pair_descriptors(eq1, a, b1, eq2, b2):
+    la1, lb1, lo1 = _parse(eq1) if isinstance(eq1, str) else tuple(map(tuple, eq1))
+    la2, lb2, lo2 = _parse(eq2) if isinstance(eq2, str) else tuple(map(tuple, eq2))
+    d1, mid_shape = _descriptor(la1, lb1, lo1, tuple(a.shape), tuple(a.stride()), tuple(b1.shape),
+                                tuple(b1.stride()), a.dtype)
+    if len(la2) != len(mid_shape):
+        raise RuntimeError("second equation's first operand does not match the first result")
+    d2, out_shape = _descriptor(la2, lb2, lo2, mid_shape, _dense_strides(mid_shape), tuple(b2.shape),
+                                tuple(b2.stride()), a.dtype)
+    return d1, d2, out_shape
+
+
+def pair_info(eq1, a_shape, b1_shape, eq2, b2_shape, dtype=torch.complex64):
+    """Planner decision for fusing two consecutive steps (host only); None if not fusable."""
+    class _S:  # shape/stride carrier
+        def __init__(self, shape):
+            self.shape, self._st, self.dtype = tuple(shape), _dense_strides(tuple(shape)), dtype
+
+        def stride(self):
+            return self._st
+    d1, d2, out_shape = _pair_descriptors(eq1, _S(a_shape), _S(b1_shape), eq2, _S(b2_shape))
+    info = N.ArtnStepInfo()
+    rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(info))
+    if rc == -2:
+        return None
+    N.check(rc)
+    res = {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+    res["out_shape"] = out_shape
+    return res
+
+
+def contract2(eq1, a, b1, eq2, b2):
+    """einsum(eq2, einsum(eq1, a, b1), b2) in ONE pass over HBM through artn_contract2: the
+    intermediate never leaves LDS.  Returns None when the planner declines to fuse the
+    pair (the caller then runs the two steps one after the other)."""
+    for t in (a, b1, b2):
+        N.require_gpu(t, "contract2")
+    if not (a.dtype == b1.dtype == b2.dtype == torch.complex64) or not a.is_contiguous():
+        return None
+    b1, b2 = _as_operand(b1), _as_operand(b2)
+    d1, d2, out_shape = _pair_descriptors(eq1, a, b1, eq2, b2)
+    key = (id(d1), id(d2))
+    info = _pair_cache.get(key)
+    if info is None:
+        q = N.ArtnStepInfo()
+        rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
+        if rc == -2:
+            info = False
+        else:
+            N.check(rc)
+            info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
+        _pair_cache[key] = info
+    if info is False:
+        return None
+    out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        e0 = e1 = None
+        if profiler is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        N.check(N.lib().artn_contract2(ctypes.byref(d1), ctypes.byref(d2), a.data_ptr(), b1.data_ptr(),
+                                       b2.data_ptr(), out.data_ptr(), N.current_stream_ptr(a.device)))
+        if profiler is not None:
+            e1.record()
+            profiler.record(info, e0, e1)
+    return out
+
+
 def step_info(eq, a_shape, b_shape, dtype=torch.complex64, a_stride=None, b_stride=None):
     """Planner decision for one step (host only, works without a GPU)."""
     la, lb, lo = _parse(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
@@ -165,20 +244,96 @@ def step_info(eq, a_shape, b_shape, dtype=torch.complex64, a_stride=None, b_stri
 # ----------------------------------------------------------------------------------------
 # dense executor
 # ----------------------------------------------------------------------------------------
+FUSE_MIN_NUMEL = 1 << 22  # pairs are fused only when the shared operand is at least this big
+
+
+def fusion_schedule(scheme):
+    """Execution order with candidate fused pairs.
+
+    The big "state" tensor is operand 0 of every step that touches it (rep tensor of the
+    larger child, reference contraction.py:41-46).  Two steps s < s' with the same first
+    operand i, such that no step in between reads or writes tensor i, can run as one pass:
+    the steps in between only build the small operand of s' from other tensors and are
+    moved in front of s (they do not depend on it).  Returns a list of
+    ("one", n) / ("pair", n, n') entries covering every step exactly once."""
+    order, done = [], set()
+    n_steps = len(scheme)
+    for n in range(n_steps):
+        if n in done:
+            continue
+        i, j = scheme[n][0]
+        partner = None
+        for m in range(n + 1, n_steps):
+            if m in done:
+                continue
+            i2, j2 = scheme[m][0]
+            if i2 == i:
+                partner = m
+                break
+            if j2 == i or i2 == j or j2 == j:
+                break
+        if partner is not None:
+            for m in range(n + 1, partner):
+                if m not in done:
+                    order.append(("one", m))
+                    done.add(m)
+            order.append(("pair", n, partner))
+            done.update((n, partner))
+        else:
+            order.append(("one", n))
+            done.add(n)
+    return order
+
+
+_schedule_cache = {}
+
+
 def tensor_contraction(tensors, scheme):
     """Run a dense scheme: for each ((i, j), eq): tensors[i] <- contract(eq, tensors[i],
     tensors[j]); returns the last tensors[i] (reference contraction.py:62-76; `tensors` is
-    mutated the same way)."""
-    i = None
-    for n, step in enumerate(scheme):
-        i, j = step[0]
-        try:
-            tensors[i] = contract(step[1], tensors[i], tensors[j])
-        except Exception as e:
-            raise RuntimeError(f"tensor_contraction failed at step {n} {step[0]} {step[1]!r}: {e}") from e
-    if i is None:
+    mutated the same way).
+
+    Behind the unchanged entry point, two consecutive steps on the same big tensor are
+    executed as ONE pass over HBM when their contracted bits fit one LDS tile
+    (artn_contract2); results are those of the step-by-step order."""
+    if len(scheme) == 0:
         raise RuntimeError("empty contraction scheme")
-    return tensors[i]
+    key = id(scheme)
+    hit = _schedule_cache.get(key)
+    if hit is None or hit[0] is not scheme:
+        hit = _schedule_cache[key] = (scheme, fusion_schedule(scheme))
+        if len(_schedule_cache) > 64:
+            _schedule_cache.clear()
+            _schedule_cache[key] = hit
+    last = scheme[-1][0][0]
+
+    def one(n):
+        (i, j), eq = scheme[n][0], scheme[n][1]
+        try:
+            tensors[i] = contract(eq, tensors[i], tensors[j])
+        except Exception as e:
+            raise RuntimeError(f"tensor_contraction failed at step {n} {scheme[n][0]} {eq!r}: {e}") from e
+
+    for entry in hit[1]:
+        if entry[0] == "one":
+            one(entry[1])
+            continue
+        n, m = entry[1], entry[2]
+        (i, j), eq1 = scheme[n][0], scheme[n][1]
+        (_, j2), eq2 = scheme[m][0], scheme[m][1]
+        fused = None
+        a = tensors[i]
+        if isinstance(a, torch.Tensor) and a.is_cuda and a.numel() >= FUSE_MIN_NUMEL:
+            try:
+                fused = contract2(eq1, a, tensors[j], eq2, tensors[j2])
+            except Exception as e:
+                raise RuntimeError(f"tensor_contraction failed at fused steps {n}+{m}: {e}") from e
+        if fused is None:
+            one(n)
+            one(m)
+        else:
+            tensors[i] = fused
+    return tensors[last]
 
 
 # ----------------------------------------------------------------------------------------

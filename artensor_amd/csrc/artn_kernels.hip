@@ -47,57 +47,123 @@ static int fail(int code, const std::string &msg) {
   } while (0)
 
 // ----------------------------------------------------------------------------------------
-// bit-permuted complex GEMM
+// bit-permuted complex GEMM, one or two stages per pass
 // ----------------------------------------------------------------------------------------
 // Lane roles inside one v_mfma_f32_32x32x2_f32 (D[i][j] += sum_kk Aop[i][kk] * Bop[kk][j]):
 //   i = real output column n' = 2*n_local + (0: re, 1: im)   -> Aop lane l: [i = l&31][kk = l>>5]
-//   j = tile column m (32 elements of the A tile)              -> Bop lane l: [kk = l>>5][j = l&31]
-//   kk = h = l>>5 selects complex K index kc = 2*s + h; the re and im parts of that A
+//   j = tile column m (32 elements of the input tile)          -> Bop lane l: [kk = l>>5][j = l&31]
+//   kk = h = l>>5 selects complex K index kc = 2*s + h; the re and im parts of that input
 //   element are fed by two consecutive MFMAs (phase p = 0, 1), so one 8-byte LDS read
 //   serves two MFMAs.
 // Accumulator (guide section 3): lane l holds column j = l&31 and rows
 //   i = (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15  =>  n_local = (r&3)/2 + 2*h + 4*(r>>2),
 //   (acc[4q+2b], acc[4q+2b+1]) = (re, im) of n_local = b + 2h + 4q.
+//
+// LDS holds two regions.  Copy-in fills R0; stage 1 reads R0 and scatters its result tile
+// into R1; a fused second stage reads R1 and scatters into R0; copy-out streams the last
+// region written.  Stages never write the region they read, so a wave needs no barrier
+// between its MFMA chain and its scatter, and sub-tiles are a run-time loop (one 16-register
+// accumulator whatever the tile size).
+//
 // Register discipline: everything that is the same for all lanes lives in SGPRs and is
 // recomputed from the kernel argument per tile; per-lane state is a handful of 32-bit
-// offsets.  OPAQUE() stops the compiler from hoisting per-chunk address arithmetic out of
-// the tile loop (that hoisting, not the algorithm, is what used to cost >100 VGPRs).
+// offsets.  OPAQUE_V() stops the compiler from hoisting per-chunk address arithmetic out
+// of the tile loop (that hoisting, not the algorithm, used to cost >100 VGPRs).
 #define OPAQUE_V(x) asm volatile("" : "+v"(x))
 
-// Tile index -> element offsets of the tile in A, B, C (all wave-uniform: SALU only).
-__device__ __forceinline__ void tile_offsets(const ArtnBitsPlan &P, long tile, long &offA, long &offB, long &offC) {
-  long r = tile;
-  offA = offB = offC = 0;
+// Diagnostic build only (make stamps): per-phase cycle sums of every wave, never in the product.
+#ifdef ARTN_STAMPS
+#define ARTN_N_STAMPS 8
+__device__ unsigned long long artn_stamp_buf[4096 * ARTN_N_STAMPS];
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[ARTN_N_STAMPS] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i)                                                   \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                            \
+    st_acc[i] += now_ - st_prev;                                   \
+    st_prev = now_;                                                \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+#define STAMP_FLUSH                                                                   \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 4096)          \
+    for (int q_ = 0; q_ < ARTN_N_STAMPS; ++q_)                                        \
+      artn_stamp_buf[(blockIdx.x * 4 + (threadIdx.x >> 6)) * ARTN_N_STAMPS + q_] = st_acc[q_];
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+// Tile index -> element offsets of the tile in A, B1, B2, C.
+// Reading the plan's outer-axis table with scalar loads inside the tile loop costs thousands
+// of cycles per tile (dependent s_load latency), so lane d of every wave keeps outer axis d
+// in registers for the whole kernel; per tile each lane extracts its own digit of the tile
+// index and a 6-step wave reduction sums the four offset contributions.
+struct TileOff {
+  long a, b1, b2, c;
+};
+struct OuterLane {
+  long div;      // product of the extents of the faster outer axes
+  long ext;      // 0 for lanes beyond n_outer
+  int shift, lg; // power-of-two prefix axes: digit = (tile >> shift) & (ext - 1)
+  long sA, sB1, sB2, sC;
+};
+__device__ __forceinline__ OuterLane outer_lane(const ArtnBitsPlan &P, int lane) {
+  OuterLane o = {1, 0, 0, -1, 0, 0, 0, 0};
+  long div = 1;
+  int shift = 0;
+  bool pow2_prefix = true;
   for (int d = 0; d < P.n_outer; ++d) {
-    const long ext = P.outer[d].ext;
-    long x;
-    if (P.outer[d].log2ext >= 0) {
-      x = r & (ext - 1);
-      r >>= P.outer[d].log2ext;
-    } else {
-      x = r % ext;
-      r /= ext;
+    if (P.outer[d].log2ext < 0) pow2_prefix = false;
+    if (d == lane) {
+      o.div = div;
+      o.ext = P.outer[d].ext;
+      o.lg = pow2_prefix ? P.outer[d].log2ext : -1;
+      o.shift = shift;
+      o.sA = P.outer[d].sA;
+      o.sB1 = P.outer[d].sB1;
+      o.sB2 = P.outer[d].sB2;
+      o.sC = P.outer[d].sC;
     }
-    offA += x * P.outer[d].sA;
-    offB += x * P.outer[d].sB;
-    offC += x * P.outer[d].sC;
+    div *= P.outer[d].ext;
+    if (P.outer[d].log2ext >= 0) shift += P.outer[d].log2ext;
   }
+  return o;
+}
+__device__ __forceinline__ long wave_sum_uniform(long x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)x);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x >> 32));
+  return (long)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ TileOff tile_offsets(const OuterLane &o, long tile) {
+  long x = 0;
+  if (o.ext > 0) x = o.lg >= 0 ? ((tile >> o.shift) & (o.ext - 1)) : ((tile / o.div) % o.ext);
+  TileOff t;
+  t.a = wave_sum_uniform(x * o.sA);
+  t.b1 = wave_sum_uniform(x * o.sB1);
+  t.b2 = wave_sum_uniform(x * o.sB2);
+  t.c = wave_sum_uniform(x * o.sC);
+  return t;
 }
 
-// Copy-in, split in two so the loads of tile t+1 can be in flight while tile t is computed:
+// Copy-in, split in two so the loads of tile t+1 are in flight while tile t is computed:
 // issue_loads puts 8 x 16 B per thread in flight (uniform 64-bit base in SGPRs + one 32-bit
 // per-lane byte offset); store_lds writes them to LDS linearly.  With fewer than 8 chunks
 // per thread (small tiles) the surplus slots re-load an earlier chunk and are not stored.
-__device__ __forceinline__ void issue_loads(f32x4 (&v)[8], const char *__restrict__ Abase, const ArtnBitsPlan &P,
+// hi[b] = byte stride of tile-local bit 9+b (0 beyond the tile).
+__device__ __forceinline__ void issue_loads(f32x4 (&v)[8], const char *__restrict__ Abase, const long (&hi)[4],
                                             unsigned lane_off, int i0, int n_iters) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int i = (i0 + u) & (n_iters - 1);
     long off = 0;
 #pragma unroll
-    for (int b = 9; b < ARTN_TILE_BITS_MAX; ++b)
-      if (b < P.T_in && ((i >> (b - 9)) & 1)) off += P.in_stride[b];
-    v[u] = *reinterpret_cast<const f32x4 *>(Abase + off * 8 + lane_off);
+    for (int b = 0; b < 4; ++b)
+      if ((i >> b) & 1) off += hi[b];
+    v[u] = *reinterpret_cast<const f32x4 *>(Abase + off + lane_off);
   }
 }
 __device__ __forceinline__ void store_lds(const f32x4 (&v)[8], char *ldsb, unsigned tid16, int i0, int n_iters) {
@@ -106,22 +172,152 @@ __device__ __forceinline__ void store_lds(const f32x4 (&v)[8], char *ldsb, unsig
     if (i0 + u < n_iters) *reinterpret_cast<f32x4 *>(ldsb + tid16 + (i0 + u) * (ARTN_WG_THREADS * 16)) = v[u];
 }
 
-template <int KB, int PM>
-__global__ __launch_bounds__(ARTN_WG_THREADS, (KB <= 5 ? 4 : 3)) void artn_k_bits(const float2 *__restrict__ A,
-                                                               const float2 *__restrict__ B,
-                                                               float2 *__restrict__ C,
-                                                               const ArtnBitsPlan P) {
-  constexpr int S = 1 << (KB - 1); // complex K pairs
+// Per-wave / per-lane constants of one stage, computed once per kernel.
+template <int KB>
+struct StageConst {
+  unsigned lane_in, lane_out, lane_b; // per-lane byte offsets: LDS input tile, LDS output tile, small operand
+  bool w_valid;
+  unsigned kin[KB > 1 ? KB : 2];      // byte offset of K bit b in the LDS input tile
+  long kb[KB > 1 ? KB : 2];           // byte stride of K bit b in the small operand
+  unsigned o0, o2, o3;                // byte offsets of N bits 0, 2, 3 in the LDS output tile
+  int nt_eff, wm, wm_count, msubs;
+  const uint2 *msub_tab;              // LDS table: sub-tile -> (input, output) byte offsets
+};
+template <int KB>
+__device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, int j, int h, int wave, const uint2 *tab) {
+  StageConst<KB> L;
+  const int wn = wave & ((1 << st.wn_log2) - 1);
+  L.wm = wave >> st.wn_log2;
+  L.wm_count = 4 >> st.wn_log2;
+  L.msubs = 1 << (st.m_bits - 5);
+  L.nt_eff = st.nt < 4 ? st.nt : 4;
+  L.msub_tab = tab;
+  L.lane_in = (unsigned)h << (st.k_in_pos[0] + 3);
+  L.lane_out = 0;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) {
+    if ((j >> b) & 1) {
+      L.lane_in += 8u << st.lane_in_pos[b];
+      L.lane_out += 8u << st.lane_out_pos[b];
+    }
+  }
+  if (st.nt > 1) L.lane_out += (unsigned)h << (st.n_out_pos[1] + 3);
+  const int nloc = j >> 1;
+  L.w_valid = (nloc >> L.nt_eff) == 0;
+  L.lane_b = (unsigned)h * (unsigned)st.k_b_stride[0] * 8u;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if (b < L.nt_eff && ((nloc >> b) & 1)) L.lane_b += (unsigned)st.n_b_stride[b] * 8u;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    if (b < st.wn_log2 && ((wn >> b) & 1)) {
+      L.lane_out += 8u << st.n_out_pos[4 + b];
+      L.lane_b += (unsigned)st.n_b_stride[4 + b] * 8u;
+    }
+  }
+#pragma unroll
+  for (int b = 1; b < KB; ++b) {
+    L.kin[b] = 8u << st.k_in_pos[b];
+    L.kb[b] = st.k_b_stride[b] * 8;
+  }
+  L.o0 = st.nt > 0 ? 8u << st.n_out_pos[0] : 0;
+  L.o2 = st.nt > 2 ? 8u << st.n_out_pos[2] : 0;
+  L.o3 = st.nt > 3 ? 8u << st.n_out_pos[3] : 0;
+  return L;
+}
+// Fill the LDS sub-tile table of a stage (all threads cooperate; caller barriers).
+__device__ __forceinline__ void fill_msub_table(const ArtnStage &st, uint2 *tab, int tid) {
+  const int msubs = 1 << (st.m_bits - 5);
+  for (int m = tid; m < msubs; m += ARTN_WG_THREADS) {
+    unsigned oi = 0, oo = 0;
+    for (int b = 0; b < st.m_bits - 5; ++b) {
+      if ((m >> b) & 1) {
+        oi += 8u << st.msub_in_pos[b];
+        oo += 8u << st.msub_out_pos[b];
+      }
+    }
+    tab[m] = make_uint2(oi, oo);
+  }
+}
+
+// Small-operand fragments of this lane: W[n' = lane&31][(kc = 2s + h, p)], p = 0 (x re) / 1 (x im).
+template <int KB>
+__device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1 << (KB - 1)],
+                                       const char *__restrict__ Bbase, const StageConst<KB> &L, int ro) {
+  constexpr int S = 1 << (KB - 1);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    long ko = 0;
+#pragma unroll
+    for (int b = 1; b < KB; ++b)
+      if ((s >> (b - 1)) & 1) ko += L.kb[b];
+    float2 bv = make_float2(0.f, 0.f);
+    if (L.w_valid) bv = *reinterpret_cast<const float2 *>(Bbase + ko + L.lane_b);
+    W0[s] = ro ? bv.y : bv.x;
+    W1[s] = ro ? bv.x : -bv.y;
+  }
+}
+
+// One stage on this wave's sub-tiles: for each, a chain of 2^KB MFMAs over the contracted
+// bits (LDS reads one step ahead of the MFMAs that consume them), then the scatter of the
+// 32 x 16 complex result into the output region.
+template <int KB>
+__device__ __forceinline__ void run_stage(const StageConst<KB> &L, const char *in, char *out,
+                                          const float (&W0)[1 << (KB - 1)], const float (&W1)[1 << (KB - 1)], int h) {
+  constexpr int S = 1 << (KB - 1);
+  for (int msub = L.wm; msub < L.msubs; msub += L.wm_count) {
+    const uint2 mo = L.msub_tab[msub];
+    unsigned li = L.lane_in + mo.x, lo = L.lane_out + mo.y;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float2 a_next = *reinterpret_cast<const float2 *>(in + li);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float2 a = a_next;
+      if (s + 1 < S) {
+        unsigned ko = 0;
+#pragma unroll
+        for (int b = 1; b < KB; ++b)
+          if (((s + 1) >> (b - 1)) & 1) ko += L.kin[b];
+        a_next = *reinterpret_cast<const float2 *>(in + li + ko);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[s], a.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[s], a.y, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int b0 = 0; b0 < 2; ++b0) {
+        const int nl = b0 + 2 * h + 4 * (q & 1) + 8 * (q >> 1);
+        if ((nl >> L.nt_eff) == 0) {
+          const unsigned o = lo + b0 * L.o0 + (q & 1) * L.o2 + (q >> 1) * L.o3;
+          *reinterpret_cast<float2 *>(out + o) = make_float2(acc[4 * q + 2 * b0], acc[4 * q + 2 * b0 + 1]);
+        }
+      }
+    }
+  }
+}
+
+// KB2 == 0: single stage.
+template <int KB1, int KB2>
+__global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *__restrict__ A,
+                                                                  const float2 *__restrict__ B1,
+                                                                  const float2 *__restrict__ B2,
+                                                                  float2 *__restrict__ C, const ArtnBitsPlan P) {
+  constexpr int S1 = 1 << (KB1 - 1);
+  constexpr int KB2e = KB2 > 0 ? KB2 : 1;
+  constexpr int S2 = 1 << (KB2e - 1);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  char *ldsb = reinterpret_cast<char *>(smem);
+  char *R0 = reinterpret_cast<char *>(smem);
+  char *R1 = R0 + (8u << P.r0_bits);
+  uint2 *tab1 = reinterpret_cast<uint2 *>(R1 + (8u << P.T_mid));
+  uint2 *tab2 = tab1 + (1 << (P.st[0].m_bits - 5));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int wn = wave & ((1 << P.wn_log2) - 1);
-  const int wm = wave >> P.wn_log2;
-  const int nt_eff = P.nt < 4 ? P.nt : 4;
+  const int j = lane & 31, h = lane >> 5, ro = j & 1;
 
   // ---- copy phases: thread handles 16-byte chunks c = tid + 256*i (tile-local elements 2c, 2c+1);
   //      per-lane byte offsets fit 32 bits (checked by the planner)
@@ -133,171 +329,108 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KB <= 5 ? 4 : 3)) void artn_k_bit
       out_lane += (unsigned)P.out_stride[b] * 8u;
     }
   }
+  long in_hi[4], out_hi[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    in_hi[b] = 9 + b < P.T_in ? P.in_stride[9 + b] * 8 : 0;
+    out_hi[b] = 9 + b < P.T_out ? P.out_stride[9 + b] * 8 : 0;
+  }
   const unsigned tid16 = tid * 16;
   const int n_in_iters = 1 << (P.T_in - 9), n_out_iters = 1 << (P.T_out - 9);
+  const long n_tiles = P.n_tiles;
 
-  // ---- MFMA phase: per-lane tile-local byte offsets
-  unsigned lane_in = (unsigned)h << (P.k_in_pos[0] + 3), lane_out = 0;
-#pragma unroll
-  for (int b = 0; b < 5; ++b) {
-    if ((j >> b) & 1) {
-      lane_in += 8u << P.lane_in_pos[b];
-      lane_out += 8u << P.lane_out_pos[b];
-    }
-  }
-  if (P.nt > 1) lane_out += (unsigned)h << (P.n_out_pos[1] + 3);
-
-  // ---- small-operand fragments: lane (i = lane&31, h) needs W[n'=i][(kc = 2s+h, p)]
-  const int ro = j & 1, nloc = j >> 1;
-  const bool w_valid = (nloc >> nt_eff) == 0;
-  unsigned lane_b = (unsigned)h * (unsigned)P.k_b_stride[0] * 8u;
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-    if (b < nt_eff && ((nloc >> b) & 1)) lane_b += (unsigned)P.n_b_stride[b] * 8u;
-  float W0[S], W1[S];
-  long prev_offB = -1;
+  // ---- per-stage constants, sub-tile tables, outer-axis digits
+  fill_msub_table(P.st[0], tab1, tid);
+  if (KB2 > 0) fill_msub_table(P.st[1], tab2, tid);
+  const StageConst<KB1> L1 = stage_const<KB1>(P.st[0], j, h, wave, tab1);
+  const StageConst<KB2e> L2 = stage_const<KB2e>(P.st[KB2 > 0 ? 1 : 0], j, h, wave, tab2);
+  const OuterLane OL = outer_lane(P, lane);
+  float W10[S1], W11[S1], W20[S2], W21[S2];
+  long prev_b1 = -1, prev_b2 = -1;
+  __syncthreads();
 
   // software pipeline: the loads of the next tile are issued before this tile's MFMA phase
   f32x4 v[8];
   const bool prefetch = n_in_iters <= 8;
-  if (prefetch && (long)blockIdx.x < P.n_tiles) {
-    long oa, ob, oc;
-    tile_offsets(P, blockIdx.x, oa, ob, oc);
-    issue_loads(v, reinterpret_cast<const char *>(A + oa), P, in_lane, 0, n_in_iters);
+  TileOff off = {0, 0, 0, 0};
+  if ((long)blockIdx.x < n_tiles) {
+    off = tile_offsets(OL, blockIdx.x);
+    if (prefetch) issue_loads(v, reinterpret_cast<const char *>(A + off.a), in_hi, in_lane, 0, n_in_iters);
   }
 
-  for (long tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
-    long offA, offB, offC;
-    tile_offsets(P, tile, offA, offB, offC);
-
-    if (offB != prev_offB) {
-      prev_offB = offB;
-      long wn_b = 0;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-        if (b < P.wn_log2 && ((wn >> b) & 1)) wn_b += P.n_b_stride[4 + b];
-      const char *Bbase = reinterpret_cast<const char *>(B + offB + wn_b);
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        long ko = 0;
-#pragma unroll
-        for (int b = 1; b < KB; ++b)
-          if ((s >> (b - 1)) & 1) ko += P.k_b_stride[b];
-        float2 bv = make_float2(0.f, 0.f);
-        if (w_valid) bv = *reinterpret_cast<const float2 *>(Bbase + ko * 8 + lane_b);
-        W0[s] = ro ? bv.y : bv.x;
-        W1[s] = ro ? bv.x : -bv.y;
-      }
+  STAMP_DECL
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (off.b1 != prev_b1) {
+      prev_b1 = off.b1;
+      load_w<KB1>(W10, W11, reinterpret_cast<const char *>(B1 + off.b1), L1, ro);
     }
+    if (KB2 > 0 && off.b2 != prev_b2) {
+      prev_b2 = off.b2;
+      load_w<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
+    }
+    const long next = tile + gridDim.x;
+    TileOff noff = off;
+    if (next < n_tiles) noff = tile_offsets(OL, next);
+    STAMP(0); // W reload, next tile's offsets
 
-    // ---- copy-in: global (16 B per lane, runs of 2^run_in elements) -> LDS (linear)
+    // ---- copy-in: global (16 B per lane, runs of 2^run_in elements) -> LDS region 0 (linear)
     {
       unsigned lo = in_lane, t16 = tid16;
       OPAQUE_V(lo);
       OPAQUE_V(t16);
       if (prefetch) {
-        __syncthreads(); // previous tile's copy-out has finished reading LDS
-        store_lds(v, ldsb, t16, 0, n_in_iters);
+        if (KB2 > 0) __syncthreads(); // fused: previous tile's copy-out has finished reading R0
+        STAMP(1); // barrier before LDS refill
+        store_lds(v, R0, t16, 0, n_in_iters);
+        STAMP(2); // wait for the prefetched loads + LDS write
         __syncthreads();
-        const long next = tile + gridDim.x;
-        if (next < P.n_tiles) {
-          long oa, ob, oc;
-          tile_offsets(P, next, oa, ob, oc);
-          issue_loads(v, reinterpret_cast<const char *>(A + oa), P, lo, 0, n_in_iters);
-        }
+        STAMP(3); // barrier after LDS fill
+        if (next < n_tiles) issue_loads(v, reinterpret_cast<const char *>(A + noff.a), in_hi, lo, 0, n_in_iters);
       } else {
-        const char *Abase = reinterpret_cast<const char *>(A + offA);
+        const char *Abase = reinterpret_cast<const char *>(A + off.a);
         for (int i0 = 0; i0 < n_in_iters; i0 += 8) {
-          issue_loads(v, Abase, P, lo, i0, n_in_iters);
-          if (i0 == 0) __syncthreads();
-          store_lds(v, ldsb, t16, i0, n_in_iters);
+          issue_loads(v, Abase, in_hi, lo, i0, n_in_iters);
+          if (i0 == 0 && KB2 > 0) __syncthreads();
+          store_lds(v, R0, t16, i0, n_in_iters);
         }
         __syncthreads();
       }
     }
+    STAMP(4); // issue of the next tile's loads
 
-    // ---- MFMA
-    f32x16 acc[PM];
-    unsigned msub_out[PM];
-    {
-      unsigned li = lane_in;
-      OPAQUE_V(li);
-      unsigned msub_in[PM];
-#pragma unroll
-      for (int pm = 0; pm < PM; ++pm) {
-        const int msub = wm * PM + pm;
-        unsigned oi = 0, oo = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (b < P.mt - 5 && ((msub >> b) & 1)) {
-            oi += 8u << P.msub_in_pos[b];
-            oo += 8u << P.msub_out_pos[b];
-          }
-        }
-        msub_in[pm] = oi;
-        msub_out[pm] = oo;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[pm][e] = 0.f;
-      }
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        unsigned ko = 0;
-#pragma unroll
-        for (int b = 1; b < KB; ++b)
-          if ((s >> (b - 1)) & 1) ko += 8u << P.k_in_pos[b];
-#pragma unroll
-        for (int pm = 0; pm < PM; ++pm) {
-          const float2 a = *reinterpret_cast<const float2 *>(ldsb + li + msub_in[pm] + ko);
-          acc[pm] = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[s], a.x, acc[pm], 0, 0, 0);
-          acc[pm] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[s], a.y, acc[pm], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads(); // every wave is done reading the input tile
-
-    // ---- accumulators -> LDS in output-tile order (in place over the input tile)
-    {
-      unsigned lo = lane_out;
-      OPAQUE_V(lo);
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-        if (b < P.wn_log2 && ((wn >> b) & 1)) lo += 8u << P.n_out_pos[4 + b];
-      const unsigned o0 = P.nt > 0 ? 8u << P.n_out_pos[0] : 0;
-      const unsigned o2 = P.nt > 2 ? 8u << P.n_out_pos[2] : 0;
-      const unsigned o3 = P.nt > 3 ? 8u << P.n_out_pos[3] : 0;
-#pragma unroll
-      for (int pm = 0; pm < PM; ++pm) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int b0 = 0; b0 < 2; ++b0) {
-            const int nl = b0 + 2 * h + 4 * (q & 1) + 8 * (q >> 1);
-            if ((nl >> nt_eff) == 0) {
-              const unsigned o = lo + msub_out[pm] + b0 * o0 + (q & 1) * o2 + (q >> 1) * o3;
-              *reinterpret_cast<float2 *>(ldsb + o) = make_float2(acc[pm][4 * q + 2 * b0], acc[pm][4 * q + 2 * b0 + 1]);
-            }
-          }
-        }
-      }
-    }
+    // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
+    run_stage<KB1>(L1, R0, R1, W10, W11, h);
+    STAMP(5); // stage 1
     __syncthreads();
+    const char *outr = R1;
+    if (KB2 > 0) {
+      STAMP(6); // barrier after stage 1
+      run_stage<KB2e>(L2, R1, R0, W20, W21, h);
+      STAMP(5); // stage 2 (same bucket as stage 1)
+      __syncthreads();
+      outr = R0;
+    }
+    STAMP(6); // barrier after the last stage
 
     // ---- copy-out: LDS (linear) -> global (16 B per lane, runs of 2^run_out elements)
     {
-      char *Cbase = reinterpret_cast<char *>(C + offC);
+      char *Cbase = reinterpret_cast<char *>(C + off.c);
       unsigned lo = out_lane, t16 = tid16;
       OPAQUE_V(lo);
       OPAQUE_V(t16);
       for (int i = 0; i < n_out_iters; ++i) {
-        long off = 0;
+        long o = 0;
 #pragma unroll
-        for (int b = 9; b < ARTN_TILE_BITS_MAX; ++b)
-          if (b < P.T_out && ((i >> (b - 9)) & 1)) off += P.out_stride[b];
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(ldsb + t16 + i * (ARTN_WG_THREADS * 16));
-        *reinterpret_cast<f32x4 *>(Cbase + off * 8 + lo) = v;
+        for (int b = 0; b < 4; ++b)
+          if ((i >> b) & 1) o += out_hi[b];
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(outr + t16 + i * (ARTN_WG_THREADS * 16));
+        *reinterpret_cast<f32x4 *>(Cbase + o + lo) = x;
       }
     }
+    STAMP(7); // copy-out (LDS reads + store issue)
+    off = noff;
   }
+  STAMP_FLUSH
 }
 
 // ----------------------------------------------------------------------------------------
@@ -431,30 +564,47 @@ static bool env_flag(const char *name) {
   return v && v[0] && v[0] != '0';
 }
 
-template <int KB>
-static hipError_t launch_bits_pm(const ArtnPlan &p, const float2 *A, const float2 *B, float2 *C,
+template <int KB1>
+static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, float2 *C,
                                  hipStream_t st) {
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
   const size_t lds = (size_t)p.info.lds_bytes;
-  switch (p.bits.pm) {
-    case 1: hipLaunchKernelGGL((artn_k_bits<KB, 1>), grid, block, lds, st, A, B, C, p.bits); break;
-    case 2: hipLaunchKernelGGL((artn_k_bits<KB, 2>), grid, block, lds, st, A, B, C, p.bits); break;
-    case 4: hipLaunchKernelGGL((artn_k_bits<KB, 4>), grid, block, lds, st, A, B, C, p.bits); break;
+  const int k2 = p.bits.n_stages == 2 ? p.bits.st[1].k : 0;
+#define ARTN_LAUNCH(K2)                                                                                   \
+  case K2: {                                                                                              \
+    auto kern = artn_k_bits<KB1, K2>;                                                                     \
+    if (lds > 64 * 1024) {                                                                                \
+      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                                      \
+    }                                                                                                     \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                                 \
+    break;                                                                                                \
+  }
+  switch (k2) {
+    ARTN_LAUNCH(0)
+    ARTN_LAUNCH(1)
+    ARTN_LAUNCH(2)
+    ARTN_LAUNCH(3)
+    ARTN_LAUNCH(4)
+    ARTN_LAUNCH(5)
+    ARTN_LAUNCH(6)
     default: return hipErrorInvalidValue;
   }
+#undef ARTN_LAUNCH
   return hipGetLastError();
 }
 
-static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B, void *C, hipStream_t st) {
-  const float2 *a = (const float2 *)A, *b = (const float2 *)B;
+static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C,
+                              hipStream_t st) {
+  const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2;
   float2 *c = (float2 *)C;
-  switch (p.bits.k) {
-    case 1: return launch_bits_pm<1>(p, a, b, c, st);
-    case 2: return launch_bits_pm<2>(p, a, b, c, st);
-    case 3: return launch_bits_pm<3>(p, a, b, c, st);
-    case 4: return launch_bits_pm<4>(p, a, b, c, st);
-    case 5: return launch_bits_pm<5>(p, a, b, c, st);
-    case 6: return launch_bits_pm<6>(p, a, b, c, st);
+  switch (p.bits.st[0].k) {
+    case 1: return launch_bits_k2<1>(p, a, b1, b2, c, st);
+    case 2: return launch_bits_k2<2>(p, a, b1, b2, c, st);
+    case 3: return launch_bits_k2<3>(p, a, b1, b2, c, st);
+    case 4: return launch_bits_k2<4>(p, a, b1, b2, c, st);
+    case 5: return launch_bits_k2<5>(p, a, b1, b2, c, st);
+    case 6: return launch_bits_k2<6>(p, a, b1, b2, c, st);
   }
   return hipErrorInvalidValue;
 }
@@ -493,7 +643,7 @@ int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, 
   if (rc) return fail(rc, err);
   hipStream_t st = (hipStream_t)stream;
   if (p.kernel == ARTN_KERNEL_BITS_MFMA) {
-    HIP_TRY(launch_bits(p, A, B, C, st));
+    HIP_TRY(launch_bits(p, A, B, nullptr, C, st));
     return ARTN_OK;
   }
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
@@ -507,6 +657,42 @@ int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, 
   HIP_TRY(hipGetLastError());
   return ARTN_OK;
 }
+
+int artn_contract2_query(const ArtnStepDesc *d1, const ArtnStepDesc *d2, ArtnStepInfo *info) {
+  if (!info) return fail(ARTN_E_INVALID, "null info");
+  ArtnPlan p;
+  std::string err;
+  if (env_flag("ARTN_NO_FUSE")) return fail(ARTN_E_UNSUPPORTED, "not fusable: ARTN_NO_FUSE is set");
+  const int64_t min_tiles = env_flag("ARTN_FORCE_BITS") ? 1 : 32;
+  int rc = artn::make_plan_fused(d1, d2, p, err, g_ncu, min_tiles);
+  if (rc) return fail(rc, err);
+  *info = p.info;
+  return ARTN_OK;
+}
+
+int artn_contract2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A, const void *B1, const void *B2,
+                   void *C, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (!A || !B1 || !B2 || !C) return fail(ARTN_E_INVALID, "null operand pointer");
+  if ((((uintptr_t)A | (uintptr_t)C) & 15) != 0) return fail(ARTN_E_UNSUPPORTED, "not fusable: operands not 16-byte aligned");
+  if (env_flag("ARTN_NO_FUSE")) return fail(ARTN_E_UNSUPPORTED, "not fusable: ARTN_NO_FUSE is set");
+  ArtnPlan p;
+  std::string err;
+  const int64_t min_tiles = env_flag("ARTN_FORCE_BITS") ? 1 : 32;
+  int rc = artn::make_plan_fused(d1, d2, p, err, g_ncu, min_tiles);
+  if (rc) return fail(rc, err);
+  HIP_TRY(launch_bits(p, A, B1, B2, C, (hipStream_t)stream));
+  return ARTN_OK;
+}
+
+#ifdef ARTN_STAMPS
+// diagnostic build only: copy the per-wave phase sums to the host and clear them
+int artn_debug_read_stamps(unsigned long long *host, int n_waves) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(artn_stamp_buf), sizeof(unsigned long long) * ARTN_N_STAMPS * n_waves));
+  return ARTN_OK;
+}
+#endif
 
 int artn_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t nrows, int64_t row_bytes,
                      int64_t src_rows, int32_t *err_flag, void *stream) {

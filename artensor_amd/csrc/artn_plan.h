@@ -1,4 +1,4 @@
-// artn_plan.h -- host-side lowering of one pairwise contraction step (ArtnStepDesc, the
+// artn_plan.h -- host-side lowering of pairwise contraction steps (ArtnStepDesc, the
 // label-list form of the einsum strings built at /root/reference/artensor/contraction.py:13-20)
 // into the launch plan consumed by the gfx950 kernels in artn_kernels.hip.
 //
@@ -13,8 +13,11 @@
 //   N bits  -- carried by B and C only   (free bits of the small operand)
 //   H axes  -- carried by all three      (batch: the sparse path's shared row label)
 // A *tile* is the set {all K bits} u {M_t: a subset of M bits} of A, staged in LDS by one
-// workgroup; it yields the C tile {M_t} u {N_t}.  Everything else is an *outer* axis
-// enumerated by the tile index.
+// workgroup; a *stage* multiplies it by the small operand and scatters the result tile
+// {M_t} u {N_t} into a second LDS region.  A plan has one stage (one reference step) or
+// two (two consecutive steps on the same state tensor fused into ONE pass over HBM: the
+// second stage contracts bits of the first stage's result while it is still in LDS).
+// Everything not inside the tile is an *outer* axis enumerated by the tile index.
 #ifndef ARTN_PLAN_H
 #define ARTN_PLAN_H
 
@@ -27,36 +30,43 @@
 
 #include "artn.h"
 
-#define ARTN_MAX_OUTER 40
-#define ARTN_TILE_BITS_MAX 13 /* 2^13 complex64 = 64 KiB of LDS */
+#define ARTN_MAX_OUTER 36
+#define ARTN_TILE_BITS_MAX 13 /* 2^13 complex64 = 64 KiB per LDS region */
 #define ARTN_TILE_BITS_TARGET 12
+#define ARTN_LDS_BUDGET (128 * 1024)
 #define ARTN_WG_THREADS 256
 
 struct ArtnOuterDim {
   int64_t ext;
-  int64_t sA, sB, sC; /* element strides; 0 where the operand does not carry the axis */
-  int32_t log2ext;    /* >= 0 for powers of two, -1 otherwise */
+  int64_t sA, sB1, sB2, sC; /* element strides; 0 where the operand does not carry the axis */
+  int32_t log2ext;          /* >= 0 for powers of two, -1 otherwise */
   int32_t pad_;
+};
+
+// One MFMA stage: LDS region `in` (tile-local bit order of its input tile) -> region `out`.
+struct ArtnStage {
+  int32_t k, nt;           // contracted bits, N bits produced inside the tile
+  int32_t wn_log2;         // waves along n' tiles (16 complex n each): max(0, nt - 4)
+  int32_t m_bits;          // free input-tile bits = 5 lane bits + sub-tile bits
+  int32_t lane_in_pos[5], lane_out_pos[5]; // MFMA column bit j -> tile-local bit (in / out)
+  int32_t msub_in_pos[9], msub_out_pos[9]; // sub-tile bit      -> tile-local bit (in / out)
+  int32_t k_in_pos[6];                     // K bit i (kc bit i) -> tile-local input bit
+  int32_t n_out_pos[6];                    // N_t bit i          -> tile-local output bit
+  int64_t k_b_stride[6];                   // K bit i   -> small-operand element stride
+  int64_t n_b_stride[6];                   // N_t bit i -> small-operand element stride
 };
 
 // Launch plan of the LDS-tiled bit-permuted complex GEMM (kernel argument, POD).
 struct ArtnBitsPlan {
-  int32_t k, mt, nt;        // K / M_t / N_t bit counts
-  int32_t T_in, T_out;      // k + mt, mt + nt
-  int32_t wn_log2;          // waves along n' tiles (16 complex n each): max(0, nt - 4)
-  int32_t wm_log2;          // waves along m sub-tiles: 2 - wn_log2
-  int32_t pm;               // m sub-tiles (32 m each) per wave: 2^(mt-5) / 2^wm_log2
+  int32_t n_stages;
+  int32_t T_in, T_mid, T_out; // log2 elements: input tile, tile between the stages, output tile
+  int32_t r0_bits;            // LDS region 0 holds 2^r0_bits elements (region 1 follows it)
+  int32_t run_in, run_out;    // tile-local bits [0,run) are global bits [0,run)
   int32_t n_outer;
-  int32_t run_in, run_out;  // tile-local bits [0,run) are global bits [0,run)
   int64_t n_tiles;
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
-  int32_t lane_in_pos[5], lane_out_pos[5];   // MFMA column bit j -> tile-local in/out bit
-  int32_t msub_in_pos[4], msub_out_pos[4];   // m sub-tile bit    -> tile-local in/out bit
-  int32_t k_in_pos[6];                       // K bit i (kc bit i) -> tile-local in bit
-  int32_t n_out_pos[6];                      // N_t bit i          -> tile-local out bit
-  int64_t k_b_stride[6];                     // K bit i   -> B element stride
-  int64_t n_b_stride[6];                     // N_t bit i -> B element stride
+  ArtnStage st[2];
   ArtnOuterDim outer[ARTN_MAX_OUTER];
 };
 
@@ -86,9 +96,9 @@ namespace artn {
 // Development knobs (environment: ARTN_WG_PER_CU, ARTN_TILE_TARGET, ARTN_RUN_MAX); the
 // defaults are what ships.
 struct Tuning {
-  int wg_per_cu = 4;    // persistent workgroups per CU (grid = CUs * this)
+  int wg_per_cu = 2;  // persistent workgroups per CU (grid = CUs * this), capped by LDS
   int tile_target = ARTN_TILE_BITS_TARGET;
-  int run_max = 4;      // longest contiguous run (log2 elements) the tile is forced to keep
+  int run_max = 4;    // longest contiguous run (log2 elements) the tile is forced to keep
 };
 static inline Tuning &tuning() {
   static Tuning t = [] {
@@ -100,14 +110,6 @@ static inline Tuning &tuning() {
   }();
   return t;
 }
-
-struct Axis {
-  int64_t ext, sA, sB, sC; // stride -1 = absent
-  bool bit;
-  bool inA() const { return sA >= 0; }
-  bool inB() const { return sB >= 0; }
-  bool inC() const { return sC >= 0; }
-};
 
 static inline int ilog2_exact(int64_t v) {
   if (v <= 0 || (v & (v - 1))) return -1;
@@ -123,7 +125,7 @@ static inline int validate(const ArtnStepDesc *d, std::string &err) {
   if (d->n_labels < 0 || d->n_labels > ARTN_MAX_LABELS) { err = "n_labels out of range"; return ARTN_E_INVALID; }
   for (int l = 0; l < d->n_labels; ++l) {
     if (d->extent[l] < 1) { err = "label extent < 1"; return ARTN_E_INVALID; }
-    bool a = d->stride_a[l] >= 0, b = d->stride_b[l] >= 0, c = d->stride_c[l] >= 0;
+    bool a = d->stride_a[l] >= 0, b = d->stride_b[l] >= 0;
     if (!a && !b) { err = "label carried by neither input operand"; return ARTN_E_INVALID; }
   }
   // C must be dense row-major over its labels: sorted by stride, stride_i = prod of faster extents
@@ -184,67 +186,142 @@ static inline bool make_generic(const ArtnStepDesc *d, ArtnPlan &p, std::string 
   return true;
 }
 
-// The bit-GEMM planner.  Returns false (with p.why_generic set) when the step does not
-// fit the MFMA kernel's envelope.
-static inline bool make_bits(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles) {
-  if (d->dtype != ARTN_C64) { p.why_generic = "dtype is not complex64"; return false; }
-  std::vector<Axis> ax;
+// ----------------------------------------------------------------------------------------
+// bit-GEMM planner (one step, or two fused steps d1: A,B1->C1 and d2: C1,B2->C2)
+// ----------------------------------------------------------------------------------------
+// An axis of the (possibly fused) problem.  Strides are element strides, -1 = absent.
+// For a single step sB2 is absent and sC (the final output stride) == sC1.
+struct Axis {
+  int64_t ext;
+  int64_t sA, sB1, sC1, sB2, sC;
+  bool bit;
+  bool k1() const { return sA >= 0 && sB1 >= 0 && sC1 < 0; }
+  bool m1() const { return sA >= 0 && sB1 < 0 && sC1 >= 0; }
+  bool n1() const { return sA < 0 && sB1 >= 0 && sC1 >= 0; }
+  bool h1() const { return sA >= 0 && sB1 >= 0 && sC1 >= 0; }
+  bool k2() const { return sC1 >= 0 && sB2 >= 0 && sC < 0; } // contracted by stage 2
+  bool n2() const { return sC1 < 0 && sB2 >= 0 && sC >= 0; } // produced by stage 2
+};
+
+static inline void expand_axes(const ArtnStepDesc *d, std::vector<Axis> &ax) {
   for (int l = 0; l < d->n_labels; ++l) {
     int64_t e = d->extent[l];
     if (e == 1) continue;
     int lg = ilog2_exact(e);
-    if (lg > 0) {
-      for (int jb = 0; jb < lg; ++jb) {
-        Axis a;
-        a.ext = 2;
-        a.bit = true;
-        a.sA = d->stride_a[l] >= 0 ? d->stride_a[l] << jb : -1;
-        a.sB = d->stride_b[l] >= 0 ? d->stride_b[l] << jb : -1;
-        a.sC = d->stride_c[l] >= 0 ? d->stride_c[l] << jb : -1;
-        ax.push_back(a);
-      }
-    } else {
-      Axis a{e, d->stride_a[l], d->stride_b[l], d->stride_c[l], false};
+    int parts = lg > 0 ? lg : 1;
+    for (int jb = 0; jb < parts; ++jb) {
+      Axis a;
+      a.bit = lg > 0;
+      a.ext = lg > 0 ? 2 : e;
+      int sh = lg > 0 ? jb : 0;
+      a.sA = d->stride_a[l] >= 0 ? d->stride_a[l] << sh : -1;
+      a.sB1 = d->stride_b[l] >= 0 ? d->stride_b[l] << sh : -1;
+      a.sC1 = d->stride_c[l] >= 0 ? d->stride_c[l] << sh : -1;
+      a.sB2 = -1;
+      a.sC = a.sC1;
       ax.push_back(a);
     }
   }
-  std::vector<int> K, M, N, O; // O: outer-only axes (H batch axes, non power-of-two free axes)
+}
+
+// Fuse the axes of d2 (whose operand A is d1's C) into `ax`.  Returns false if the two
+// descriptors do not chain bit for bit.
+static inline bool chain_axes(const ArtnStepDesc *d2, std::vector<Axis> &ax, std::string &why) {
+  std::vector<Axis> ax2;
+  expand_axes(d2, ax2); // here sA = position in C1, sB1 = stride in B2, sC1 = stride in C2
+  for (auto &a : ax) a.sC = -1;
+  std::vector<bool> used(ax2.size(), false);
+  for (auto &a : ax) {
+    if (a.sC1 < 0) continue;
+    bool found = false;
+    for (size_t i = 0; i < ax2.size(); ++i) {
+      if (used[i] || ax2[i].sA != a.sC1) continue;
+      if (ax2[i].ext != a.ext) { why = "fused steps disagree on an axis extent"; return false; }
+      a.sB2 = ax2[i].sB1;
+      a.sC = ax2[i].sC1;
+      used[i] = true;
+      found = true;
+      break;
+    }
+    if (!found) { why = "second step does not carry every axis of the first result"; return false; }
+  }
+  for (size_t i = 0; i < ax2.size(); ++i) {
+    if (used[i]) continue;
+    if (ax2[i].sA >= 0) { why = "second step carries an axis the first result lacks"; return false; }
+    Axis a = ax2[i];
+    a.sA = -1; a.sB1 = -1; a.sC1 = -1;
+    a.sB2 = ax2[i].sB1;
+    a.sC = ax2[i].sC1;
+    ax.push_back(a);
+  }
+  return true;
+}
+
+static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, ArtnPlan &p, int n_cu,
+                             int64_t min_tiles) {
+  if (d1->dtype != ARTN_C64 || (d2 && d2->dtype != ARTN_C64)) { p.why_generic = "dtype is not complex64"; return false; }
+  const bool fused = d2 != nullptr;
+  std::vector<Axis> ax;
+  expand_axes(d1, ax);
+  if (fused && !chain_axes(d2, ax, p.why_generic)) return false;
+
+  // ---- classify
+  std::vector<int> K1, M1, N1, K2, N2, O; // O: outer-only axes (batch / non power-of-two free axes)
   for (int i = 0; i < (int)ax.size(); ++i) {
     const Axis &a = ax[i];
-    if (a.inA() && a.inB() && !a.inC()) {
-      if (!a.bit) { p.why_generic = "contracted label with a non power-of-two extent"; return false; }
-      K.push_back(i);
-    } else if (a.inA() && !a.inB() && a.inC()) {
-      (a.bit ? M : O).push_back(i);
-    } else if (!a.inA() && a.inB() && a.inC()) {
-      (a.bit ? N : O).push_back(i);
-    } else if (a.inA() && a.inB() && a.inC()) {
-      O.push_back(i);
-    } else {
-      p.why_generic = "label summed out of a single operand";
-      return false;
+    if (a.sA >= 0 || a.sB1 >= 0) { // lives in stage 1
+      if (a.k1()) {
+        if (!a.bit) { p.why_generic = "contracted label with a non power-of-two extent"; return false; }
+        K1.push_back(i);
+      } else if (a.m1() || a.n1()) {
+        if (fused && a.sB2 >= 0 && a.sC >= 0) { p.why_generic = "batch axis in the second fused step"; return false; }
+        if (fused && a.k2()) {
+          if (!a.bit) { p.why_generic = "contracted label with a non power-of-two extent"; return false; }
+          K2.push_back(i);
+          (a.m1() ? M1 : N1).push_back(i);
+        } else if (fused && a.sC < 0) {
+          p.why_generic = "label summed out of a single operand";
+          return false;
+        } else if (a.bit) {
+          (a.m1() ? M1 : N1).push_back(i);
+        } else {
+          O.push_back(i);
+        }
+      } else if (a.h1()) {
+        if (fused) { p.why_generic = "batch axis in a fused pair"; return false; }
+        O.push_back(i);
+      } else {
+        p.why_generic = "label summed out of a single operand";
+        return false;
+      }
+    } else { // only in stage 2's small operand
+      if (!a.n2()) { p.why_generic = "label summed out of a single operand"; return false; }
+      if (a.bit) N2.push_back(i); else O.push_back(i);
     }
   }
-  const int k = (int)K.size(), m = (int)M.size(), n = (int)N.size();
-  if (k < 1 || k > 6) { p.why_generic = "contracted bit count outside 1..6"; return false; }
+  const int k1 = (int)K1.size(), k2 = (int)K2.size();
+  if (k1 < 1 || k1 > 6) { p.why_generic = "contracted bit count outside 1..6"; return false; }
+  if (fused && (k2 < 1 || k2 > 6)) { p.why_generic = "contracted bit count outside 1..6 (second step)"; return false; }
   auto byA = [&](int x, int y) { return ax[x].sA < ax[y].sA; };
+  auto byC1 = [&](int x, int y) { return ax[x].sC1 < ax[y].sC1; };
   auto byC = [&](int x, int y) { return ax[x].sC < ax[y].sC; };
-  std::sort(K.begin(), K.end(), byA);
-  std::sort(M.begin(), M.end(), byA);
-  std::sort(N.begin(), N.end(), byC);
+  std::sort(K1.begin(), K1.end(), byA);
+  std::sort(M1.begin(), M1.end(), byA);
+  std::sort(N1.begin(), N1.end(), byC1);
+  std::sort(K2.begin(), K2.end(), byC1);
+  std::sort(N2.begin(), N2.end(), byC);
+  auto in_set = [](const std::vector<int> &v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
 
-  // contiguous run at the bottom of A (over K u M bits) and of C (over M u N bits)
+  // contiguous run at the bottom of A (over K1 u M1 bits) and of the final C (bits that reach it)
   auto run_len = [&](bool in_side) {
     int r = 0;
     for (; r < tuning().run_max; ++r) {
       bool found = false;
       for (int i = 0; i < (int)ax.size() && !found; ++i) {
         const Axis &a = ax[i];
-        if (!a.bit) continue;
-        bool cls = in_side ? (a.inA() && !(a.inA() && a.inB() && a.inC()))
-                           : (a.inC() && !(a.inA() && a.inB() && a.inC()));
+        if (!a.bit || in_set(O, i)) continue;
         int64_t s = in_side ? a.sA : a.sC;
-        if (cls && s == (int64_t(1) << r)) found = true;
+        if (s == (int64_t(1) << r)) found = true;
       }
       if (!found) break;
     }
@@ -253,79 +330,119 @@ static inline bool make_bits(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   int run_in = run_len(true), run_out = run_len(false);
   if (run_in < 1 || run_out < 1) { p.why_generic = "no contiguous 16-byte run at the bottom of A or C"; return false; }
 
-  // N_t: forced by the output run, then lowest C positions
-  int nt_target = std::min(n, std::min(6, std::max(k, 4)));
-  std::vector<int> Mt, Nt;
-  int mt_min = 0, mt_max = 0, wn_log2 = 0;
+  // ---- choose the tile
+  const int n1 = (int)N1.size(), n2 = (int)N2.size();
+  std::vector<int> Mt, N1t, N2t;
+  int T_in = 0, T_mid = 0, T_out = 0;
   for (;;) {
-    Nt.clear();
-    Mt.clear();
-    for (int i : N)
-      if (ax[i].sC < (int64_t(1) << run_out)) Nt.push_back(i);
-    for (int i : N) {
-      if ((int)Nt.size() >= nt_target) break;
-      if (std::find(Nt.begin(), Nt.end(), i) == Nt.end()) Nt.push_back(i);
+    Mt.clear(); N1t.clear(); N2t.clear();
+    const int64_t rin = int64_t(1) << run_in, rout = int64_t(1) << run_out;
+    // forced members
+    for (int i : M1)
+      if (ax[i].sA < rin || (ax[i].sC >= 0 && ax[i].sC < rout) || in_set(K2, i)) Mt.push_back(i);
+    for (int i : N1)
+      if ((ax[i].sC >= 0 && ax[i].sC < rout) || in_set(K2, i)) N1t.push_back(i);
+    for (int i : N2)
+      if (ax[i].sC < rout) N2t.push_back(i);
+    // grow N tiles towards full 16-column MFMA tiles (lowest result positions first)
+    int n1_target = std::min(n1, std::min(6, std::max(k1, 4)));
+    for (int i : N1) { if ((int)N1t.size() >= n1_target) break; if (!in_set(N1t, i)) N1t.push_back(i); }
+    int n2_target = std::min(n2, std::min(6, std::max(k2, 4)));
+    for (int i : N2) { if ((int)N2t.size() >= n2_target) break; if (!in_set(N2t, i)) N2t.push_back(i); }
+    bool ok = (int)N1t.size() <= 6 && (int)N2t.size() <= 6;
+    // grow M_t towards the target tile size (lowest A positions first), within the LDS budget
+    auto sizes = [&](int mt) {
+      T_in = k1 + mt;
+      T_mid = mt + (int)N1t.size();
+      T_out = fused ? T_mid - k2 + (int)N2t.size() : T_mid;
+    };
+    auto fits = [&](int mt) {
+      sizes(mt);
+      if (T_in > ARTN_TILE_BITS_MAX || T_mid > ARTN_TILE_BITS_MAX || T_out > ARTN_TILE_BITS_MAX) return false;
+      int r0 = fused ? std::max(T_in, T_out) : T_in;
+      return (8LL << r0) + (8LL << T_mid) <= ARTN_LDS_BUDGET;
+    };
+    if (ok && fits((int)Mt.size())) {
+      int target = tuning().tile_target;
+      for (int i : M1) {
+        if (in_set(Mt, i)) continue;
+        sizes((int)Mt.size());
+        int biggest = std::max(T_in, std::max(T_mid, T_out));
+        if (((int)Mt.size() >= 5 && biggest >= target) || !fits((int)Mt.size() + 1)) break;
+        Mt.push_back(i);
+      }
+      sizes((int)Mt.size());
+      break;
     }
-    if ((int)Nt.size() > 6) { p.why_generic = "too many forced N bits"; return false; }
-    int nt = (int)Nt.size();
-    wn_log2 = std::max(0, nt - 4);
-    mt_max = std::min(std::min(9 - wn_log2, ARTN_TILE_BITS_MAX - k), ARTN_TILE_BITS_MAX - nt);
-    mt_min = std::max(5, 7 - wn_log2);
-    for (int i : M)
-      if (ax[i].sA < (int64_t(1) << run_in) || ax[i].sC < (int64_t(1) << run_out)) Mt.push_back(i);
-    if ((int)Mt.size() <= mt_max) break;
     // too many forced bits: shorten the longer run and retry
     if (run_out >= run_in && run_out > 1) --run_out;
     else if (run_in > 1) --run_in;
     else { p.why_generic = "forced tile bits exceed the LDS tile"; return false; }
   }
-  if (mt_min > mt_max) { p.why_generic = "tile envelope empty"; return false; }
-  int mt_target = std::min(mt_max, std::max(mt_min, tuning().tile_target - k));
-  for (int i : M) {
-    if ((int)Mt.size() >= mt_target) break;
-    if (std::find(Mt.begin(), Mt.end(), i) == Mt.end()) Mt.push_back(i);
-  }
-  if ((int)Mt.size() < mt_min) { p.why_generic = "too few free A bits for a tile"; return false; }
-  const int mt = (int)Mt.size(), nt = (int)Nt.size();
+  const int mt = (int)Mt.size(), nt1 = (int)N1t.size(), nt2 = (int)N2t.size();
+  if (mt < 5) { p.why_generic = "too few free A bits for a tile"; return false; }
+  const int m2 = T_mid - k2; // free bits of stage 2's input tile
+  if (fused && m2 < 5) { p.why_generic = "too few free bits for the second stage"; return false; }
+  if (mt - 5 > 9 || (fused && m2 - 5 > 9)) { p.why_generic = "too many sub-tile bits"; return false; }
 
   ArtnBitsPlan &b = p.bits;
   memset(&b, 0, sizeof(b));
-  b.k = k; b.mt = mt; b.nt = nt;
-  b.T_in = k + mt; b.T_out = mt + nt;
-  b.wn_log2 = wn_log2; b.wm_log2 = 2 - wn_log2;
-  b.pm = (1 << (mt - 5)) >> b.wm_log2;
+  b.n_stages = fused ? 2 : 1;
+  b.T_in = T_in; b.T_mid = T_mid; b.T_out = T_out;
+  b.r0_bits = fused ? std::max(T_in, T_out) : T_in;
   b.run_in = run_in; b.run_out = run_out;
-  if (b.pm < 1 || b.pm > 4) { p.why_generic = "m sub-tiles per wave outside 1..4"; return false; }
 
-  // tile-local orders
-  std::vector<int> tin(K), tout(Mt);
+  // ---- tile-local orders: input (by A stride), mid (by C1 stride), output (by final C stride)
+  std::vector<int> tin(K1), tmid(Mt), tout;
   tin.insert(tin.end(), Mt.begin(), Mt.end());
-  tout.insert(tout.end(), Nt.begin(), Nt.end());
+  tmid.insert(tmid.end(), N1t.begin(), N1t.end());
   std::sort(tin.begin(), tin.end(), byA);
-  std::sort(tout.begin(), tout.end(), byC);
-  auto pos_in = [&](int axis) { return (int)(std::find(tin.begin(), tin.end(), axis) - tin.begin()); };
-  auto pos_out = [&](int axis) { return (int)(std::find(tout.begin(), tout.end(), axis) - tout.begin()); };
-  for (int i = 0; i < b.T_in; ++i) b.in_stride[i] = ax[tin[i]].sA;
-  for (int i = 0; i < b.T_out; ++i) b.out_stride[i] = ax[tout[i]].sC;
+  std::sort(tmid.begin(), tmid.end(), byC1);
+  if (fused) {
+    for (int i : tmid) if (!in_set(K2, i)) tout.push_back(i);
+    tout.insert(tout.end(), N2t.begin(), N2t.end());
+    std::sort(tout.begin(), tout.end(), byC);
+  } else {
+    tout = tmid;
+  }
+  auto pos = [](const std::vector<int> &v, int axis) { return (int)(std::find(v.begin(), v.end(), axis) - v.begin()); };
+  for (int i = 0; i < T_in; ++i) b.in_stride[i] = ax[tin[i]].sA;
+  for (int i = 0; i < T_out; ++i) b.out_stride[i] = ax[tout[i]].sC;
   for (int i = 0; i < run_in; ++i)
     if (b.in_stride[i] != (int64_t(1) << i)) { p.why_generic = "internal: input run broken"; return false; }
   for (int i = 0; i < run_out; ++i)
     if (b.out_stride[i] != (int64_t(1) << i)) { p.why_generic = "internal: output run broken"; return false; }
-  std::vector<int> Mts(Mt);
-  std::sort(Mts.begin(), Mts.end(), [&](int x, int y) { return pos_in(x) < pos_in(y); });
-  for (int i = 0; i < 5; ++i) { b.lane_in_pos[i] = pos_in(Mts[i]); b.lane_out_pos[i] = pos_out(Mts[i]); }
-  for (int i = 5; i < mt; ++i) { b.msub_in_pos[i - 5] = pos_in(Mts[i]); b.msub_out_pos[i - 5] = pos_out(Mts[i]); }
-  for (int i = 0; i < k; ++i) { b.k_in_pos[i] = pos_in(K[i]); b.k_b_stride[i] = ax[K[i]].sB; }
-  for (int i = 0; i < nt; ++i) { b.n_out_pos[i] = pos_out(Nt[i]); b.n_b_stride[i] = ax[Nt[i]].sB; }
 
-  // outer axes: N-outer fastest (tiles sharing an A tile run together), then M-outer by A stride,
-  // then batch / generic axes by A (or B) stride
+  auto fill_stage = [&](ArtnStage &s, const std::vector<int> &Kx, const std::vector<int> &Mx,
+                        const std::vector<int> &Nx, const std::vector<int> &tile_in,
+                        const std::vector<int> &tile_out, bool second) {
+    s.k = (int)Kx.size();
+    s.nt = (int)Nx.size();
+    s.wn_log2 = std::max(0, s.nt - 4);
+    s.m_bits = (int)Mx.size();
+    std::vector<int> Ms(Mx);
+    std::sort(Ms.begin(), Ms.end(), [&](int x, int y) { return pos(tile_in, x) < pos(tile_in, y); });
+    for (int i = 0; i < 5; ++i) { s.lane_in_pos[i] = pos(tile_in, Ms[i]); s.lane_out_pos[i] = pos(tile_out, Ms[i]); }
+    for (int i = 5; i < s.m_bits; ++i) { s.msub_in_pos[i - 5] = pos(tile_in, Ms[i]); s.msub_out_pos[i - 5] = pos(tile_out, Ms[i]); }
+    for (int i = 0; i < s.k; ++i) { s.k_in_pos[i] = pos(tile_in, Kx[i]); s.k_b_stride[i] = second ? ax[Kx[i]].sB2 : ax[Kx[i]].sB1; }
+    for (int i = 0; i < s.nt; ++i) { s.n_out_pos[i] = pos(tile_out, Nx[i]); s.n_b_stride[i] = second ? ax[Nx[i]].sB2 : ax[Nx[i]].sB1; }
+  };
+  fill_stage(b.st[0], K1, Mt, N1t, tin, tmid, false);
+  if (fused) {
+    std::vector<int> M2t;
+    for (int i : tmid) if (!in_set(K2, i)) M2t.push_back(i);
+    fill_stage(b.st[1], K2, M2t, N2t, tmid, tout, true);
+  }
+
+  // ---- outer axes: N-outer fastest (tiles sharing an A tile run together), then M-outer by A
+  //      stride, then batch / generic axes
   std::vector<int> outer;
-  for (int i : N) if (std::find(Nt.begin(), Nt.end(), i) == Nt.end()) outer.push_back(i);
-  for (int i : M) if (std::find(Mt.begin(), Mt.end(), i) == Mt.end()) outer.push_back(i);
+  for (int i : N2) if (!in_set(N2t, i)) outer.push_back(i);
+  for (int i : N1) if (!in_set(N1t, i)) outer.push_back(i);
+  for (int i : M1) if (!in_set(Mt, i)) outer.push_back(i);
   std::sort(O.begin(), O.end(), [&](int x, int y) {
-    int64_t sx = ax[x].inA() ? ax[x].sA : ax[x].sB, sy = ax[y].inA() ? ax[y].sA : ax[y].sB;
-    return sx < sy;
+    auto key = [&](int z) { return ax[z].sA >= 0 ? ax[z].sA : (ax[z].sB1 >= 0 ? ax[z].sB1 : ax[z].sB2); };
+    return key(x) < key(y);
   });
   outer.insert(outer.end(), O.begin(), O.end());
   b.n_tiles = 1;
@@ -334,19 +451,19 @@ static inline bool make_bits(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
     const Axis &a = ax[i];
     ArtnOuterDim od;
     od.ext = a.ext;
-    od.sA = a.inA() ? a.sA : 0;
-    od.sB = a.inB() ? a.sB : 0;
-    od.sC = a.inC() ? a.sC : 0;
+    od.sA = a.sA >= 0 ? a.sA : 0;
+    od.sB1 = a.sB1 >= 0 ? a.sB1 : 0;
+    od.sB2 = a.sB2 >= 0 ? a.sB2 : 0;
+    od.sC = a.sC >= 0 ? a.sC : 0;
     od.log2ext = ilog2_exact(a.ext);
     od.pad_ = 0;
     b.n_tiles *= a.ext;
-    if (!a.inA()) a_rereads *= a.ext;
+    if (a.sA < 0) a_rereads *= a.ext;
     if (b.n_outer > 0) { // merge with the previous dim when both are powers of two and contiguous everywhere
       ArtnOuterDim &pr = b.outer[b.n_outer - 1];
-      bool okA = (pr.sA == 0 && od.sA == 0) || (pr.sA != 0 && od.sA == pr.sA * pr.ext);
-      bool okB = (pr.sB == 0 && od.sB == 0) || (pr.sB != 0 && od.sB == pr.sB * pr.ext);
-      bool okC = (pr.sC == 0 && od.sC == 0) || (pr.sC != 0 && od.sC == pr.sC * pr.ext);
-      if (pr.log2ext >= 0 && od.log2ext >= 0 && okA && okB && okC && pr.log2ext + od.log2ext < 31) {
+      auto okf = [&](int64_t ps, int64_t ns) { return (ps == 0 && ns == 0) || (ps != 0 && ns == ps * pr.ext); };
+      if (pr.log2ext >= 0 && od.log2ext >= 0 && okf(pr.sA, od.sA) && okf(pr.sB1, od.sB1) && okf(pr.sB2, od.sB2) &&
+          okf(pr.sC, od.sC) && pr.log2ext + od.log2ext < 31) {
         pr.ext *= od.ext;
         pr.log2ext += od.log2ext;
         continue;
@@ -356,6 +473,7 @@ static inline bool make_bits(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
     b.outer[b.n_outer++] = od;
   }
 
+  // ---- envelope checks
   // the copy phases move 16 bytes (two elements) per lane and need every thread busy
   if (b.T_in < 9 || b.T_out < 9) { p.why_generic = "tile smaller than one copy pass"; return false; }
   for (int i = 1; i < b.T_in; ++i) if (b.in_stride[i] & 1) { p.why_generic = "odd A stride"; return false; }
@@ -364,29 +482,47 @@ static inline bool make_bits(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
     if ((b.outer[i].sA & 1) || (b.outer[i].sC & 1)) { p.why_generic = "odd outer stride"; return false; }
   {
     // per-lane byte offsets inside the kernel are 32-bit: copy chunks span tile bits 1..8,
-    // the small operand is addressed by its N_t / K bits
-    int64_t si = 0, so = 0, sb = 0;
+    // the small operands are addressed by their N_t / K bits
+    int64_t si = 0, so = 0;
     for (int i = 1; i <= 8; ++i) { si += b.in_stride[i]; so += b.out_stride[i]; }
-    for (int i = 0; i < nt; ++i) sb += b.n_b_stride[i];
-    for (int i = 0; i < k; ++i) sb += b.k_b_stride[i];
     const int64_t lim = (int64_t(1) << 28) - 1; // elements: * 8 B < 2^31
-    if (si > lim || so > lim || sb > lim) { p.why_generic = "lane offsets exceed 32 bits"; return false; }
+    bool wide = si > lim || so > lim;
+    for (int s = 0; s < b.n_stages; ++s) {
+      int64_t sb = 0;
+      for (int i = 0; i < b.st[s].nt; ++i) sb += b.st[s].n_b_stride[i];
+      for (int i = 0; i < b.st[s].k; ++i) sb += b.st[s].k_b_stride[i];
+      wide = wide || sb > lim;
+    }
+    if (wide) { p.why_generic = "lane offsets exceed 32 bits"; return false; }
   }
   if (b.n_tiles < min_tiles) { p.why_generic = "too few tiles to fill the chip"; return false; }
 
   p.kernel = ARTN_KERNEL_BITS_MFMA;
   ArtnStepInfo &f = p.info;
   f.kernel = ARTN_KERNEL_BITS_MFMA;
-  f.k_bits = k; f.m_tile_bits = mt; f.n_tile_bits = nt;
+  f.k_bits = k1; f.m_tile_bits = mt; f.n_tile_bits = nt1;
   f.tile_in_bits = b.T_in; f.tile_out_bits = b.T_out;
   f.run_in_bits = run_in; f.run_out_bits = run_out;
-  f.lds_bytes = 8 << std::max(b.T_in, b.T_out);
+  // two tile regions + the sub-tile offset tables of both stages (8 bytes per sub-tile)
+  f.lds_bytes = (int32_t)((8LL << b.r0_bits) + (8LL << b.T_mid) + (8LL << (mt - 5)) + (fused ? (8LL << (m2 - 5)) : 0));
   f.n_tiles = b.n_tiles;
   f.a_rereads = a_rereads;
+  f.k2_bits = k2; f.n2_tile_bits = nt2; f.tile_mid_bits = b.T_mid;
   int wg_per_cu = std::max(1, std::min(tuning().wg_per_cu, (160 * 1024) / f.lds_bytes));
   f.grid = (int32_t)std::min<int64_t>(b.n_tiles, (int64_t)n_cu * wg_per_cu);
-  (void)m;
   return true;
+}
+
+static inline void step_cost(const ArtnStepDesc *d, double &flops, double &na, double &nb, double &nc) {
+  double prod = 1;
+  na = nb = nc = 1;
+  for (int l = 0; l < d->n_labels; ++l) {
+    prod *= (double)d->extent[l];
+    if (d->stride_a[l] >= 0) na *= (double)d->extent[l];
+    if (d->stride_b[l] >= 0) nb *= (double)d->extent[l];
+    if (d->stride_c[l] >= 0) nc *= (double)d->extent[l];
+  }
+  flops = 8.0 * prod;
 }
 
 // min_tiles: below this many LDS tiles the strided kernel is used instead (a handful of
@@ -396,17 +532,29 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   int rc = validate(d, err);
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
-  double prod = 1, na = 1, nb = 1, nc = 1;
-  for (int l = 0; l < d->n_labels; ++l) {
-    prod *= (double)d->extent[l];
-    if (d->stride_a[l] >= 0) na *= (double)d->extent[l];
-    if (d->stride_b[l] >= 0) nb *= (double)d->extent[l];
-    if (d->stride_c[l] >= 0) nc *= (double)d->extent[l];
-  }
-  bool ok = allow_bits && make_bits(d, p, n_cu, min_tiles);
+  bool ok = allow_bits && make_bits(d, nullptr, p, n_cu, min_tiles);
   if (!ok && !make_generic(d, p, err)) return ARTN_E_UNSUPPORTED;
-  p.info.flops = 8.0 * prod;
+  double na, nb, nc;
+  step_cost(d, p.info.flops, na, nb, nc);
   p.info.bytes = (d->dtype == ARTN_C64 ? 8.0 : 16.0) * (na + nb + nc);
+  return ARTN_OK;
+}
+
+// Two consecutive steps on the same big operand, d2's A being d1's C, in ONE pass.
+// Fails with ARTN_E_UNSUPPORTED (err says why) when the pair does not fit one LDS tile;
+// the caller then runs the two steps one after the other.
+static inline int make_plan_fused(const ArtnStepDesc *d1, const ArtnStepDesc *d2, ArtnPlan &p, std::string &err,
+                                  int n_cu = 256, int64_t min_tiles = 32) {
+  int rc = validate(d1, err);
+  if (!rc) rc = validate(d2, err);
+  if (rc) return rc;
+  memset(&p.info, 0, sizeof(p.info));
+  if (!make_bits(d1, d2, p, n_cu, min_tiles)) { err = "not fusable: " + p.why_generic; return ARTN_E_UNSUPPORTED; }
+  double f1, f2, a1, b1, c1, a2, b2, c2;
+  step_cost(d1, f1, a1, b1, c1);
+  step_cost(d2, f2, a2, b2, c2);
+  p.info.flops = f1 + f2;
+  p.info.bytes = 8.0 * (a1 + b1 + b2 + c2); // the intermediate C1 never touches HBM
   return ARTN_OK;
 }
 

@@ -77,6 +77,10 @@ typedef struct ArtnStepInfo {
   int64_t a_rereads;    /* how many tiles read each A element (outer-N split)   */
   double flops;         /* 8 * prod(all extents) real FLOP (c64 MAC = 8)        */
   double bytes;         /* compulsory: 8|16 * (numel A + numel B + numel C)     */
+  int32_t k2_bits;      /* fused pair: contracted bits of the second step (else 0) */
+  int32_t n2_tile_bits; /* fused pair: free B2 bits inside a tile                  */
+  int32_t tile_mid_bits;/* log2 elements of the tile between the two stages        */
+  int32_t reserved_;
 } ArtnStepInfo;
 
 int artn_abi_version(void);
@@ -90,6 +94,20 @@ int artn_contract_query(const ArtnStepDesc *d, ArtnStepInfo *info);
 
 /* Enqueue one pairwise contraction (replaces torch.einsum at contraction.py:70 etc.). */
 int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *stream);
+
+/*
+ * Two consecutive steps on the same big operand in ONE pass over HBM:
+ *     C1 = contract(d1; A, B1);  C = contract(d2; C1, B2)
+ * i.e. two successive iterations of the loop at artensor/contraction.py:66-70 whose first
+ * operand is the same `tensors[i]` (the growing state tensor is always operand 0,
+ * contraction.py:41-46).  d2's stride_a must describe d1's dense result C1, which is
+ * never written to memory: the second contraction runs on the tile while it is in LDS.
+ * artn_contract2_query / artn_contract2 return ARTN_E_UNSUPPORTED when the pair does not
+ * fit one LDS tile (artn_last_error() says why); callers then issue two artn_contract.
+ */
+int artn_contract2_query(const ArtnStepDesc *d1, const ArtnStepDesc *d2, ArtnStepInfo *info);
+int artn_contract2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A, const void *B1,
+                   const void *B2, void *C, void *stream);
 
 /*
  * dst[r, :] = src[idx[r], :] for r < nrows, rows of `row_bytes` bytes (multiple of 8).
@@ -107,8 +125,7 @@ int artn_axpy_c64(void *acc, const void *x, int64_t n, void *stream);
 
 /* out[0] = max_i |x[i]| over n complex64 elements (float32, device pointer), then
  * x[i] /= out[0]: the running renormalisation of artensor/contraction.py:197-200
- * (`norm_factor = tensors[i].abs().max(); tensors[i] /= norm_factor`).
- * `scratch` is a device buffer of at least 4 bytes that the call zeroes itself. */
+ * (`norm_factor = tensors[i].abs().max(); tensors[i] /= norm_factor`). */
 int artn_absmax_normalize_c64(void *x, int64_t n, float *out_absmax, void *stream);
 
 #ifdef __cplusplus

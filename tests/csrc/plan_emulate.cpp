@@ -1,28 +1,85 @@
 // CPU emulation of artn_k_bits (artensor_amd/csrc/artn_kernels.hip), TEST-ONLY.
 // It replays the kernel thread by thread -- copy-in chunks, per-lane fragment offsets,
-// the 32x32x2 MFMA lane maps of the gfx950 guide, the in-place LDS transpose and the
-// copy-out -- from the same ArtnBitsPlan the GPU receives, so the planner's index algebra
-// can be checked against the oracle on a box without a GPU.  Never linked into the product.
+// the 32x32x2 MFMA lane maps of the gfx950 guide, the scatter into the second LDS region,
+// the optional fused second stage and the copy-out -- from the same ArtnBitsPlan the GPU
+// receives, so the planner's index algebra can be checked against the oracle on a box
+// without a GPU.  Never linked into the product.
 #include <complex>
 #include <vector>
 #include "artn_plan.h"
 
 typedef std::complex<float> cf;
 
-static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B, cf *C) {
-  const int KB = P.k, PM = P.pm, S = 1 << (KB - 1);
-  const int nt_eff = P.nt < 4 ? P.nt : 4;
-  std::vector<cf> lds((size_t)1 << std::max(P.T_in, P.T_out));
+static void run_stage(const ArtnStage &st, const cf *in, cf *out, const cf *B, int64_t offB) {
+  const int KB = st.k, S = 1 << (KB - 1);
+  const int nt_eff = st.nt < 4 ? st.nt : 4;
+  const int wm_count = 4 >> st.wn_log2, msubs = 1 << (st.m_bits - 5);
+  const int o0 = st.nt > 0 ? 1 << st.n_out_pos[0] : 0, o2 = st.nt > 2 ? 1 << st.n_out_pos[2] : 0,
+            o3 = st.nt > 3 ? 1 << st.n_out_pos[3] : 0;
+  for (int wave = 0; wave < 4; ++wave) {
+    const int wn = wave & ((1 << st.wn_log2) - 1), wm = wave >> st.wn_log2;
+    for (int msub = wm; msub < msubs; msub += wm_count) {
+      int oi = 0, oo = 0;
+      for (int b = 0; b < st.m_bits - 5; ++b)
+        if ((msub >> b) & 1) { oi += 1 << st.msub_in_pos[b]; oo += 1 << st.msub_out_pos[b]; }
+      float acc[64][16];
+      for (auto &r : acc) for (float &x : r) x = 0.f;
+      int lane_out[64];
+      for (int s = 0; s < S; ++s) {
+        int ko = 0; int64_t kbo = 0;
+        for (int b = 1; b < KB; ++b) if ((s >> (b - 1)) & 1) { ko += 1 << st.k_in_pos[b]; kbo += st.k_b_stride[b]; }
+        float W0[64], W1[64], ax[64], ay[64];
+        for (int lane = 0; lane < 64; ++lane) {
+          const int j = lane & 31, h = lane >> 5, ro = j & 1, nloc = j >> 1;
+          int li = h << st.k_in_pos[0], lo = 0;
+          for (int b = 0; b < 5; ++b) if ((j >> b) & 1) { li += 1 << st.lane_in_pos[b]; lo += 1 << st.lane_out_pos[b]; }
+          if (st.nt > 1) lo += h << st.n_out_pos[1];
+          int64_t lb = (int64_t)h * st.k_b_stride[0];
+          for (int b = 0; b < nt_eff; ++b) if ((nloc >> b) & 1) lb += st.n_b_stride[b];
+          for (int b = 0; b < st.wn_log2; ++b) if ((wn >> b) & 1) { lo += 1 << st.n_out_pos[4 + b]; lb += st.n_b_stride[4 + b]; }
+          lane_out[lane] = lo;
+          cf bv(0.f, 0.f);
+          if ((nloc >> nt_eff) == 0) bv = B[offB + lb + kbo];
+          W0[lane] = ro ? bv.imag() : bv.real();
+          W1[lane] = ro ? bv.real() : -bv.imag();
+          const cf a = in[li + oi + ko];
+          ax[lane] = a.real(); ay[lane] = a.imag();
+        }
+        // two v_mfma_f32_32x32x2_f32: D[i][j] += sum_kk Aop[i][kk] * Bop[kk][j]
+        for (int phase = 0; phase < 2; ++phase) {
+          const float *Wp = phase ? W1 : W0, *ap = phase ? ay : ax;
+          for (int lane = 0; lane < 64; ++lane)
+            for (int rr = 0; rr < 16; ++rr) {
+              const int i = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5), jj = lane & 31;
+              for (int kk = 0; kk < 2; ++kk) acc[lane][rr] += Wp[i + 32 * kk] * ap[jj + 32 * kk];
+            }
+        }
+      }
+      for (int lane = 0; lane < 64; ++lane) {
+        const int h = lane >> 5;
+        for (int q = 0; q < 4; ++q)
+          for (int b0 = 0; b0 < 2; ++b0) {
+            const int nl = b0 + 2 * h + 4 * (q & 1) + 8 * (q >> 1);
+            if ((nl >> nt_eff) == 0)
+              out[lane_out[lane] + oo + b0 * o0 + (q & 1) * o2 + (q >> 1) * o3] =
+                  cf(acc[lane][4 * q + 2 * b0], acc[lane][4 * q + 2 * b0 + 1]);
+          }
+      }
+    }
+  }
+}
+
+static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf *B2, cf *C) {
+  std::vector<cf> R0((size_t)1 << P.r0_bits), R1((size_t)1 << P.T_mid);
   const int n_in_iters = 1 << (P.T_in - 9), n_out_iters = 1 << (P.T_out - 9);
   for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
-    int64_t r = tile, offA = 0, offB = 0, offC = 0;
+    int64_t r = tile, offA = 0, offB1 = 0, offB2 = 0, offC = 0;
     for (int d = 0; d < P.n_outer; ++d) {
       int64_t ext = P.outer[d].ext, x;
       if (P.outer[d].log2ext >= 0) { x = r & (ext - 1); r >>= P.outer[d].log2ext; }
       else { x = r % ext; r /= ext; }
-      offA += x * P.outer[d].sA; offB += x * P.outer[d].sB; offC += x * P.outer[d].sC;
+      offA += x * P.outer[d].sA; offB1 += x * P.outer[d].sB1; offB2 += x * P.outer[d].sB2; offC += x * P.outer[d].sC;
     }
-    // copy-in
     for (int tid = 0; tid < 256; ++tid) {
       int64_t in_lane = 0;
       for (int b = 1; b <= 8; ++b) if ((tid >> (b - 1)) & 1) in_lane += P.in_stride[b];
@@ -30,79 +87,16 @@ static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B, cf *C) {
         int64_t off = 0;
         for (int b = 9; b < P.T_in; ++b) if ((i >> (b - 9)) & 1) off += P.in_stride[b];
         const cf *src = A + offA + in_lane + off;
-        lds[2 * (tid + 256 * i)] = src[0];
-        lds[2 * (tid + 256 * i) + 1] = src[1];
+        R0[2 * (tid + 256 * i)] = src[0];
+        R0[2 * (tid + 256 * i) + 1] = src[1];
       }
     }
-    // MFMA phase, wave by wave; results kept per wave/lane until every wave has read LDS
-    std::vector<float> acc((size_t)4 * 64 * PM * 16, 0.f);
-    for (int wave = 0; wave < 4; ++wave) {
-      const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
-      int64_t wn_b = 0;
-      for (int b = 0; b < P.wn_log2; ++b) if ((wn >> b) & 1) wn_b += P.n_b_stride[4 + b];
-      for (int pm = 0; pm < PM; ++pm) {
-        const int msub = wm * PM + pm;
-        int msub_in = 0;
-        for (int b = 0; b < P.mt - 5; ++b) if ((msub >> b) & 1) msub_in += 1 << P.msub_in_pos[b];
-        for (int s = 0; s < S; ++s) {
-          int ko = 0; int64_t kbo = 0;
-          for (int b = 1; b < KB; ++b) if ((s >> (b - 1)) & 1) { ko += 1 << P.k_in_pos[b]; kbo += P.k_b_stride[b]; }
-          float W0[64], W1[64], ax[64], ay[64];
-          for (int lane = 0; lane < 64; ++lane) {
-            const int j = lane & 31, h = lane >> 5;
-            int lane_in = h << P.k_in_pos[0];
-            for (int b = 0; b < 5; ++b) if ((j >> b) & 1) lane_in += 1 << P.lane_in_pos[b];
-            const int ro = j & 1, nloc = j >> 1;
-            int64_t lane_b = (int64_t)h * P.k_b_stride[0] + wn_b;
-            for (int b = 0; b < nt_eff; ++b) if ((nloc >> b) & 1) lane_b += P.n_b_stride[b];
-            cf bv(0.f, 0.f);
-            if ((nloc >> nt_eff) == 0) bv = B[offB + lane_b + kbo];
-            W0[lane] = ro ? bv.imag() : bv.real();
-            W1[lane] = ro ? bv.real() : -bv.imag();
-            cf a = lds[lane_in + msub_in + ko];
-            ax[lane] = a.real(); ay[lane] = a.imag();
-          }
-          // two v_mfma_f32_32x32x2_f32: D[i][j] += sum_kk Aop[i][kk] * Bop[kk][j]
-          for (int phase = 0; phase < 2; ++phase) {
-            const float *Wp = phase ? W1 : W0, *ap = phase ? ay : ax;
-            for (int lane = 0; lane < 64; ++lane)
-              for (int rr = 0; rr < 16; ++rr) {
-                const int i = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5), jj = lane & 31;
-                float sum = acc[((size_t)(wave * 64 + lane) * PM + pm) * 16 + rr];
-                for (int kk = 0; kk < 2; ++kk) sum += Wp[i + 32 * kk] * ap[jj + 32 * kk];
-                acc[((size_t)(wave * 64 + lane) * PM + pm) * 16 + rr] = sum;
-              }
-          }
-        }
-      }
+    run_stage(P.st[0], R0.data(), R1.data(), B1, offB1);
+    const cf *outr = R1.data();
+    if (P.n_stages == 2) {
+      run_stage(P.st[1], R1.data(), R0.data(), B2, offB2);
+      outr = R0.data();
     }
-    // accumulators -> LDS (output-tile order)
-    const int o0 = P.nt > 0 ? 1 << P.n_out_pos[0] : 0, o2 = P.nt > 2 ? 1 << P.n_out_pos[2] : 0,
-              o3 = P.nt > 3 ? 1 << P.n_out_pos[3] : 0;
-    for (int wave = 0; wave < 4; ++wave) {
-      const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
-      int wn_out = 0;
-      for (int b = 0; b < P.wn_log2; ++b) if ((wn >> b) & 1) wn_out += 1 << P.n_out_pos[4 + b];
-      for (int lane = 0; lane < 64; ++lane) {
-        const int j = lane & 31, h = lane >> 5;
-        int lane_out = wn_out;
-        for (int b = 0; b < 5; ++b) if ((j >> b) & 1) lane_out += 1 << P.lane_out_pos[b];
-        if (P.nt > 1) lane_out += h << P.n_out_pos[1];
-        for (int pm = 0; pm < PM; ++pm) {
-          const int msub = wm * PM + pm;
-          int msub_out = 0;
-          for (int b = 0; b < P.mt - 5; ++b) if ((msub >> b) & 1) msub_out += 1 << P.msub_out_pos[b];
-          const float *a = &acc[((size_t)(wave * 64 + lane) * PM + pm) * 16];
-          for (int q = 0; q < 4; ++q)
-            for (int b0 = 0; b0 < 2; ++b0) {
-              const int nl = b0 + 2 * h + 4 * (q & 1) + 8 * (q >> 1);
-              if ((nl >> nt_eff) == 0)
-                lds[lane_out + msub_out + b0 * o0 + (q & 1) * o2 + (q >> 1) * o3] = cf(a[4 * q + 2 * b0], a[4 * q + 2 * b0 + 1]);
-            }
-        }
-      }
-    }
-    // copy-out
     for (int tid = 0; tid < 256; ++tid) {
       int64_t out_lane = 0;
       for (int b = 1; b <= 8; ++b) if ((tid >> (b - 1)) & 1) out_lane += P.out_stride[b];
@@ -110,8 +104,8 @@ static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B, cf *C) {
         int64_t off = 0;
         for (int b = 9; b < P.T_out; ++b) if ((i >> (b - 9)) & 1) off += P.out_stride[b];
         cf *dst = C + offC + out_lane + off;
-        dst[0] = lds[2 * (tid + 256 * i)];
-        dst[1] = lds[2 * (tid + 256 * i) + 1];
+        dst[0] = outr[2 * (tid + 256 * i)];
+        dst[1] = outr[2 * (tid + 256 * i) + 1];
       }
     }
   }
@@ -139,7 +133,19 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
   if (rc) return rc;
   if (kernel_used) *kernel_used = p.kernel;
   if (d->dtype != ARTN_C64) return ARTN_E_UNSUPPORTED;
-  if (p.kernel == ARTN_KERNEL_BITS_MFMA) run_bits(p.bits, (const cf *)A, (const cf *)B, (cf *)C);
+  if (p.kernel == ARTN_KERNEL_BITS_MFMA) run_bits(p.bits, (const cf *)A, (const cf *)B, nullptr, (cf *)C);
   else run_generic(p.gen, (const cf *)A, (const cf *)B, (cf *)C);
+  return 0;
+}
+
+// Fused pair.  Returns ARTN_E_UNSUPPORTED when the planner declines to fuse.
+extern "C" int artn_emulate2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A, const void *B1,
+                             const void *B2, void *C, ArtnStepInfo *info) {
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::make_plan_fused(d1, d2, p, err, 256, 1);
+  if (rc) return rc;
+  if (info) *info = p.info;
+  run_bits(p.bits, (const cf *)A, (const cf *)B1, (const cf *)B2, (cf *)C);
   return 0;
 }

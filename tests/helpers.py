@@ -85,3 +85,52 @@ def emulate(eq, a, b, force_generic=False):
                                  out.ctypes.data_as(ctypes.c_void_p), int(force_generic), ctypes.byref(used))
     assert rc == 0, rc
     return out, used.value
+
+
+def shrink_pair(eq1, a_shape, b1_shape, eq2, b2_shape, max_log2=17):
+    """Surrogate of two consecutive big steps (eq2's first operand is eq1's result, matched
+    by position): drop axes that are free in BOTH steps, highest A positions first."""
+    lhs, lo1 = eq1.split("->")
+    la1, lb1 = lhs.split(",")
+    lhs2, lo2 = eq2.split("->")
+    la2, lb2 = lhs2.split(",")
+    la1, lo1, la2, lo2 = list(la1), list(lo1), list(la2), list(lo2)
+    a_shape = list(a_shape)
+    numel = int(np.prod(a_shape))
+    pos = 0
+    while numel > 2 ** max_log2 and pos < len(la1):
+        lab = la1[pos]
+        if lab not in lb1 and lab in lo1:
+            lab2 = la2[lo1.index(lab)]
+            if lab2 not in lb2 and lab2 in lo2:
+                numel //= a_shape[pos]
+                la1.pop(pos)
+                a_shape.pop(pos)
+                k = lo1.index(lab)
+                lo1.pop(k)
+                la2.pop(k)
+                lo2.remove(lab2)
+                continue
+        pos += 1
+    return ("".join(la1) + "," + lb1 + "->" + "".join(lo1), tuple(a_shape), tuple(b1_shape),
+            "".join(la2) + "," + lb2 + "->" + "".join(lo2), tuple(b2_shape))
+
+
+def emulate2(eq1, a, b1, eq2, b2):
+    """Fused pair through the emulator; returns the result or None if the planner declines."""
+    import torch
+    from artensor_amd import contraction as C
+    from artensor_amd import _native as N
+    emu = emulator()
+    emu.artn_emulate2.restype = ctypes.c_int
+    ta, tb1, tb2 = torch.from_numpy(a), torch.from_numpy(b1), torch.from_numpy(b2)
+    d1, d2, out_shape = C._pair_descriptors(eq1, ta, tb1, eq2, tb2)
+    out = np.zeros(out_shape, dtype=np.complex64)
+    info = N.ArtnStepInfo()
+    rc = emu.artn_emulate2(ctypes.byref(d1), ctypes.byref(d2), a.ctypes.data_as(ctypes.c_void_p),
+                           b1.ctypes.data_as(ctypes.c_void_p), b2.ctypes.data_as(ctypes.c_void_p),
+                           out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info))
+    if rc == -2:
+        return None, None
+    assert rc == 0, rc
+    return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}

@@ -119,6 +119,79 @@ def test_n30_big_steps_surrogates():
         assert rel(hip_step(eq2, a, b), oracle.einsum_pair(eq2, a, b)) < STEP_TOL, (n, eq2)
 
 
+def test_n30_fused_pairs_surrogates():
+    """Two consecutive big steps in ONE pass (artn_contract2): all 13 fusable pairs of the
+    n30 scheme, both steps truncated consistently to 2^22 elements, against the oracle run
+    step by step."""
+    from artensor_amd.contraction import fusion_schedule, contract2
+    from helpers import shrink_pair
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    pairs = [e for e in fusion_schedule(case.scheme) if e[0] == "pair" and np.prod(steps[e[1]][1]) >= 2 ** 22]
+    assert len(pairs) == 13
+    fused = 0
+    for _, n, m in pairs:
+        eq1, sa, sb1 = steps[n]
+        eq2, _, sb2 = steps[m]
+        e1, a_s, b1_s, e2, b2_s = shrink_pair(eq1, sa, sb1, eq2, sb2, max_log2=22)
+        rng = np.random.default_rng(n)
+        a, b1, b2 = crandn(rng, a_s), crandn(rng, b1_s), crandn(rng, b2_s)
+        got = contract2(e1, gpu(a), gpu(b1), e2, gpu(b2))
+        if got is None:
+            continue
+        fused += 1
+        want = oracle.einsum_pair(e2, oracle.einsum_pair(e1, a, b1), b2)
+        assert rel(got.cpu().numpy(), want) < STEP_TOL, (n, m)
+    assert fused >= 10
+
+
+def test_random_fused_pairs(monkeypatch):
+    from artensor_amd.contraction import contract2
+    monkeypatch.setenv("ARTN_FORCE_BITS", "1")
+    rng = np.random.default_rng(3)
+    done = 0
+    for trial in range(40):
+        ra = int(rng.integers(13, 19))
+        k1, n1, k2, n2 = (int(x) for x in rng.integers(1, 7, size=4))
+        la = [chr(65 + x) for x in range(ra)]
+        kl1 = list(rng.choice(la, size=k1, replace=False))
+        nl1 = [chr(97 + x) for x in range(n1)]
+        lb1 = kl1 + nl1
+        rng.shuffle(lb1)
+        lo1 = [x for x in la if x not in kl1] + nl1
+        rng.shuffle(lo1)
+        if k2 > len(lo1) - 6:
+            continue
+        kl2 = list(rng.choice(lo1, size=k2, replace=False))
+        nl2 = [chr(110 + x) for x in range(n2)]
+        lb2 = kl2 + nl2
+        rng.shuffle(lb2)
+        lo2 = [x for x in lo1 if x not in kl2] + nl2
+        rng.shuffle(lo2)
+        eq1 = "".join(la) + "," + "".join(lb1) + "->" + "".join(lo1)
+        eq2 = "".join(lo1) + "," + "".join(lb2) + "->" + "".join(lo2)
+        a, b1, b2 = crandn(rng, (2,) * ra), crandn(rng, (2,) * len(lb1)), crandn(rng, (2,) * len(lb2))
+        got = contract2(eq1, gpu(a), gpu(b1), eq2, gpu(b2))
+        if got is None:
+            continue
+        want = oracle.einsum_pair(eq2, oracle.einsum_pair(eq1, a, b1), b2)
+        assert rel(got.cpu().numpy(), want) < STEP_TOL, (eq1, eq2)
+        done += 1
+    assert done >= 15
+
+
+def test_fused_and_unfused_schemes_agree(monkeypatch):
+    case = load_case(os.path.join(GOLDEN, "n30_dense_sliced3.npz"))
+    sliced = A.apply_slice(case.fresh_tensors(device=DEV), case.slicing_indices, [0, 1, 1])
+    fused = A.tensor_contraction(dict(sliced), case.scheme)
+    monkeypatch.setenv("ARTN_NO_FUSE", "1")
+    A.contraction._pair_cache.clear()
+    plain = A.tensor_contraction(dict(sliced), case.scheme)
+    A.contraction._pair_cache.clear()
+    d = (fused - plain).abs().max().item()
+    assert d <= 1e-5 * plain.abs().max().item()
+
+
 def test_batch_generic_dims_and_edge_cases():
     rng = np.random.default_rng(5)
     cases = [

@@ -40,7 +40,7 @@ def test_n30_big_steps_surrogates():
         # and the full-size step must be planned onto the MFMA kernel
         info = step_info(eq, sa, sb)
         assert info["kernel"] == KERNEL_BITS, (n, eq, info)
-        assert info["lds_bytes"] <= 64 * 1024
+        assert info["lds_bytes"] <= 72 * 1024
     assert n_bits >= 20  # the surrogates themselves mostly take the MFMA plan
 
 
@@ -83,3 +83,83 @@ def test_whole_n12_scheme_through_emulator():
     raw = tensors[case.scheme[-1][0][0]]
     want = case.arrays["raw"]
     assert np.abs(raw - want).max() / np.abs(want).max() < 5e-6
+
+
+def test_fusion_schedule_covers_every_step_once():
+    from artensor_amd.contraction import fusion_schedule
+    for name in ["n12_dense", "n30_dense", "n30_dense_sliced3", "rand_D2_closed"]:
+        case = load_case(os.path.join(GOLDEN, name + ".npz"))
+        sched = fusion_schedule(case.scheme)
+        seen = []
+        for e in sched:
+            seen += list(e[1:])
+        assert sorted(seen) == list(range(len(case.scheme)))
+        # dependencies: a step may only run after every earlier step touching its tensors
+        when = {}
+        for t, e in enumerate(sched):
+            for n in e[1:]:
+                when[n] = t
+        for n, step in enumerate(case.scheme):
+            for m in range(n):
+                if set(step[0]) & set(case.scheme[m][0]):
+                    assert when[m] <= when[n], (name, m, n)
+
+
+def test_n30_fused_pairs_surrogates():
+    """Every fusable pair of big n30 steps, both steps truncated consistently to 2^16."""
+    from artensor_amd.contraction import fusion_schedule, pair_info
+    from helpers import emulate2, shrink_pair
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    pairs = [e for e in fusion_schedule(case.scheme) if e[0] == "pair" and np.prod(steps[e[1]][1]) >= 2 ** 22]
+    assert len(pairs) == 13
+    fused = 0
+    for _, n, m in pairs:
+        eq1, sa, sb1 = steps[n]
+        eq2, _, sb2 = steps[m]
+        assert pair_info(eq1, sa, sb1, eq2, sb2) is not None, (n, m)
+        e1, a_s, b1_s, e2, b2_s = shrink_pair(eq1, sa, sb1, eq2, sb2, max_log2=16)
+        rng = np.random.default_rng(n)
+        a, b1, b2 = crandn(rng, a_s), crandn(rng, b1_s), crandn(rng, b2_s)
+        want = oracle.einsum_pair(e2, oracle.einsum_pair(e1, a, b1), b2)
+        got, info = emulate2(e1, a, b1, e2, b2)
+        if got is None:
+            continue
+        fused += 1
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (n, m)
+    assert fused >= 10
+
+
+def test_random_fused_pairs():
+    from helpers import emulate2
+    rng = np.random.default_rng(3)
+    done = 0
+    for trial in range(40):
+        ra = int(rng.integers(13, 17))
+        k1, n1, k2, n2 = (int(x) for x in rng.integers(1, 5, size=4))
+        la = [chr(65 + x) for x in range(ra)]
+        kl1 = list(rng.choice(la, size=k1, replace=False))
+        nl1 = [chr(97 + x) for x in range(n1)]
+        lb1 = kl1 + nl1
+        rng.shuffle(lb1)
+        lo1 = [x for x in la if x not in kl1] + nl1
+        rng.shuffle(lo1)
+        if k2 > len(lo1) - 6:
+            continue
+        kl2 = list(rng.choice(lo1, size=k2, replace=False))
+        nl2 = [chr(110 + x) for x in range(n2)]
+        lb2 = kl2 + nl2
+        rng.shuffle(lb2)
+        lo2 = [x for x in lo1 if x not in kl2] + nl2
+        rng.shuffle(lo2)
+        eq1 = "".join(la) + "," + "".join(lb1) + "->" + "".join(lo1)
+        eq2 = "".join(lo1) + "," + "".join(lb2) + "->" + "".join(lo2)
+        a, b1, b2 = crandn(rng, (2,) * ra), crandn(rng, (2,) * len(lb1)), crandn(rng, (2,) * len(lb2))
+        got, info = emulate2(eq1, a, b1, eq2, b2)
+        if got is None:
+            continue
+        want = oracle.einsum_pair(eq2, oracle.einsum_pair(eq1, a, b1), b2)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (eq1, eq2)
+        done += 1
+    assert done >= 15
