@@ -73,9 +73,9 @@ static int fail(int code, const std::string &msg) {
 
 // Diagnostic build only (make stamps): per-phase cycle sums of every wave, never in the product.
 #ifdef ARTN_STAMPS
-#define ARTN_N_STAMPS 8
+#define ARTN_N_STAMPS 12
 __device__ unsigned long long artn_stamp_buf[4096 * ARTN_N_STAMPS];
-#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[ARTN_N_STAMPS] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[ARTN_N_STAMPS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i)                                                   \
   do {                                                             \
     __builtin_amdgcn_sched_barrier(0);                             \
@@ -97,55 +97,81 @@ __device__ unsigned long long artn_stamp_buf[4096 * ARTN_N_STAMPS];
 
 // Tile index -> element offsets of the tile in A, B1, B2, C.
 // Reading the plan's outer-axis table with scalar loads inside the tile loop costs thousands
-// of cycles per tile (dependent s_load latency), so lane d of every wave keeps outer axis d
-// in registers for the whole kernel; per tile each lane extracts its own digit of the tile
-// index and a 6-step wave reduction sums the four offset contributions.
+// of cycles per tile (dependent s_load latency).  The outer axes that are powers of two
+// come first, so over their bits the map tile -> offset is bit-linear: at kernel start the
+// workgroup tabulates it per 4-bit nibble of the tile index in LDS (16 entries x 4 offsets
+// per nibble); per tile a handful of independent uniform-address LDS reads and adds replace
+// the scalar loop.  Non power-of-two axes (batch rows of the sparse path) sit above those
+// bits and are decoded from the plan the slow way.
 struct TileOff {
   long a, b1, b2, c;
 };
-struct OuterLane {
-  long div;      // product of the extents of the faster outer axes
-  long ext;      // 0 for lanes beyond n_outer
-  int shift, lg; // power-of-two prefix axes: digit = (tile >> shift) & (ext - 1)
-  long sA, sB1, sB2, sC;
+struct OffTab {
+  const long *tab; // LDS: [nibble index][16][4]
+  int n_nib;       // nibbles covering the power-of-two prefix
+  int pow2_bits;   // bits of that prefix
+  int first_generic;
 };
-__device__ __forceinline__ OuterLane outer_lane(const ArtnBitsPlan &P, int lane) {
-  OuterLane o = {1, 0, 0, -1, 0, 0, 0, 0};
-  long div = 1;
-  int shift = 0;
-  bool pow2_prefix = true;
-  for (int d = 0; d < P.n_outer; ++d) {
-    if (P.outer[d].log2ext < 0) pow2_prefix = false;
-    if (d == lane) {
-      o.div = div;
-      o.ext = P.outer[d].ext;
-      o.lg = pow2_prefix ? P.outer[d].log2ext : -1;
-      o.shift = shift;
-      o.sA = P.outer[d].sA;
-      o.sB1 = P.outer[d].sB1;
-      o.sB2 = P.outer[d].sB2;
-      o.sC = P.outer[d].sC;
+__device__ __forceinline__ OffTab build_offset_table(const ArtnBitsPlan &P, long *tab, int tid) {
+  OffTab T;
+  int bits = 0, d = 0;
+  for (; d < P.n_outer && P.outer[d].log2ext >= 0; ++d) bits += P.outer[d].log2ext;
+  T.tab = tab;
+  T.pow2_bits = bits;
+  T.n_nib = (bits + 3) >> 2;
+  T.first_generic = d;
+  if (tid < 16 * T.n_nib) {
+    const int nibble = tid >> 4, val = tid & 15;
+    long a = 0, b1 = 0, b2 = 0, c = 0;
+    for (int b = 0; b < 4; ++b) {
+      const int bit = 4 * nibble + b;
+      if (!((val >> b) & 1) || bit >= bits) continue;
+      int lo = 0;
+      for (int e = 0; e < T.first_generic; ++e) { // which axis owns tile bit `bit`
+        const int lg = P.outer[e].log2ext;
+        if (bit < lo + lg) {
+          const int r = bit - lo;
+          a += P.outer[e].sA << r;
+          b1 += P.outer[e].sB1 << r;
+          b2 += P.outer[e].sB2 << r;
+          c += P.outer[e].sC << r;
+          break;
+        }
+        lo += lg;
+      }
     }
-    div *= P.outer[d].ext;
-    if (P.outer[d].log2ext >= 0) shift += P.outer[d].log2ext;
+    long *e = tab + (long)tid * 4;
+    e[0] = a; e[1] = b1; e[2] = b2; e[3] = c;
   }
-  return o;
+  return T;
 }
-__device__ __forceinline__ long wave_sum_uniform(long x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+__device__ __forceinline__ long uniform64(long x) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)x);
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x >> 32));
   return (long)(((unsigned long)hi << 32) | lo);
 }
-__device__ __forceinline__ TileOff tile_offsets(const OuterLane &o, long tile) {
-  long x = 0;
-  if (o.ext > 0) x = o.lg >= 0 ? ((tile >> o.shift) & (o.ext - 1)) : ((tile / o.div) % o.ext);
-  TileOff t;
-  t.a = wave_sum_uniform(x * o.sA);
-  t.b1 = wave_sum_uniform(x * o.sB1);
-  t.b2 = wave_sum_uniform(x * o.sB2);
-  t.c = wave_sum_uniform(x * o.sC);
+__device__ __forceinline__ TileOff tile_offsets(const ArtnBitsPlan &P, const OffTab &T, long tile) {
+  long a = 0, b1 = 0, b2 = 0, c = 0;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    if (n < T.n_nib) {
+      const long *e = T.tab + ((n << 4) + (int)((tile >> (4 * n)) & 15)) * 4;
+      a += e[0]; b1 += e[1]; b2 += e[2]; c += e[3];
+    }
+  }
+  TileOff t = {uniform64(a), uniform64(b1), uniform64(b2), uniform64(c)};
+  if (T.first_generic < P.n_outer) { // rare: batch axes with arbitrary extents
+    long r = tile >> T.pow2_bits;
+    for (int d = T.first_generic; d < P.n_outer; ++d) {
+      const long ext = P.outer[d].ext;
+      const long x = r % ext;
+      r /= ext;
+      t.a += x * P.outer[d].sA;
+      t.b1 += x * P.outer[d].sB1;
+      t.b2 += x * P.outer[d].sB2;
+      t.c += x * P.outer[d].sC;
+    }
+  }
   return t;
 }
 
@@ -163,13 +189,30 @@ __device__ __forceinline__ void issue_loads(f32x4 (&v)[8], const char *__restric
 #pragma unroll
     for (int b = 0; b < 4; ++b)
       if ((i >> b) & 1) off += hi[b];
+#ifdef ARTN_ABLATE_MEM
+    v[u] = f32x4{1.f, 2.f, 3.f, 4.f};
+    asm volatile("" : "+v"(v[u]) : "s"(Abase), "v"(lane_off));
+#else
     v[u] = *reinterpret_cast<const f32x4 *>(Abase + off + lane_off);
+#endif
   }
 }
 __device__ __forceinline__ void store_lds(const f32x4 (&v)[8], char *ldsb, unsigned tid16, int i0, int n_iters) {
 #pragma unroll
   for (int u = 0; u < 8; ++u)
     if (i0 + u < n_iters) *reinterpret_cast<f32x4 *>(ldsb + tid16 + (i0 + u) * (ARTN_WG_THREADS * 16)) = v[u];
+}
+
+// XOR swizzle of an LDS region (ArtnStage::swz_*), applied to byte offsets.  It is linear over
+// XOR and every LDS address below is a sum of disjoint bit fields, so each field is swizzled
+// once at kernel start and the fields are combined with XOR: no per-access cost.
+__device__ __forceinline__ unsigned swz(unsigned byte_off, const ArtnStage *z) {
+  if (z) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < z->swz_n && ((byte_off >> (z->swz_src[i] + 3)) & 1)) byte_off ^= 8u << z->swz_dst[i];
+  }
+  return byte_off;
 }
 
 // Per-wave / per-lane constants of one stage, computed once per kernel.
@@ -183,8 +226,10 @@ struct StageConst {
   int nt_eff, wm, wm_count, msubs;
   const uint2 *msub_tab;              // LDS table: sub-tile -> (input, output) byte offsets
 };
+// zin: stage whose output region this stage reads (nullptr: the unswizzled copy-in region).
 template <int KB>
-__device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, int j, int h, int wave, const uint2 *tab) {
+__device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const ArtnStage *zin, int j, int h, int wave,
+                                                      const uint2 *tab) {
   StageConst<KB> L;
   const int wn = wave & ((1 << st.wn_log2) - 1);
   L.wm = wave >> st.wn_log2;
@@ -217,16 +262,18 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, int j
   }
 #pragma unroll
   for (int b = 1; b < KB; ++b) {
-    L.kin[b] = 8u << st.k_in_pos[b];
+    L.kin[b] = swz(8u << st.k_in_pos[b], zin);
     L.kb[b] = st.k_b_stride[b] * 8;
   }
-  L.o0 = st.nt > 0 ? 8u << st.n_out_pos[0] : 0;
-  L.o2 = st.nt > 2 ? 8u << st.n_out_pos[2] : 0;
-  L.o3 = st.nt > 3 ? 8u << st.n_out_pos[3] : 0;
+  L.o0 = st.nt > 0 ? swz(8u << st.n_out_pos[0], &st) : 0;
+  L.o2 = st.nt > 2 ? swz(8u << st.n_out_pos[2], &st) : 0;
+  L.o3 = st.nt > 3 ? swz(8u << st.n_out_pos[3], &st) : 0;
+  L.lane_in = swz(L.lane_in, zin);
+  L.lane_out = swz(L.lane_out, &st);
   return L;
 }
 // Fill the LDS sub-tile table of a stage (all threads cooperate; caller barriers).
-__device__ __forceinline__ void fill_msub_table(const ArtnStage &st, uint2 *tab, int tid) {
+__device__ __forceinline__ void fill_msub_table(const ArtnStage &st, const ArtnStage *zin, uint2 *tab, int tid) {
   const int msubs = 1 << (st.m_bits - 5);
   for (int m = tid; m < msubs; m += ARTN_WG_THREADS) {
     unsigned oi = 0, oo = 0;
@@ -236,7 +283,7 @@ __device__ __forceinline__ void fill_msub_table(const ArtnStage &st, uint2 *tab,
         oo += 8u << st.msub_out_pos[b];
       }
     }
-    tab[m] = make_uint2(oi, oo);
+    tab[m] = make_uint2(swz(oi, zin), swz(oo, &st));
   }
 }
 
@@ -259,19 +306,30 @@ __device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1
 }
 
 // One stage on this wave's sub-tiles: for each, a chain of 2^KB MFMAs over the contracted
-// bits (LDS reads one step ahead of the MFMAs that consume them), then the scatter of the
-// 32 x 16 complex result into the output region.
+// bits (LDS reads one step ahead of the MFMAs that consume them; the next sub-tile's table
+// entry and first operand are fetched while the current chain runs), then the scatter of
+// the 32 x 16 complex result into the output region.
 template <int KB>
 __device__ __forceinline__ void run_stage(const StageConst<KB> &L, const char *in, char *out,
-                                          const float (&W0)[1 << (KB - 1)], const float (&W1)[1 << (KB - 1)], int h) {
+                                          const float (&W0)[1 << (KB - 1)], const float (&W1)[1 << (KB - 1)], int h
+#ifdef ARTN_STAMPS
+                                          , unsigned long long &st_prev, unsigned long long (&st_acc)[ARTN_N_STAMPS]
+#endif
+                                          ) {
   constexpr int S = 1 << (KB - 1);
-  for (int msub = L.wm; msub < L.msubs; msub += L.wm_count) {
-    const uint2 mo = L.msub_tab[msub];
-    unsigned li = L.lane_in + mo.x, lo = L.lane_out + mo.y;
+  int msub = L.wm;
+  if (msub >= L.msubs) return;
+  uint2 mo = L.msub_tab[msub];
+  float2 a_next = *reinterpret_cast<const float2 *>(in + (L.lane_in ^ mo.x));
+  for (; msub < L.msubs; msub += L.wm_count) {
+    const unsigned li = L.lane_in ^ mo.x, lo = L.lane_out ^ mo.y;
+    const int nmsub = msub + L.wm_count;
+    uint2 mo_n = mo;
+    if (nmsub < L.msubs) mo_n = L.msub_tab[nmsub];
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    float2 a_next = *reinterpret_cast<const float2 *>(in + li);
+    STAMP(8); // sub-tile setup (table entry, first operand)
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const float2 a = a_next;
@@ -279,23 +337,33 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, const char *i
         unsigned ko = 0;
 #pragma unroll
         for (int b = 1; b < KB; ++b)
-          if (((s + 1) >> (b - 1)) & 1) ko += L.kin[b];
-        a_next = *reinterpret_cast<const float2 *>(in + li + ko);
+          if (((s + 1) >> (b - 1)) & 1) ko ^= L.kin[b];
+        a_next = *reinterpret_cast<const float2 *>(in + (li ^ ko));
+      } else if (nmsub < L.msubs) {
+        a_next = *reinterpret_cast<const float2 *>(in + (L.lane_in ^ mo_n.x));
       }
+#ifdef ARTN_ABLATE_MFMA
+      asm volatile("" ::"v"(a.x), "v"(a.y), "v"(W0[s]), "v"(W1[s]));
+#else
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[s], a.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[s], a.y, acc, 0, 0, 0);
+#endif
     }
+    asm volatile("" : "+v"(acc));
+    STAMP(9); // MFMA chain
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
       for (int b0 = 0; b0 < 2; ++b0) {
         const int nl = b0 + 2 * h + 4 * (q & 1) + 8 * (q >> 1);
         if ((nl >> L.nt_eff) == 0) {
-          const unsigned o = lo + b0 * L.o0 + (q & 1) * L.o2 + (q >> 1) * L.o3;
+          const unsigned o = lo ^ (b0 ? L.o0 : 0u) ^ ((q & 1) ? L.o2 : 0u) ^ ((q >> 1) ? L.o3 : 0u);
           *reinterpret_cast<float2 *>(out + o) = make_float2(acc[4 * q + 2 * b0], acc[4 * q + 2 * b0 + 1]);
         }
       }
     }
+    STAMP(10); // scatter
+    mo = mo_n;
   }
 }
 
@@ -313,6 +381,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
   char *R1 = R0 + (8u << P.r0_bits);
   uint2 *tab1 = reinterpret_cast<uint2 *>(R1 + (8u << P.T_mid));
   uint2 *tab2 = tab1 + (1 << (P.st[0].m_bits - 5));
+  long *offtab = reinterpret_cast<long *>(tab2 + (KB2 > 0 ? 1 << (P.st[1].m_bits - 5) : 0));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -340,24 +409,39 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
   const long n_tiles = P.n_tiles;
 
   // ---- per-stage constants, sub-tile tables, outer-axis digits
-  fill_msub_table(P.st[0], tab1, tid);
-  if (KB2 > 0) fill_msub_table(P.st[1], tab2, tid);
-  const StageConst<KB1> L1 = stage_const<KB1>(P.st[0], j, h, wave, tab1);
-  const StageConst<KB2e> L2 = stage_const<KB2e>(P.st[KB2 > 0 ? 1 : 0], j, h, wave, tab2);
-  const OuterLane OL = outer_lane(P, lane);
+  fill_msub_table(P.st[0], nullptr, tab1, tid);
+  if (KB2 > 0) fill_msub_table(P.st[1], &P.st[0], tab2, tid);
+  const StageConst<KB1> L1 = stage_const<KB1>(P.st[0], nullptr, j, h, wave, tab1);
+  const StageConst<KB2e> L2 = stage_const<KB2e>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2);
+  // copy-out reads the last stage's (swizzled) output region
+  const ArtnStage *zout = &P.st[KB2 > 0 ? 1 : 0];
+  const unsigned tid16_out = swz(tid16, zout);
+  unsigned out_i_swz[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out_i_swz[i] = swz(i * (ARTN_WG_THREADS * 16), zout);
+  const OffTab OT = build_offset_table(P, offtab, tid);
   float W10[S1], W11[S1], W20[S2], W21[S2];
   long prev_b1 = -1, prev_b2 = -1;
-  __syncthreads();
+  __syncthreads(); // tables are in LDS
 
   // software pipeline: the loads of the next tile are issued before this tile's MFMA phase
   f32x4 v[8];
   const bool prefetch = n_in_iters <= 8;
   TileOff off = {0, 0, 0, 0};
   if ((long)blockIdx.x < n_tiles) {
-    off = tile_offsets(OL, blockIdx.x);
+    off = tile_offsets(P, OT, blockIdx.x);
     if (prefetch) issue_loads(v, reinterpret_cast<const char *>(A + off.a), in_hi, in_lane, 0, n_in_iters);
   }
 
+  // Two workgroups share a CU and run the same phase sequence; started together they stay
+  // in lockstep and fight for the same unit (both in their MFMA chains, then both in their
+  // LDS/copy phases).  Delay the one whose waves sit in the odd wave slots by about half a
+  // tile period so one computes while the other moves data.
+  if (P.stagger > 0) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1; // HW_ID.wave_id bit 0
+    if (slot)
+      for (int q = 0; q < P.stagger; ++q) __builtin_amdgcn_s_sleep(32);
+  }
   STAMP_DECL
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     if (off.b1 != prev_b1) {
@@ -370,7 +454,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
     }
     const long next = tile + gridDim.x;
     TileOff noff = off;
-    if (next < n_tiles) noff = tile_offsets(OL, next);
+    if (next < n_tiles) noff = tile_offsets(P, OT, next);
     STAMP(0); // W reload, next tile's offsets
 
     // ---- copy-in: global (16 B per lane, runs of 2^run_in elements) -> LDS region 0 (linear)
@@ -399,13 +483,21 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
     STAMP(4); // issue of the next tile's loads
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
+#ifdef ARTN_STAMPS
+    run_stage<KB1>(L1, R0, R1, W10, W11, h, st_prev, st_acc);
+#else
     run_stage<KB1>(L1, R0, R1, W10, W11, h);
+#endif
     STAMP(5); // stage 1
     __syncthreads();
     const char *outr = R1;
     if (KB2 > 0) {
       STAMP(6); // barrier after stage 1
+#ifdef ARTN_STAMPS
+      run_stage<KB2e>(L2, R1, R0, W20, W21, h, st_prev, st_acc);
+#else
       run_stage<KB2e>(L2, R1, R0, W20, W21, h);
+#endif
       STAMP(5); // stage 2 (same bucket as stage 1)
       __syncthreads();
       outr = R0;
@@ -415,16 +507,24 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
     // ---- copy-out: LDS (linear) -> global (16 B per lane, runs of 2^run_out elements)
     {
       char *Cbase = reinterpret_cast<char *>(C + off.c);
-      unsigned lo = out_lane, t16 = tid16;
+      unsigned lo = out_lane, t16 = tid16_out;
       OPAQUE_V(lo);
       OPAQUE_V(t16);
-      for (int i = 0; i < n_out_iters; ++i) {
-        long o = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if ((i >> b) & 1) o += out_hi[b];
-        const f32x4 x = *reinterpret_cast<const f32x4 *>(outr + t16 + i * (ARTN_WG_THREADS * 16));
-        *reinterpret_cast<f32x4 *>(Cbase + o + lo) = x;
+      for (int i = 0; i < 16; ++i) {
+        if (i < n_out_iters) {
+          long o = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if ((i >> b) & 1) o += out_hi[b];
+          const f32x4 x = *reinterpret_cast<const f32x4 *>(outr + (t16 ^ out_i_swz[i]));
+#ifdef ARTN_ABLATE_MEM
+          asm volatile("" ::"v"(x), "s"(Cbase), "v"(lo));
+          if (tile < 0) *reinterpret_cast<f32x4 *>(Cbase + o + lo) = x;
+#else
+          *reinterpret_cast<f32x4 *>(Cbase + o + lo) = x;
+#endif
+        }
       }
     }
     STAMP(7); // copy-out (LDS reads + store issue)

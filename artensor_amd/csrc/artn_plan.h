@@ -54,6 +54,12 @@ struct ArtnStage {
   int32_t n_out_pos[6];                    // N_t bit i          -> tile-local output bit
   int64_t k_b_stride[6];                   // K bit i   -> small-operand element stride
   int64_t n_b_stride[6];                   // N_t bit i -> small-operand element stride
+  // XOR swizzle of this stage's OUTPUT region: element-offset bit swz_dst[i] ^= bit swz_src[i].
+  // The 16 lanes of one ds_write_b64 group differ in MFMA column bits 0..3; where those sit
+  // above the 128-byte bank window (tile-local position >= 4) they are folded into a free
+  // position 1..3 so the group spreads over the banks (at most 2-way conflicts remain).
+  int32_t swz_n, swz_src[3], swz_dst[3];
+  int32_t pad_;
 };
 
 // Launch plan of the LDS-tiled bit-permuted complex GEMM (kernel argument, POD).
@@ -63,6 +69,8 @@ struct ArtnBitsPlan {
   int32_t r0_bits;            // LDS region 0 holds 2^r0_bits elements (region 1 follows it)
   int32_t run_in, run_out;    // tile-local bits [0,run) are global bits [0,run)
   int32_t n_outer;
+  int32_t stagger;            // start-up delay of the odd wave slots, in units of 2048 cycles
+  int32_t pad_;
   int64_t n_tiles;
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
@@ -93,12 +101,14 @@ struct ArtnPlan {
 
 namespace artn {
 
-// Development knobs (environment: ARTN_WG_PER_CU, ARTN_TILE_TARGET, ARTN_RUN_MAX); the
+// Development knobs (environment: ARTN_WG_PER_CU, ARTN_TILE_TARGET, ARTN_RUN_MAX, ARTN_SWIZZLE); the
 // defaults are what ships.
 struct Tuning {
   int wg_per_cu = 2;  // persistent workgroups per CU (grid = CUs * this), capped by LDS
   int tile_target = ARTN_TILE_BITS_TARGET;
   int run_max = 4;    // longest contiguous run (log2 elements) the tile is forced to keep
+  int swizzle = 1;    // XOR-swizzle stage output regions against LDS bank conflicts
+  int stagger = 0;    // start-up delay of every other workgroup on a CU (x 2048 cycles)
 };
 static inline Tuning &tuning() {
   static Tuning t = [] {
@@ -106,6 +116,8 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_WG_PER_CU")) x.wg_per_cu = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_TILE_TARGET")) x.tile_target = std::min(ARTN_TILE_BITS_MAX, std::max(9, atoi(e)));
     if (const char *e = getenv("ARTN_RUN_MAX")) x.run_max = std::min(6, std::max(1, atoi(e)));
+    if (const char *e = getenv("ARTN_SWIZZLE")) x.swizzle = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_STAGGER")) x.stagger = std::max(0, atoi(e));
     return x;
   }();
   return t;
@@ -391,6 +403,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   b.T_in = T_in; b.T_mid = T_mid; b.T_out = T_out;
   b.r0_bits = fused ? std::max(T_in, T_out) : T_in;
   b.run_in = run_in; b.run_out = run_out;
+  b.stagger = tuning().stagger;
 
   // ---- tile-local orders: input (by A stride), mid (by C1 stride), output (by final C stride)
   std::vector<int> tin(K1), tmid(Mt), tout;
@@ -426,6 +439,20 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     for (int i = 5; i < s.m_bits; ++i) { s.msub_in_pos[i - 5] = pos(tile_in, Ms[i]); s.msub_out_pos[i - 5] = pos(tile_out, Ms[i]); }
     for (int i = 0; i < s.k; ++i) { s.k_in_pos[i] = pos(tile_in, Kx[i]); s.k_b_stride[i] = second ? ax[Kx[i]].sB2 : ax[Kx[i]].sB1; }
     for (int i = 0; i < s.nt; ++i) { s.n_out_pos[i] = pos(tile_out, Nx[i]); s.n_b_stride[i] = second ? ax[Nx[i]].sB2 : ax[Nx[i]].sB1; }
+    // output-region swizzle
+    s.swz_n = 0;
+    bool taken[4] = {true, false, false, false}; // position 0 (the 8-byte half) is never a target
+    for (int i = 0; i < 4; ++i) if (s.lane_out_pos[i] < 4) taken[s.lane_out_pos[i]] = true;
+    for (int i = 0; i < 4 && tuning().swizzle; ++i) {
+      if (s.lane_out_pos[i] < 4) continue;
+      int f = -1;
+      for (int c = 1; c < 4; ++c) if (!taken[c]) { f = c; break; }
+      if (f < 0) break;
+      taken[f] = true;
+      s.swz_src[s.swz_n] = s.lane_out_pos[i];
+      s.swz_dst[s.swz_n] = f;
+      ++s.swz_n;
+    }
   };
   fill_stage(b.st[0], K1, Mt, N1t, tin, tmid, false);
   if (fused) {
@@ -504,7 +531,13 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   f.tile_in_bits = b.T_in; f.tile_out_bits = b.T_out;
   f.run_in_bits = run_in; f.run_out_bits = run_out;
   // two tile regions + the sub-tile offset tables of both stages (8 bytes per sub-tile)
-  f.lds_bytes = (int32_t)((8LL << b.r0_bits) + (8LL << b.T_mid) + (8LL << (mt - 5)) + (fused ? (8LL << (m2 - 5)) : 0));
+  {
+    int pow2_bits = 0;
+    for (int i = 0; i < b.n_outer && b.outer[i].log2ext >= 0; ++i) pow2_bits += b.outer[i].log2ext;
+    if (pow2_bits > 32) { p.why_generic = "more than 2^32 tiles"; return false; }
+    const int64_t off_tab = 512LL * ((pow2_bits + 3) / 4); // tile-offset table: 16 x 4 longs per nibble
+    f.lds_bytes = (int32_t)((8LL << b.r0_bits) + (8LL << b.T_mid) + (8LL << (mt - 5)) + (fused ? (8LL << (m2 - 5)) : 0) + off_tab);
+  }
   f.n_tiles = b.n_tiles;
   f.a_rereads = a_rereads;
   f.k2_bits = k2; f.n2_tile_bits = nt2; f.tile_mid_bits = b.T_mid;

@@ -10,7 +10,15 @@
 
 typedef std::complex<float> cf;
 
-static void run_stage(const ArtnStage &st, const cf *in, cf *out, const cf *B, int64_t offB) {
+// element-offset form of the kernel's byte-offset swizzle
+static int swz(int off, const ArtnStage *z) {
+  if (z)
+    for (int i = 0; i < z->swz_n; ++i)
+      if ((off >> z->swz_src[i]) & 1) off ^= 1 << z->swz_dst[i];
+  return off;
+}
+
+static void run_stage(const ArtnStage &st, const ArtnStage *zin, const cf *in, cf *out, const cf *B, int64_t offB) {
   const int KB = st.k, S = 1 << (KB - 1);
   const int nt_eff = st.nt < 4 ? st.nt : 4;
   const int wm_count = 4 >> st.wn_log2, msubs = 1 << (st.m_bits - 5);
@@ -42,7 +50,7 @@ static void run_stage(const ArtnStage &st, const cf *in, cf *out, const cf *B, i
           if ((nloc >> nt_eff) == 0) bv = B[offB + lb + kbo];
           W0[lane] = ro ? bv.imag() : bv.real();
           W1[lane] = ro ? bv.real() : -bv.imag();
-          const cf a = in[li + oi + ko];
+          const cf a = in[swz(li + oi + ko, zin)];
           ax[lane] = a.real(); ay[lane] = a.imag();
         }
         // two v_mfma_f32_32x32x2_f32: D[i][j] += sum_kk Aop[i][kk] * Bop[kk][j]
@@ -61,7 +69,7 @@ static void run_stage(const ArtnStage &st, const cf *in, cf *out, const cf *B, i
           for (int b0 = 0; b0 < 2; ++b0) {
             const int nl = b0 + 2 * h + 4 * (q & 1) + 8 * (q >> 1);
             if ((nl >> nt_eff) == 0)
-              out[lane_out[lane] + oo + b0 * o0 + (q & 1) * o2 + (q >> 1) * o3] =
+              out[swz(lane_out[lane] + oo + b0 * o0 + (q & 1) * o2 + (q >> 1) * o3, &st)] =
                   cf(acc[lane][4 * q + 2 * b0], acc[lane][4 * q + 2 * b0 + 1]);
           }
       }
@@ -91,11 +99,13 @@ static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf 
         R0[2 * (tid + 256 * i) + 1] = src[1];
       }
     }
-    run_stage(P.st[0], R0.data(), R1.data(), B1, offB1);
+    run_stage(P.st[0], nullptr, R0.data(), R1.data(), B1, offB1);
     const cf *outr = R1.data();
+    const ArtnStage *zout = &P.st[0];
     if (P.n_stages == 2) {
-      run_stage(P.st[1], R1.data(), R0.data(), B2, offB2);
+      run_stage(P.st[1], &P.st[0], R1.data(), R0.data(), B2, offB2);
       outr = R0.data();
+      zout = &P.st[1];
     }
     for (int tid = 0; tid < 256; ++tid) {
       int64_t out_lane = 0;
@@ -104,8 +114,8 @@ static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf 
         int64_t off = 0;
         for (int b = 9; b < P.T_out; ++b) if ((i >> (b - 9)) & 1) off += P.out_stride[b];
         cf *dst = C + offC + out_lane + off;
-        dst[0] = outr[2 * (tid + 256 * i)];
-        dst[1] = outr[2 * (tid + 256 * i) + 1];
+        dst[0] = outr[swz(2 * (tid + 256 * i), zout)];
+        dst[1] = outr[swz(2 * (tid + 256 * i), zout) + 1];
       }
     }
   }

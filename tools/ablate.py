@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Timing-only ablation of artn_k_bits on chosen n30 steps (needs `make ablate`); results are wrong by design."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import artensor_amd as A
+from artensor_amd.contraction import contract2
+from artensor_amd.fixtures import load_case
+from helpers import dense_scheme_shapes, GOLDEN
+case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+steps = dense_scheme_shapes(case)
+gen = torch.Generator(device="cuda").manual_seed(0)
+def rnd(shape):
+    return torch.view_as_complex(torch.randn(tuple(shape) + (2,), device="cuda", generator=gen))
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+tag = os.path.basename(os.environ.get("ARTN_LIB", "product"))
+out = []
+for n in (78, 88, 139):
+    eq, sa, sb = steps[n]
+    a, b = rnd(sa), rnd(sb)
+    out.append(f"s{n}:{timed(lambda: A.contract(eq, a, b)):.2f}")
+    del a, b
+for (n, m) in ((101, 104), (93, 97), (108, 112), (139, 144)):
+    eq1, sa, sb1 = steps[n]; eq2, _, sb2 = steps[m]
+    a, b1, b2 = rnd(sa), rnd(sb1), rnd(sb2)
+    out.append(f"p{n}+{m}:{timed(lambda: contract2(eq1, a, b1, eq2, b2)):.2f}")
+    del a, b1, b2
+print(f"{tag:34s}", " ".join(out))

@@ -12,15 +12,15 @@ from artensor_amd.contraction import contract2, fusion_schedule
 from artensor_amd.fixtures import load_case
 from helpers import dense_scheme_shapes, GOLDEN
 
-NAMES = ["offsets+W", "barrier(pre-fill)", "load-wait+LDS fill", "barrier(fill)", "issue loads", "stages", "barrier(stage)", "copy-out"]
+NAMES = ["offsets+W", "barrier(pre-fill)", "load-wait+LDS fill", "barrier(fill)", "issue loads", "stage other", "barrier(stage)", "copy-out", "subtile setup", "mfma chain", "scatter", "-"]
 lib = N.lib()
 lib.artn_debug_read_stamps.restype = ctypes.c_int
 
 def report(tag, ms):
     n = 2048
-    buf = (ctypes.c_ulonglong * (8 * n))()
+    buf = (ctypes.c_ulonglong * (12 * n))()
     assert lib.artn_debug_read_stamps(buf, n) == 0
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.float64)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 12).astype(np.float64)
     a = a[a.sum(axis=1) > 0]
     tot = a.sum(axis=1).mean()
     print(f"{tag}: {ms:.2f} ms, {len(a)} waves, mean cycles/wave {tot:.3e}")
