@@ -408,7 +408,60 @@ def case_n30_sliced(k=3):
     print("n30_sliced", k, "bonds", chosen, "log10 tc/slice", tc)
 
 
+def _dump_tree(ctree):
+    """Planner products as plain data (what contraction.py:23-59 / :208-341 consume):
+    vertices with their bond lists IN THE ITERATION ORDER the reference saw."""
+    ctree.mark_rep_tensor()
+    verts = {}
+
+    def walk(v):
+        key = ",".join(map(str, sorted(v.contain_tensors)))
+        verts[key] = dict(contain_tensors=sorted(int(x) for x in v.contain_tensors),
+                          contain_bonds=[str(b) for b in list(v.contain_bonds)], sc=float(v.sc),
+                          left=None, right=None)
+        if v.left and v.right:
+            verts[key]["left"] = walk(v.left)
+            verts[key]["right"] = walk(v.right)
+        return key
+
+    root = walk(ctree.tree[ctree.all_tensors])
+    fq = ctree.tn.final_qubits
+    return dict(root=root, vertices=verts,
+                tensor_bonds={str(k): [str(b) for b in v] for k, v in ctree.tn.tensor_bonds.items()},
+                final_qubits=sorted(int(x) for x in fq) if fq is not None else [])
+
+
+def case_trees():
+    """Trees + the schemes the reference compiled from them (scheme-compiler parity)."""
+    import json
+    out = {}
+    sim, _ = plan(N12_QSIM, [], 30)
+    scheme, output_bonds = contraction_scheme(deepcopy(sim.ctree))
+    out["n12_dense"] = dict(tree=_dump_tree(deepcopy(sim.ctree)), output_bonds=[str(b) for b in output_bonds],
+                            scheme=[[list(map(int, e)), eq] for e, eq in scheme])
+    rng = np.random.RandomState(3)
+    bits = sorted({np.binary_repr(x, 12) for x in rng.randint(0, 4096, size=40)})
+    for name, sc_target in (("n12_sparse", 30), ("n12_sparse_chunked", 8), ("n12_sparse_chunked6", 6)):
+        sim, _ = plan(N12_QSIM, bits, 30)
+        scheme, bonds, sorted_bits = contraction_scheme_sparse(deepcopy(sim.ctree), bits, sc_target=sc_target)
+        steps = []
+        for st in scheme:
+            rec = dict(edge=list(map(int, st[0])), eq=st[1],
+                       batch=[[np.asarray(x).tolist() for x in st[2][0]], [np.asarray(x).tolist() for x in st[2][1]]])
+            if len(st) == 5:
+                rec["rshape"] = None if st[3] is None else list(st[3])
+                rec["next_shape"] = list(st[4])
+            steps.append(rec)
+        out[name] = dict(tree=_dump_tree(deepcopy(sim.ctree)), bitstrings=bits, sc_target=sc_target,
+                         bonds=[str(b) for b in bonds], bitstrings_sorted=list(sorted_bits), scheme=steps)
+        print(name, len(scheme), "steps,", sum(len(s) == 5 for s in scheme), "5-tuples,",
+              sum(len(s[2][0]) > 1 for s in scheme), "chunked")
+    with open(os.path.join(HERE, "trees.json"), "w") as f:
+        json.dump(out, f)
+
+
 CASES = {
+    "trees": case_trees,
     "n12_dense": case_n12_dense,
     "n12_sparse5": case_n12_sparse5,
     "n12_sparse_sliced": case_n12_sparse_sliced,

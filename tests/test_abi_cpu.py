@@ -1,0 +1,86 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/artn.h declares, refuses to compute without a GPU (no CPU fallback), and its
+host-only planner answers queries."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import artensor_amd as A
+from artensor_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "artn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(artn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = N.lib()
+    names = declared_symbols()
+    assert len(names) >= 10
+    assert names == N.exported_symbols()
+    for name in names:
+        assert hasattr(lib, name), name
+    assert lib.artn_abi_version() == 1
+    assert lib.artn_device_count() >= 0
+
+
+def test_struct_layouts_match_header():
+    # sizes the C side was compiled with (ArtnStepDesc: 2 int32 + 4 arrays of 96 int64)
+    assert ctypes.sizeof(N.ArtnStepDesc) == 8 + 4 * 96 * 8
+    assert ctypes.sizeof(N.ArtnStepInfo) == 10 * 4 + 2 * 8 + 2 * 8 + 4 * 4
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the CPU-only refusal")
+def test_no_cpu_fallback_anywhere():
+    a = torch.zeros(2, 2, dtype=torch.complex64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        A.contract("ab,bc->ac", a, a)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        A.tensor_contraction({0: a, 1: a}, [((0, 1), "ab,bc->ac")])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        A.tensor_contraction_sparse({0: a, 1: a}, [((0, 1), "ab,bc->ac", [[torch.tensor([0])], [torch.tensor([0])]])])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        A.accumulate(a, a)
+    # the raw ABI refuses too: no device -> ARTN_E_NODEVICE, never a host computation
+    d, _ = A.contraction._descriptor(("a", "b"), ("b", "c"), ("a", "c"), (2, 2), (2, 1), (2, 2), (2, 1), torch.complex64)
+    buf = np.zeros(8, dtype=np.complex64)
+    p = buf.ctypes.data_as(ctypes.c_void_p)
+    assert N.lib().artn_contract(ctypes.byref(d), p, p, p, None) == -4
+    assert b"gfx950" in N.lib().artn_last_error()
+    assert N.lib().artn_axpy_c64(p, p, 4, None) == -4
+
+
+def test_planner_query_and_errors():
+    info = A.step_info("ab,bc->ac", (2, 2), (2, 2))
+    assert info["kernel"] == N.KERNEL_GENERIC and info["flops"] == 64.0 and info["out_shape"] == (2, 2)
+    la = "ABCDEFGHIJKLMNOPQRSTUV"
+    info = A.step_info(la + ",DKRUvwxyX->" + "".join(c for c in la if c not in "DKRU") + "vwxyX", (2,) * 22, (2,) * 9)
+    assert info["kernel"] == N.KERNEL_BITS_MFMA and info["k_bits"] == 4
+    assert info["lds_bytes"] <= 160 * 1024 and info["run_in_bits"] >= 1
+    with pytest.raises(RuntimeError):
+        A.step_info("ab,bc", (2, 2), (2, 2))
+    with pytest.raises(RuntimeError):
+        A.step_info("aab,bc->ac", (2, 2, 2), (2, 2))
+    with pytest.raises(RuntimeError):
+        A.step_info("ab,bc->ad", (2, 2), (2, 2))
+    with pytest.raises(RuntimeError):
+        A.step_info("ab,bc->ac", (2, 3), (2, 2))
+
+
+def test_label_tuples_lift_the_alphabet_limit():
+    # 60 distinct labels: more than the reference's 50-letter einsum alphabet (contraction.py:9-10)
+    la = tuple(range(40))
+    lb = tuple(range(36, 60))
+    lo = tuple(x for x in la if x < 36) + tuple(x for x in lb if x >= 40)
+    info = A.step_info((la, lb, lo), (2,) * 40, (2,) * 24)
+    assert info["flops"] == 8.0 * 2.0 ** 60
+    with pytest.raises(RuntimeError, match="alphabet"):
+        A.einsum_eq_convert(([list(la)], [list(lb)])[0] + [list(lb)], list(lo))
