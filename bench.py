@@ -184,6 +184,14 @@ def main():
         value = world * args.steps * flops_per_step / dt / 1e12
         achieved = bits["flops"] / (bits["ms"] * 1e-3) / 1e12 if bits["ms"] else 0.0
         hbm_gbs = bits["bytes"] / (bits["ms"] * 1e-3) / 1e9 if bits["ms"] else 0.0
+        # HBM bytes per launch of the dominant kernel come from separate rocprofv3 PMC passes
+        # (tools/profile_round.sh -> profiles/rNN_traffic.json); bench.py cannot run them itself
+        traffic = None
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+        if tfiles:
+            with open(tfiles[-1]) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
         line = {
             "metric": "contracted TFLOP/s, Sycamore n30 m14 full-amplitude (8 real FLOP per complex MAC)",
             "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -196,7 +204,8 @@ def main():
                        "max_rel_err_vs_reference": rel_err},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": bits["bytes"] / max(bits["launches"], 1),
                 "kernel": "artn_k_bits", "launches_per_step": bits["launches"] / max(args.steps, 1),
                 "avg_launch_ms": bits["ms"] / max(bits["launches"], 1),
                 "hbm_achieved_GBs": hbm_gbs, "hbm_frac": hbm_gbs / HBM_PEAK_GBS,

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<round>/ (rocprofv3 CSVs) into profiles/<round>_*.{csv,md,json}."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
+DST = os.path.join(ROOT, "profiles")
+os.makedirs(DST, exist_ok=True)
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+stats = one("kt/**/*_kernel_stats.csv")
+shutil.copy(stats, os.path.join(DST, f"{R}_kernel_stats.csv"))
+rows = list(csv.DictReader(open(stats)))
+
+
+def counters(sub):
+    f = one(f"{sub}/**/*_counter_collection.csv")
+    per = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if "artn_k_bits" not in r["Kernel_Name"]:
+            continue
+        d = per.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"].split("(")[0].replace("void ", ""),
+                                              "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    return per
+
+
+sq, fe, wr = counters("pmc_sq"), counters("pmc_fetch"), counters("pmc_write")
+big = lambda per: [d for d in per.values() if d["t1"] - d["t0"] > 1e6]  # launches longer than 1 ms
+md = [f"# rocprofv3 summary, round {R}", "",
+      "Command: `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (Sycamore n30 m14 full amplitude, 1 x MI355X).",
+      "Kernel trace and each PMC group were collected in separate rocprofv3 runs.", "",
+      "## Kernel time (rocprofv3 --kernel-trace --stats)", "",
+      "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+for r in rows[:12]:
+    name = r["Name"].split("(")[0].replace("void ", "")[:60]
+    md.append(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+bits = [r for r in rows if "artn_k_bits" in r["Name"]]
+tot_ns = sum(float(r["TotalDurationNs"]) for r in bits)
+tot_calls = sum(int(r["Calls"]) for r in bits)
+md += ["", f"All `artn_k_bits<KB1,KB2>` instantiations together: {tot_calls} launches, {tot_ns / 1e6:.2f} ms, "
+           f"average {tot_ns / tot_calls / 1e3:.1f} us per launch (4 contractions: 1 warm-up + 3 timed).", ""]
+
+fb, wb = big(fe), big(wr)
+fetch = sum(d.get("FETCH_SIZE", 0) for d in fb) * 1024 * 2  # KB -> B; gfx950 halves wide reads (guide)
+write = sum(d.get("WRITE_SIZE", 0) for d in wb) * 1024
+n = max(len(fb), 1)
+md += ["## HBM traffic of the MFMA kernel (launches > 1 ms)", "",
+       f"* FETCH_SIZE x 2 (gfx950 counts 128-B requests at 64 B): {fetch / n / 2**30:.3f} GiB per launch",
+       f"* WRITE_SIZE: {write / max(len(wb), 1) / 2**30:.3f} GiB per launch",
+       f"* launches counted: {len(fb)} (fetch pass), {len(wb)} (write pass)", ""]
+sb = big(sq)
+if sb:
+    mf = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for d in sb)
+    dur = sum(d["t1"] - d["t0"] for d in sb) * 1e-9
+    ga = sum(d.get("GRBM_GUI_ACTIVE", 0) for d in fb)
+    clk = ga / 8 / (sum(d["t1"] - d["t0"] for d in fb) * 1e-9) if fb else 0
+    conf = sum(d.get("SQ_LDS_BANK_CONFLICT", 0) for d in sb) / max(sum(d.get("SQ_LDS_IDX_ACTIVE", 0) for d in sb), 1)
+    md += ["## Matrix-core and LDS counters (launches > 1 ms)", "",
+           f"* SQ_VALU_MFMA_BUSY_CYCLES / (duration x 1024 SIMDs x clock): "
+           f"{mf / (dur * 1024 * (clk or 2.2e9)):.3f}  (clock from GRBM_GUI_ACTIVE / 8 / time = {clk / 1e9:.2f} GHz)",
+           f"* SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: {conf:.3f}",
+           f"* SQ_WAIT_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}",
+           f"* SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_INST_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}", ""]
+bj = os.path.join(SRC, "bench_under_rocprof.json")
+if os.path.exists(bj) and os.path.getsize(bj):
+    md += ["## bench.py line of the kernel-trace run", "", "```", open(bj).read().strip(), "```", ""]
+open(os.path.join(DST, f"{R}_summary.md"), "w").write("\n".join(md))
+json.dump({"round": R, "kernel": "artn_k_bits", "launches_over_1ms": len(fb),
+           "hbm_bytes_per_launch": (fetch / n + write / max(len(wb), 1)),
+           "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / max(len(wb), 1),
+           "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE in separate passes, launches > 1 ms"},
+          open(os.path.join(DST, f"{R}_traffic.json"), "w"), indent=1)
+print("\n".join(md))
