@@ -175,32 +175,42 @@ __device__ __forceinline__ TileOff tile_offsets(const ArtnBitsPlan &P, const Off
   return t;
 }
 
-// Copy-in, split in two so the loads of tile t+1 are in flight while tile t is computed:
-// issue_loads puts 8 x 16 B per thread in flight (uniform 64-bit base in SGPRs + one 32-bit
-// per-lane byte offset); store_lds writes them to LDS linearly.  With fewer than 8 chunks
-// per thread (small tiles) the surplus slots re-load an earlier chunk and are not stored.
+// Copy-in.  Full-size tiles (2^12 elements: exactly 8 x 16 B per thread) are software
+// pipelined: issue_loads puts the 8 chunks of tile t+1 in flight (uniform 64-bit base in SGPRs
+// + one 32-bit per-lane byte offset) while tile t is computed, store_lds writes them to LDS
+// linearly.  Every issued load is consumed: a load whose result is never used leaves the
+// compiler a pending write to guard, and it does so with vmcnt waits in the middle of the MFMA
+// chain that drain the whole prefetch.  Other tile sizes take the plain loop of copy_in_sync.
 // hi[b] = byte stride of tile-local bit 9+b (0 beyond the tile).
-__device__ __forceinline__ void issue_loads(f32x4 (&v)[8], const char *__restrict__ Abase, const long (&hi)[4],
-                                            unsigned lane_off, int i0, int n_iters) {
+__device__ __forceinline__ long chunk_off(const long (&hi)[4], int i) {
+  long off = 0;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int i = (i0 + u) & (n_iters - 1);
-    long off = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-      if ((i >> b) & 1) off += hi[b];
-#ifdef ARTN_ABLATE_MEM
-    v[u] = f32x4{1.f, 2.f, 3.f, 4.f};
-    asm volatile("" : "+v"(v[u]) : "s"(Abase), "v"(lane_off));
-#else
-    v[u] = *reinterpret_cast<const f32x4 *>(Abase + off + lane_off);
-#endif
-  }
+  for (int b = 0; b < 4; ++b)
+    if ((i >> b) & 1) off += hi[b];
+  return off;
 }
-__device__ __forceinline__ void store_lds(const f32x4 (&v)[8], char *ldsb, unsigned tid16, int i0, int n_iters) {
+__device__ __forceinline__ f32x4 load_chunk(const char *__restrict__ Abase, long off, unsigned lane_off) {
+#ifdef ARTN_ABLATE_MEM
+  f32x4 r = f32x4{1.f, 2.f, 3.f, 4.f};
+  asm volatile("" : "+v"(r) : "s"(Abase), "v"(lane_off));
+  return r;
+#else
+  return *reinterpret_cast<const f32x4 *>(Abase + off + lane_off);
+#endif
+}
+__device__ __forceinline__ void issue_loads(f32x4 (&v)[8], const char *__restrict__ Abase, const long (&hi)[4],
+                                            unsigned lane_off) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
-    if (i0 + u < n_iters) *reinterpret_cast<f32x4 *>(ldsb + tid16 + (i0 + u) * (ARTN_WG_THREADS * 16)) = v[u];
+  for (int u = 0; u < 8; ++u) v[u] = load_chunk(Abase, chunk_off(hi, u), lane_off);
+}
+__device__ __forceinline__ void store_lds(const f32x4 (&v)[8], char *ldsb, unsigned tid16) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4 *>(ldsb + tid16 + u * (ARTN_WG_THREADS * 16)) = v[u];
+}
+__device__ __forceinline__ void copy_in_sync(const char *__restrict__ Abase, const long (&hi)[4], unsigned lane_off,
+                                             char *ldsb, unsigned tid16, int n_iters) {
+  for (int i = 0; i < n_iters; ++i)
+    *reinterpret_cast<f32x4 *>(ldsb + tid16 + i * (ARTN_WG_THREADS * 16)) = load_chunk(Abase, chunk_off(hi, i), lane_off);
 }
 
 // XOR swizzle of an LDS region (ArtnStage::swz_*), applied to byte offsets.  It is linear over
@@ -303,6 +313,11 @@ __device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1
     W0[s] = ro ? bv.y : bv.x;
     W1[s] = ro ? bv.x : -bv.y;
   }
+  // Consume the fragments HERE: the reload is conditional, and if the compiler is left to
+  // place the s_waitcnt for these loads at their first use (inside the MFMA chain) it emits an
+  // unconditional vmcnt(0) there, which drains the next tile's prefetched loads every tile.
+#pragma unroll
+  for (int s = 0; s < S; ++s) asm volatile("" : "+v"(W0[s]), "+v"(W1[s]));
 }
 
 // One stage on this wave's sub-tiles: for each, a chain of 2^KB MFMAs over the contracted
@@ -424,26 +439,28 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
   long prev_b1 = -1, prev_b2 = -1;
   __syncthreads(); // tables are in LDS
 
-  // software pipeline: the loads of the next tile are issued before this tile's MFMA phase
+  // Software pipeline over tiles.  Order of one iteration (tile t is already in R0):
+  //   stages(t) -> result region to registers x[] -> refill R0 with tile t+1 (loads issued one
+  //   iteration ago) -> stores(t) from x[] -> issue loads(t+2).
+  // The refill waits on loads that are followed in the (in-order) VMEM queue by nothing, so
+  // its s_waitcnt never waits for stores issued after them; the stores have a whole stage
+  // phase to drain before the next refill looks at the counter.
   f32x4 v[8];
-  const bool prefetch = n_in_iters <= 8;
-  TileOff off = {0, 0, 0, 0};
-  if ((long)blockIdx.x < n_tiles) {
-    off = tile_offsets(P, OT, blockIdx.x);
-    if (prefetch) issue_loads(v, reinterpret_cast<const char *>(A + off.a), in_hi, in_lane, 0, n_in_iters);
+  const bool prefetch = n_in_iters == 8 && n_out_iters <= 8;
+  TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
+  const long t0 = blockIdx.x, G = gridDim.x;
+  if (t0 < n_tiles) {
+    off = tile_offsets(P, OT, t0);
+    copy_in_sync(reinterpret_cast<const char *>(A + off.a), in_hi, in_lane, R0, tid16, n_in_iters);
+    if (t0 + G < n_tiles) {
+      noff = tile_offsets(P, OT, t0 + G);
+      if (prefetch) issue_loads(v, reinterpret_cast<const char *>(A + noff.a), in_hi, in_lane);
+    }
   }
+  __syncthreads();
 
-  // Two workgroups share a CU and run the same phase sequence; started together they stay
-  // in lockstep and fight for the same unit (both in their MFMA chains, then both in their
-  // LDS/copy phases).  Delay the one whose waves sit in the odd wave slots by about half a
-  // tile period so one computes while the other moves data.
-  if (P.stagger > 0) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1; // HW_ID.wave_id bit 0
-    if (slot)
-      for (int q = 0; q < P.stagger; ++q) __builtin_amdgcn_s_sleep(32);
-  }
   STAMP_DECL
-  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (long tile = t0; tile < n_tiles; tile += G) {
     if (off.b1 != prev_b1) {
       prev_b1 = off.b1;
       load_w<KB1>(W10, W11, reinterpret_cast<const char *>(B1 + off.b1), L1, ro);
@@ -452,35 +469,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
       prev_b2 = off.b2;
       load_w<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
     }
-    const long next = tile + gridDim.x;
-    TileOff noff = off;
-    if (next < n_tiles) noff = tile_offsets(P, OT, next);
-    STAMP(0); // W reload, next tile's offsets
-
-    // ---- copy-in: global (16 B per lane, runs of 2^run_in elements) -> LDS region 0 (linear)
-    {
-      unsigned lo = in_lane, t16 = tid16;
-      OPAQUE_V(lo);
-      OPAQUE_V(t16);
-      if (prefetch) {
-        if (KB2 > 0) __syncthreads(); // fused: previous tile's copy-out has finished reading R0
-        STAMP(1); // barrier before LDS refill
-        store_lds(v, R0, t16, 0, n_in_iters);
-        STAMP(2); // wait for the prefetched loads + LDS write
-        __syncthreads();
-        STAMP(3); // barrier after LDS fill
-        if (next < n_tiles) issue_loads(v, reinterpret_cast<const char *>(A + noff.a), in_hi, lo, 0, n_in_iters);
-      } else {
-        const char *Abase = reinterpret_cast<const char *>(A + off.a);
-        for (int i0 = 0; i0 < n_in_iters; i0 += 8) {
-          issue_loads(v, Abase, in_hi, lo, i0, n_in_iters);
-          if (i0 == 0 && KB2 > 0) __syncthreads();
-          store_lds(v, R0, t16, i0, n_in_iters);
-        }
-        __syncthreads();
-      }
-    }
-    STAMP(4); // issue of the next tile's loads
+    const long next = tile + G, next2 = tile + 2 * G;
+    TileOff n2off = noff;
+    if (next2 < n_tiles) n2off = tile_offsets(P, OT, next2);
+    STAMP(0); // W reload, offsets of the tile after next
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
 #ifdef ARTN_STAMPS
@@ -488,28 +480,59 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
 #else
     run_stage<KB1>(L1, R0, R1, W10, W11, h);
 #endif
-    STAMP(5); // stage 1
+    STAMP(5);
     __syncthreads();
     const char *outr = R1;
     if (KB2 > 0) {
-      STAMP(6); // barrier after stage 1
+      STAMP(6);
 #ifdef ARTN_STAMPS
       run_stage<KB2e>(L2, R1, R0, W20, W21, h, st_prev, st_acc);
 #else
       run_stage<KB2e>(L2, R1, R0, W20, W21, h);
 #endif
-      STAMP(5); // stage 2 (same bucket as stage 1)
+      STAMP(5);
       __syncthreads();
       outr = R0;
     }
-    STAMP(6); // barrier after the last stage
+    STAMP(6); // barriers after the stages
 
-    // ---- copy-out: LDS (linear) -> global (16 B per lane, runs of 2^run_out elements)
-    {
-      char *Cbase = reinterpret_cast<char *>(C + off.c);
-      unsigned lo = out_lane, t16 = tid16_out;
-      OPAQUE_V(lo);
-      OPAQUE_V(t16);
+    unsigned lo_in = in_lane, lo_out = out_lane, t16 = tid16, t16o = tid16_out;
+    OPAQUE_V(lo_in);
+    OPAQUE_V(lo_out);
+    OPAQUE_V(t16);
+    OPAQUE_V(t16o);
+    char *Cbase = reinterpret_cast<char *>(C + off.c);
+    if (prefetch) {
+      // result tile -> registers
+      f32x4 x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < n_out_iters) x[i] = *reinterpret_cast<const f32x4 *>(outr + (t16o ^ out_i_swz[i]));
+      if (KB2 > 0) __syncthreads(); // fused: the result sat in R0, which is refilled next
+      STAMP(1);
+      // refill R0 with the next tile (its loads were issued one iteration ago)
+      if (next < n_tiles) store_lds(v, R0, t16);
+      STAMP(2);
+      // stores of this tile, then the loads of the tile after next
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < n_out_iters) {
+          long o = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if ((i >> b) & 1) o += out_hi[b];
+#ifdef ARTN_ABLATE_MEM
+          asm volatile("" ::"v"(x[i]), "s"(Cbase), "v"(lo_out));
+#else
+          *reinterpret_cast<f32x4 *>(Cbase + o + lo_out) = x[i];
+#endif
+        }
+      }
+      STAMP(7);
+      if (next2 < n_tiles) issue_loads(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
+      STAMP(4);
+    } else {
+      // big tiles (2^13): no register prefetch; stream out, then load the next tile
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (i < n_out_iters) {
@@ -517,18 +540,21 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
 #pragma unroll
           for (int b = 0; b < 4; ++b)
             if ((i >> b) & 1) o += out_hi[b];
-          const f32x4 x = *reinterpret_cast<const f32x4 *>(outr + (t16 ^ out_i_swz[i]));
+          const f32x4 xx = *reinterpret_cast<const f32x4 *>(outr + (t16o ^ out_i_swz[i]));
 #ifdef ARTN_ABLATE_MEM
-          asm volatile("" ::"v"(x), "s"(Cbase), "v"(lo));
-          if (tile < 0) *reinterpret_cast<f32x4 *>(Cbase + o + lo) = x;
+          asm volatile("" ::"v"(xx), "s"(Cbase), "v"(lo_out));
 #else
-          *reinterpret_cast<f32x4 *>(Cbase + o + lo) = x;
+          *reinterpret_cast<f32x4 *>(Cbase + o + lo_out) = xx;
 #endif
         }
       }
+      if (KB2 > 0) __syncthreads();
+      if (next < n_tiles) copy_in_sync(reinterpret_cast<const char *>(A + noff.a), in_hi, lo_in, R0, t16, n_in_iters);
     }
-    STAMP(7); // copy-out (LDS reads + store issue)
+    __syncthreads(); // R0 holds the next tile; every wave is done with the result region
+    STAMP(3);
     off = noff;
+    noff = n2off;
   }
   STAMP_FLUSH
 }

@@ -343,13 +343,17 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   if (run_in < 1 || run_out < 1) { p.why_generic = "no contiguous 16-byte run at the bottom of A or C"; return false; }
 
   // ---- choose the tile
+  // Forced members: every M bit inside the input/output runs (16-byte lanes in >= 2^run x 8 B
+  // contiguous pieces), every bit the second stage contracts.  A pass whose forced bits push a
+  // tile to 2^13 elements needs 128 KiB of LDS and runs one workgroup per CU, which costs
+  // more than shorter runs do: so run lengths are shortened (down to 32 B) until the tile
+  // fits the 2^12 target; only if that is impossible is the first LDS-feasible choice taken.
   const int n1 = (int)N1.size(), n2 = (int)N2.size();
   std::vector<int> Mt, N1t, N2t;
   int T_in = 0, T_mid = 0, T_out = 0;
-  for (;;) {
+  auto try_runs = [&](int rin_bits, int rout_bits, bool need_target) {
     Mt.clear(); N1t.clear(); N2t.clear();
-    const int64_t rin = int64_t(1) << run_in, rout = int64_t(1) << run_out;
-    // forced members
+    const int64_t rin = int64_t(1) << rin_bits, rout = int64_t(1) << rout_bits;
     for (int i : M1)
       if (ax[i].sA < rin || (ax[i].sC >= 0 && ax[i].sC < rout) || in_set(K2, i)) Mt.push_back(i);
     for (int i : N1)
@@ -361,8 +365,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     for (int i : N1) { if ((int)N1t.size() >= n1_target) break; if (!in_set(N1t, i)) N1t.push_back(i); }
     int n2_target = std::min(n2, std::min(6, std::max(k2, 4)));
     for (int i : N2) { if ((int)N2t.size() >= n2_target) break; if (!in_set(N2t, i)) N2t.push_back(i); }
-    bool ok = (int)N1t.size() <= 6 && (int)N2t.size() <= 6;
-    // grow M_t towards the target tile size (lowest A positions first), within the LDS budget
+    if ((int)N1t.size() > 6 || (int)N2t.size() > 6) return false;
     auto sizes = [&](int mt) {
       T_in = k1 + mt;
       T_mid = mt + (int)N1t.size();
@@ -374,22 +377,34 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
       int r0 = fused ? std::max(T_in, T_out) : T_in;
       return (8LL << r0) + (8LL << T_mid) <= ARTN_LDS_BUDGET;
     };
-    if (ok && fits((int)Mt.size())) {
-      int target = tuning().tile_target;
-      for (int i : M1) {
-        if (in_set(Mt, i)) continue;
-        sizes((int)Mt.size());
-        int biggest = std::max(T_in, std::max(T_mid, T_out));
-        if (((int)Mt.size() >= 5 && biggest >= target) || !fits((int)Mt.size() + 1)) break;
-        Mt.push_back(i);
-      }
+    if (!fits((int)Mt.size())) return false;
+    const int target = tuning().tile_target;
+    if (need_target && std::max(T_in, std::max(T_mid, T_out)) > target && (int)Mt.size() >= 5) return false;
+    // grow M_t towards the target tile size (lowest A positions first), within the LDS budget
+    for (int i : M1) {
+      if (in_set(Mt, i)) continue;
       sizes((int)Mt.size());
-      break;
+      int biggest = std::max(T_in, std::max(T_mid, T_out));
+      if (((int)Mt.size() >= 5 && biggest >= target) || !fits((int)Mt.size() + 1)) break;
+      Mt.push_back(i);
     }
-    // too many forced bits: shorten the longer run and retry
-    if (run_out >= run_in && run_out > 1) --run_out;
-    else if (run_in > 1) --run_in;
-    else { p.why_generic = "forced tile bits exceed the LDS tile"; return false; }
+    sizes((int)Mt.size());
+    return true;
+  };
+  {
+    bool done = false;
+    const int r_in0 = run_in, r_out0 = run_out;
+    for (int pass = 0; pass < 2 && !done; ++pass) {      // pass 0: must fit the target tile
+      for (int cut = 0; cut <= 6 && !done; ++cut) {      // total bits shaved off the two runs
+        for (int co = (cut + 1) / 2; co >= 0 && !done; --co) {
+          const int ci = cut - co;                       // shave the output run first
+          const int ri = r_in0 - ci, ro = r_out0 - co;
+          if (ri < std::min(r_in0, 2) || ro < std::min(r_out0, 2) || ri < 1 || ro < 1) continue;
+          if (try_runs(ri, ro, pass == 0)) { run_in = ri; run_out = ro; done = true; }
+        }
+      }
+    }
+    if (!done) { p.why_generic = "forced tile bits exceed the LDS tile"; return false; }
   }
   const int mt = (int)Mt.size(), nt1 = (int)N1t.size(), nt2 = (int)N2t.size();
   if (mt < 5) { p.why_generic = "too few free A bits for a tile"; return false; }
