@@ -85,6 +85,16 @@ __device__ unsigned long long artn_stamp_buf[4096 * ARTN_N_STAMPS];
     st_prev = now_;                                                \
     __builtin_amdgcn_sched_barrier(0);                             \
   } while (0)
+__device__ unsigned long long artn_phase_buf[1024 * 16];
+#define PHASE_MARK(k)                                                                                  \
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                         \
+    const long it_ = (tile - t0) / G;                                                                  \
+    if (it_ == 0 && (k) == 0) {                                                                        \
+      artn_phase_buf[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     \
+      artn_phase_buf[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    \
+    }                                                                                                  \
+    if (it_ >= 20 && it_ < 27) artn_phase_buf[blockIdx.x * 16 + 2 + 2 * (it_ - 20) + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  }
 #define STAMP_FLUSH                                                                   \
   if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 4096)          \
     for (int q_ = 0; q_ < ARTN_N_STAMPS; ++q_)                                        \
@@ -93,6 +103,7 @@ __device__ unsigned long long artn_stamp_buf[4096 * ARTN_N_STAMPS];
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_FLUSH
+#define PHASE_MARK(k)
 #endif
 
 // Tile index -> element offsets of the tile in A, B1, B2, C.
@@ -320,52 +331,40 @@ __device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1
   for (int s = 0; s < S; ++s) asm volatile("" : "+v"(W0[s]), "+v"(W1[s]));
 }
 
-// One stage on this wave's sub-tiles: for each, a chain of 2^KB MFMAs over the contracted
-// bits (LDS reads one step ahead of the MFMAs that consume them; the next sub-tile's table
-// entry and first operand are fetched while the current chain runs), then the scatter of
-// the 32 x 16 complex result into the output region.
+// One stage on this wave's sub-tiles.  Per sub-tile: a chain of 2^KB MFMAs over the
+// contracted bits, then the scatter of the 32 x 16 complex result into the output region.
+// The chain must never wait on LDS and the scatter must not sit between two chains, so the
+// stage is software-pipelined over "units" of CH <= 16 chain steps:
+//   * the operands of unit u+1 (CH x ds_read_b64) are issued before the MFMAs of unit u,
+//     into the other half of a ping-pong register buffer;
+//   * accumulators ping-pong too: the scatter of sub-tile i is issued after the first MFMA
+//     pair of sub-tile i+1, so the LDS writes drain under that chain.
 template <int KB>
-__device__ __forceinline__ void run_stage(const StageConst<KB> &L, const char *in, char *out,
-                                          const float (&W0)[1 << (KB - 1)], const float (&W1)[1 << (KB - 1)], int h
-#ifdef ARTN_STAMPS
-                                          , unsigned long long &st_prev, unsigned long long (&st_acc)[ARTN_N_STAMPS]
-#endif
-                                          ) {
-  constexpr int S = 1 << (KB - 1);
-  int msub = L.wm;
-  if (msub >= L.msubs) return;
-  uint2 mo = L.msub_tab[msub];
-  float2 a_next = *reinterpret_cast<const float2 *>(in + (L.lane_in ^ mo.x));
-  for (; msub < L.msubs; msub += L.wm_count) {
-    const unsigned li = L.lane_in ^ mo.x, lo = L.lane_out ^ mo.y;
-    const int nmsub = msub + L.wm_count;
-    uint2 mo_n = mo;
-    if (nmsub < L.msubs) mo_n = L.msub_tab[nmsub];
-    f32x16 acc;
+struct StageRun {
+  static constexpr int S = 1 << (KB - 1);
+  static constexpr int CH = S < 16 ? S : 16; // chain steps per unit
+  static constexpr int UPS = S / CH;         // units per sub-tile (1, or 2 for KB = 6)
+  const StageConst<KB> &L;
+  const char *in;
+  char *out;
+  const float (&W0)[S];
+  const float (&W1)[S];
+  int h;
+
+  __device__ __forceinline__ unsigned ko(int s) const {
+    unsigned k = 0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    STAMP(8); // sub-tile setup (table entry, first operand)
+    for (int b = 1; b < KB; ++b)
+      if ((s >> (b - 1)) & 1) k ^= L.kin[b];
+    return k;
+  }
+  // operands of one unit: steps [base, base + CH) of the sub-tile at LDS offset li
+  template <int BASE>
+  __device__ __forceinline__ void load_unit(float2 (&buf)[CH], unsigned li) const {
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float2 a = a_next;
-      if (s + 1 < S) {
-        unsigned ko = 0;
-#pragma unroll
-        for (int b = 1; b < KB; ++b)
-          if (((s + 1) >> (b - 1)) & 1) ko ^= L.kin[b];
-        a_next = *reinterpret_cast<const float2 *>(in + (li ^ ko));
-      } else if (nmsub < L.msubs) {
-        a_next = *reinterpret_cast<const float2 *>(in + (L.lane_in ^ mo_n.x));
-      }
-#ifdef ARTN_ABLATE_MFMA
-      asm volatile("" ::"v"(a.x), "v"(a.y), "v"(W0[s]), "v"(W1[s]));
-#else
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[s], a.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[s], a.y, acc, 0, 0, 0);
-#endif
-    }
-    asm volatile("" : "+v"(acc));
-    STAMP(9); // MFMA chain
+    for (int s = 0; s < CH; ++s) buf[s] = *reinterpret_cast<const float2 *>(in + (li ^ ko(BASE + s)));
+  }
+  __device__ __forceinline__ void scatter(const f32x16 &acc, unsigned lo) const {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -377,9 +376,92 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, const char *i
         }
       }
     }
-    STAMP(10); // scatter
-    mo = mo_n;
   }
+  // MFMAs of one unit; after the first pair, the pending scatter of the previous sub-tile
+  template <int BASE>
+  __device__ __forceinline__ void chain_unit(f32x16 &acc, const float2 (&buf)[CH], bool pending, const f32x16 &pacc,
+                                             unsigned plo) const {
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+#ifdef ARTN_ABLATE_MFMA
+      asm volatile("" ::"v"(buf[s].x), "v"(buf[s].y), "v"(W0[BASE + s]), "v"(W1[BASE + s]));
+#else
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[BASE + s], buf[s].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[BASE + s], buf[s].y, acc, 0, 0, 0);
+#endif
+      if (s == 0 && BASE == 0 && pending) scatter(pacc, plo);
+    }
+  }
+  __device__ __forceinline__ void zero(f32x16 &acc) const {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  }
+
+  __device__ __forceinline__ void run() const {
+    int msub = L.wm;
+    if (msub >= L.msubs) return;
+    float2 bA[CH], bB[CH];
+    f32x16 acc0, acc1;
+    uint2 mo = L.msub_tab[msub];
+    load_unit<0>(bA, L.lane_in ^ mo.x);
+    bool pending = false;
+    unsigned plo = 0;
+    // two sub-tiles per trip so buffers and accumulators have static names
+    for (;;) {
+      // ---- even sub-tile: operands in bA (first unit), result in acc0
+      {
+        const unsigned li = L.lane_in ^ mo.x, lo = L.lane_out ^ mo.y;
+        const int nmsub = msub + L.wm_count;
+        const bool more = nmsub < L.msubs;
+        uint2 mo_n = mo;
+        if (more) mo_n = L.msub_tab[nmsub];
+        zero(acc0);
+        if (UPS == 2) {
+          load_unit<(UPS == 2 ? CH : 0)>(bB, li);
+          chain_unit<0>(acc0, bA, pending, acc1, plo);
+          if (more) load_unit<0>(bA, L.lane_in ^ mo_n.x);
+          chain_unit<(UPS == 2 ? CH : 0)>(acc0, bB, false, acc1, plo);
+        } else {
+          if (more) load_unit<0>(bB, L.lane_in ^ mo_n.x);
+          chain_unit<0>(acc0, bA, pending, acc1, plo);
+        }
+        pending = true;
+        plo = lo;
+        if (!more) { scatter(acc0, plo); return; }
+        msub = nmsub;
+        mo = mo_n;
+      }
+      // ---- odd sub-tile: operands in bB (UPS == 1) or bA (UPS == 2), result in acc1
+      {
+        const unsigned li = L.lane_in ^ mo.x, lo = L.lane_out ^ mo.y;
+        const int nmsub = msub + L.wm_count;
+        const bool more = nmsub < L.msubs;
+        uint2 mo_n = mo;
+        if (more) mo_n = L.msub_tab[nmsub];
+        zero(acc1);
+        if (UPS == 2) {
+          load_unit<(UPS == 2 ? CH : 0)>(bB, li);
+          chain_unit<0>(acc1, bA, pending, acc0, plo);
+          if (more) load_unit<0>(bA, L.lane_in ^ mo_n.x);
+          chain_unit<(UPS == 2 ? CH : 0)>(acc1, bB, false, acc0, plo);
+        } else {
+          if (more) load_unit<0>(bA, L.lane_in ^ mo_n.x);
+          chain_unit<0>(acc1, bB, pending, acc0, plo);
+        }
+        plo = lo;
+        if (!more) { scatter(acc1, plo); return; }
+        msub = nmsub;
+        mo = mo_n;
+      }
+    }
+  }
+};
+
+template <int KB>
+__device__ __forceinline__ void run_stage(const StageConst<KB> &L, const char *in, char *out,
+                                          const float (&W0)[1 << (KB - 1)], const float (&W1)[1 << (KB - 1)], int h) {
+  StageRun<KB> r{L, in, out, W0, W1, h};
+  r.run();
 }
 
 // KB2 == 0: single stage.
@@ -473,28 +555,22 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
     TileOff n2off = noff;
     if (next2 < n_tiles) n2off = tile_offsets(P, OT, next2);
     STAMP(0); // W reload, offsets of the tile after next
+    PHASE_MARK(0);
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
-#ifdef ARTN_STAMPS
-    run_stage<KB1>(L1, R0, R1, W10, W11, h, st_prev, st_acc);
-#else
     run_stage<KB1>(L1, R0, R1, W10, W11, h);
-#endif
     STAMP(5);
     __syncthreads();
     const char *outr = R1;
     if (KB2 > 0) {
       STAMP(6);
-#ifdef ARTN_STAMPS
-      run_stage<KB2e>(L2, R1, R0, W20, W21, h, st_prev, st_acc);
-#else
       run_stage<KB2e>(L2, R1, R0, W20, W21, h);
-#endif
       STAMP(5);
       __syncthreads();
       outr = R0;
     }
     STAMP(6); // barriers after the stages
+    PHASE_MARK(1);
 
     unsigned lo_in = in_lane, lo_out = out_lane, t16 = tid16, t16o = tid16_out;
     OPAQUE_V(lo_in);
@@ -813,6 +889,11 @@ int artn_contract2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A
 
 #ifdef ARTN_STAMPS
 // diagnostic build only: copy the per-wave phase sums to the host and clear them
+int artn_debug_read_phases(unsigned long long *host) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(artn_phase_buf), sizeof(unsigned long long) * 1024 * 16));
+  return ARTN_OK;
+}
 int artn_debug_read_stamps(unsigned long long *host, int n_waves) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(artn_stamp_buf), sizeof(unsigned long long) * ARTN_N_STAMPS * n_waves));
