@@ -285,7 +285,66 @@ def fusion_schedule(scheme):
     return order
 
 
-_schedule_cache = {}
+_plan_cache = {}
+
+
+class _Op:
+    """One launch of a compiled dense scheme: a single step or a fused pair."""
+    __slots__ = ("steps", "i", "j", "j2", "d1", "d2", "out_shape", "info")
+
+
+def _compile_dense(scheme, shapes, dtype):
+    """Resolve a dense scheme once: execution order, fused pairs (host-only planner queries),
+    descriptors and result shapes.  Everything the per-call loop needs except pointers."""
+    shapes = dict(shapes)
+    fuse_ok = dtype == torch.complex64
+    ops = []
+
+    def single(n):
+        (i, j), eq = scheme[n][0], scheme[n][1]
+        la, lb, lo = _parse(eq)
+        op = _Op()
+        op.steps, op.i, op.j, op.j2, op.d2 = (n,), i, j, None, None
+        op.d1, op.out_shape = _descriptor(la, lb, lo, shapes[i], _dense_strides(shapes[i]), shapes[j],
+                                          _dense_strides(shapes[j]), dtype)
+        op.info = None
+        shapes[i] = op.out_shape
+        ops.append(op)
+
+    for entry in fusion_schedule(scheme):
+        if entry[0] == "one":
+            single(entry[1])
+            continue
+        n, m = entry[1], entry[2]
+        (i, j), eq1 = scheme[n][0], scheme[n][1]
+        (_, j2), eq2 = scheme[m][0], scheme[m][1]
+        numel = 1
+        for e in shapes[i]:
+            numel *= e
+        info = None
+        if fuse_ok and numel >= FUSE_MIN_NUMEL:
+            la1, lb1, lo1 = _parse(eq1)
+            la2, lb2, lo2 = _parse(eq2)
+            d1, mid = _descriptor(la1, lb1, lo1, shapes[i], _dense_strides(shapes[i]), shapes[j],
+                                  _dense_strides(shapes[j]), dtype)
+            if len(la2) == len(mid):
+                d2, out_shape = _descriptor(la2, lb2, lo2, mid, _dense_strides(mid), shapes[j2],
+                                            _dense_strides(shapes[j2]), dtype)
+                q = N.ArtnStepInfo()
+                rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
+                if rc == 0:
+                    info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
+                elif rc != -2:
+                    N.check(rc)
+        if info is None:
+            single(n)
+            single(m)
+            continue
+        op = _Op()
+        op.steps, op.i, op.j, op.j2, op.d1, op.d2, op.out_shape, op.info = (n, m), i, j, j2, d1, d2, out_shape, info
+        shapes[i] = out_shape
+        ops.append(op)
+    return ops
 
 
 def tensor_contraction(tensors, scheme):
@@ -293,47 +352,72 @@ def tensor_contraction(tensors, scheme):
     tensors[j]); returns the last tensors[i] (reference contraction.py:62-76; `tensors` is
     mutated the same way).
 
-    Behind the unchanged entry point, two consecutive steps on the same big tensor are
-    executed as ONE pass over HBM when their contracted bits fit one LDS tile
-    (artn_contract2); results are those of the step-by-step order."""
+    Behind the unchanged entry point the scheme is compiled once (per scheme object and leaf
+    shapes) into a launch list; two consecutive steps on the same big tensor execute as ONE
+    pass over HBM when their contracted bits fit one LDS tile (artn_contract2).  Results are
+    those of the step-by-step order."""
     if len(scheme) == 0:
         raise RuntimeError("empty contraction scheme")
-    key = id(scheme)
-    hit = _schedule_cache.get(key)
-    if hit is None or hit[0] is not scheme:
-        hit = _schedule_cache[key] = (scheme, fusion_schedule(scheme))
-        if len(_schedule_cache) > 64:
-            _schedule_cache.clear()
-            _schedule_cache[key] = hit
-    last = scheme[-1][0][0]
-
-    def one(n):
-        (i, j), eq = scheme[n][0], scheme[n][1]
-        try:
-            tensors[i] = contract(eq, tensors[i], tensors[j])
-        except Exception as e:
-            raise RuntimeError(f"tensor_contraction failed at step {n} {scheme[n][0]} {eq!r}: {e}") from e
-
-    for entry in hit[1]:
-        if entry[0] == "one":
-            one(entry[1])
+    ids = tensors.keys() if isinstance(tensors, dict) else range(len(tensors))
+    used = set()
+    for step in scheme:
+        used.update(step[0])
+    first = None
+    shapes = {}
+    for k in ids:
+        if k not in used:
             continue
-        n, m = entry[1], entry[2]
-        (i, j), eq1 = scheme[n][0], scheme[n][1]
-        (_, j2), eq2 = scheme[m][0], scheme[m][1]
-        fused = None
-        a = tensors[i]
-        if isinstance(a, torch.Tensor) and a.is_cuda and a.numel() >= FUSE_MIN_NUMEL:
-            try:
-                fused = contract2(eq1, a, tensors[j], eq2, tensors[j2])
-            except Exception as e:
-                raise RuntimeError(f"tensor_contraction failed at fused steps {n}+{m}: {e}") from e
-        if fused is None:
-            one(n)
-            one(m)
-        else:
-            tensors[i] = fused
-    return tensors[last]
+        t = tensors[k]
+        N.require_gpu(t, "tensor_contraction")
+        if first is None:
+            first = t
+        elif t.dtype != first.dtype or t.device != first.device:
+            raise RuntimeError("all tensors of a scheme must share dtype and device")
+        if not t.is_contiguous():
+            tensors[k] = t = t.contiguous()
+        shapes[k] = tuple(t.shape)
+    if first is None or first.dtype not in _DTYPES:
+        raise RuntimeError("tensor_contraction needs complex64 or complex128 GPU tensors")
+    key = (id(scheme), first.dtype, tuple(sorted(shapes.items())), N.lib().artn_contract2_query is not None,
+           bool(__import__("os").environ.get("ARTN_NO_FUSE")))
+    hit = _plan_cache.get(key)
+    if hit is None or hit[0] is not scheme:
+        try:
+            ops = _compile_dense(scheme, shapes, first.dtype)
+        except KeyError as e:
+            raise RuntimeError(f"scheme refers to tensor id {e} that was not supplied") from e
+        if len(_plan_cache) > 64:
+            _plan_cache.clear()
+        hit = _plan_cache[key] = (scheme, ops)
+    ops = hit[1]
+    lib = N.lib()
+    dtype, device = first.dtype, first.device
+    byref = ctypes.byref
+    with torch.cuda.device(device):
+        stream = N.current_stream_ptr(device)
+        for op in ops:
+            a, b = tensors[op.i], tensors[op.j]
+            out = torch.empty(op.out_shape, dtype=dtype, device=device)
+            if profiler is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if op.d2 is None:
+                rc = lib.artn_contract(byref(op.d1), a.data_ptr(), b.data_ptr(), out.data_ptr(), stream) if out.numel() else 0
+            else:
+                b2 = tensors[op.j2]
+                rc = lib.artn_contract2(byref(op.d1), byref(op.d2), a.data_ptr(), b.data_ptr(), b2.data_ptr(),
+                                        out.data_ptr(), stream)
+            if rc != 0:
+                msg = lib.artn_last_error()
+                raise RuntimeError(f"tensor_contraction failed at step(s) {op.steps} "
+                                   f"{[scheme[n][1] for n in op.steps]}: {msg.decode() if msg else rc}")
+            if profiler is not None:
+                e1.record()
+                if op.info is None:
+                    op.info = _query(op.d1)
+                profiler.record(op.info, e0, e1)
+            tensors[op.i] = out
+    return tensors[scheme[-1][0][0]]
 
 
 # ----------------------------------------------------------------------------------------
