@@ -13,6 +13,9 @@ $(LIB): $(CSRC)/artn_kernels.hip $(CSRC)/artn_plan.h include/artn.h
 stamps: $(CSRC)/artn_kernels.hip $(CSRC)/artn_plan.h include/artn.h
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_STAMPS -Iinclude -I$(CSRC) $< -o tools/libartn_hip_stamps.so
 
+phases: $(CSRC)/artn_kernels.hip $(CSRC)/artn_plan.h include/artn.h
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_PHASES -Iinclude -I$(CSRC) $< -o tools/libartn_hip_phases.so
+
 # timing-only ablations (wrong results by construction; never loaded by the product)
 ablate: $(CSRC)/artn_kernels.hip $(CSRC)/artn_plan.h include/artn.h
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MFMA -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomfma.so

@@ -85,16 +85,6 @@ __device__ unsigned long long artn_stamp_buf[4096 * ARTN_N_STAMPS];
     st_prev = now_;                                                \
     __builtin_amdgcn_sched_barrier(0);                             \
   } while (0)
-__device__ unsigned long long artn_phase_buf[1024 * 16];
-#define PHASE_MARK(k)                                                                                  \
-  if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                         \
-    const long it_ = (tile - t0) / G;                                                                  \
-    if (it_ == 0 && (k) == 0) {                                                                        \
-      artn_phase_buf[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     \
-      artn_phase_buf[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    \
-    }                                                                                                  \
-    if (it_ >= 20 && it_ < 27) artn_phase_buf[blockIdx.x * 16 + 2 + 2 * (it_ - 20) + (k)] = __builtin_amdgcn_s_memrealtime(); \
-  }
 #define STAMP_FLUSH                                                                   \
   if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 4096)          \
     for (int q_ = 0; q_ < ARTN_N_STAMPS; ++q_)                                        \
@@ -103,6 +93,21 @@ __device__ unsigned long long artn_phase_buf[1024 * 16];
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_FLUSH
+#endif
+// Cheap phase marks (make phases): thread 0 of each workgroup records s_memrealtime at up to 8
+// points of iterations 20..21 plus its HW_ID / XCC_ID.
+#if defined(ARTN_STAMPS) || defined(ARTN_PHASES)
+__device__ unsigned long long artn_phase_buf[1024 * 20];
+#define PHASE_MARK(k)                                                                                  \
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                         \
+    const long it_ = (tile - t0) / G;                                                                  \
+    if (it_ == 0 && (k) == 0) {                                                                        \
+      artn_phase_buf[blockIdx.x * 20 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     \
+      artn_phase_buf[blockIdx.x * 20 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    \
+    }                                                                                                  \
+    if (it_ >= 20 && it_ < 22) artn_phase_buf[blockIdx.x * 20 + 2 + 9 * (it_ - 20) + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  }
+#else
 #define PHASE_MARK(k)
 #endif
 
@@ -541,6 +546,14 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
   }
   __syncthreads();
 
+  // Two workgroups share a CU and run the same phase sequence.  Left alone they settle into
+  // near-lockstep (tools/phases.py: stage phases 67 % of the period, start offset 0.2 of it
+  // whatever the start-up stagger -- lockstep is an attractor): both fight for the matrix
+  // pipe in their stage phases and both leave it idle in their copy phases.  Raising the
+  // issue priority of ONE of the two (the one whose waves sit in the odd wave slots) during
+  // its MFMA stages only breaks the symmetry: its chains never wait, the other workgroup's
+  // chains fill the pipe while it copies, and the pair locks into alternation (offset 0.48).
+  const bool stage_prio = P.stage_prio && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1); // HW_ID.wave_id bit 0
   STAMP_DECL
   for (long tile = t0; tile < n_tiles; tile += G) {
     if (off.b1 != prev_b1) {
@@ -558,19 +571,23 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
     PHASE_MARK(0);
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
+    if (stage_prio) __builtin_amdgcn_s_setprio(2);
     run_stage<KB1>(L1, R0, R1, W10, W11, h);
+    if (stage_prio && KB2 == 0) __builtin_amdgcn_s_setprio(0);
+    PHASE_MARK(1);
     STAMP(5);
     __syncthreads();
     const char *outr = R1;
     if (KB2 > 0) {
       STAMP(6);
       run_stage<KB2e>(L2, R1, R0, W20, W21, h);
+      if (stage_prio) __builtin_amdgcn_s_setprio(0);
       STAMP(5);
       __syncthreads();
       outr = R0;
     }
     STAMP(6); // barriers after the stages
-    PHASE_MARK(1);
+    PHASE_MARK(2);
 
     unsigned lo_in = in_lane, lo_out = out_lane, t16 = tid16, t16o = tid16_out;
     OPAQUE_V(lo_in);
@@ -585,9 +602,11 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
       for (int i = 0; i < 8; ++i)
         if (i < n_out_iters) x[i] = *reinterpret_cast<const f32x4 *>(outr + (t16o ^ out_i_swz[i]));
       if (KB2 > 0) __syncthreads(); // fused: the result sat in R0, which is refilled next
+      PHASE_MARK(3);
       STAMP(1);
       // refill R0 with the next tile (its loads were issued one iteration ago)
       if (next < n_tiles) store_lds(v, R0, t16);
+      PHASE_MARK(4);
       STAMP(2);
       // stores of this tile, then the loads of the tile after next
 #pragma unroll
@@ -604,8 +623,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
 #endif
         }
       }
+      PHASE_MARK(5);
       STAMP(7);
       if (next2 < n_tiles) issue_loads(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
+      PHASE_MARK(6);
       STAMP(4);
     } else {
       // big tiles (2^13): no register prefetch; stream out, then load the next tile
@@ -628,6 +649,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
       if (next < n_tiles) copy_in_sync(reinterpret_cast<const char *>(A + noff.a), in_hi, lo_in, R0, t16, n_in_iters);
     }
     __syncthreads(); // R0 holds the next tile; every wave is done with the result region
+    PHASE_MARK(7);
     STAMP(3);
     off = noff;
     noff = n2off;
@@ -887,13 +909,15 @@ int artn_contract2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A
   return ARTN_OK;
 }
 
-#ifdef ARTN_STAMPS
-// diagnostic build only: copy the per-wave phase sums to the host and clear them
+#if defined(ARTN_STAMPS) || defined(ARTN_PHASES)
+// diagnostic builds only
 int artn_debug_read_phases(unsigned long long *host) {
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(artn_phase_buf), sizeof(unsigned long long) * 1024 * 16));
+  HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(artn_phase_buf), sizeof(unsigned long long) * 1024 * 20));
   return ARTN_OK;
 }
+#endif
+#ifdef ARTN_STAMPS
 int artn_debug_read_stamps(unsigned long long *host, int n_waves) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(artn_stamp_buf), sizeof(unsigned long long) * ARTN_N_STAMPS * n_waves));

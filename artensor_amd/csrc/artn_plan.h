@@ -69,7 +69,7 @@ struct ArtnBitsPlan {
   int32_t r0_bits;            // LDS region 0 holds 2^r0_bits elements (region 1 follows it)
   int32_t run_in, run_out;    // tile-local bits [0,run) are global bits [0,run)
   int32_t n_outer;
-  int32_t stagger;            // start-up delay of the odd wave slots, in units of 2048 cycles
+  int32_t stage_prio;         // 1: one of the two co-resident workgroups runs its MFMA stages at s_setprio 2
   int32_t pad_;
   int64_t n_tiles;
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
@@ -101,14 +101,14 @@ struct ArtnPlan {
 
 namespace artn {
 
-// Development knobs (environment: ARTN_WG_PER_CU, ARTN_TILE_TARGET, ARTN_RUN_MAX, ARTN_SWIZZLE); the
+// Development knobs (environment: ARTN_WG_PER_CU, ARTN_TILE_TARGET, ARTN_RUN_MAX, ARTN_SWIZZLE, ARTN_STAGE_PRIO); the
 // defaults are what ships.
 struct Tuning {
   int wg_per_cu = 2;  // persistent workgroups per CU (grid = CUs * this), capped by LDS
   int tile_target = ARTN_TILE_BITS_TARGET;
   int run_max = 4;    // longest contiguous run (log2 elements) the tile is forced to keep
   int swizzle = 1;    // XOR-swizzle stage output regions against LDS bank conflicts
-  int stagger = 0;    // start-up delay of every other workgroup on a CU (x 2048 cycles)
+  int stage_prio = 1; // asymmetric MFMA-stage priority between the two workgroups of a CU
 };
 static inline Tuning &tuning() {
   static Tuning t = [] {
@@ -117,7 +117,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_TILE_TARGET")) x.tile_target = std::min(ARTN_TILE_BITS_MAX, std::max(9, atoi(e)));
     if (const char *e = getenv("ARTN_RUN_MAX")) x.run_max = std::min(6, std::max(1, atoi(e)));
     if (const char *e = getenv("ARTN_SWIZZLE")) x.swizzle = atoi(e) != 0;
-    if (const char *e = getenv("ARTN_STAGGER")) x.stagger = std::max(0, atoi(e));
+    if (const char *e = getenv("ARTN_STAGE_PRIO")) x.stage_prio = atoi(e) != 0;
     return x;
   }();
   return t;
@@ -418,7 +418,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   b.T_in = T_in; b.T_mid = T_mid; b.T_out = T_out;
   b.r0_bits = fused ? std::max(T_in, T_out) : T_in;
   b.run_in = run_in; b.run_out = run_out;
-  b.stagger = tuning().stagger;
+  b.stage_prio = tuning().stage_prio;
 
   // ---- tile-local orders: input (by A stride), mid (by C1 stride), output (by final C stride)
   std::vector<int> tin(K1), tmid(Mt), tout;
