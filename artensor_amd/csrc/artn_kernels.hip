@@ -123,10 +123,12 @@ struct TileOff {
   long a, b1, b2, c;
 };
 struct OffTab {
-  const long *tab; // LDS: [nibble index][16][4]
-  int n_nib;       // nibbles covering the power-of-two prefix
-  int pow2_bits;   // bits of that prefix
+  const long *tab;   // LDS: [nibble index][16][4]
+  const long *delta; // LDS: [c][4] = offsets(t + G) - offsets(t) when (t / G) ends in c one-bits (G a power of two)
+  int n_nib;         // nibbles covering the power-of-two prefix
+  int pow2_bits;     // bits of that prefix
   int first_generic;
+  int g_log2;        // log2 of the grid size if it is a power of two inside the prefix, else -1
 };
 __device__ __forceinline__ OffTab build_offset_table(const ArtnBitsPlan &P, long *tab, int tid) {
   OffTab T;
@@ -159,6 +161,41 @@ __device__ __forceinline__ OffTab build_offset_table(const ArtnBitsPlan &P, long
     long *e = tab + (long)tid * 4;
     e[0] = a; e[1] = b1; e[2] = b2; e[3] = c;
   }
+  // Grid-stride increments: with G = 2^g, tile + G flips the trailing ones of (tile >> g) and
+  // sets the next bit, so the offset difference depends only on the number c of trailing ones.
+  long *dl = tab + 8 * 16 * 4;
+  T.delta = dl;
+  const int G = gridDim.x;
+  T.g_log2 = -1;
+  if ((G & (G - 1)) == 0 && T.first_generic == P.n_outer) {
+    int g = 0;
+    while ((1 << g) < G) ++g;
+    if (g <= bits) T.g_log2 = g;
+  }
+  if (T.g_log2 >= 0 && tid >= 128 && tid < 128 + 32) {
+    const int cnum = tid - 128; // number of trailing ones
+    long d[4] = {0, 0, 0, 0};
+    for (int b = 0; b <= cnum; ++b) {
+      const int bit = T.g_log2 + b;
+      if (bit >= bits) break;
+      int lo = 0;
+      for (int e = 0; e < T.first_generic; ++e) {
+        const int lg = P.outer[e].log2ext;
+        if (bit < lo + lg) {
+          const int r = bit - lo;
+          const long sgn = b == cnum ? 1 : -1;
+          d[0] += sgn * (P.outer[e].sA << r);
+          d[1] += sgn * (P.outer[e].sB1 << r);
+          d[2] += sgn * (P.outer[e].sB2 << r);
+          d[3] += sgn * (P.outer[e].sC << r);
+          break;
+        }
+        lo += lg;
+      }
+    }
+    long *e = dl + cnum * 4;
+    e[0] = d[0]; e[1] = d[1]; e[2] = d[2]; e[3] = d[3];
+  }
   return T;
 }
 __device__ __forceinline__ long uniform64(long x) {
@@ -188,6 +225,17 @@ __device__ __forceinline__ TileOff tile_offsets(const ArtnBitsPlan &P, const Off
       t.c += x * P.outer[d].sC;
     }
   }
+  return t;
+}
+
+// offsets(tile + G) from offsets(tile): one 32-byte LDS lookup when the grid is a power of two
+__device__ __forceinline__ TileOff next_offsets(const ArtnBitsPlan &P, const OffTab &T, const TileOff &cur, long tile,
+                                                long G) {
+  if (T.g_log2 < 0) return tile_offsets(P, T, tile + G);
+  const unsigned hi = (unsigned)(tile >> T.g_log2);
+  const int c = __builtin_ctz(~hi);
+  const long *e = T.delta + c * 4;
+  TileOff t = {uniform64(cur.a + e[0]), uniform64(cur.b1 + e[1]), uniform64(cur.b2 + e[2]), uniform64(cur.c + e[3])};
   return t;
 }
 
@@ -566,7 +614,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
     }
     const long next = tile + G, next2 = tile + 2 * G;
     TileOff n2off = noff;
-    if (next2 < n_tiles) n2off = tile_offsets(P, OT, next2);
+    if (next2 < n_tiles) n2off = next_offsets(P, OT, noff, next, G);
     STAMP(0); // W reload, offsets of the tile after next
     PHASE_MARK(0);
 

@@ -550,7 +550,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     int pow2_bits = 0;
     for (int i = 0; i < b.n_outer && b.outer[i].log2ext >= 0; ++i) pow2_bits += b.outer[i].log2ext;
     if (pow2_bits > 32) { p.why_generic = "more than 2^32 tiles"; return false; }
-    const int64_t off_tab = 512LL * ((pow2_bits + 3) / 4); // tile-offset table: 16 x 4 longs per nibble
+    const int64_t off_tab = 512LL * 8 + 32 * 32; // tile-offset nibble tables (8 x 16 x 4 longs) + grid-stride deltas
     f.lds_bytes = (int32_t)((8LL << b.r0_bits) + (8LL << b.T_mid) + (8LL << (mt - 5)) + (fused ? (8LL << (m2 - 5)) : 0) + off_tab);
   }
   f.n_tiles = b.n_tiles;
