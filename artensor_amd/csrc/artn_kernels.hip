@@ -239,6 +239,21 @@ __device__ __forceinline__ TileOff next_offsets(const ArtnBitsPlan &P, const Off
   return t;
 }
 
+// LDS accesses by 32-bit byte address.  artn_k_bits has no static __shared__ data, so its
+// dynamic LDS segment starts at byte 0 of the workgroup's allocation (checked once at kernel
+// start): addresses are plain integers, no base register and no add per access.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef v2f_t __attribute__((address_space(3))) lds_v2f_t;
+typedef f32x4 __attribute__((address_space(3))) lds_v4f_t;
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+typedef u2_t __attribute__((address_space(3))) lds_u2_t;
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+__device__ __forceinline__ v2f_t lds_read8(unsigned a) { return *(lds_v2f_t *)(unsigned long)a; }
+__device__ __forceinline__ void lds_write8(unsigned a, v2f_t v) { *(lds_v2f_t *)(unsigned long)a = v; }
+__device__ __forceinline__ f32x4 lds_read16(unsigned a) { return *(lds_v4f_t *)(unsigned long)a; }
+__device__ __forceinline__ void lds_write16(unsigned a, f32x4 v) { *(lds_v4f_t *)(unsigned long)a = v; }
+__device__ __forceinline__ u2_t lds_read_u2(unsigned a) { return *(lds_u2_t *)(unsigned long)a; }
+
 // Copy-in.  Full-size tiles (2^12 elements: exactly 8 x 16 B per thread) are software
 // pipelined: issue_loads puts the 8 chunks of tile t+1 in flight (uniform 64-bit base in SGPRs
 // + one 32-bit per-lane byte offset) while tile t is computed, store_lds writes them to LDS
@@ -267,14 +282,14 @@ __device__ __forceinline__ void issue_loads(f32x4 (&v)[8], const char *__restric
 #pragma unroll
   for (int u = 0; u < 8; ++u) v[u] = load_chunk(Abase, chunk_off(hi, u), lane_off);
 }
-__device__ __forceinline__ void store_lds(const f32x4 (&v)[8], char *ldsb, unsigned tid16) {
+__device__ __forceinline__ void store_lds(const f32x4 (&v)[8], unsigned ldsb, unsigned tid16) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4 *>(ldsb + tid16 + u * (ARTN_WG_THREADS * 16)) = v[u];
+  for (int u = 0; u < 8; ++u) lds_write16(ldsb + tid16 + u * (ARTN_WG_THREADS * 16), v[u]);
 }
 __device__ __forceinline__ void copy_in_sync(const char *__restrict__ Abase, const long (&hi)[4], unsigned lane_off,
-                                             char *ldsb, unsigned tid16, int n_iters) {
+                                             unsigned ldsb, unsigned tid16, int n_iters) {
   for (int i = 0; i < n_iters; ++i)
-    *reinterpret_cast<f32x4 *>(ldsb + tid16 + i * (ARTN_WG_THREADS * 16)) = load_chunk(Abase, chunk_off(hi, i), lane_off);
+    lds_write16(ldsb + tid16 + i * (ARTN_WG_THREADS * 16), load_chunk(Abase, chunk_off(hi, i), lane_off));
 }
 
 // XOR swizzle of an LDS region (ArtnStage::swz_*), applied to byte offsets.  It is linear over
@@ -298,12 +313,12 @@ struct StageConst {
   long kb[KB > 1 ? KB : 2];           // byte stride of K bit b in the small operand
   unsigned o0, o2, o3;                // byte offsets of N bits 0, 2, 3 in the LDS output tile
   int nt_eff, wm, wm_count, msubs;
-  const uint2 *msub_tab;              // LDS table: sub-tile -> (input, output) byte offsets
+  unsigned msub_tab;                  // LDS byte address of the table: sub-tile -> (input, output) byte offsets
 };
 // zin: stage whose output region this stage reads (nullptr: the unswizzled copy-in region).
 template <int KB>
 __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const ArtnStage *zin, int j, int h, int wave,
-                                                      const uint2 *tab) {
+                                                      unsigned tab, unsigned in_base, unsigned out_base) {
   StageConst<KB> L;
   const int wn = wave & ((1 << st.wn_log2) - 1);
   L.wm = wave >> st.wn_log2;
@@ -342,8 +357,9 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
   L.o0 = st.nt > 0 ? swz(8u << st.n_out_pos[0], &st) : 0;
   L.o2 = st.nt > 2 ? swz(8u << st.n_out_pos[2], &st) : 0;
   L.o3 = st.nt > 3 ? swz(8u << st.n_out_pos[3], &st) : 0;
-  L.lane_in = swz(L.lane_in, zin);
-  L.lane_out = swz(L.lane_out, &st);
+  // region bases are multiples of the region size: XOR-ing them in equals adding them
+  L.lane_in = swz(L.lane_in, zin) ^ in_base;
+  L.lane_out = swz(L.lane_out, &st) ^ out_base;
   return L;
 }
 // Fill the LDS sub-tile table of a stage (all threads cooperate; caller barriers).
@@ -398,8 +414,6 @@ struct StageRun {
   static constexpr int CH = S < 16 ? S : 16; // chain steps per unit
   static constexpr int UPS = S / CH;         // units per sub-tile (1, or 2 for KB = 6)
   const StageConst<KB> &L;
-  const char *in;
-  char *out;
   const float (&W0)[S];
   const float (&W1)[S];
   int h;
@@ -413,11 +427,22 @@ struct StageRun {
   }
   // operands of one unit: steps [base, base + CH) of the sub-tile at LDS offset li
   template <int BASE>
-  __device__ __forceinline__ void load_unit(float2 (&buf)[CH], unsigned li) const {
+  __device__ __forceinline__ void load_unit(v2f_t (&buf)[CH], unsigned li) const {
 #pragma unroll
-    for (int s = 0; s < CH; ++s) buf[s] = *reinterpret_cast<const float2 *>(in + (li ^ ko(BASE + s)));
+    for (int s = 0; s < CH; ++s) buf[s] = lds_read8(li ^ ko(BASE + s));
   }
   __device__ __forceinline__ void scatter(const f32x16 &acc, unsigned lo) const {
+    if (L.nt_eff == 4) { // full 16-column tile: no per-lane predicate (the common case, n >= 4)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int b0 = 0; b0 < 2; ++b0) {
+          const unsigned o = lo ^ (b0 ? L.o0 : 0u) ^ ((q & 1) ? L.o2 : 0u) ^ ((q >> 1) ? L.o3 : 0u);
+          lds_write8(o, v2f_t{acc[4 * q + 2 * b0], acc[4 * q + 2 * b0 + 1]});
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -425,14 +450,14 @@ struct StageRun {
         const int nl = b0 + 2 * h + 4 * (q & 1) + 8 * (q >> 1);
         if ((nl >> L.nt_eff) == 0) {
           const unsigned o = lo ^ (b0 ? L.o0 : 0u) ^ ((q & 1) ? L.o2 : 0u) ^ ((q >> 1) ? L.o3 : 0u);
-          *reinterpret_cast<float2 *>(out + o) = make_float2(acc[4 * q + 2 * b0], acc[4 * q + 2 * b0 + 1]);
+          lds_write8(o, v2f_t{acc[4 * q + 2 * b0], acc[4 * q + 2 * b0 + 1]});
         }
       }
     }
   }
   // MFMAs of one unit; after the first pair, the pending scatter of the previous sub-tile
   template <int BASE>
-  __device__ __forceinline__ void chain_unit(f32x16 &acc, const float2 (&buf)[CH], bool pending, const f32x16 &pacc,
+  __device__ __forceinline__ void chain_unit(f32x16 &acc, const v2f_t (&buf)[CH], bool pending, const f32x16 &pacc,
                                              unsigned plo) const {
 #pragma unroll
     for (int s = 0; s < CH; ++s) {
@@ -453,9 +478,9 @@ struct StageRun {
   __device__ __forceinline__ void run() const {
     int msub = L.wm;
     if (msub >= L.msubs) return;
-    float2 bA[CH], bB[CH];
+    v2f_t bA[CH], bB[CH];
     f32x16 acc0, acc1;
-    uint2 mo = L.msub_tab[msub];
+    u2_t mo = lds_read_u2(L.msub_tab + msub * 8);
     load_unit<0>(bA, L.lane_in ^ mo.x);
     bool pending = false;
     unsigned plo = 0;
@@ -466,8 +491,8 @@ struct StageRun {
         const unsigned li = L.lane_in ^ mo.x, lo = L.lane_out ^ mo.y;
         const int nmsub = msub + L.wm_count;
         const bool more = nmsub < L.msubs;
-        uint2 mo_n = mo;
-        if (more) mo_n = L.msub_tab[nmsub];
+        u2_t mo_n = mo;
+        if (more) mo_n = lds_read_u2(L.msub_tab + nmsub * 8);
         zero(acc0);
         if (UPS == 2) {
           load_unit<(UPS == 2 ? CH : 0)>(bB, li);
@@ -489,8 +514,8 @@ struct StageRun {
         const unsigned li = L.lane_in ^ mo.x, lo = L.lane_out ^ mo.y;
         const int nmsub = msub + L.wm_count;
         const bool more = nmsub < L.msubs;
-        uint2 mo_n = mo;
-        if (more) mo_n = L.msub_tab[nmsub];
+        u2_t mo_n = mo;
+        if (more) mo_n = lds_read_u2(L.msub_tab + nmsub * 8);
         zero(acc1);
         if (UPS == 2) {
           load_unit<(UPS == 2 ? CH : 0)>(bB, li);
@@ -511,9 +536,9 @@ struct StageRun {
 };
 
 template <int KB>
-__device__ __forceinline__ void run_stage(const StageConst<KB> &L, const char *in, char *out,
-                                          const float (&W0)[1 << (KB - 1)], const float (&W1)[1 << (KB - 1)], int h) {
-  StageRun<KB> r{L, in, out, W0, W1, h};
+__device__ __forceinline__ void run_stage(const StageConst<KB> &L, const float (&W0)[1 << (KB - 1)],
+                                          const float (&W1)[1 << (KB - 1)], int h) {
+  StageRun<KB> r{L, W0, W1, h};
   r.run();
 }
 
@@ -527,9 +552,12 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
   constexpr int KB2e = KB2 > 0 ? KB2 : 1;
   constexpr int S2 = 1 << (KB2e - 1);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  char *R0 = reinterpret_cast<char *>(smem);
-  char *R1 = R0 + (8u << P.r0_bits);
-  uint2 *tab1 = reinterpret_cast<uint2 *>(R1 + (8u << P.T_mid));
+  if ((unsigned)(unsigned long)(lds_byte_t *)smem != 0) __builtin_trap(); // see lds_read8
+  // the larger region first: each region base is then a multiple of that region's size, so
+  // XOR-ing the base into an in-region offset equals adding it
+  const unsigned R0 = P.T_mid > P.r0_bits ? 8u << P.T_mid : 0u, R1 = P.T_mid > P.r0_bits ? 0u : 8u << P.r0_bits;
+  const unsigned regions_end = (8u << P.r0_bits) + (8u << P.T_mid);
+  uint2 *tab1 = reinterpret_cast<uint2 *>(smem + regions_end);
   uint2 *tab2 = tab1 + (1 << (P.st[0].m_bits - 5));
   long *offtab = reinterpret_cast<long *>(tab2 + (KB2 > 0 ? 1 << (P.st[1].m_bits - 5) : 0));
 
@@ -561,8 +589,9 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
   // ---- per-stage constants, sub-tile tables, outer-axis digits
   fill_msub_table(P.st[0], nullptr, tab1, tid);
   if (KB2 > 0) fill_msub_table(P.st[1], &P.st[0], tab2, tid);
-  const StageConst<KB1> L1 = stage_const<KB1>(P.st[0], nullptr, j, h, wave, tab1);
-  const StageConst<KB2e> L2 = stage_const<KB2e>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2);
+  const unsigned tab1_a = regions_end, tab2_a = tab1_a + (8u << (P.st[0].m_bits - 5));
+  const StageConst<KB1> L1 = stage_const<KB1>(P.st[0], nullptr, j, h, wave, tab1_a, R0, R1);
+  const StageConst<KB2e> L2 = stage_const<KB2e>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2_a, R1, R0);
   // copy-out reads the last stage's (swizzled) output region
   const ArtnStage *zout = &P.st[KB2 > 0 ? 1 : 0];
   const unsigned tid16_out = swz(tid16, zout);
@@ -620,15 +649,15 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
     if (stage_prio) __builtin_amdgcn_s_setprio(2);
-    run_stage<KB1>(L1, R0, R1, W10, W11, h);
+    run_stage<KB1>(L1, W10, W11, h);
     if (stage_prio && KB2 == 0) __builtin_amdgcn_s_setprio(0);
     PHASE_MARK(1);
     STAMP(5);
     __syncthreads();
-    const char *outr = R1;
+    unsigned outr = R1;
     if (KB2 > 0) {
       STAMP(6);
-      run_stage<KB2e>(L2, R1, R0, W20, W21, h);
+      run_stage<KB2e>(L2, W20, W21, h);
       if (stage_prio) __builtin_amdgcn_s_setprio(0);
       STAMP(5);
       __syncthreads();
@@ -648,7 +677,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
       f32x4 x[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (i < n_out_iters) x[i] = *reinterpret_cast<const f32x4 *>(outr + (t16o ^ out_i_swz[i]));
+        if (i < n_out_iters) x[i] = lds_read16(outr + (t16o ^ out_i_swz[i]));
       if (KB2 > 0) __syncthreads(); // fused: the result sat in R0, which is refilled next
       PHASE_MARK(3);
       STAMP(1);
@@ -685,7 +714,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
 #pragma unroll
           for (int b = 0; b < 4; ++b)
             if ((i >> b) & 1) o += out_hi[b];
-          const f32x4 xx = *reinterpret_cast<const f32x4 *>(outr + (t16o ^ out_i_swz[i]));
+          const f32x4 xx = lds_read16(outr + (t16o ^ out_i_swz[i]));
 #ifdef ARTN_ABLATE_MEM
           asm volatile("" ::"v"(xx), "s"(Cbase), "v"(lo_out));
 #else
