@@ -61,6 +61,7 @@ _EXPORTS = {
     "artn_last_error": (ctypes.c_char_p, []),
     "artn_device_count": (ctypes.c_int, []),
     "artn_contract_query": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepInfo)]),
+    "artn_last_plan_note": (ctypes.c_char_p, []),
     "artn_contract": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p]),
     "artn_contract2_query": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepDesc),

@@ -238,6 +238,7 @@ def step_info(eq, a_shape, b_shape, dtype=torch.complex64, a_stride=None, b_stri
                                tuple(b_stride or dense(b_shape)), dtype)
     res = dict(_query(d))
     res["out_shape"] = out_shape
+    res["note"] = N.lib().artn_last_plan_note().decode()
     return res
 
 

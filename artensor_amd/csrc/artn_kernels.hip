@@ -35,6 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // error plumbing
 // ----------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+static thread_local std::string g_note; // why the last planned step fell back to the strided kernel
 static int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
@@ -929,8 +930,11 @@ int artn_contract_query(const ArtnStepDesc *d, ArtnStepInfo *info) {
   int rc = artn::make_plan(d, p, err, g_ncu, !no_bits, min_tiles);
   if (rc) return fail(rc, err);
   *info = p.info;
+  g_note = p.kernel == ARTN_KERNEL_GENERIC ? p.why_generic : std::string();
   return ARTN_OK;
 }
+
+const char *artn_last_plan_note(void) { return g_note.c_str(); }
 
 int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *stream) {
   if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");

@@ -91,6 +91,9 @@ int artn_device_count(void);
 
 /* Host-only: run the planner for `d` and report its decision. */
 int artn_contract_query(const ArtnStepDesc *d, ArtnStepInfo *info);
+/* Why the step of the last artn_contract_query on this thread was given to the strided
+ * kernel ("" if it was not). */
+const char *artn_last_plan_note(void);
 
 /* Enqueue one pairwise contraction (replaces torch.einsum at contraction.py:70 etc.). */
 int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *stream);
