@@ -313,6 +313,9 @@ struct StageConst {
   unsigned kin[KB > 1 ? KB : 2];      // byte offset of K bit b in the LDS input tile
   long kb[KB > 1 ? KB : 2];           // byte stride of K bit b in the small operand
   unsigned o0, o2, o3;                // byte offsets of N bits 0, 2, 3 in the LDS output tile
+  int k_hi;                           // contracted bits beyond the chain (0..2), looped over
+  unsigned kin_hi[2];
+  long kb_hi[2];
   int nt_eff, wm, wm_count, msubs;
   unsigned msub_tab;                  // LDS byte address of the table: sub-tile -> (input, output) byte offsets
 };
@@ -355,6 +358,12 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
     L.kin[b] = swz(8u << st.k_in_pos[b], zin);
     L.kb[b] = st.k_b_stride[b] * 8;
   }
+  L.k_hi = st.k > KB ? st.k - KB : 0;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    L.kin_hi[b] = b < L.k_hi ? swz(8u << st.k_in_pos[KB + b], zin) : 0u;
+    L.kb_hi[b] = b < L.k_hi ? st.k_b_stride[KB + b] * 8 : 0;
+  }
   L.o0 = st.nt > 0 ? swz(8u << st.n_out_pos[0], &st) : 0;
   L.o2 = st.nt > 2 ? swz(8u << st.n_out_pos[2], &st) : 0;
   L.o3 = st.nt > 3 ? swz(8u << st.n_out_pos[3], &st) : 0;
@@ -382,6 +391,7 @@ __device__ __forceinline__ void fill_msub_table(const ArtnStage &st, const ArtnS
 template <int KB>
 __device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1 << (KB - 1)],
                                        const char *__restrict__ Bbase, const StageConst<KB> &L, int ro) {
+  // (callers add the byte offset of looped-over contracted bits to Bbase)
   constexpr int S = 1 << (KB - 1);
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -409,15 +419,17 @@ __device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1
 //     into the other half of a ping-pong register buffer;
 //   * accumulators ping-pong too: the scatter of sub-tile i is issued after the first MFMA
 //     pair of sub-tile i+1, so the LDS writes drain under that chain.
-template <int KB>
+template <int KB, bool BIGK>
 struct StageRun {
   static constexpr int S = 1 << (KB - 1);
   static constexpr int CH = S < 16 ? S : 16; // chain steps per unit
   static constexpr int UPS = S / CH;         // units per sub-tile (1, or 2 for KB = 6)
   const StageConst<KB> &L;
-  const float (&W0)[S];
-  const float (&W1)[S];
+  float (&W0)[S];
+  float (&W1)[S];
   int h;
+  const char *Bbase; // small operand of this tile (only read when contracted bits are looped over)
+  int ro;
 
   __device__ __forceinline__ unsigned ko(int s) const {
     unsigned k = 0;
@@ -476,7 +488,51 @@ struct StageRun {
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   }
 
+  // More than 6 contracted bits: the extra ones are looped over, the fragments reloaded for
+  // each of their values, accumulators (at most two sub-tiles per wave: the tile is all K) kept.
+  __device__ __forceinline__ void run_big_k() const {
+    const int m0 = L.wm, m1 = L.wm + L.wm_count;
+    const bool has0 = m0 < L.msubs, has1 = m1 < L.msubs;
+    if (!has0) return;
+    const u2_t mo0 = lds_read_u2(L.msub_tab + m0 * 8);
+    u2_t mo1 = mo0;
+    if (has1) mo1 = lds_read_u2(L.msub_tab + m1 * 8);
+    f32x16 acc0, acc1;
+    zero(acc0);
+    zero(acc1);
+    v2f_t buf[CH];
+    const int n_hi = 1 << L.k_hi;
+    for (int hi = 0; hi < n_hi; ++hi) {
+      unsigned kin = 0;
+      long kb = 0;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if ((hi >> b) & 1) { kin ^= L.kin_hi[b]; kb += L.kb_hi[b]; }
+      load_w<KB>(W0, W1, Bbase + kb, L, ro);
+      static_assert(UPS <= 2, "chain split in at most two units");
+      load_unit<0>(buf, L.lane_in ^ mo0.x ^ kin);
+      chain_unit<0>(acc0, buf, false, acc1, 0);
+      if (UPS == 2) {
+        load_unit<(UPS == 2 ? CH : 0)>(buf, L.lane_in ^ mo0.x ^ kin);
+        chain_unit<(UPS == 2 ? CH : 0)>(acc0, buf, false, acc1, 0);
+      }
+      if (has1) {
+        load_unit<0>(buf, L.lane_in ^ mo1.x ^ kin);
+        chain_unit<0>(acc1, buf, false, acc0, 0);
+        if (UPS == 2) {
+          load_unit<(UPS == 2 ? CH : 0)>(buf, L.lane_in ^ mo1.x ^ kin);
+          chain_unit<(UPS == 2 ? CH : 0)>(acc1, buf, false, acc0, 0);
+        }
+      }
+    }
+    scatter(acc0, L.lane_out ^ mo0.y);
+    if (has1) scatter(acc1, L.lane_out ^ mo1.y);
+  }
+
   __device__ __forceinline__ void run() const {
+    if constexpr (BIGK) { // 7 or 8 contracted bits: only instantiated for the single-stage KB = 6 kernel
+      if (L.k_hi > 0) { run_big_k(); return; }
+    }
     int msub = L.wm;
     if (msub >= L.msubs) return;
     v2f_t bA[CH], bB[CH];
@@ -536,15 +592,15 @@ struct StageRun {
   }
 };
 
-template <int KB>
-__device__ __forceinline__ void run_stage(const StageConst<KB> &L, const float (&W0)[1 << (KB - 1)],
-                                          const float (&W1)[1 << (KB - 1)], int h) {
-  StageRun<KB> r{L, W0, W1, h};
+template <int KB, bool BIGK>
+__device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1 << (KB - 1)],
+                                          float (&W1)[1 << (KB - 1)], int h, const char *Bbase, int ro) {
+  StageRun<KB, BIGK> r{L, W0, W1, h, Bbase, ro};
   r.run();
 }
 
-// KB2 == 0: single stage.
-template <int KB1, int KB2>
+// KB2 == 0: single stage.  BIGK: 7 or 8 contracted bits (KB1 = 6 of them in the chain).
+template <int KB1, int KB2, bool BIGK>
 __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *__restrict__ A,
                                                                   const float2 *__restrict__ B1,
                                                                   const float2 *__restrict__ B2,
@@ -634,7 +690,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
   const bool stage_prio = P.stage_prio && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1); // HW_ID.wave_id bit 0
   STAMP_DECL
   for (long tile = t0; tile < n_tiles; tile += G) {
-    if (off.b1 != prev_b1) {
+    if (off.b1 != prev_b1 && !(BIGK && L1.k_hi > 0)) { // (with looped-over contracted bits the stage loads its own fragments)
       prev_b1 = off.b1;
       load_w<KB1>(W10, W11, reinterpret_cast<const char *>(B1 + off.b1), L1, ro);
     }
@@ -650,7 +706,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
     if (stage_prio) __builtin_amdgcn_s_setprio(2);
-    run_stage<KB1>(L1, W10, W11, h);
+    run_stage<KB1, BIGK>(L1, W10, W11, h, reinterpret_cast<const char *>(B1 + off.b1), ro);
     if (stage_prio && KB2 == 0) __builtin_amdgcn_s_setprio(0);
     PHASE_MARK(1);
     STAMP(5);
@@ -658,7 +714,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
     unsigned outr = R1;
     if (KB2 > 0) {
       STAMP(6);
-      run_stage<KB2e>(L2, W20, W21, h);
+      run_stage<KB2e, false>(L2, W20, W21, h, reinterpret_cast<const char *>(B2 + off.b2), ro);
       if (stage_prio) __builtin_amdgcn_s_setprio(0);
       STAMP(5);
       __syncthreads();
@@ -874,13 +930,22 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
   const int k2 = p.bits.n_stages == 2 ? p.bits.st[1].k : 0;
 #define ARTN_LAUNCH(K2)                                                                                   \
   case K2: {                                                                                              \
-    auto kern = artn_k_bits<KB1, K2>;                                                                     \
+    auto kern = artn_k_bits<KB1, K2, false>;                                                              \
     if (lds > 64 * 1024) {                                                                                \
       hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return e;                                                                      \
     }                                                                                                     \
     hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                                 \
     break;                                                                                                \
+  }
+  if (KB1 == 6 && k2 == 0 && p.bits.st[0].k > 6) {
+    auto kern = artn_k_bits<(KB1 == 6 ? 6 : 1), 0, true>;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
+    return hipGetLastError();
   }
   switch (k2) {
     ARTN_LAUNCH(0)
@@ -900,7 +965,7 @@ static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, 
                               hipStream_t st) {
   const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2;
   float2 *c = (float2 *)C;
-  switch (p.bits.st[0].k) {
+  switch (std::min(p.bits.st[0].k, 6)) {
     case 1: return launch_bits_k2<1>(p, a, b1, b2, c, st);
     case 2: return launch_bits_k2<2>(p, a, b1, b2, c, st);
     case 3: return launch_bits_k2<3>(p, a, b1, b2, c, st);

@@ -50,9 +50,9 @@ struct ArtnStage {
   int32_t m_bits;          // free input-tile bits = 5 lane bits + sub-tile bits
   int32_t lane_in_pos[5], lane_out_pos[5]; // MFMA column bit j -> tile-local bit (in / out)
   int32_t msub_in_pos[9], msub_out_pos[9]; // sub-tile bit      -> tile-local bit (in / out)
-  int32_t k_in_pos[6];                     // K bit i (kc bit i) -> tile-local input bit
+  int32_t k_in_pos[8];                     // K bit i (kc bit i) -> tile-local input bit
   int32_t n_out_pos[6];                    // N_t bit i          -> tile-local output bit
-  int64_t k_b_stride[6];                   // K bit i   -> small-operand element stride
+  int64_t k_b_stride[8];                   // K bit i   -> small-operand element stride
   int64_t n_b_stride[6];                   // N_t bit i -> small-operand element stride
   // XOR swizzle of this stage's OUTPUT region: element-offset bit swz_dst[i] ^= bit swz_src[i].
   // The 16 lanes of one ds_write_b64 group differ in MFMA column bits 0..3; where those sit
@@ -312,7 +312,9 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     }
   }
   const int k1 = (int)K1.size(), k2 = (int)K2.size();
-  if (k1 < 1 || k1 > 6) { p.why_generic = "contracted bit count outside 1..6"; return false; }
+  // up to 6 contracted bits run as one MFMA chain with the small operand in registers; a 7th
+  // and 8th are looped over inside the stage (fragments reloaded per value, single steps only)
+  if (k1 < 1 || k1 > (fused ? 6 : 8)) { p.why_generic = "contracted bit count outside 1..8 (1..6 when fused)"; return false; }
   if (fused && (k2 < 1 || k2 > 6)) { p.why_generic = "contracted bit count outside 1..6 (second step)"; return false; }
   auto byA = [&](int x, int y) { return ax[x].sA < ax[y].sA; };
   auto byC1 = [&](int x, int y) { return ax[x].sC1 < ax[y].sC1; };
@@ -361,7 +363,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     for (int i : N2)
       if (ax[i].sC < rout) N2t.push_back(i);
     // grow N tiles towards full 16-column MFMA tiles (lowest result positions first)
-    int n1_target = std::min(n1, std::min(6, std::max(k1, 4)));
+    int n1_target = std::min(n1, std::min(6, std::max(std::min(k1, 6), 4)));
     for (int i : N1) { if ((int)N1t.size() >= n1_target) break; if (!in_set(N1t, i)) N1t.push_back(i); }
     int n2_target = std::min(n2, std::min(6, std::max(k2, 4)));
     for (int i : N2) { if ((int)N2t.size() >= n2_target) break; if (!in_set(N2t, i)) N2t.push_back(i); }
@@ -385,7 +387,8 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
       if (in_set(Mt, i)) continue;
       sizes((int)Mt.size());
       int biggest = std::max(T_in, std::max(T_mid, T_out));
-      if (((int)Mt.size() >= 5 && biggest >= target) || !fits((int)Mt.size() + 1)) break;
+      const bool enough = (int)Mt.size() >= 5 && T_in >= 9 && T_out >= 9; // one full copy pass per tile
+      if ((enough && biggest >= target) || !fits((int)Mt.size() + 1)) break;
       Mt.push_back(i);
     }
     sizes((int)Mt.size());

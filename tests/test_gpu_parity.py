@@ -62,7 +62,7 @@ def test_no_cpu_fallback():
 
 @pytest.mark.parametrize("force", ["ARTN_FORCE_BITS", "ARTN_FORCE_GENERIC", None])
 @pytest.mark.parametrize("k,n,ra", [(1, 1, 12), (2, 0, 13), (3, 3, 14), (4, 4, 15), (5, 5, 15), (6, 6, 16),
-                                    (4, 7, 13), (6, 2, 16), (1, 6, 12), (5, 1, 14), (3, 4, 20)])
+                                    (4, 7, 13), (6, 2, 16), (1, 6, 12), (5, 1, 14), (7, 3, 15), (8, 4, 15), (7, 6, 16), (8, 0, 14), (3, 4, 20)])
 def test_random_bit_steps(monkeypatch, force, k, n, ra):
     if force:
         monkeypatch.setenv(force, "1")
