@@ -105,6 +105,38 @@ def _as_operand(t):
     return t
 
 
+MAX_TILE_K_BITS = 8  # contracted bits one LDS tile of the MFMA kernel can hold
+
+
+def _split_big_k(la, lb, lo, a, b):
+    """More contracted bits than one LDS tile holds (closing steps of the sparse path contract
+    15 bonds at once): keep the slowest-varying contracted labels as a temporary batch label,
+    run the MFMA kernel per value, then sum that label out -- split-K with the partial results
+    in HBM.  Returns None when the step does not need / allow it."""
+    if a.dtype != torch.complex64:
+        return None
+    ka = [(a.stride(la.index(x)), x) for x in la if x in lb and x not in lo]
+    bits = 0
+    for _, x in ka:
+        e = a.shape[la.index(x)]
+        if e & (e - 1):
+            return None
+        bits += e.bit_length() - 1
+    if bits <= MAX_TILE_K_BITS or a.numel() < (1 << 20):
+        return None
+    ka.sort(reverse=True)  # highest A stride first
+    outer = []
+    for _, x in ka:
+        if bits <= MAX_TILE_K_BITS:
+            break
+        outer.append(x)
+        bits -= a.shape[la.index(x)].bit_length() - 1
+    mid = tuple(outer) + tuple(lo)
+    part = contract((la, lb, mid), a, b)
+    one = torch.ones((), dtype=a.dtype, device=a.device)
+    return (mid, (), tuple(lo)), part, one
+
+
 def contract(eq, a, b, out=None):
     """C = einsum(eq, a, b) on the GPU through artn_contract (stands in for torch.einsum at
     reference contraction.py:70,147,156,163,169,179,181,190).  `eq` is an einsum string or
@@ -112,6 +144,9 @@ def contract(eq, a, b, out=None):
     la, lb, lo = _parse(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
     N.require_gpu(a, "contract")
     N.require_gpu(b, "contract")
+    split = _split_big_k(la, lb, lo, a, b) if a.is_cuda and b.is_cuda and a.dtype == b.dtype else None
+    if split is not None:
+        (la, lb, lo), a, b = split
     if a.dtype != b.dtype or a.dtype not in _DTYPES:
         raise RuntimeError(f"operands must both be complex64 or complex128, got {a.dtype} and {b.dtype}")
     if a.device != b.device:

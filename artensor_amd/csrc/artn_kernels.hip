@@ -640,7 +640,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
     out_hi[b] = 9 + b < P.T_out ? P.out_stride[9 + b] * 8 : 0;
   }
   const unsigned tid16 = tid * 16;
-  const int n_in_iters = 1 << (P.T_in - 9), n_out_iters = 1 << (P.T_out - 9);
+  const int n_in_iters = 1 << (P.T_in - 9);
+  // output tiles smaller than one copy pass (2^9 elements): one pass, upper threads idle
+  const int n_out_iters = P.T_out >= 9 ? 1 << (P.T_out - 9) : 1;
+  const bool out_active = P.T_out >= 9 || tid < (1 << (P.T_out - 1));
   const long n_tiles = P.n_tiles;
 
   // ---- per-stage constants, sub-tile tables, outer-axis digits
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
       f32x4 x[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (i < n_out_iters) x[i] = lds_read16(outr + (t16o ^ out_i_swz[i]));
+        if (i < n_out_iters && out_active) x[i] = lds_read16(outr + (t16o ^ out_i_swz[i]));
       if (KB2 > 0) __syncthreads(); // fused: the result sat in R0, which is refilled next
       PHASE_MARK(3);
       STAMP(1);
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
       // stores of this tile, then the loads of the tile after next
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if (i < n_out_iters) {
+        if (i < n_out_iters && out_active) {
           long o = 0;
 #pragma unroll
           for (int b = 0; b < 4; ++b)
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
       // big tiles (2^13): no register prefetch; stream out, then load the next tile
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        if (i < n_out_iters) {
+        if (i < n_out_iters && out_active) {
           long o = 0;
 #pragma unroll
           for (int b = 0; b < 4; ++b)

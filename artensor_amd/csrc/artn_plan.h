@@ -387,7 +387,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
       if (in_set(Mt, i)) continue;
       sizes((int)Mt.size());
       int biggest = std::max(T_in, std::max(T_mid, T_out));
-      const bool enough = (int)Mt.size() >= 5 && T_in >= 9 && T_out >= 9; // one full copy pass per tile
+      const bool enough = (int)Mt.size() >= 5 && T_in >= 9 && T_out >= 9; // prefer one full copy pass per tile
       if ((enough && biggest >= target) || !fits((int)Mt.size() + 1)) break;
       Mt.push_back(i);
     }
@@ -520,7 +520,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
 
   // ---- envelope checks
   // the copy phases move 16 bytes (two elements) per lane and need every thread busy
-  if (b.T_in < 9 || b.T_out < 9) { p.why_generic = "tile smaller than one copy pass"; return false; }
+  if (b.T_in < 9 || b.T_out < 5) { p.why_generic = "tile smaller than one copy pass"; return false; }
   for (int i = 1; i < b.T_in; ++i) if (b.in_stride[i] & 1) { p.why_generic = "odd A stride"; return false; }
   for (int i = 1; i < b.T_out; ++i) if (b.out_stride[i] & 1) { p.why_generic = "odd C stride"; return false; }
   for (int i = 0; i < b.n_outer; ++i)
@@ -529,7 +529,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     // per-lane byte offsets inside the kernel are 32-bit: copy chunks span tile bits 1..8,
     // the small operands are addressed by their N_t / K bits
     int64_t si = 0, so = 0;
-    for (int i = 1; i <= 8; ++i) { si += b.in_stride[i]; so += b.out_stride[i]; }
+    for (int i = 1; i <= 8; ++i) { si += b.in_stride[i]; if (i < b.T_out) so += b.out_stride[i]; }
     const int64_t lim = (int64_t(1) << 28) - 1; // elements: * 8 B < 2^31
     bool wide = si > lim || so > lim;
     for (int s = 0; s < b.n_stages; ++s) {

@@ -79,7 +79,7 @@ static void run_stage(const ArtnStage &st, const ArtnStage *zin, const cf *in, c
 
 static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf *B2, cf *C) {
   std::vector<cf> R0((size_t)1 << P.r0_bits), R1((size_t)1 << P.T_mid);
-  const int n_in_iters = 1 << (P.T_in - 9), n_out_iters = 1 << (P.T_out - 9);
+  const int n_in_iters = 1 << (P.T_in - 9), n_out_iters = P.T_out >= 9 ? 1 << (P.T_out - 9) : 1;
   for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
     int64_t r = tile, offA = 0, offB1 = 0, offB2 = 0, offC = 0;
     for (int d = 0; d < P.n_outer; ++d) {
@@ -108,6 +108,7 @@ static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf 
       zout = &P.st[1];
     }
     for (int tid = 0; tid < 256; ++tid) {
+      if (P.T_out < 9 && tid >= (1 << (P.T_out - 1))) continue;
       int64_t out_lane = 0;
       for (int b = 1; b <= 8; ++b) if ((tid >> (b - 1)) & 1) out_lane += P.out_stride[b];
       for (int i = 0; i < n_out_iters; ++i) {
