@@ -322,6 +322,7 @@ def fusion_schedule(scheme):
 
 
 _plan_cache = {}
+_schedule_cache = {}
 
 
 class _Op:
@@ -505,6 +506,43 @@ def _normalize_inplace(t):
     return amax
 
 
+def _sparse_step(tensors, step):
+    """One step of the sparse executor: the four branches of reference contraction.py:140-191."""
+    i, j = step[0]
+    eq = step[1]
+    batch_i, batch_j = step[2]
+    if len(batch_i) > 1:
+        src_i, src_j = tensors[i], tensors[j]
+        la, lb, lo = _parse(eq)
+        rows = [len(x) for x in batch_i]
+        first = None
+        r0 = 0
+        for k in range(len(batch_i)):
+            gi, gj = gather_rows(src_i, batch_i[k]), gather_rows(src_j, batch_j[k])
+            if first is None:
+                ext = dict(zip(la, gi.shape))
+                ext.update(zip(lb, gj.shape))
+                first = torch.empty((sum(rows),) + tuple(ext[x] for x in lo[1:]), dtype=gi.dtype, device=gi.device)
+            contract(eq, gi, gj, out=first[r0:r0 + rows[k]])
+            r0 += rows[k]
+        if step[3]:
+            first = first.reshape((-1,) + tuple(step[3][1:]))
+        tensors[j] = []
+        tensors[i] = first
+    elif len(step) > 3 and len(batch_i) == len(batch_j) == 1:
+        tensors[i] = gather_rows(tensors[i], batch_i[0])
+        tensors[j] = gather_rows(tensors[j], batch_j[0])
+        tensors[i] = contract(eq, tensors[i], tensors[j])
+    elif len(step) > 3:
+        tensors[i] = contract(eq, tensors[i], tensors[j]).reshape(step[3])
+        if len(batch_i) == 1:
+            tensors[i] = gather_rows(tensors[i], batch_i[0])
+        tensors[j] = []
+    else:
+        tensors[i] = contract(eq, tensors[i], tensors[j])
+        tensors[j] = []
+
+
 def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=False):
     """Run a sparse-state scheme (reference contraction.py:132-205); the four branches are
     keyed exactly like the reference:
@@ -515,56 +553,60 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
     (C) other 5-tuples: contraction with both batch labels in the output, merged by a
         free reshape, then an optional row select
     (D) 3-tuples: plain contraction.
-    Consumed operands are released (`tensors[j] = []`) as the reference does."""
-    factor = None
-    i = None
-    for n, step in enumerate(contraction_scheme):
-        i, j = step[0]
-        eq = step[1]
-        batch_i, batch_j = step[2]
-        try:
-            if len(batch_i) > 1:
-                src_i, src_j = tensors[i], tensors[j]
-                la, lb, lo = _parse(eq)
-                rows = [len(x) for x in batch_i]
-                first = None
-                r0 = 0
-                for k in range(len(batch_i)):
-                    gi, gj = gather_rows(src_i, batch_i[k]), gather_rows(src_j, batch_j[k])
-                    if first is None:
-                        ext = dict(zip(la, gi.shape))
-                        ext.update(zip(lb, gj.shape))
-                        first = torch.empty((sum(rows),) + tuple(ext[x] for x in lo[1:]),
-                                            dtype=gi.dtype, device=gi.device)
-                    contract(eq, gi, gj, out=first[r0:r0 + rows[k]])
-                    r0 += rows[k]
-                if step[3]:
-                    first = first.reshape((-1,) + tuple(step[3][1:]))
-                tensors[j] = []
-                tensors[i] = first
-            elif len(step) > 3 and len(batch_i) == len(batch_j) == 1:
-                tensors[i] = gather_rows(tensors[i], batch_i[0])
-                tensors[j] = gather_rows(tensors[j], batch_j[0])
-                tensors[i] = contract(eq, tensors[i], tensors[j])
-            elif len(step) > 3:
-                tensors[i] = contract(eq, tensors[i], tensors[j]).reshape(step[3])
-                if len(batch_i) == 1:
-                    tensors[i] = gather_rows(tensors[i], batch_i[0])
-                tensors[j] = []
-            else:
-                tensors[i] = contract(eq, tensors[i], tensors[j])
-                tensors[j] = []
-        except Exception as e:
-            raise RuntimeError(f"tensor_contraction_sparse failed at step {n} {step[0]} {eq!r}: {e}") from e
-        if scientific_notation:
-            amax = _normalize_inplace(tensors[i])
-            lg = torch.log10(amax)
-            factor = lg if factor is None else factor + lg
-    if i is None:
+    Consumed operands are released (`tensors[j] = []`) as the reference does.  Two consecutive
+    (D) steps on the same big tensor run as one fused pass, like in the dense executor
+    (not when scientific_notation renormalises after every step)."""
+    if len(contraction_scheme) == 0:
         raise RuntimeError("empty contraction scheme")
+    scheme = contraction_scheme
+    key = id(scheme)
+    hit = _schedule_cache.get(key)
+    if hit is None or hit[0] is not scheme:
+        if len(_schedule_cache) > 64:
+            _schedule_cache.clear()
+        hit = _schedule_cache[key] = (scheme, fusion_schedule(scheme))
+    factor = None
+    last = scheme[-1][0][0]
+
+    def one(n):
+        try:
+            _sparse_step(tensors, scheme[n])
+        except Exception as e:
+            raise RuntimeError(f"tensor_contraction_sparse failed at step {n} {scheme[n][0]} {scheme[n][1]!r}: {e}") from e
+
+    def normalize(i):
+        nonlocal factor
+        lg = torch.log10(_normalize_inplace(tensors[i]))
+        factor = lg if factor is None else factor + lg
+
     if scientific_notation:
-        return factor.reshape(()).to(tensors[i].dtype), tensors[i]
-    return tensors[i]
+        for n in range(len(scheme)):
+            one(n)
+            normalize(scheme[n][0][0])
+        return factor.reshape(()).to(tensors[last].dtype), tensors[last]
+
+    for entry in hit[1]:
+        if entry[0] == "one":
+            one(entry[1])
+            continue
+        n, m = entry[1], entry[2]
+        s1, s2 = scheme[n], scheme[m]
+        fused = None
+        a = tensors[s1[0][0]]
+        if (len(s1) == 3 and len(s2) == 3 and len(s1[2][0]) <= 1 and len(s2[2][0]) <= 1
+                and isinstance(a, torch.Tensor) and a.is_cuda and a.numel() >= FUSE_MIN_NUMEL):
+            try:
+                fused = contract2(s1[1], a, tensors[s1[0][1]], s2[1], tensors[s2[0][1]])
+            except Exception as e:
+                raise RuntimeError(f"tensor_contraction_sparse failed at fused steps {n}+{m}: {e}") from e
+        if fused is None:
+            one(n)
+            one(m)
+        else:
+            tensors[s1[0][0]] = fused
+            tensors[s1[0][1]] = []
+            tensors[s2[0][1]] = []
+    return tensors[last]
 
 
 # ----------------------------------------------------------------------------------------
