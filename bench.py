@@ -89,6 +89,63 @@ def cpu_baseline(case, budget_log2=25):
     }
 
 
+def bench_n53(args, A, dev, world, rank, dist):
+    """BASELINE configs[3]: Sycamore n53 m14 (derived from the bundled m20 circuit), amplitude of
+    one bitstring, 14 sliced bonds = 16 384 independent slices.  Weak scaling: every step each
+    rank contracts `--slices` slices of its round-robin shard and accumulates; ONE reduce of the
+    accumulator over RCCL closes the timed region."""
+    from artensor_amd.fixtures import load_case
+    case = load_case(os.path.join(ROOT, "tests", "golden", "n53_m14_sliced.npz"))
+    leaves = case.fresh_tensors(device=dev)
+    n_b = len(case.slicing_indices)
+    flops_slice = 8.0 * 10 ** case.meta["log10_tc"]
+    per_step = args.slices
+
+    def run(first, count):
+        mine = [(first + q) * world + rank for q in range(count)]
+        return A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=dev,
+                                    slices=mine, reduce=None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        run(w * per_step, per_step)
+    barrier()
+    t0 = time.perf_counter()
+    acc = torch.zeros(1, dtype=torch.complex64, device=dev)
+    base = args.warmup * per_step
+    for k in range(args.steps):
+        A.accumulate(acc, run(base + k * per_step, per_step))
+    if world > 1:
+        dist.all_reduce(torch.view_as_real(acc))
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        n_slices = world * args.steps * per_step
+        value = n_slices * flops_slice / dt / 1e12
+        print(json.dumps({
+            "metric": "contracted TFLOP/s, Sycamore n53 m14 sliced amplitude (8 real FLOP per complex MAC)",
+            "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "c64 (fp32 MFMA)", "data": "synthetic",
+            "config": {"workload": "Sycamore n53 m14 (first 14 cycles of the bundled m20 circuit), 1 bitstring, "
+                                   "14 sliced bonds, tests/golden/n53_m14_sliced.npz",
+                       "slices_per_rank_per_step": per_step, "slices_timed": n_slices,
+                       "flops_per_slice": flops_slice, "parallelism": f"slices sharded over {world} rank(s), one reduce",
+                       "frac_mfma_peak": value / world / MFMA_F32_PEAK_TFLOPS,
+                       "partial_amplitude": [float(acc.real.item()), float(acc.imag.item())]},
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +153,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", default=None, help="write a per-launch table of the MFMA kernel to this file")
+    ap.add_argument("--workload", default="n30", choices=["n30", "n53"],
+                    help="n30: BASELINE configs[1] (default, the metric's config); n53: configs[3], the "
+                         "slice-sharded Sycamore n53 m14 contraction with one RCCL reduce at the end")
+    ap.add_argument("--slices", type=int, default=4, help="n53: slices per rank per step")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -114,6 +175,8 @@ def main():
     from artensor_amd import contraction as C
     from artensor_amd.fixtures import load_case
 
+    if args.workload == "n53":
+        return bench_n53(args, A, dev, world, rank, dist)
     case = load_case(os.path.join(ROOT, "tests", "golden", "n30_dense.npz"))
     leaves = case.fresh_tensors(device=dev)  # resident in HBM before the timed region
     flops_per_step = 8.0 * 10 ** case.meta["log10_tc"]

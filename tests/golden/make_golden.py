@@ -460,7 +460,89 @@ def case_trees():
         json.dump(out, f)
 
 
+N53_M20 = os.path.join(REF, "examples", "circuits", "circuit_n53_m20_s0_e0_pABCDCDAB.qsim")
+N53_M14 = "/tmp/circuit_n53_m14_trunc.qsim"
+
+
+def n53_m14_qsim():
+    """BASELINE config 4 names Sycamore n53 m14; the reference bundles only m20.  Derivation
+    (SURVEY.md 8c): the first 14 cycles (layers 0..55) of the bundled m20 file plus its final
+    single-qubit layer (80) renumbered 56.  Input-format conversion to /tmp, nothing stored."""
+    if not os.path.exists(N53_M14):
+        out = []
+        with open(N53_M20) as f:
+            lines = f.read().splitlines()
+        out.append(lines[0])
+        for ln in lines[1:]:
+            parts = ln.split()
+            layer = int(parts[0])
+            if layer < 56:
+                out.append(ln)
+            elif layer == 80:
+                out.append(" ".join(["56"] + parts[1:]))
+        with open(N53_M14, "w") as f:
+            f.write("\n".join(out) + "\n")
+    return N53_M14
+
+
+def case_n53_plan():
+    """n53 m14 (derived), one bitstring, sc_target 30: plan + leaf tensors + slicing indices."""
+    bits = ["0" * 53]
+    sim, meta = plan(n53_m14_qsim(), bits, 30)
+    # With a single bitstring the chunking rule of contraction.py:288-297 (chunks when
+    # log2(rows) + rank > sc_target - 2) produces chunks of int(1 / 8) = 0 rows and the
+    # reference executor then dies on an empty tensor.  Recompile the scheme from the same
+    # tree with the chunk threshold out of reach; the tree / slicing stay those of sc_target 30.
+    sim.update_scheme(40, bits)
+    assert all(len(st[2][0]) <= 1 for st in sim.scheme)
+    meta["scheme_chunk_threshold"] = 40
+    meta["n_slicing"] = len(sim.slicing_indices)
+    meta["reference_slice_loop_well_defined"] = bool(slicing_ok(sim))
+    meta["derivation"] = "first 14 cycles of circuit_n53_m20_s0_e0_pABCDCDAB.qsim + its final 1-qubit layer"
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    # The reference computes a sliced bond's dim as its position in tensor_bonds[tid]
+    # (simulation.py:62-65), but in the sparse pattern a final-qubit tensor carries a leading
+    # batch dim that tensor_bonds does not list (shape (2, 2) for bonds ['35-0']): select()
+    # then hits the batch dim.  Stored here are the dims of the actual tensors.
+    fixed, touched = {}, 0
+    for bond, lst in sim.slicing_indices.items():
+        fixed[bond] = []
+        for tid, ind in lst:
+            shift = tensors[tid].dim() - len(sim.tensor_bonds[tid])
+            touched += shift != 0
+            fixed[bond].append((tid, ind + shift))
+    meta["slicing_dims_shifted_for_batch_dim"] = int(touched)
+    save_case(os.path.join(HERE, "n53_m14_sliced.npz"), tensors, sim.scheme, meta, slicing_indices=fixed)
+    print("n53_m14 plan:", len(sim.scheme), "steps,", len(sim.slicing_indices), "sliced bonds, log10 tc/slice",
+          meta["log10_tc"], "reference loop well defined:", meta["reference_slice_loop_well_defined"])
+
+
+def case_n53_slice0():
+    """Reference sparse executor on slice 0 of the n53 plan (CPU, ~half an hour, ~25 GB).
+    The slice is applied with the unsliced-index semantics (artensor_amd.apply_slice), which is
+    what the reference loop means wherever it is well defined."""
+    from artensor_amd.fixtures import load_case
+    from artensor_amd.simulation import apply_slice, slice_assignments
+    path = os.path.join(HERE, "n53_m14_sliced.npz")
+    case = load_case(path)
+    out = {}
+    for s in (0,):
+        cfg = slice_assignments(len(case.slicing_indices), s)
+        sliced = apply_slice(case.fresh_tensors(), case.slicing_indices, cfg)
+        t0 = time.time()
+        res = tensor_contraction_sparse(sliced, case.scheme)
+        out[f"slice{s}"] = res.reshape(-1).numpy().copy()
+        print("n53 slice", s, res.reshape(-1), time.time() - t0, "s", flush=True)
+    meta = case.meta
+    for k in ("tensor_ids", "steps", "slicing_indices"):
+        meta.pop(k, None)
+    meta["reference_cpu_seconds_per_slice"] = time.time() - t0
+    save_case(path, case.tensors, case.scheme, meta, arrays=out, slicing_indices=case.slicing_indices)
+
+
 CASES = {
+    "n53_plan": case_n53_plan,
+    "n53_slice0": case_n53_slice0,
     "trees": case_trees,
     "n12_dense": case_n12_dense,
     "n12_sparse5": case_n12_sparse5,

@@ -392,3 +392,34 @@ def test_more_contracted_bits_than_a_tile_holds():
         eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
         a, b = crandn(rng, (2,) * ra), crandn(rng, (2,) * len(lb))
         assert rel(hip_step(eq, a, b), oracle.einsum_pair(eq, a, b)) < 2e-5, eq
+
+
+def test_n53_slices(monkeypatch):
+    """BASELINE config 4 (Sycamore n53 m14, derived from the bundled m20 circuit; one bitstring,
+    14 sliced bonds): slice 0 against the reference executor's CPU result, and the slice loop
+    on a handful of slices against the sum of the single-slice results."""
+    case = load_case(os.path.join(GOLDEN, "n53_m14_sliced.npz"))
+    n_b = len(case.slicing_indices)
+    assert n_b == 14 and len(case.scheme) == 326
+    leaves = case.fresh_tensors(device=DEV)
+
+    def one(s):
+        sliced = A.apply_slice(leaves, case.slicing_indices, A.slice_assignments(n_b, s))
+        return A.tensor_contraction_sparse(sliced, case.scheme).reshape(-1).cpu().numpy()
+
+    got0 = one(0)
+    if "slice0" in case.arrays:
+        want = case.arrays["slice0"]
+        assert np.abs(got0 - want).max() <= 2e-5 * np.abs(want).max()
+    slices = [0, 5, 777, 16383]
+    singles = sum(one(s) for s in slices)
+    loop = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV,
+                                slices=slices).cpu().numpy()
+    assert np.abs(loop - singles).max() <= 1e-5 * np.abs(singles).max()
+    # fused and unfused execution agree on a slice
+    monkeypatch.setenv("ARTN_NO_FUSE", "1")
+    A.contraction._pair_cache.clear()
+    plain = one(5)
+    A.contraction._pair_cache.clear()
+    monkeypatch.delenv("ARTN_NO_FUSE")
+    assert np.abs(plain - one(5)).max() <= 1e-5 * np.abs(plain).max()
