@@ -428,8 +428,10 @@ struct StageRun {
   float (&W0)[S];
   float (&W1)[S];
   int h;
-  const char *Bbase; // small operand of this tile (only read when contracted bits are looped over)
-  int ro;
+  // 7-8 contracted bits (BIGK): fragments for every value of the looped-over bits, all in
+  // registers (the instantiation runs one wave per SIMD, so 512 VGPRs are available)
+  float (&WH0)[BIGK ? 3 : 1][S];
+  float (&WH1)[BIGK ? 3 : 1][S];
 
   __device__ __forceinline__ unsigned ko(int s) const {
     unsigned k = 0;
@@ -488,8 +490,51 @@ struct StageRun {
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   }
 
-  // More than 6 contracted bits: the extra ones are looped over, the fragments reloaded for
-  // each of their values, accumulators (at most two sub-tiles per wave: the tile is all K) kept.
+  // More than 6 contracted bits: the extra one or two are looped over.  The tile holds all K
+  // bits, so a wave has at most two sub-tiles; accumulators stay in registers across the loop,
+  // fragments of value 0 live in W0/W1 and of values 1..3 in WH0/WH1, operands ping-pong.
+  template <int HI>
+  __device__ __forceinline__ const float (&w0(void) const)[S] {
+    if constexpr (HI == 0) return W0; else return WH0[(BIGK ? HI - 1 : 0)];
+  }
+  template <int HI>
+  __device__ __forceinline__ const float (&w1(void) const)[S] {
+    if constexpr (HI == 0) return W1; else return WH1[(BIGK ? HI - 1 : 0)];
+  }
+  template <int HI, int BASE>
+  __device__ __forceinline__ void chain_hi(f32x16 &acc, const v2f_t (&buf)[CH]) const {
+    const float(&a0)[S] = w0<HI>();
+    const float(&a1)[S] = w1<HI>();
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[BASE + s], buf[s].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[BASE + s], buf[s].y, acc, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ unsigned kin_of(int hi) const {
+    unsigned kin = 0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      if ((hi >> b) & 1) kin ^= L.kin_hi[b];
+    return kin;
+  }
+  // one sub-tile: units (hi, half) in sequence, operands of the next unit loaded before the
+  // MFMAs of the current one
+  template <int HI>
+  __device__ __forceinline__ void sub_hi(f32x16 &acc, v2f_t (&bA)[CH], v2f_t (&bB)[CH], unsigned li, int n_hi) const {
+    if (HI >= n_hi) return;
+    const unsigned base = li ^ kin_of(HI);
+    if (UPS == 2) {
+      load_unit<(UPS == 2 ? CH : 0)>(bB, base);
+      chain_hi<HI, 0>(acc, bA);
+      if (HI + 1 < n_hi) load_unit<0>(bA, li ^ kin_of(HI + 1));
+      chain_hi<HI, (UPS == 2 ? CH : 0)>(acc, bB);
+    } else {
+      // (KB = 6 always has two units; kept for completeness)
+      chain_hi<HI, 0>(acc, bA);
+      if (HI + 1 < n_hi) load_unit<0>(bA, li ^ kin_of(HI + 1));
+    }
+  }
   __device__ __forceinline__ void run_big_k() const {
     const int m0 = L.wm, m1 = L.wm + L.wm_count;
     const bool has0 = m0 < L.msubs, has1 = m1 < L.msubs;
@@ -497,36 +542,31 @@ struct StageRun {
     const u2_t mo0 = lds_read_u2(L.msub_tab + m0 * 8);
     u2_t mo1 = mo0;
     if (has1) mo1 = lds_read_u2(L.msub_tab + m1 * 8);
+    const int n_hi = 1 << L.k_hi;
+    v2f_t bA[CH], bB[CH];
     f32x16 acc0, acc1;
     zero(acc0);
-    zero(acc1);
-    v2f_t buf[CH];
-    const int n_hi = 1 << L.k_hi;
-    for (int hi = 0; hi < n_hi; ++hi) {
-      unsigned kin = 0;
-      long kb = 0;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-        if ((hi >> b) & 1) { kin ^= L.kin_hi[b]; kb += L.kb_hi[b]; }
-      load_w<KB>(W0, W1, Bbase + kb, L, ro);
-      static_assert(UPS <= 2, "chain split in at most two units");
-      load_unit<0>(buf, L.lane_in ^ mo0.x ^ kin);
-      chain_unit<0>(acc0, buf, false, acc1, 0);
-      if (UPS == 2) {
-        load_unit<(UPS == 2 ? CH : 0)>(buf, L.lane_in ^ mo0.x ^ kin);
-        chain_unit<(UPS == 2 ? CH : 0)>(acc0, buf, false, acc1, 0);
-      }
-      if (has1) {
-        load_unit<0>(buf, L.lane_in ^ mo1.x ^ kin);
-        chain_unit<0>(acc1, buf, false, acc0, 0);
-        if (UPS == 2) {
-          load_unit<(UPS == 2 ? CH : 0)>(buf, L.lane_in ^ mo1.x ^ kin);
-          chain_unit<(UPS == 2 ? CH : 0)>(acc1, buf, false, acc0, 0);
-        }
-      }
+    {
+      const unsigned li = L.lane_in ^ mo0.x;
+      load_unit<0>(bA, li);
+      sub_hi<0>(acc0, bA, bB, li, n_hi);
+      sub_hi<1>(acc0, bA, bB, li, n_hi);
+      sub_hi<2>(acc0, bA, bB, li, n_hi);
+      sub_hi<3>(acc0, bA, bB, li, n_hi);
     }
-    scatter(acc0, L.lane_out ^ mo0.y);
-    if (has1) scatter(acc1, L.lane_out ^ mo1.y);
+    if (has1) {
+      zero(acc1);
+      const unsigned li = L.lane_in ^ mo1.x;
+      load_unit<0>(bA, li);
+      sub_hi<0>(acc1, bA, bB, li, n_hi);
+      scatter(acc0, L.lane_out ^ mo0.y); // drains under the second sub-tile's chains
+      sub_hi<1>(acc1, bA, bB, li, n_hi);
+      sub_hi<2>(acc1, bA, bB, li, n_hi);
+      sub_hi<3>(acc1, bA, bB, li, n_hi);
+      scatter(acc1, L.lane_out ^ mo1.y);
+    } else {
+      scatter(acc0, L.lane_out ^ mo0.y);
+    }
   }
 
   __device__ __forceinline__ void run() const {
@@ -594,14 +634,16 @@ struct StageRun {
 
 template <int KB, bool BIGK>
 __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1 << (KB - 1)],
-                                          float (&W1)[1 << (KB - 1)], int h, const char *Bbase, int ro) {
-  StageRun<KB, BIGK> r{L, W0, W1, h, Bbase, ro};
+                                          float (&W1)[1 << (KB - 1)], int h,
+                                          float (&WH0)[BIGK ? 3 : 1][1 << (KB - 1)],
+                                          float (&WH1)[BIGK ? 3 : 1][1 << (KB - 1)]) {
+  StageRun<KB, BIGK> r{L, W0, W1, h, WH0, WH1};
   r.run();
 }
 
 // KB2 == 0: single stage.  BIGK: 7 or 8 contracted bits (KB1 = 6 of them in the chain).
 template <int KB1, int KB2, bool BIGK>
-__global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *__restrict__ A,
+__global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(const float2 *__restrict__ A,
                                                                   const float2 *__restrict__ B1,
                                                                   const float2 *__restrict__ B2,
                                                                   float2 *__restrict__ C, const ArtnBitsPlan P) {
@@ -660,6 +702,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
   for (int i = 0; i < 16; ++i) out_i_swz[i] = swz(i * (ARTN_WG_THREADS * 16), zout);
   const OffTab OT = build_offset_table(P, offtab, tid);
   float W10[S1], W11[S1], W20[S2], W21[S2];
+  float WH0[BIGK ? 3 : 1][S1], WH1[BIGK ? 3 : 1][S1], WD0[1][S2], WD1[1][S2]; // BIGK: fragments of looped-over values 1..3
   long prev_b1 = -1, prev_b2 = -1;
   __syncthreads(); // tables are in LDS
 
@@ -693,9 +736,22 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
   const bool stage_prio = P.stage_prio && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1); // HW_ID.wave_id bit 0
   STAMP_DECL
   for (long tile = t0; tile < n_tiles; tile += G) {
-    if (off.b1 != prev_b1 && !(BIGK && L1.k_hi > 0)) { // (with looped-over contracted bits the stage loads its own fragments)
+    if (off.b1 != prev_b1) {
       prev_b1 = off.b1;
-      load_w<KB1>(W10, W11, reinterpret_cast<const char *>(B1 + off.b1), L1, ro);
+      const char *Bb = reinterpret_cast<const char *>(B1 + off.b1);
+      load_w<KB1>(W10, W11, Bb, L1, ro);
+      if constexpr (BIGK) { // fragments of the looped-over contracted bits' values 1..3
+#pragma unroll
+        for (int hi = 1; hi < 4; ++hi) {
+          if (hi < (1 << L1.k_hi)) {
+            long kbo = 0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              if ((hi >> b) & 1) kbo += L1.kb_hi[b];
+            load_w<KB1>(WH0[hi - 1], WH1[hi - 1], Bb + kbo, L1, ro);
+          }
+        }
+      }
     }
     if (KB2 > 0 && off.b2 != prev_b2) {
       prev_b2 = off.b2;
@@ -709,7 +765,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
     if (stage_prio) __builtin_amdgcn_s_setprio(2);
-    run_stage<KB1, BIGK>(L1, W10, W11, h, reinterpret_cast<const char *>(B1 + off.b1), ro);
+    run_stage<KB1, BIGK>(L1, W10, W11, h, WH0, WH1);
     if (stage_prio && KB2 == 0) __builtin_amdgcn_s_setprio(0);
     PHASE_MARK(1);
     STAMP(5);
@@ -717,7 +773,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits(const float2 *
     unsigned outr = R1;
     if (KB2 > 0) {
       STAMP(6);
-      run_stage<KB2e, false>(L2, W20, W21, h, reinterpret_cast<const char *>(B2 + off.b2), ro);
+      run_stage<KB2e, false>(L2, W20, W21, h, WD0, WD1);
       if (stage_prio) __builtin_amdgcn_s_setprio(0);
       STAMP(5);
       __syncthreads();
