@@ -278,14 +278,16 @@ __device__ __forceinline__ f32x4 load_chunk(const char *__restrict__ Abase, long
   return *reinterpret_cast<const f32x4 *>(Abase + off + lane_off);
 #endif
 }
-__device__ __forceinline__ void issue_loads(f32x4 (&v)[8], const char *__restrict__ Abase, const long (&hi)[4],
+template <int NV>
+__device__ __forceinline__ void issue_loads(f32x4 (&v)[NV], const char *__restrict__ Abase, const long (&hi)[4],
                                             unsigned lane_off) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) v[u] = load_chunk(Abase, chunk_off(hi, u), lane_off);
+  for (int u = 0; u < NV; ++u) v[u] = load_chunk(Abase, chunk_off(hi, u), lane_off);
 }
-__device__ __forceinline__ void store_lds(const f32x4 (&v)[8], unsigned ldsb, unsigned tid16) {
+template <int NV>
+__device__ __forceinline__ void store_lds(const f32x4 (&v)[NV], unsigned ldsb, unsigned tid16) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) lds_write16(ldsb + tid16 + u * (ARTN_WG_THREADS * 16), v[u]);
+  for (int u = 0; u < NV; ++u) lds_write16(ldsb + tid16 + u * (ARTN_WG_THREADS * 16), v[u]);
 }
 __device__ __forceinline__ void copy_in_sync(const char *__restrict__ Abase, const long (&hi)[4], unsigned lane_off,
                                              unsigned ldsb, unsigned tid16, int n_iters) {
@@ -712,8 +714,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   // The refill waits on loads that are followed in the (in-order) VMEM queue by nothing, so
   // its s_waitcnt never waits for stores issued after them; the stores have a whole stage
   // phase to drain before the next refill looks at the counter.
-  f32x4 v[8];
-  const bool prefetch = n_in_iters == 8 && n_out_iters <= 8;
+  // (the 7-8 bit instantiation runs one wave per SIMD and prefetches 2^13-element tiles)
+  constexpr int NV = BIGK ? 16 : 8;
+  f32x4 v[NV];
+  const bool prefetch = n_in_iters == NV && n_out_iters <= 8;
   TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
   const long t0 = blockIdx.x, G = gridDim.x;
   if (t0 < n_tiles) {

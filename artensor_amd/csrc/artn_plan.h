@@ -380,7 +380,8 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
       return (8LL << r0) + (8LL << T_mid) <= ARTN_LDS_BUDGET;
     };
     if (!fits((int)Mt.size())) return false;
-    const int target = tuning().tile_target;
+    // 7-8 contracted bits: the kernel instantiation for them prefetches 2^13-element tiles
+    const int target = k1 > 6 ? ARTN_TILE_BITS_MAX : tuning().tile_target;
     if (need_target && std::max(T_in, std::max(T_mid, T_out)) > target && (int)Mt.size() >= 5) return false;
     // grow M_t towards the target tile size (lowest A positions first), within the LDS budget
     for (int i : M1) {
