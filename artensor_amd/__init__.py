@@ -20,6 +20,7 @@ from .contraction import (  # noqa: F401
 )
 from .fixtures import load_case, save_case  # noqa: F401
 from .simulation import (  # noqa: F401
+    SliceRunner,
     TensorNetworkSimulation,
     accumulate,
     apply_slice,

@@ -477,9 +477,31 @@ def _device_index(idx, device):
     return dev
 
 
+_identity_cache = {}
+_flag_cache = {}
+
+
+def _is_identity(idx, rows):
+    """True when `idx` is 0, 1, ..., rows-1: the gather would copy the tensor onto itself (every
+    row select of a single-bitstring scheme is of this kind; checked once per index tensor)."""
+    key = id(idx)
+    hit = _identity_cache.get(key)
+    if hit is None or hit[0] is not idx:
+        flat = torch.as_tensor(idx, dtype=torch.int64).reshape(-1).cpu()
+        n = flat.numel()
+        ident = n if bool(torch.equal(flat, torch.arange(n, dtype=torch.int64))) else -1
+        if len(_identity_cache) > 4096:
+            _identity_cache.clear()
+        hit = _identity_cache[key] = (idx, ident)
+    return hit[1] == rows
+
+
 def gather_rows(t, idx):
-    """t[idx] along dim 0 through artn_gather_rows (reference contraction.py:149-150 etc.)."""
+    """t[idx] along dim 0 through artn_gather_rows (reference contraction.py:149-150 etc.).
+    An index that selects every row in order returns `t` itself (the reference copies)."""
     N.require_gpu(t, "gather_rows")
+    if t.dim() > 0 and _is_identity(idx, t.shape[0]):
+        return t
     t = t.contiguous()
     dev_idx = _device_index(idx, t.device)
     nrows = dev_idx.numel()
@@ -487,7 +509,9 @@ def gather_rows(t, idx):
     if out.numel() == 0:
         return out
     row_bytes = (t.numel() // t.shape[0]) * t.element_size()
-    flag = torch.zeros(1, dtype=torch.int32, device=t.device)
+    flag = _flag_cache.get(t.device)   # sticky out-of-range flag, one per device
+    if flag is None:
+        flag = _flag_cache[t.device] = torch.zeros(1, dtype=torch.int32, device=t.device)
     with torch.cuda.device(t.device):
         N.check(N.lib().artn_gather_rows(t.data_ptr(), dev_idx.data_ptr(), out.data_ptr(), nrows, row_bytes,
                                          t.shape[0], flag.data_ptr(), N.current_stream_ptr(t.device)))

@@ -21,6 +21,7 @@
 // [2K x 2N] block matrix [[re, im], [-im, re]]; C comes out as interleaved complex64.
 // 8*M*K*N real FLOP, exactly the 8 FLOP per complex multiply-add the metric counts.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <mutex>
@@ -985,6 +986,21 @@ static bool env_flag(const char *name) {
   return v && v[0] && v[0] != '0';
 }
 
+// Kernels that need more than 64 KiB of dynamic LDS must say so once per device; repeating
+// the call per launch is needless host work and is not welcome during stream capture.
+template <auto Kern>
+static hipError_t ensure_lds(size_t lds) {
+  static std::atomic<int> have[16];
+  if (lds <= 64 * 1024) return hipSuccess;
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  std::atomic<int> &h = have[dev & 15];
+  if ((int)lds <= h.load(std::memory_order_relaxed)) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void *)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) h.store((int)lds, std::memory_order_relaxed);
+  return e;
+}
+
 template <int KB1>
 static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, float2 *C,
                                  hipStream_t st) {
@@ -994,19 +1010,13 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
 #define ARTN_LAUNCH(K2)                                                                                   \
   case K2: {                                                                                              \
     auto kern = artn_k_bits<KB1, K2, false>;                                                              \
-    if (lds > 64 * 1024) {                                                                                \
-      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) return e;                                                                      \
-    }                                                                                                     \
+    if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false>>(lds); e != hipSuccess) return e;           \
     hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                                 \
     break;                                                                                                \
   }
   if (KB1 == 6 && k2 == 0 && p.bits.st[0].k > 6) {
     auto kern = artn_k_bits<(KB1 == 6 ? 6 : 1), 0, true>;
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = ensure_lds<artn_k_bits<(KB1 == 6 ? 6 : 1), 0, true>>(lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
     return hipGetLastError();
   }

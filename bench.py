@@ -101,10 +101,13 @@ def bench_n53(args, A, dev, world, rank, dist):
     flops_slice = 8.0 * 10 ** case.meta["log10_tc"]
     per_step = args.slices
 
+    # one runner for the whole job: slice 0 runs from the host, slice 1 is captured, the rest replay
+    runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=dev)
+
     def run(first, count):
         mine = [(first + q) * world + rank for q in range(count)]
-        return A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=dev,
-                                    slices=mine, reduce=None)
+        return A.sliced_contraction(None, case.scheme, case.slicing_indices, (1,), sparse=True, device=dev,
+                                    slices=mine, reduce=None, runner=runner)
 
     def barrier():
         if world > 1:

@@ -238,6 +238,9 @@ def test_gather_axpy_normalize():
         idx = torch.from_numpy(rng.integers(0, shape[0], size=53))
         got = A.contraction.gather_rows(gpu(t), idx).cpu().numpy()
         assert np.array_equal(got, t[idx.numpy()])
+    t = crandn(rng, (6, 2, 2))  # every row in order: the tensor itself comes back
+    assert np.array_equal(A.contraction.gather_rows(gpu(t), torch.arange(6)).cpu().numpy(), t)
+    assert np.array_equal(A.contraction.gather_rows(gpu(t), torch.arange(5)).cpu().numpy(), t[:5])
     empty = A.contraction.gather_rows(gpu(crandn(rng, (4, 2))), torch.zeros(0, dtype=torch.int64))
     assert empty.shape == (0, 2)
     # out-of-range rows are zero-filled and flagged, never read
@@ -416,6 +419,10 @@ def test_n53_slices(monkeypatch):
     loop = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV,
                                 slices=slices).cpu().numpy()
     assert np.abs(loop - singles).max() <= 1e-5 * np.abs(singles).max()
+    # the loop above replayed slices 777 and 16383 from a captured HIP graph: same launches, same bits
+    eager = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV,
+                                 slices=slices, graph=False).cpu().numpy()
+    assert np.array_equal(loop, eager)
     # fused and unfused execution agree on a slice
     monkeypatch.setenv("ARTN_NO_FUSE", "1")
     A.contraction._pair_cache.clear()
