@@ -375,7 +375,10 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     };
     auto fits = [&](int mt) {
       sizes(mt);
-      if (T_in > ARTN_TILE_BITS_MAX || T_mid > ARTN_TILE_BITS_MAX || T_out > ARTN_TILE_BITS_MAX) return false;
+      // a fused pair only pays with two workgroups per CU (2^12-element regions): with 2^13 it
+      // measured slower than the two steps one after the other
+      const int tmax = fused ? ARTN_TILE_BITS_MAX - 1 : ARTN_TILE_BITS_MAX;
+      if (T_in > tmax || T_mid > tmax || T_out > tmax) return false;
       int r0 = fused ? std::max(T_in, T_out) : T_in;
       return (8LL << r0) + (8LL << T_mid) <= ARTN_LDS_BUDGET;
     };

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from .contraction import tensor_contraction, tensor_contraction_sparse
+from .contraction import _parse, _sparse_step, contract, tensor_contraction, tensor_contraction_sparse
 
 __all__ = ["slice_assignments", "rank_slices", "apply_slice", "accumulate", "sliced_contraction",
            "SliceRunner", "TensorNetworkSimulation"]
@@ -25,9 +25,18 @@ def slice_assignments(n_bonds, s):
     return [int(c) for c in np.binary_repr(s, n_bonds)] if n_bonds else []
 
 
-def rank_slices(n_slices, rank, world_size):
-    """Slices of `rank`: round-robin, so every rank gets the same count +-1."""
-    return range(rank, n_slices, world_size)
+def rank_slices(n_slices, rank, world_size, gray=False):
+    """Slices of `rank`: round-robin (s = rank + world_size * t), so every rank gets the same
+    count +-1.  gray=True visits the same set with t in reflected-Gray-code order: consecutive
+    slices then differ in ONE sliced bond (when the counts are powers of two), which is what
+    SliceRunner's reuse of slice-independent intermediate tensors feeds on."""
+    count = len(range(rank, n_slices, world_size))
+    if not gray:
+        return range(rank, n_slices, world_size)
+    span = 1
+    while span < count:
+        span *= 2
+    return [rank + world_size * g for g in (t ^ (t >> 1) for t in range(span)) if g < count]
 
 
 def apply_slice(tensors, slicing_indices, config):
@@ -67,19 +76,94 @@ def accumulate(acc, x):
     return acc
 
 
+SMALL_NUMEL = 1 << 16  # operands and result of a "small" step have at most this many elements
+
+
+def split_scheme(scheme, shapes):
+    """Separate the steps that only combine small, leaf-derived tensors from the rest.
+
+    A circuit scheme is a few big steps on the state tensor plus hundreds of tiny ones that
+    build the small operands of later big steps out of leaf tensors; none of the tiny ones
+    depends on the state.  Returns (small, main, out_shapes): `small` = indices of un-chunked steps
+    whose operands are leaves or results of other small steps and whose operands and result
+    have at most SMALL_NUMEL elements; `main` = the remaining steps in scheme order (a valid
+    scheme once the results of the small steps are supplied as tensors).  `shapes` maps tensor
+    id -> leaf shape."""
+    shapes = dict(shapes)
+    tainted = set()
+    small, main = [], []
+
+    def numel(sh):
+        n = 1
+        for e in sh:
+            n *= e
+        return n
+
+    for n, step in enumerate(scheme):
+        i, j = step[0]
+        out_shape = None
+        if (isinstance(step[1], str) and i not in tainted and j not in tainted and i in shapes and j in shapes
+                and (len(step) == 2 or (len(step[2][0]) <= 1 and len(step[2][1]) <= 1))):
+            out_shape = _small_step_shape(step, shapes[i], shapes[j])
+        if out_shape is not None and max(numel(shapes[i]), numel(shapes[j]), numel(out_shape)) <= SMALL_NUMEL:
+            small.append(n)
+            shapes[i] = out_shape
+        else:
+            main.append(step)
+            tainted.add(i)
+            shapes.pop(i, None)
+    return small, main, shapes
+
+
+def _small_step_shape(step, si, sj):
+    """Result shape of one dense step or one un-chunked sparse step (the branches of
+    contraction._sparse_step / reference contraction.py:176-191), None if the equation does not
+    match the operand ranks."""
+    sparse5 = len(step) > 3
+    bi, bj = step[2] if len(step) > 2 else ([], [])
+    both = sparse5 and len(bi) == 1 and len(bj) == 1
+    if both:  # branch (B): one row gather per operand, then the batched contraction
+        si, sj = (len(bi[0]),) + tuple(si[1:]), (len(bj[0]),) + tuple(sj[1:])
+    la, lb, lo = _parse(step[1])
+    if len(la) != len(si) or len(lb) != len(sj):
+        return None
+    ext = dict(zip(la, si))
+    ext.update(zip(lb, sj))
+    out = tuple(ext[x] for x in lo)
+    if sparse5 and not both:  # branch (C): reshape merges the batch labels, optional row select
+        n = 1
+        for e in out:
+            n *= e
+        rs = list(step[3])
+        known = 1
+        for e in rs:
+            if e != -1:
+                known *= e
+        if known == 0 or n % known:
+            return None
+        out = tuple(n // known if e == -1 else e for e in rs)
+        if len(bi) == 1:
+            out = (len(bi[0]),) + out[1:]
+    return out
+
+
 class SliceRunner:
     """Runs slices of one sliced contraction on one device and accumulates them.
 
-    Every slice executes the same launch sequence on leaf tensors of the same shapes; only the
-    contents of the sliced leaves differ.  With `graph=True`, the first slice runs eagerly (it
-    also fills the descriptor / plan / index caches), the second is captured into a HIP graph
-    together with its accumulation, and every further slice is: copy the selected leaf slices
-    into the static input buffers, replay -- no per-launch host work for the ~300 launches
-    of a slice.
+    Every slice executes the same scheme on leaf tensors of the same shapes; only the contents
+    of the sliced leaves differ, and a small intermediate tensor depends only on the sliced
+    bonds that touch the leaves below it.  The runner therefore evaluates the small steps
+    itself (split_scheme) and keeps each result together with the values of the bonds it
+    depends on: a slice recomputes only the small steps whose bonds changed since the previous
+    slice (with Gray-ordered slices: the two root paths of ONE bond instead of ~340 launches of
+    ~10 us each on n53 m14), then hands the remaining big steps to the executor.
+
+    graph=True instead captures one whole slice (all steps) into a HIP graph and replays it:
+    no per-launch host work at all, for hosts that cannot keep the GPU busy.
     """
 
     def __init__(self, tensors, scheme, slicing_indices, out_shape, sparse=False, dtype=torch.complex64,
-                 device="cuda", graph="auto", _execute=None, _accumulate=None):
+                 device="cuda", graph=False, reuse_small=True, _execute=None, _accumulate=None):
         self.execute = _execute or (tensor_contraction_sparse if sparse else tensor_contraction)
         self.add = _accumulate or accumulate
         self.scheme = scheme
@@ -90,17 +174,35 @@ class SliceRunner:
         self.n_bonds = len(self.slicing_indices)
         self.collect = torch.zeros(tuple(out_shape), dtype=dtype, device=device)
         seams = _execute is not None or _accumulate is not None
-        # "auto" is off: measured on n53 m14 the host already keeps the GPU 100 % busy
-        # (rocprofv3 kernel trace: no idle gaps), so replay gains nothing there; it is for
-        # hosts that cannot keep up (many ranks per socket)
-        self.use_graph = graph is True and not seams and self.device.type == "cuda" and self.n_bonds > 0
-        self._selects = {}
+        on_gpu = not seams and self.device.type == "cuda" and self.n_bonds > 0
+        self.use_graph = graph is True and on_gpu
+        self._selects = {}    # tensor id -> {dim: position of the bond in the slice configuration}
         for x, (bond, lst) in enumerate(self.slicing_indices.items()):
             for tid, dim in lst:
                 self._selects.setdefault(tid, {})[dim] = x
         self._static = None
         self._graph = None
         self._eager_done = 0
+        # reuse of small intermediates across slices
+        self.reuse_small = bool(reuse_small) and on_gpu and not self.use_graph
+        self.small_steps_run = 0
+        if self.reuse_small:
+            shapes = {}
+            for k, t in self.leaves.items():
+                if isinstance(t, torch.Tensor):
+                    sel = self._selects.get(k, {})
+                    shapes[k] = tuple(e for d, e in enumerate(t.shape) if d not in sel)
+            small, main, _ = split_scheme(scheme, shapes)
+            self._small, self._main = small, main
+            rel = {tid: frozenset(sel.values()) for tid, sel in self._selects.items()}
+            self._step_rel = {}
+            for n in small:
+                i, j = scheme[n][0]
+                rel[i] = rel.get(i, frozenset()) | rel.get(j, frozenset())
+                self._step_rel[n] = tuple(sorted(rel[i]))
+            self._leaf_rel = {tid: tuple(sorted(sel.values())) for tid, sel in self._selects.items()}
+            self._memo = {}
+            self._last_id = scheme[-1][0][0]
 
     def _index(self, tid, cfg):
         sel, t = self._selects[tid], self.leaves[tid]
@@ -114,10 +216,40 @@ class SliceRunner:
         res = self.execute(inputs, self.scheme)
         self.add(self.collect, res.reshape(self.collect.shape))
 
+    def _one_reusing(self, cfg):
+        memo = self._memo
+        cur = dict(self.leaves)
+        for tid, pos in self._leaf_rel.items():
+            key = tuple(cfg[x] for x in pos)
+            hit = memo.get(("leaf", tid))
+            if hit is None or hit[0] != key:
+                hit = memo[("leaf", tid)] = (key, self.leaves[tid][self._index(tid, cfg)].contiguous())
+            cur[tid] = hit[1]
+        for n in self._small:
+            i, j = self.scheme[n][0]
+            key = tuple(cfg[x] for x in self._step_rel[n])
+            hit = memo.get(n)
+            if hit is None or hit[0] != key:
+                step = self.scheme[n]
+                if len(step) == 2:
+                    val = contract(step[1], cur[i], cur[j])
+                else:  # sparse step: the executor's own branch logic on a scratch pair
+                    scratch = {i: cur[i], j: cur[j]}
+                    _sparse_step(scratch, step)
+                    val = scratch[i]
+                hit = memo[n] = (key, val)
+                self.small_steps_run += 1
+            cur[i] = hit[1]
+        res = self.execute(cur, self._main) if self._main else cur[self._last_id]
+        self.add(self.collect, res.reshape(self.collect.shape))
+
     def run(self, slices):
         """Contract the given slice numbers and add them to `self.collect` (returned)."""
         for s in slices:
             cfg = slice_assignments(self.n_bonds, s)
+            if self.reuse_small:
+                self._one_reusing(cfg)
+                continue
             if not self.use_graph:
                 sliced = apply_slice(self.leaves, self.slicing_indices, cfg) if self.n_bonds else dict(self.leaves)
                 self._one(sliced)
@@ -145,15 +277,17 @@ class SliceRunner:
 
 def sliced_contraction(tensors, scheme, slicing_indices, out_shape, sparse=False, permute_dims=None,
                        dtype=torch.complex64, device="cuda", group=None, slices=None, reduce="all",
-                       graph="auto", runner=None, _execute=None, _accumulate=None):
+                       graph=False, reuse_small=True, runner=None, _execute=None, _accumulate=None):
     """The slice loop (reference simulation.py:101-116) on one rank of `group`.
 
     tensors         leaf tensors (dict or list) already on `device` or movable to it
     slices          explicit slice numbers for this rank (default: round-robin shard)
     reduce          "all" -> every rank returns the full sum (all_reduce);
                     "root" -> only rank 0 does (reduce to 0); None -> local partial sum
-    graph           True: replay slices from a captured HIP graph (see SliceRunner);
-                    False / "auto": launch every slice from the host
+    reuse_small     keep small intermediate tensors across slices and recompute only those whose
+                    sliced bonds changed (see SliceRunner); the default shard is then visited
+                    in Gray-code order
+    graph           True: replay whole slices from a captured HIP graph instead
     runner          a SliceRunner to reuse across calls (its accumulator is zeroed first)
     _execute/_accumulate   test seams: the world_size-2 gloo tests of the sharding and
                     reduction logic run on CPU boxes and inject a CPU executor; the
@@ -165,11 +299,11 @@ def sliced_contraction(tensors, scheme, slicing_indices, out_shape, sparse=False
     world = dist.get_world_size(group) if distributed else 1
     if runner is None:
         runner = SliceRunner(tensors, scheme, slicing_indices, out_shape, sparse=sparse, dtype=dtype, device=device,
-                             graph=graph, _execute=_execute, _accumulate=_accumulate)
+                             graph=graph, reuse_small=reuse_small, _execute=_execute, _accumulate=_accumulate)
     else:
         runner.collect.zero_()
     if slices is None:
-        slices = rank_slices(2 ** runner.n_bonds, rank, world)
+        slices = rank_slices(2 ** runner.n_bonds, rank, world, gray=runner.reuse_small)
     collect = runner.run(slices)
     if distributed and reduce is not None:
         buf = torch.view_as_real(collect)

@@ -105,7 +105,8 @@ def bench_n53(args, A, dev, world, rank, dist):
     runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=dev)
 
     def run(first, count):
-        mine = [(first + q) * world + rank for q in range(count)]
+        # Gray-code order over this rank's shard: consecutive slices differ in one sliced bond
+        mine = [((first + q) ^ ((first + q) >> 1)) * world + rank for q in range(count)]
         return A.sliced_contraction(None, case.scheme, case.slicing_indices, (1,), sparse=True, device=dev,
                                     slices=mine, reduce=None, runner=runner)
 

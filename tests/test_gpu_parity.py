@@ -419,10 +419,23 @@ def test_n53_slices(monkeypatch):
     loop = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV,
                                 slices=slices).cpu().numpy()
     assert np.abs(loop - singles).max() <= 1e-5 * np.abs(singles).max()
-    # the loop above replayed slices 777 and 16383 from a captured HIP graph: same launches, same bits
-    eager = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV,
-                                 slices=slices, graph=False).cpu().numpy()
-    assert np.array_equal(loop, eager)
+    # the loop above kept the small intermediates across slices; without that reuse, and with whole
+    # slices replayed from a captured HIP graph (same launches, same bits as the plain loop)
+    plain_loop = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV,
+                                      slices=slices, reuse_small=False).cpu().numpy()
+    assert np.abs(loop - plain_loop).max() <= 1e-5 * np.abs(plain_loop).max()
+    replay = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV,
+                                  slices=slices, reuse_small=False, graph=True).cpu().numpy()
+    assert np.array_equal(replay, plain_loop)
+    # Gray-ordered shard: consecutive slices differ in one bond, so only a few small steps rerun
+    runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV)
+    order = A.rank_slices(2 ** n_b, 3, 8, gray=True)[:6]
+    runner.run(order[:1])
+    first = runner.small_steps_run
+    runner.run(order[1:])
+    assert first > 250 and runner.small_steps_run - first < 5 * 40
+    want = sum(one(s) for s in order)
+    assert np.abs(runner.collect.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
     # fused and unfused execution agree on a slice
     monkeypatch.setenv("ARTN_NO_FUSE", "1")
     A.contraction._pair_cache.clear()
