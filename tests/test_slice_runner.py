@@ -1,0 +1,77 @@
+"""Host logic of the slice loop that needs no GPU: Gray-ordered shards and the split of a scheme
+into slice-reusable small steps and the remaining big steps (artensor_amd/simulation.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import artensor_amd as A
+from artensor_amd import simulation as S
+from artensor_amd.fixtures import load_case
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("n,world", [(16, 1), (16, 4), (1 << 14, 8), (64, 2)])
+def test_gray_shard_is_a_permutation_with_single_bit_steps(n, world):
+    for rank in range(world):
+        plain = list(A.rank_slices(n, rank, world))
+        gray = list(A.rank_slices(n, rank, world, gray=True))
+        assert sorted(gray) == plain
+        for a, b in zip(gray, gray[1:]):
+            assert bin(a ^ b).count("1") == 1
+
+
+def test_gray_shard_uneven_world():
+    # 3 ranks over 16 slices: counts 6, 5, 5; still the same sets
+    seen = []
+    for rank in range(3):
+        gray = list(A.rank_slices(16, rank, 3, gray=True))
+        assert sorted(gray) == list(A.rank_slices(16, rank, 3))
+        seen += gray
+    assert sorted(seen) == list(range(16))
+
+
+def _sliced_shapes(case, leaves):
+    sel = {}
+    for x, (bond, lst) in enumerate(case.slicing_indices.items()):
+        for tid, dim in lst:
+            sel.setdefault(tid, {})[dim] = x
+    items = leaves.items() if isinstance(leaves, dict) else enumerate(leaves)
+    return {k: tuple(e for d, e in enumerate(t.shape) if d not in sel.get(k, {})) for k, t in items}
+
+
+@pytest.mark.parametrize("name,limit", [("rand_D2_open_sliced", 8), ("rand_D2_closed_sliced", 4),
+                                        ("n12_sparse_sliced", 32), ("n12_sparse_sliced", 1 << 16)])
+def test_split_scheme_small_then_main_equals_whole(name, limit, monkeypatch):
+    """Evaluating the small steps first (what SliceRunner keeps across slices) and handing the
+    rest to the executor gives the executor's result on the whole scheme -- checked with the CPU
+    oracle as executor on slice 0 of the sliced fixtures."""
+    monkeypatch.setattr(S, "SMALL_NUMEL", limit)
+    case = load_case(os.path.join(GOLDEN, name + ".npz"))
+    sparse = case.meta.get("pattern") == "sparse"
+    n_b = len(case.slicing_indices)
+    leaves = A.apply_slice(case.fresh_tensors(device="cpu"), case.slicing_indices, A.slice_assignments(n_b, 0))
+    items = leaves.items() if isinstance(leaves, dict) else enumerate(leaves)
+    np_leaves = {k: t.numpy() for k, t in items}
+    small, main, _ = S.split_scheme(case.scheme, {k: v.shape for k, v in np_leaves.items()})
+    assert len(small) + len(main) == len(case.scheme)
+    assert [s for s in case.scheme if any(s is m for m in main)] == main  # scheme order kept
+    run = oracle.tensor_contraction_sparse if sparse else oracle.tensor_contraction
+    whole = run(dict(np_leaves), case.scheme)
+    cur = dict(np_leaves)
+    for n in small:
+        step = case.scheme[n]
+        i, j = step[0]
+        scratch = {i: cur[i], j: cur[j]}
+        run(scratch, [step])
+        cur[i] = scratch[i]
+    got = run(cur, main) if main else cur[case.scheme[-1][0][0]]
+    assert np.abs(np.asarray(got) - np.asarray(whole)).max() <= 1e-6 * max(np.abs(whole).max(), 1e-30)
+    if limit == 1 << 16:
+        assert not main  # n12: every step is small
+    else:
+        assert small and main
