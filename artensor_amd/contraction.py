@@ -108,21 +108,37 @@ def _as_operand(t):
 MAX_TILE_K_BITS = 8  # contracted bits one LDS tile of the MFMA kernel can hold
 
 
-def _split_big_k(la, lb, lo, a, b):
-    """More contracted bits than one LDS tile holds (closing steps of the sparse path contract
-    15 bonds at once): keep the slowest-varying contracted labels as a temporary batch label,
-    run the MFMA kernel per value, then sum that label out -- split-K with the partial results
-    in HBM.  Returns None when the step does not need / allow it."""
-    if a.dtype != torch.complex64:
+_ONE = object()  # operand id of the scalar 1 in a compiled sum-out op
+_ones = {}
+
+
+def _one_scalar(dtype, device):
+    key = (dtype, str(device))
+    t = _ones.get(key)
+    if t is None:
+        t = _ones[key] = torch.ones((), dtype=dtype, device=device)
+    return t
+
+
+def _big_k_outer(la, lb, lo, a_shape, a_stride=None):
+    """Contracted labels to turn into a temporary batch label when a step contracts more bits
+    than one LDS tile holds: the slowest-varying ones of A, until MAX_TILE_K_BITS remain.
+    None when the step does not need / allow it."""
+    numel = 1
+    for e in a_shape:
+        numel *= e
+    if numel < (1 << 20):
         return None
-    ka = [(a.stride(la.index(x)), x) for x in la if x in lb and x not in lo]
+    if a_stride is None:
+        a_stride = _dense_strides(tuple(a_shape))
+    ka = [(a_stride[n], x) for n, x in enumerate(la) if x in lb and x not in lo]
     bits = 0
     for _, x in ka:
-        e = a.shape[la.index(x)]
+        e = a_shape[la.index(x)]
         if e & (e - 1):
             return None
         bits += e.bit_length() - 1
-    if bits <= MAX_TILE_K_BITS or a.numel() < (1 << 20):
+    if bits <= MAX_TILE_K_BITS:
         return None
     ka.sort(reverse=True)  # highest A stride first
     outer = []
@@ -130,11 +146,23 @@ def _split_big_k(la, lb, lo, a, b):
         if bits <= MAX_TILE_K_BITS:
             break
         outer.append(x)
-        bits -= a.shape[la.index(x)].bit_length() - 1
+        bits -= a_shape[la.index(x)].bit_length() - 1
+    return outer
+
+
+def _split_big_k(la, lb, lo, a, b):
+    """More contracted bits than one LDS tile holds (closing steps of the sparse path contract
+    15 bonds at once): keep the slowest-varying contracted labels as a temporary batch label,
+    run the MFMA kernel per value, then sum that label out -- split-K with the partial results
+    in HBM.  Returns None when the step does not need / allow it."""
+    if a.dtype != torch.complex64:
+        return None
+    outer = _big_k_outer(la, lb, lo, tuple(a.shape), tuple(a.stride()))
+    if not outer:
+        return None
     mid = tuple(outer) + tuple(lo)
     part = contract((la, lb, mid), a, b)
-    one = torch.ones((), dtype=a.dtype, device=a.device)
-    return (mid, (), tuple(lo)), part, one
+    return (mid, (), tuple(lo)), part, _one_scalar(a.dtype, a.device)
 
 
 def contract(eq, a, b, out=None):
@@ -337,16 +365,26 @@ def _compile_dense(scheme, shapes, dtype):
     fuse_ok = dtype == torch.complex64
     ops = []
 
+    def emit(n, i, j, la, lb, lo, sa, sb):
+        op = _Op()
+        op.steps, op.i, op.j, op.j2, op.d2 = (n,), i, j, None, None
+        op.d1, op.out_shape = _descriptor(la, lb, lo, sa, _dense_strides(sa), sb, _dense_strides(sb), dtype)
+        op.info = None
+        ops.append(op)
+        return op.out_shape
+
     def single(n):
         (i, j), eq = scheme[n][0], scheme[n][1]
         la, lb, lo = _parse(eq)
-        op = _Op()
-        op.steps, op.i, op.j, op.j2, op.d2 = (n,), i, j, None, None
-        op.d1, op.out_shape = _descriptor(la, lb, lo, shapes[i], _dense_strides(shapes[i]), shapes[j],
-                                          _dense_strides(shapes[j]), dtype)
-        op.info = None
-        shapes[i] = op.out_shape
-        ops.append(op)
+        outer = _big_k_outer(la, lb, lo, shapes[i]) if dtype == torch.complex64 else None
+        if outer:
+            # more contracted bits than one LDS tile holds (big x big steps of random networks):
+            # split-K through a temporary batch label, then sum it out (see _split_big_k)
+            mid = tuple(outer) + tuple(lo)
+            mid_shape = emit(n, i, j, la, lb, mid, shapes[i], shapes[j])
+            shapes[i] = emit(n, i, _ONE, mid, (), lo, mid_shape, ())
+        else:
+            shapes[i] = emit(n, i, j, la, lb, lo, shapes[i], shapes[j])
 
     for entry in fusion_schedule(scheme):
         if entry[0] == "one":
@@ -433,7 +471,8 @@ def tensor_contraction(tensors, scheme):
     with torch.cuda.device(device):
         stream = N.current_stream_ptr(device)
         for op in ops:
-            a, b = tensors[op.i], tensors[op.j]
+            a = tensors[op.i]
+            b = _one_scalar(dtype, device) if op.j is _ONE else tensors[op.j]
             out = torch.empty(op.out_shape, dtype=dtype, device=device)
             if profiler is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

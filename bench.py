@@ -89,25 +89,43 @@ def cpu_baseline(case, budget_log2=25):
     }
 
 
-def bench_n53(args, A, dev, world, rank, dist):
-    """BASELINE configs[3]: Sycamore n53 m14 (derived from the bundled m20 circuit), amplitude of
-    one bitstring, 14 sliced bonds = 16 384 independent slices.  Weak scaling: every step each
-    rank contracts `--slices` slices of its round-robin shard and accumulates; ONE reduce of the
-    accumulator over RCCL closes the timed region."""
+SLICED_WORKLOADS = {
+    # name: (fixture, sparse executor?, description)
+    "n53": ("n53_m14_sliced.npz", True,
+            "Sycamore n53 m14 (first 14 cycles of the bundled m20 circuit), 1 bitstring, 14 sliced bonds"),
+    "rand2": ("rand_D2_nv260_sliced.npz", False,
+              "random 3-regular tensor network, bond dimension 2, 260 tensors, closed, 12 sliced bonds (sc 30)"),
+    "rand4": ("rand_D4_nv100.npz", False,
+              "random 3-regular tensor network, bond dimension 4, 100 tensors, closed, no slicing (sc 28)"),
+}
+
+
+def bench_sliced(args, A, dev, world, rank, dist):
+    """Slice-sharded workloads (BASELINE configs[3] and the random networks of north_star): every
+    step each rank contracts `--slices` slices of its round-robin shard, in Gray-code order, and
+    accumulates; ONE reduce of the accumulator over RCCL closes the timed region.  Weak scaling.
+    A network without sliced bonds (rand4) is contracted whole, `--slices` times per step."""
     from artensor_amd.fixtures import load_case
-    case = load_case(os.path.join(ROOT, "tests", "golden", "n53_m14_sliced.npz"))
+    fixture, sparse, what = SLICED_WORKLOADS[args.workload]
+    case = load_case(os.path.join(ROOT, "tests", "golden", fixture))
     leaves = case.fresh_tensors(device=dev)
     n_b = len(case.slicing_indices)
     flops_slice = 8.0 * 10 ** case.meta["log10_tc"]
     per_step = args.slices
-
-    # one runner for the whole job: slice 0 runs from the host, slice 1 is captured, the rest replay
-    runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=dev)
+    # one runner for the whole job: small intermediates are kept across slices
+    runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (1,), sparse=sparse, device=dev)
+    # slice 0 against the reference's value (outside the timed region)
+    want = case.arrays["slice0"].reshape(-1)
+    got = A.sliced_contraction(None, case.scheme, case.slicing_indices, (1,), sparse=sparse, device=dev,
+                               slices=[0], reduce=None, runner=runner).reshape(-1).cpu().numpy()
+    rel_err = float(np.abs(got - want).max() / np.abs(want).max())
 
     def run(first, count):
-        # Gray-code order over this rank's shard: consecutive slices differ in one sliced bond
-        mine = [((first + q) ^ ((first + q) >> 1)) * world + rank for q in range(count)]
-        return A.sliced_contraction(None, case.scheme, case.slicing_indices, (1,), sparse=True, device=dev,
+        if n_b == 0:
+            mine = [0] * count
+        else:  # Gray-code order over this rank's shard: consecutive slices differ in one sliced bond
+            mine = [(((first + q) ^ ((first + q) >> 1)) * world + rank) % (2 ** n_b) for q in range(count)]
+        return A.sliced_contraction(None, case.scheme, case.slicing_indices, (1,), sparse=sparse, device=dev,
                                     slices=mine, reduce=None, runner=runner)
 
     def barrier():
@@ -135,16 +153,18 @@ def bench_n53(args, A, dev, world, rank, dist):
         n_slices = world * args.steps * per_step
         value = n_slices * flops_slice / dt / 1e12
         print(json.dumps({
-            "metric": "contracted TFLOP/s, Sycamore n53 m14 sliced amplitude (8 real FLOP per complex MAC)",
+            "metric": f"contracted TFLOP/s, {args.workload} sliced contraction (8 real FLOP per complex MAC)",
             "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "c64 (fp32 MFMA)", "data": "synthetic",
-            "config": {"workload": "Sycamore n53 m14 (first 14 cycles of the bundled m20 circuit), 1 bitstring, "
-                                   "14 sliced bonds, tests/golden/n53_m14_sliced.npz",
+            "config": {"workload": f"{what}, tests/golden/{fixture}",
                        "slices_per_rank_per_step": per_step, "slices_timed": n_slices,
-                       "flops_per_slice": flops_slice, "parallelism": f"slices sharded over {world} rank(s), one reduce",
+                       "flops_per_slice": flops_slice,
+                       "parallelism": (f"slices sharded over {world} rank(s), one reduce" if n_b else
+                                       ("replicas" if world > 1 else "single")),
                        "frac_mfma_peak": value / world / MFMA_F32_PEAK_TFLOPS,
-                       "partial_amplitude": [float(acc.real.item()), float(acc.imag.item())]},
+                       "slice0_rel_err_vs_reference": rel_err,
+                       "partial_sum": [float(acc.real.item()), float(acc.imag.item())]},
         }), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -157,10 +177,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", default=None, help="write a per-launch table of the MFMA kernel to this file")
-    ap.add_argument("--workload", default="n30", choices=["n30", "n53"],
+    ap.add_argument("--workload", default="n30", choices=["n30"] + sorted(SLICED_WORKLOADS),
                     help="n30: BASELINE configs[1] (default, the metric's config); n53: configs[3], the "
-                         "slice-sharded Sycamore n53 m14 contraction with one RCCL reduce at the end")
-    ap.add_argument("--slices", type=int, default=4, help="n53: slices per rank per step")
+                         "slice-sharded Sycamore n53 m14 contraction with one RCCL reduce at the end; "
+                         "rand2 / rand4: random 3-regular tensor networks of bond dimension 2 (sliced) / 4")
+    ap.add_argument("--slices", type=int, default=4, help="sliced workloads: slices per rank per step")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -179,8 +200,8 @@ def main():
     from artensor_amd import contraction as C
     from artensor_amd.fixtures import load_case
 
-    if args.workload == "n53":
-        return bench_n53(args, A, dev, world, rank, dist)
+    if args.workload in SLICED_WORKLOADS:
+        return bench_sliced(args, A, dev, world, rank, dist)
     case = load_case(os.path.join(ROOT, "tests", "golden", "n30_dense.npz"))
     leaves = case.fresh_tensors(device=dev)  # resident in HBM before the timed region
     flops_per_step = 8.0 * 10 ** case.meta["log10_tc"]

@@ -540,7 +540,42 @@ def case_n53_slice0():
     save_case(path, case.tensors, case.scheme, meta, arrays=out, slicing_indices=case.slicing_indices)
 
 
+def case_random_bench():
+    """Benchmark-scale random tensor networks (SURVEY 8d input 2: 3-regular graphs, seed 0, leaves
+    complex(randn, randn) / D^1.5, planned by the reference's find_order, trials 4, iters 5):
+      * D = 2, 260 vertices, closed, sc_target 30 -> sliced; the reference executor's value of
+        slice 0 pins the fixture (about a minute of CPU);
+      * D = 4, 100 vertices, closed, sc_target 30 -> no slicing (the reference slice loop is
+        only defined for D = 2 bonds); the reference's full value pins it."""
+    from artensor_amd.simulation import apply_slice, slice_assignments
+    for nv, D, name in [(260, 2, "rand_D2_nv260_sliced"), (100, 4, "rand_D4_nv100")]:
+        tensors, tensor_bonds, bond_dims = _rand_tn(nv, D, 0, 0)
+        order, slicing_bonds, ctree = find_order(
+            deepcopy(tensor_bonds), deepcopy(bond_dims), [], 0, 1, sc_target=30,
+            trials=4, iters=5, betas=np.linspace(3.0, 21.0, 61), start_seed=0, slicing_repeat=1)
+        scheme, output_bonds = contraction_scheme(deepcopy(ctree))
+        assert list(output_bonds) == []
+        slicing_indices = {}
+        for bond in slicing_bonds:
+            slicing_indices[bond] = [(tid, tensor_bonds[tid].index(bond))
+                                     for tid in tensor_bonds if bond in tensor_bonds[tid]]
+        tc, sc = ctree.tree_complexity()[:2]
+        cfg = slice_assignments(len(slicing_bonds), 0)
+        sliced = apply_slice(dict(tensors), slicing_indices, cfg) if slicing_bonds else dict(tensors)
+        t0 = time.time()
+        res = tensor_contraction(sliced, scheme)
+        dt = time.time() - t0
+        meta = dict(D=D, nv=nv, n_open=0, sc_target=30, log10_tc=float(tc), sc=float(sc), bond_dim=D,
+                    output_bonds=[], n_slicing=len(slicing_bonds), reference_cpu_seconds_per_slice=dt,
+                    graph="networkx.random_regular_graph(3, nv, seed=0)")
+        save_case(os.path.join(HERE, name + ".npz"), tensors, scheme, meta,
+                  arrays=dict(slice0=res.reshape(-1).numpy().copy()), slicing_indices=slicing_indices)
+        print(name, "steps", len(scheme), "sliced bonds", len(slicing_bonds), "log10 tc/slice", float(tc), "sc", float(sc),
+              "slice0", res.reshape(-1), f"{dt:.0f} s", flush=True)
+
+
 CASES = {
+    "random_bench": case_random_bench,
     "n53_plan": case_n53_plan,
     "n53_slice0": case_n53_slice0,
     "trees": case_trees,

@@ -443,3 +443,23 @@ def test_n53_slices(monkeypatch):
     A.contraction._pair_cache.clear()
     monkeypatch.delenv("ARTN_NO_FUSE")
     assert np.abs(plain - one(5)).max() <= 1e-5 * np.abs(plain).max()
+
+
+@pytest.mark.parametrize("name", ["rand_D2_nv260_sliced", "rand_D4_nv100"])
+def test_random_network_bench_fixtures(name):
+    """Benchmark-scale random 3-regular networks (north_star: "random tensor networks of stated
+    bond dimension"): slice 0 / the whole contraction against the reference executor's value."""
+    case = load_case(os.path.join(GOLDEN, name + ".npz"))
+    n_b = len(case.slicing_indices)
+    leaves = case.fresh_tensors(device=DEV)
+    want = case.arrays["slice0"].reshape(-1)
+    runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (1,), device=DEV)
+    got = runner.run([0]).reshape(-1).cpu().numpy().copy()
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    if n_b:
+        # a few more slices: reuse of small intermediates on/off agree
+        order = A.rank_slices(2 ** n_b, 1, 8, gray=True)[:4]
+        a = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), device=DEV, slices=order)
+        b = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), device=DEV, slices=order,
+                                 reuse_small=False)
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
