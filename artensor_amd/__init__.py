@@ -29,4 +29,6 @@ from .simulation import (  # noqa: F401
     sliced_contraction,
 )
 
+from .statevector import state_vec  # noqa: F401
+
 __version__ = "0.1.0"

@@ -47,6 +47,12 @@ def _parse(eq):
     return tuple(a), tuple(b), tuple(out)
 
 
+def _labels(eq):
+    """An equation is an einsum string or a triple of label tuples (any hashable labels: no
+    50-letter limit, reference contraction.py:9-10)."""
+    return _parse(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
+
+
 _DTYPES = {torch.complex64: N.ARTN_C64, torch.complex128: N.ARTN_C128}
 _desc_cache = {}
 
@@ -375,7 +381,7 @@ def _compile_dense(scheme, shapes, dtype):
 
     def single(n):
         (i, j), eq = scheme[n][0], scheme[n][1]
-        la, lb, lo = _parse(eq)
+        la, lb, lo = _labels(eq)
         outer = _big_k_outer(la, lb, lo, shapes[i]) if dtype == torch.complex64 else None
         if outer:
             # more contracted bits than one LDS tile holds (big x big steps of random networks):
@@ -398,8 +404,8 @@ def _compile_dense(scheme, shapes, dtype):
             numel *= e
         info = None
         if fuse_ok and numel >= FUSE_MIN_NUMEL:
-            la1, lb1, lo1 = _parse(eq1)
-            la2, lb2, lo2 = _parse(eq2)
+            la1, lb1, lo1 = _labels(eq1)
+            la2, lb2, lo2 = _labels(eq2)
             d1, mid = _descriptor(la1, lb1, lo1, shapes[i], _dense_strides(shapes[i]), shapes[j],
                                   _dense_strides(shapes[j]), dtype)
             if len(la2) == len(mid):

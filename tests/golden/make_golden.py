@@ -574,7 +574,21 @@ def case_random_bench():
               "slice0", res.reshape(-1), f"{dt:.0f} s", flush=True)
 
 
+def case_gates():
+    """Gate lists (array + bond labels per gate, in circuit order) of the n12 and n30 circuits as
+    the reference's TensorNetworkCircuit builds them (circuit.py:100-130): the input of
+    `state_vec()` (circuit.py:155-175).  n12's state vector is already in n12_dense.npz."""
+    for name, qsim in (("n12", N12_QSIM), ("n30", n30_qsim())):
+        c = TensorNetworkCircuit(qsim)
+        gates = c.circuits_tn[c.n:]
+        tensors = {k: g.array.to(torch.complex64) for k, g in enumerate(gates)}
+        meta = dict(n_qubits=int(c.n), inds=[list(map(str, g.inds)) for g in gates])
+        save_case(os.path.join(HERE, f"{name}_gates.npz"), tensors, [], meta)
+        print(name, "gates", len(gates))
+
+
 CASES = {
+    "gates": case_gates,
     "random_bench": case_random_bench,
     "n53_plan": case_n53_plan,
     "n53_slice0": case_n53_slice0,

@@ -463,3 +463,29 @@ def test_random_network_bench_fixtures(name):
         b = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), device=DEV, slices=order,
                                  reuse_small=False)
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+
+
+def test_state_vec_n12_and_n30():
+    """circuit.py:155-175 on the device.  n12: the reference's own state vector.  n30: the state
+    vector (1 270 gate applications on 2^30 amplitudes) against the tensor-network amplitudes the
+    reference computed at Google's 10 000 bitstrings -- two unrelated contraction orders."""
+    g12 = load_case(os.path.join(GOLDEN, "n12_gates.npz"))
+    gates = [(g12.tensors[k], g12.meta["inds"][k]) for k in range(len(g12.meta["inds"]))]
+    sv = A.state_vec(gates, g12.meta["n_qubits"], device=DEV).reshape(-1).cpu().numpy()
+    want = load_case(os.path.join(GOLDEN, "n12_dense.npz")).arrays["state_vec"]
+    assert amp_rel(sv, want) < 1e-5
+    g30 = load_case(os.path.join(GOLDEN, "n30_gates.npz"))
+    gates = [(g30.tensors[k], g30.meta["inds"][k]) for k in range(len(g30.meta["inds"]))]
+    sv = A.state_vec(gates, 30, device=DEV)
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    bits = case.meta["google_bitstrings"]
+    flat = (sv._base if sv._base is not None else sv).reshape(-1)   # the permute is a view
+    st = sv.stride()                                                 # (torch cannot index 30 dims at once)
+    pos = torch.tensor([sum(int(c) * st[q] for q, c in enumerate(b)) for b in bits], device=DEV)
+    at = flat[pos].cpu().numpy()
+    want = case.arrays["amps_at_google"]
+    rms = 2.0 ** -15
+    assert np.abs(at - want).max() <= 2e-5 * max(np.abs(want).max(), rms)
+    # the state is normalised
+    norm2 = sum(float((torch.view_as_real(flat[k::4]) ** 2).sum().item()) for k in range(4))
+    assert abs(norm2 - 1.0) < 1e-3
