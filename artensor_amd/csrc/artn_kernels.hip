@@ -167,7 +167,7 @@ __device__ __forceinline__ OffTab build_offset_table(const ArtnBitsPlan &P, long
   // sets the next bit, so the offset difference depends only on the number c of trailing ones.
   long *dl = tab + 8 * 16 * 4;
   T.delta = dl;
-  const int G = gridDim.x;
+  const int G = P.blocked ? 1 : gridDim.x; // distance between consecutive tiles of a workgroup
   T.g_log2 = -1;
   if ((G & (G - 1)) == 0 && T.first_generic == P.n_outer) {
     int g = 0;
@@ -689,7 +689,6 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   // output tiles smaller than one copy pass (2^9 elements): one pass, upper threads idle
   const int n_out_iters = P.T_out >= 9 ? 1 << (P.T_out - 9) : 1;
   const bool out_active = P.T_out >= 9 || tid < (1 << (P.T_out - 1));
-  const long n_tiles = P.n_tiles;
 
   // ---- per-stage constants, sub-tile tables, outer-axis digits
   fill_msub_table(P.st[0], nullptr, tab1, tid);
@@ -720,7 +719,14 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   f32x4 v[NV];
   const bool prefetch = n_in_iters == NV && n_out_iters <= 8;
   TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
-  const long t0 = blockIdx.x, G = gridDim.x;
+  // tiles of this workgroup: t0, t0 + G, ... < n_tiles (grid-stride), or one contiguous range
+  long t0 = blockIdx.x, G = gridDim.x, n_tiles = P.n_tiles;
+  if (P.blocked) {
+    const long per = (P.n_tiles + gridDim.x - 1) / gridDim.x;
+    t0 = per * blockIdx.x;
+    G = 1;
+    n_tiles = t0 + per < P.n_tiles ? t0 + per : P.n_tiles;
+  }
   if (t0 < n_tiles) {
     off = tile_offsets(P, OT, t0);
     copy_in_sync(reinterpret_cast<const char *>(A + off.a), in_hi, in_lane, R0, tid16, n_in_iters);

@@ -70,7 +70,7 @@ struct ArtnBitsPlan {
   int32_t run_in, run_out;    // tile-local bits [0,run) are global bits [0,run)
   int32_t n_outer;
   int32_t stage_prio;         // 1: one of the two co-resident workgroups runs its MFMA stages at s_setprio 2
-  int32_t pad_;
+  int32_t blocked;            // 1: a workgroup takes a contiguous range of tiles instead of a grid-stride sequence
   int64_t n_tiles;
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
@@ -521,6 +521,14 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     if (b.n_outer >= ARTN_MAX_OUTER) { p.why_generic = "too many outer axes"; return false; }
     b.outer[b.n_outer++] = od;
   }
+
+  // A batch axis (carried by A, B and C: the shared row label of the sparse path) makes the small
+  // operand a function of the tile.  Grid-stride order then changes it at every tile of a
+  // workgroup (a reload of up to 256 fragment registers per lane from global memory); in
+  // contiguous ranges the batch axes, which are the slowest tile digits, change once per row.
+  b.blocked = 0;
+  for (int i = 0; i < b.n_outer; ++i)
+    if (b.outer[i].sA != 0 && b.outer[i].sB1 != 0 && !fused) b.blocked = 1;
 
   // ---- envelope checks
   // the copy phases move 16 bytes (two elements) per lane and need every thread busy
