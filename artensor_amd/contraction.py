@@ -223,11 +223,29 @@ def _dense_strides(shape):
 _pair_cache = {}
 
 
-def _pair_descriptors(eq1, a, b1, eq2, b2):
+def _resolve_reshape(numel, shape):
+    known = 1
+    for e in shape:
+        if e != -1:
+            known *= e
+    if known == 0 or numel % known:
+        raise RuntimeError(f"cannot view {numel} elements as {tuple(shape)}")
+    return tuple(numel // known if e == -1 else e for e in shape)
+
+
+def _pair_descriptors(eq1, a, b1, eq2, b2, mid_view=None):
+    """mid_view: the shape the second equation sees the first result in (the free reshape between
+    two steps of the sparse executor, reference contraction.py:181); same memory, so only the
+    second descriptor's label split changes."""
     la1, lb1, lo1 = _parse(eq1) if isinstance(eq1, str) else tuple(map(tuple, eq1))
     la2, lb2, lo2 = _parse(eq2) if isinstance(eq2, str) else tuple(map(tuple, eq2))
     d1, mid_shape = _descriptor(la1, lb1, lo1, tuple(a.shape), tuple(a.stride()), tuple(b1.shape),
                                 tuple(b1.stride()), a.dtype)
+    if mid_view is not None:
+        numel = 1
+        for e in mid_shape:
+            numel *= e
+        mid_shape = _resolve_reshape(numel, mid_view)
     if len(la2) != len(mid_shape):
         raise RuntimeError("second equation's first operand does not match the first result")
     d2, out_shape = _descriptor(la2, lb2, lo2, mid_shape, _dense_strides(mid_shape), tuple(b2.shape),
@@ -254,16 +272,17 @@ def pair_info(eq1, a_shape, b1_shape, eq2, b2_shape, dtype=torch.complex64):
     return res
 
 
-def contract2(eq1, a, b1, eq2, b2):
+def contract2(eq1, a, b1, eq2, b2, mid_view=None):
     """einsum(eq2, einsum(eq1, a, b1), b2) in ONE pass over HBM through artn_contract2: the
     intermediate never leaves LDS.  Returns None when the planner declines to fuse the
-    pair (the caller then runs the two steps one after the other)."""
+    pair (the caller then runs the two steps one after the other).  mid_view: shape in which
+    eq2 addresses the first result (see _pair_descriptors)."""
     for t in (a, b1, b2):
         N.require_gpu(t, "contract2")
     if not (a.dtype == b1.dtype == b2.dtype == torch.complex64) or not a.is_contiguous():
         return None
     b1, b2 = _as_operand(b1), _as_operand(b2)
-    d1, d2, out_shape = _pair_descriptors(eq1, a, b1, eq2, b2)
+    d1, d2, out_shape = _pair_descriptors(eq1, a, b1, eq2, b2, mid_view)
     key = (id(d1), id(d2))
     info = _pair_cache.get(key)
     if info is None:
@@ -575,6 +594,27 @@ def _normalize_inplace(t):
     return amax
 
 
+def _out_numel(eq, a, b):
+    la, lb, lo = _parse(eq)
+    ext = dict(zip(la, a.shape))
+    ext.update(zip(lb, b.shape))
+    n = 1
+    for x in lo:
+        n *= ext[x]
+    return n
+
+
+def _fusable_kind(step):
+    """Steps the pair fusion understands: plain 3-tuples (branch D) and un-chunked 5-tuples of
+    branch (C) -- contraction, free reshape, optional row select (reference contraction.py:180-188)."""
+    bi, bj = step[2]
+    if len(bi) > 1:
+        return False
+    if len(step) == 3:
+        return True
+    return not (len(bi) == 1 and len(bj) == 1)
+
+
 def _sparse_step(tensors, step):
     """One step of the sparse executor: the four branches of reference contraction.py:140-191."""
     i, j = step[0]
@@ -662,16 +702,26 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
         s1, s2 = scheme[n], scheme[m]
         fused = None
         a = tensors[s1[0][0]]
-        if (len(s1) == 3 and len(s2) == 3 and len(s1[2][0]) <= 1 and len(s2[2][0]) <= 1
+        if (_fusable_kind(s1) and _fusable_kind(s2)
                 and isinstance(a, torch.Tensor) and a.is_cuda and a.numel() >= FUSE_MIN_NUMEL):
-            try:
-                fused = contract2(s1[1], a, tensors[s1[0][1]], s2[1], tensors[s2[0][1]])
-            except Exception as e:
-                raise RuntimeError(f"tensor_contraction_sparse failed at fused steps {n}+{m}: {e}") from e
+            # between the two contractions the first step may only reshape (free) or select every
+            # row in order (the identity): anything else needs the intermediate in memory
+            mid_view = s1[3] if len(s1) > 3 else None
+            select1 = s1[2][0][0] if len(s1) > 3 and len(s1[2][0]) == 1 else None
+            rows1 = _resolve_reshape(_out_numel(s1[1], a, tensors[s1[0][1]]), mid_view)[0] if select1 is not None else 0
+            if select1 is None or _is_identity(select1, rows1):
+                try:
+                    fused = contract2(s1[1], a, tensors[s1[0][1]], s2[1], tensors[s2[0][1]], mid_view=mid_view)
+                except Exception as e:
+                    raise RuntimeError(f"tensor_contraction_sparse failed at fused steps {n}+{m}: {e}") from e
         if fused is None:
             one(n)
             one(m)
         else:
+            if len(s2) > 3:  # branch (C) of the second step: free reshape, optional row select
+                fused = fused.reshape(s2[3])
+                if len(s2[2][0]) == 1:
+                    fused = gather_rows(fused, s2[2][0][0])
             tensors[s1[0][0]] = fused
             tensors[s1[0][1]] = []
             tensors[s2[0][1]] = []

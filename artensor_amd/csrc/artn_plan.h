@@ -286,7 +286,10 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
         if (!a.bit) { p.why_generic = "contracted label with a non power-of-two extent"; return false; }
         K1.push_back(i);
       } else if (a.m1() || a.n1()) {
-        if (fused && a.sB2 >= 0 && a.sC >= 0) { p.why_generic = "batch axis in the second fused step"; return false; }
+        if (fused && a.sB2 >= 0 && a.sC >= 0) { // batch axis of the second step: an outer axis with a B2 stride
+          O.push_back(i);
+          continue;
+        }
         if (fused && a.k2()) {
           if (!a.bit) { p.why_generic = "contracted label with a non power-of-two extent"; return false; }
           K2.push_back(i);
@@ -300,7 +303,9 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
           O.push_back(i);
         }
       } else if (a.h1()) {
-        if (fused) { p.why_generic = "batch axis in a fused pair"; return false; }
+        // batch axis of the first step; in a fused pair it must survive the second step (as a
+        // free or again as a batch axis): a batch axis the second step contracts cannot be outer
+        if (fused && a.sC < 0) { p.why_generic = "batch axis of the first step contracted by the second"; return false; }
         O.push_back(i);
       } else {
         p.why_generic = "label summed out of a single operand";
@@ -528,7 +533,8 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   // contiguous ranges the batch axes, which are the slowest tile digits, change once per row.
   b.blocked = 0;
   for (int i = 0; i < b.n_outer; ++i)
-    if (b.outer[i].sA != 0 && b.outer[i].sB1 != 0 && !fused) b.blocked = 1;
+    if ((b.outer[i].sA != 0 && b.outer[i].sB1 != 0) || (b.outer[i].sB2 != 0 && b.outer[i].sC != 0 && b.outer[i].sA != 0))
+      b.blocked = 1;
 
   // ---- envelope checks
   // the copy phases move 16 bytes (two elements) per lane and need every thread busy

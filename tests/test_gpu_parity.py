@@ -180,6 +180,49 @@ def test_random_fused_pairs(monkeypatch):
     assert done >= 15
 
 
+def test_fused_pairs_with_batch_labels(monkeypatch):
+    """Fused pairs whose steps carry a batch label (the shared rows of the sparse executor): batch
+    in both steps, in the first only, in the second only; power-of-two and ragged extents."""
+    from artensor_amd.contraction import contract2
+    monkeypatch.setenv("ARTN_FORCE_BITS", "1")
+    rng = np.random.default_rng(11)
+    done = 0
+    for trial in range(30):
+        ra = int(rng.integers(13, 18))
+        k1, n1, k2, n2 = (int(x) for x in rng.integers(1, 6, size=4))
+        hext = int(rng.choice([2, 3, 4, 7]))
+        mode = trial % 3
+        la = [chr(65 + x) for x in range(ra)]
+        kl1 = list(rng.choice(la, size=k1, replace=False))
+        nl1 = [chr(97 + x) for x in range(n1)]
+        lb1 = kl1 + nl1
+        rng.shuffle(lb1)
+        lo1 = [x for x in la if x not in kl1] + nl1
+        rng.shuffle(lo1)
+        if k2 > len(lo1) - 6:
+            continue
+        kl2 = list(rng.choice(lo1, size=k2, replace=False))
+        nl2 = [chr(110 + x) for x in range(n2)]
+        lb2 = kl2 + nl2
+        rng.shuffle(lb2)
+        lo2 = [x for x in lo1 if x not in kl2] + nl2
+        rng.shuffle(lo2)
+        la_, lo1_, lo2_ = ["z"] + la, ["z"] + lo1, ["z"] + lo2
+        lb1_ = (["z"] if mode in (0, 1) else []) + lb1
+        lb2_ = (["z"] if mode in (0, 2) else []) + lb2
+        shape = lambda labs: tuple(hext if x == "z" else 2 for x in labs)
+        eq1 = "".join(la_) + "," + "".join(lb1_) + "->" + "".join(lo1_)
+        eq2 = "".join(lo1_) + "," + "".join(lb2_) + "->" + "".join(lo2_)
+        a, b1, b2 = crandn(rng, shape(la_)), crandn(rng, shape(lb1_)), crandn(rng, shape(lb2_))
+        got = contract2(eq1, gpu(a), gpu(b1), eq2, gpu(b2))
+        if got is None:
+            continue
+        want = oracle.einsum_pair(eq2, oracle.einsum_pair(eq1, a, b1), b2)
+        assert rel(got.cpu().numpy(), want) < STEP_TOL, (eq1, eq2, hext, mode)
+        done += 1
+    assert done >= 12
+
+
 def test_fused_and_unfused_schemes_agree(monkeypatch):
     case = load_case(os.path.join(GOLDEN, "n30_dense_sliced3.npz"))
     sliced = A.apply_slice(case.fresh_tensors(device=DEV), case.slicing_indices, [0, 1, 1])
