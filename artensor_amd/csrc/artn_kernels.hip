@@ -321,6 +321,8 @@ struct StageConst {
   long kb_hi[2];
   int nt_eff, wm, wm_count, msubs;
   unsigned msub_tab;                  // LDS byte address of the table: sub-tile -> (input, output) byte offsets
+  int ksplit_wave;                    // >= 0: the waves split the chain of a big-K tile; this wave's share
+  unsigned ksplit_scratch;            // LDS byte address of the 3 x 4 KiB partial blocks
 };
 // zin: stage whose output region this stage reads (nullptr: the unswizzled copy-in region).
 template <int KB>
@@ -333,6 +335,8 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
   L.msubs = 1 << (st.m_bits - 5);
   L.nt_eff = st.nt < 4 ? st.nt : 4;
   L.msub_tab = tab;
+  L.ksplit_wave = -1;
+  L.ksplit_scratch = 0;
   L.lane_in = (unsigned)h << (st.k_in_pos[0] + 3);
   L.lane_out = 0;
 #pragma unroll
@@ -430,7 +434,7 @@ struct StageRun {
   const StageConst<KB> &L;
   float (&W0)[S];
   float (&W1)[S];
-  int h;
+  int h, lane;
   // 7-8 contracted bits (BIGK): fragments for every value of the looped-over bits, all in
   // registers (the instantiation runs one wave per SIMD, so 512 VGPRs are available)
   float (&WH0)[BIGK ? 3 : 1][S];
@@ -538,6 +542,45 @@ struct StageRun {
       if (HI + 1 < n_hi) load_unit<0>(bA, li ^ kin_of(HI + 1));
     }
   }
+  // One 32 x 16 result block per tile: wave w runs the chain segment of looped-over value w
+  // (its fragments sit in W0/W1), waves 1..3 park their partial block in LDS, wave 0 adds
+  // them in order and scatters.  Every wave reaches the barrier.
+  __device__ __forceinline__ void run_ksplit(int lane) const {
+    const int n_hi = 1 << L.k_hi, w = L.ksplit_wave;
+    const u2_t mo0 = lds_read_u2(L.msub_tab);
+    f32x16 acc0;
+    zero(acc0);
+    if (w < n_hi) {
+      v2f_t bA[CH], bB[CH];
+      const unsigned base = L.lane_in ^ mo0.x ^ kin_of(w);
+      load_unit<0>(bA, base);
+      if (UPS == 2) {
+        load_unit<(UPS == 2 ? CH : 0)>(bB, base);
+        chain_hi<0, 0>(acc0, bA);
+        chain_hi<0, (UPS == 2 ? CH : 0)>(acc0, bB);
+      } else {
+        chain_hi<0, 0>(acc0, bA);
+      }
+      if (w > 0) {
+        const unsigned dst = L.ksplit_scratch + (unsigned)(w - 1) * 4096u + (unsigned)lane * 16u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          lds_write16(dst + q * 1024u, f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]});
+      }
+    }
+    __syncthreads();
+    if (w == 0) {
+      for (int o = 1; o < n_hi; ++o) {
+        const unsigned src = L.ksplit_scratch + (unsigned)(o - 1) * 4096u + (unsigned)lane * 16u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 t = lds_read16(src + q * 1024u);
+          acc0[4 * q] += t[0]; acc0[4 * q + 1] += t[1]; acc0[4 * q + 2] += t[2]; acc0[4 * q + 3] += t[3];
+        }
+      }
+      scatter(acc0, L.lane_out ^ mo0.y);
+    }
+  }
   __device__ __forceinline__ void run_big_k() const {
     const int m0 = L.wm, m1 = L.wm + L.wm_count;
     const bool has0 = m0 < L.msubs, has1 = m1 < L.msubs;
@@ -574,6 +617,7 @@ struct StageRun {
 
   __device__ __forceinline__ void run() const {
     if constexpr (BIGK) { // 7 or 8 contracted bits: only instantiated for the single-stage KB = 6 kernel
+      if (L.ksplit_wave >= 0) { run_ksplit(lane); return; }
       if (L.k_hi > 0) { run_big_k(); return; }
     }
     int msub = L.wm;
@@ -637,10 +681,10 @@ struct StageRun {
 
 template <int KB, bool BIGK>
 __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1 << (KB - 1)],
-                                          float (&W1)[1 << (KB - 1)], int h,
+                                          float (&W1)[1 << (KB - 1)], int h, int lane,
                                           float (&WH0)[BIGK ? 3 : 1][1 << (KB - 1)],
                                           float (&WH1)[BIGK ? 3 : 1][1 << (KB - 1)]) {
-  StageRun<KB, BIGK> r{L, W0, W1, h, WH0, WH1};
+  StageRun<KB, BIGK> r{L, W0, W1, h, lane, WH0, WH1};
   r.run();
 }
 
@@ -694,7 +738,11 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   fill_msub_table(P.st[0], nullptr, tab1, tid);
   if (KB2 > 0) fill_msub_table(P.st[1], &P.st[0], tab2, tid);
   const unsigned tab1_a = regions_end, tab2_a = tab1_a + (8u << (P.st[0].m_bits - 5));
-  const StageConst<KB1> L1 = stage_const<KB1>(P.st[0], nullptr, j, h, wave, tab1_a, R0, R1);
+  StageConst<KB1> L1 = stage_const<KB1>(P.st[0], nullptr, j, h, wave, tab1_a, R0, R1);
+  if (BIGK && P.ksplit) {
+    L1.ksplit_wave = wave;
+    L1.ksplit_scratch = (regions_end + (8u << (P.st[0].m_bits - 5)) + (512u * 8u + 32u * 32u) + 15u) & ~15u;
+  }
   const StageConst<KB2e> L2 = stage_const<KB2e>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2_a, R1, R0);
   // copy-out reads the last stage's (swizzled) output region
   const ArtnStage *zout = &P.st[KB2 > 0 ? 1 : 0];
@@ -750,10 +798,17 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     if (off.b1 != prev_b1) {
       prev_b1 = off.b1;
       const char *Bb = reinterpret_cast<const char *>(B1 + off.b1);
-      load_w<KB1>(W10, W11, Bb, L1, ro);
+      long kb0 = 0; // ksplit: this wave's share of the looped-over bits, in W10/W11
+      if (BIGK && L1.ksplit_wave > 0) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if ((L1.ksplit_wave >> b) & 1) kb0 += L1.kb_hi[b];
+      }
+      load_w<KB1>(W10, W11, Bb + kb0, L1, ro);
       if constexpr (BIGK) { // fragments of the looped-over contracted bits' values 1..3
 #pragma unroll
         for (int hi = 1; hi < 4; ++hi) {
+          if (L1.ksplit_wave >= 0) break;
           if (hi < (1 << L1.k_hi)) {
             long kbo = 0;
 #pragma unroll
@@ -776,7 +831,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
     if (stage_prio) __builtin_amdgcn_s_setprio(2);
-    run_stage<KB1, BIGK>(L1, W10, W11, h, WH0, WH1);
+    run_stage<KB1, BIGK>(L1, W10, W11, h, lane, WH0, WH1);
     if (stage_prio && KB2 == 0) __builtin_amdgcn_s_setprio(0);
     PHASE_MARK(1);
     STAMP(5);
@@ -784,7 +839,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     unsigned outr = R1;
     if (KB2 > 0) {
       STAMP(6);
-      run_stage<KB2e, false>(L2, W20, W21, h, WD0, WD1);
+      run_stage<KB2e, false>(L2, W20, W21, h, lane, WD0, WD1);
       if (stage_prio) __builtin_amdgcn_s_setprio(0);
       STAMP(5);
       __syncthreads();

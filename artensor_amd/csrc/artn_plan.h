@@ -72,6 +72,8 @@ struct ArtnBitsPlan {
   int32_t stage_prio;         // 1: one of the two co-resident workgroups runs its MFMA stages at s_setprio 2
   int32_t blocked;            // 1: a workgroup takes a contiguous range of tiles instead of a grid-stride sequence
   int64_t n_tiles;
+  int32_t ksplit;             // 1: 7-8 contracted bits, one 32 x 16 block per tile: the four waves split the chain
+  int32_t pad_;
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
   ArtnStage st[2];
@@ -572,7 +574,13 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     for (int i = 0; i < b.n_outer && b.outer[i].log2ext >= 0; ++i) pow2_bits += b.outer[i].log2ext;
     if (pow2_bits > 32) { p.why_generic = "more than 2^32 tiles"; return false; }
     const int64_t off_tab = 512LL * 8 + 32 * 32; // tile-offset nibble tables (8 x 16 x 4 longs) + grid-stride deltas
-    f.lds_bytes = (int32_t)((8LL << b.r0_bits) + (8LL << b.T_mid) + (8LL << (mt - 5)) + (fused ? (8LL << (m2 - 5)) : 0) + off_tab);
+    // 7-8 contracted bits with a single 32 x 16 result block per tile (few free bits on both
+    // sides: the chunk steps of the sparse path) would keep one wave busy; the four waves take a
+    // quarter of the chain each and three partial blocks (4 KiB each) are summed through LDS
+    b.ksplit = (k1 > 6 && !fused && mt == 5 && b.st[0].wn_log2 == 0) ? 1 : 0;
+    b.pad_ = 0;
+    f.lds_bytes = (int32_t)((8LL << b.r0_bits) + (8LL << b.T_mid) + (8LL << (mt - 5)) + (fused ? (8LL << (m2 - 5)) : 0) + off_tab +
+                            (b.ksplit ? 3 * 4096 + 16 : 0));
   }
   f.n_tiles = b.n_tiles;
   f.a_rereads = a_rereads;

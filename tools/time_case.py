@@ -11,7 +11,7 @@ from artensor_amd.fixtures import load_case
 case = load_case(os.path.join(ROOT, "tests", "golden", sys.argv[1]))
 sparse = len(sys.argv) > 2 and sys.argv[2] == "sparse"
 leaves = case.fresh_tensors(device="cuda")
-nb = len(case.slicing_indices)
+nb = len(case.slicing_indices or {})
 rec = []
 orig_q = C._query
 def q(d):
