@@ -514,8 +514,12 @@ struct StageRun {
     const float(&a1)[S] = w1<HI>();
 #pragma unroll
     for (int s = 0; s < CH; ++s) {
+#ifdef ARTN_ABLATE_MFMA
+      asm volatile("" ::"v"(buf[s].x), "v"(buf[s].y), "v"(a0[BASE + s]), "v"(a1[BASE + s]));
+#else
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[BASE + s], buf[s].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[BASE + s], buf[s].y, acc, 0, 0, 0);
+#endif
     }
   }
   __device__ __forceinline__ unsigned kin_of(int hi) const {
