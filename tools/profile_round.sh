@@ -5,6 +5,7 @@
 set -u
 R=${1:-r01}
 OUT=gpurun_out/prof_$R
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
