@@ -14,6 +14,7 @@ from .contraction import (  # noqa: F401
     contraction_scheme,
     contraction_scheme_sparse,
     einsum_eq_convert,
+    precision,
     step_info,
     tensor_contraction,
     tensor_contraction_sparse,

@@ -12,7 +12,7 @@ import threading
 import torch
 
 ARTN_MAX_LABELS = 96
-ARTN_C64, ARTN_C128 = 0, 1
+ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
 KERNEL_GENERIC, KERNEL_BITS_MFMA = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

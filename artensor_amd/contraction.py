@@ -68,8 +68,36 @@ def _query(d):
     return {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
 
 
+class precision:
+    """Context manager selecting the arithmetic of the big steps of complex64 contractions:
+
+        with artensor_amd.precision("bf16"):
+            amps = artensor_amd.tensor_contraction(tensors, scheme)
+
+    "bf16": tensors stay complex64 in memory; the operands of the MFMA kernel are rounded to
+    bfloat16 (round to nearest even) and accumulated in fp32 -- the reduced-precision sampling
+    mode of BASELINE configs[4].  The reference has no such path: it is defined against this
+    package's own complex64 results (tests check state fidelity).  None / "fp32": the default."""
+    _current = None
+
+    def __init__(self, mode):
+        if mode not in (None, "fp32", "bf16"):
+            raise RuntimeError(f"unknown precision {mode!r} (use None, 'fp32' or 'bf16')")
+        self.mode = None if mode == "fp32" else mode
+
+    def __enter__(self):
+        self._prev = precision._current
+        precision._current = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        precision._current = self._prev
+        return False
+
+
 def _descriptor(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype):
-    key = (la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype)
+    reduced = precision._current == "bf16" and dtype == torch.complex64
+    key = (la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype, reduced)
     hit = _desc_cache.get(key)
     if hit is not None:
         return hit
@@ -91,7 +119,7 @@ def _descriptor(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype):
         c_stride[lab] = s
         s *= ext[lab]
     d = N.ArtnStepDesc()
-    d.dtype = _DTYPES[dtype]
+    d.dtype = N.ARTN_C64_BF16 if reduced else _DTYPES[dtype]
     d.n_labels = len(labels)
     sa, sb = dict(zip(la, a_stride)), dict(zip(lb, b_stride))
     for n, lab in enumerate(labels):
@@ -478,7 +506,7 @@ def tensor_contraction(tensors, scheme):
         shapes[k] = tuple(t.shape)
     if first is None or first.dtype not in _DTYPES:
         raise RuntimeError("tensor_contraction needs complex64 or complex128 GPU tensors")
-    key = (id(scheme), first.dtype, tuple(sorted(shapes.items())), N.lib().artn_contract2_query is not None,
+    key = (id(scheme), first.dtype, precision._current, tuple(sorted(shapes.items())), N.lib().artn_contract2_query is not None,
            bool(__import__("os").environ.get("ARTN_NO_FUSE")))
     hit = _plan_cache.get(key)
     if hit is None or hit[0] is not scheme:

@@ -325,9 +325,11 @@ struct StageConst {
   unsigned ksplit_scratch;            // LDS byte address of the 3 x 4 KiB partial blocks
 };
 // zin: stage whose output region this stage reads (nullptr: the unswizzled copy-in region).
+// hb: the contracted bit carried by the lane half h (0 for the fp32 chain: kc = 2s + h; 2 for the
+// split-bf16 chain, whose MFMA takes 8 complex kc per instruction: kc = 8g + 4h + u).
 template <int KB>
 __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const ArtnStage *zin, int j, int h, int wave,
-                                                      unsigned tab, unsigned in_base, unsigned out_base) {
+                                                      unsigned tab, unsigned in_base, unsigned out_base, int hb = 0) {
   StageConst<KB> L;
   const int wn = wave & ((1 << st.wn_log2) - 1);
   L.wm = wave >> st.wn_log2;
@@ -337,7 +339,7 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
   L.msub_tab = tab;
   L.ksplit_wave = -1;
   L.ksplit_scratch = 0;
-  L.lane_in = (unsigned)h << (st.k_in_pos[0] + 3);
+  L.lane_in = (unsigned)h << (st.k_in_pos[hb] + 3);
   L.lane_out = 0;
 #pragma unroll
   for (int b = 0; b < 5; ++b) {
@@ -349,7 +351,7 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
   if (st.nt > 1) L.lane_out += (unsigned)h << (st.n_out_pos[1] + 3);
   const int nloc = j >> 1;
   L.w_valid = (nloc >> L.nt_eff) == 0;
-  L.lane_b = (unsigned)h * (unsigned)st.k_b_stride[0] * 8u;
+  L.lane_b = (unsigned)h * (unsigned)st.k_b_stride[hb] * 8u;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
     if (b < L.nt_eff && ((nloc >> b) & 1)) L.lane_b += (unsigned)st.n_b_stride[b] * 8u;
@@ -361,7 +363,7 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
     }
   }
 #pragma unroll
-  for (int b = 1; b < KB; ++b) {
+  for (int b = 0; b < KB; ++b) {
     L.kin[b] = swz(8u << st.k_in_pos[b], zin);
     L.kb[b] = st.k_b_stride[b] * 8;
   }
@@ -418,6 +420,62 @@ __device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1
   for (int s = 0; s < S; ++s) asm volatile("" : "+v"(W0[s]), "+v"(W1[s]));
 }
 
+// Split-bf16 arithmetic.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA.  An
+// fp32 number is the exact sum of three bf16 pieces (8 significand bits each), so the product of
+// two is the sum of nine piece products; the six with piece indices i + j <= 2 carry everything
+// above 2^-23 of the product -- fp32-grade results from 6 bf16 MFMAs per 8 complex kc instead of
+// 16 fp32 MFMAs (NP = 3).  NP = 1 keeps only the leading pieces: plain bf16 operands, fp32
+// accumulation (the reduced-precision path of BASELINE configs[4]).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) { // RNE, a in the low half
+  v2f_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// (a, b) -> NP packed pieces; piece p+1 splits what piece p left over (exact subtraction)
+template <int NP>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&piece)[NP]) {
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const unsigned d = pack_bf16(a, b);
+    piece[p] = d;
+    if (p + 1 < NP) {
+      a -= __builtin_bit_cast(float, d << 16);
+      b -= __builtin_bit_cast(float, d & 0xffff0000u);
+    }
+  }
+}
+// Small-operand fragments for the split chain: WS[p][g] = 8 bf16 of piece p for the lane's row
+// n' = lane&31 and the 4 complex kc = 8g + 4h + u: element 2u multiplies re(a), 2u+1 im(a).
+template <int KB, int NP>
+__device__ __forceinline__ void load_w_split(u32x4_t (&WS)[NP][KB >= 3 ? 1 << (KB - 3) : 1],
+                                             const char *__restrict__ Bbase, const StageConst<KB> &L, int ro) {
+  constexpr int G = KB >= 3 ? 1 << (KB - 3) : 1;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      long ko = 0;
+      if (u & 1) ko += L.kb[0];
+      if (u & 2) ko += L.kb[KB > 1 ? 1 : 0];
+#pragma unroll
+      for (int b = 3; b < KB; ++b)
+        if ((g >> (b - 3)) & 1) ko += L.kb[b];
+      float2 bv = make_float2(0.f, 0.f);
+      if (L.w_valid) bv = *reinterpret_cast<const float2 *>(Bbase + ko + L.lane_b);
+      unsigned piece[NP];
+      split_pair<NP>(ro ? bv.y : bv.x, ro ? bv.x : -bv.y, piece);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) WS[p][g][u] = piece[p];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int g = 0; g < G; ++g) asm volatile("" : "+v"(WS[p][g])); // see load_w
+}
+
 // One stage on this wave's sub-tiles.  Per sub-tile: a chain of 2^KB MFMAs over the
 // contracted bits, then the scatter of the 32 x 16 complex result into the output region.
 // The chain must never wait on LDS and the scatter must not sit between two chains, so the
@@ -426,11 +484,13 @@ __device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1
 //     into the other half of a ping-pong register buffer;
 //   * accumulators ping-pong too: the scatter of sub-tile i is issued after the first MFMA
 //     pair of sub-tile i+1, so the LDS writes drain under that chain.
-template <int KB, bool BIGK>
+template <int KB, bool BIGK, int NP = 0>
 struct StageRun {
   static constexpr int S = 1 << (KB - 1);
   static constexpr int CH = S < 16 ? S : 16; // chain steps per unit
   static constexpr int UPS = S / CH;         // units per sub-tile (1, or 2 for KB = 6)
+  static constexpr bool SPLIT = NP > 0 && KB >= 3;
+  static constexpr int G = KB >= 3 ? 1 << (KB - 3) : 1;
   const StageConst<KB> &L;
   float (&W0)[S];
   float (&W1)[S];
@@ -439,12 +499,22 @@ struct StageRun {
   // registers (the instantiation runs one wave per SIMD, so 512 VGPRs are available)
   float (&WH0)[BIGK ? 3 : 1][S];
   float (&WH1)[BIGK ? 3 : 1][S];
+  u32x4_t (&WS)[SPLIT ? NP : 1][G]; // split chain: bf16 pieces of the small operand
 
+  // LDS offset of read s of a chain: fp32 chain kc = 2s + h; split chain kc = 8g + 4h + u, s = 4g + u
   __device__ __forceinline__ unsigned ko(int s) const {
     unsigned k = 0;
+    if constexpr (SPLIT) {
+      if (s & 1) k ^= L.kin[0];
+      if (s & 2) k ^= L.kin[1];
 #pragma unroll
-    for (int b = 1; b < KB; ++b)
-      if ((s >> (b - 1)) & 1) k ^= L.kin[b];
+      for (int b = 3; b < KB; ++b)
+        if ((s >> (b - 1)) & 1) k ^= L.kin[b];
+    } else {
+#pragma unroll
+      for (int b = 1; b < KB; ++b)
+        if ((s >> (b - 1)) & 1) k ^= L.kin[b];
+    }
     return k;
   }
   // operands of one unit: steps [base, base + CH) of the sub-tile at LDS offset li
@@ -481,6 +551,61 @@ struct StageRun {
   template <int BASE>
   __device__ __forceinline__ void chain_unit(f32x16 &acc, const v2f_t (&buf)[CH], bool pending, const f32x16 &pacc,
                                              unsigned plo) const {
+    if constexpr (SPLIT) {
+      // Software pipeline over the groups of 8 complex kc: the pieces of group g+1 are split
+      // (VALU) while the NT piece products of group g run on the matrix pipe.  Issue is in
+      // order, so the two streams must alternate in the instruction stream itself: after each
+      // MFMA comes the split of one element of the next group, fenced by sched_barrier so the
+      // compiler keeps that order.
+      constexpr int NPe = SPLIT ? NP : 1;
+      constexpr int NG = CH / 4;
+      constexpr int NT = NPe * (NPe + 1) / 2; // piece products kept: i + j <= NP - 1
+      u32x4_t a_cur[NPe], a_nxt[NPe];
+      auto split_elem = [&](int gg, int u, u32x4_t (&a)[NPe]) {
+        unsigned piece[NPe];
+        split_pair<NPe>(buf[4 * gg + u].x, buf[4 * gg + u].y, piece);
+#pragma unroll
+        for (int p = 0; p < NPe; ++p) a[p][u] = piece[p];
+      };
+#pragma unroll
+      for (int u = 0; u < 4; ++u) split_elem(0, u, a_cur);
+#pragma unroll
+      for (int gg = 0; gg < NG; ++gg) {
+        const int g = BASE / 4 + gg;
+        int t = 0;
+        // smallest terms first
+#pragma unroll
+        for (int sum = NPe - 1; sum >= 0; --sum) {
+#pragma unroll
+          for (int i = 0; i <= sum; ++i) {
+#ifdef ARTN_ABLATE_MFMA
+            asm volatile("" ::"v"(a_cur[sum - i]), "v"(WS[i][g]));
+#else
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, WS[i][g]),
+                                                          __builtin_bit_cast(bf16x8_t, a_cur[sum - i]), acc, 0, 0, 0);
+#endif
+            if (gg + 1 < NG) {
+              // NT >= 4 products: one element per product; fewer (NP = 1): all four after the only one
+              if (NT >= 4) {
+                if (t < 4) split_elem(gg + 1, t, a_nxt);
+              } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                  if (u * NT / 4 == t) split_elem(gg + 1, u, a_nxt);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            ++t;
+          }
+        }
+        if (gg + 1 < NG) {
+#pragma unroll
+          for (int p = 0; p < NPe; ++p) a_cur[p] = a_nxt[p];
+        }
+        if (gg == 0 && BASE == 0 && pending) scatter(pacc, plo);
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < CH; ++s) {
 #ifdef ARTN_ABLATE_MFMA
@@ -683,17 +808,19 @@ struct StageRun {
   }
 };
 
-template <int KB, bool BIGK>
+template <int KB, bool BIGK, int NP>
 __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1 << (KB - 1)],
                                           float (&W1)[1 << (KB - 1)], int h, int lane,
                                           float (&WH0)[BIGK ? 3 : 1][1 << (KB - 1)],
-                                          float (&WH1)[BIGK ? 3 : 1][1 << (KB - 1)]) {
-  StageRun<KB, BIGK> r{L, W0, W1, h, lane, WH0, WH1};
+                                          float (&WH1)[BIGK ? 3 : 1][1 << (KB - 1)],
+                                          u32x4_t (&WS)[(NP > 0 && KB >= 3) ? NP : 1][KB >= 3 ? 1 << (KB - 3) : 1]) {
+  StageRun<KB, BIGK, NP> r{L, W0, W1, h, lane, WH0, WH1, WS};
   r.run();
 }
 
 // KB2 == 0: single stage.  BIGK: 7 or 8 contracted bits (KB1 = 6 of them in the chain).
-template <int KB1, int KB2, bool BIGK>
+// NP: 0 = fp32 MFMA chains; 3 / 1 = split-bf16 chains (stages with >= 3 contracted bits).
+template <int KB1, int KB2, bool BIGK, int NP = 0>
 __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(const float2 *__restrict__ A,
                                                                   const float2 *__restrict__ B1,
                                                                   const float2 *__restrict__ B2,
@@ -742,12 +869,14 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   fill_msub_table(P.st[0], nullptr, tab1, tid);
   if (KB2 > 0) fill_msub_table(P.st[1], &P.st[0], tab2, tid);
   const unsigned tab1_a = regions_end, tab2_a = tab1_a + (8u << (P.st[0].m_bits - 5));
-  StageConst<KB1> L1 = stage_const<KB1>(P.st[0], nullptr, j, h, wave, tab1_a, R0, R1);
+  constexpr bool SP1 = NP > 0 && KB1 >= 3, SP2 = NP > 0 && KB2 >= 3;
+  constexpr int G1 = KB1 >= 3 ? 1 << (KB1 - 3) : 1, G2 = KB2e >= 3 ? 1 << (KB2e - 3) : 1;
+  StageConst<KB1> L1 = stage_const<KB1>(P.st[0], nullptr, j, h, wave, tab1_a, R0, R1, SP1 ? 2 : 0);
   if (BIGK && P.ksplit) {
     L1.ksplit_wave = wave;
     L1.ksplit_scratch = (regions_end + (8u << (P.st[0].m_bits - 5)) + (512u * 8u + 32u * 32u) + 15u) & ~15u;
   }
-  const StageConst<KB2e> L2 = stage_const<KB2e>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2_a, R1, R0);
+  const StageConst<KB2e> L2 = stage_const<KB2e>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2_a, R1, R0, SP2 ? 2 : 0);
   // copy-out reads the last stage's (swizzled) output region
   const ArtnStage *zout = &P.st[KB2 > 0 ? 1 : 0];
   const unsigned tid16_out = swz(tid16, zout);
@@ -755,7 +884,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 #pragma unroll
   for (int i = 0; i < 16; ++i) out_i_swz[i] = swz(i * (ARTN_WG_THREADS * 16), zout);
   const OffTab OT = build_offset_table(P, offtab, tid);
-  float W10[S1], W11[S1], W20[S2], W21[S2];
+  float W10[S1], W11[S1], W20[S2], W21[S2]; // (whichever of the fp32 / split fragment sets a stage does not use is dead)
+  u32x4_t WS1[SP1 ? NP : 1][G1], WS2[SP2 ? NP : 1][G2];
   float WH0[BIGK ? 3 : 1][S1], WH1[BIGK ? 3 : 1][S1], WD0[1][S2], WD1[1][S2]; // BIGK: fragments of looped-over values 1..3
   long prev_b1 = -1, prev_b2 = -1;
   __syncthreads(); // tables are in LDS
@@ -808,7 +938,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
         for (int b = 0; b < 2; ++b)
           if ((L1.ksplit_wave >> b) & 1) kb0 += L1.kb_hi[b];
       }
-      load_w<KB1>(W10, W11, Bb + kb0, L1, ro);
+      if constexpr (SP1) load_w_split<KB1, (SP1 ? NP : 1)>(WS1, Bb, L1, ro);
+      else load_w<KB1>(W10, W11, Bb + kb0, L1, ro);
       if constexpr (BIGK) { // fragments of the looped-over contracted bits' values 1..3
 #pragma unroll
         for (int hi = 1; hi < 4; ++hi) {
@@ -825,7 +956,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     }
     if (KB2 > 0 && off.b2 != prev_b2) {
       prev_b2 = off.b2;
-      load_w<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
+      if constexpr (SP2) load_w_split<KB2e, (SP2 ? NP : 1)>(WS2, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
+      else load_w<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
     }
     const long next = tile + G, next2 = tile + 2 * G;
     TileOff n2off = noff;
@@ -835,7 +967,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
     if (stage_prio) __builtin_amdgcn_s_setprio(2);
-    run_stage<KB1, BIGK>(L1, W10, W11, h, lane, WH0, WH1);
+    run_stage<KB1, BIGK, NP>(L1, W10, W11, h, lane, WH0, WH1, WS1);
     if (stage_prio && KB2 == 0) __builtin_amdgcn_s_setprio(0);
     PHASE_MARK(1);
     STAMP(5);
@@ -843,7 +975,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     unsigned outr = R1;
     if (KB2 > 0) {
       STAMP(6);
-      run_stage<KB2e, false>(L2, W20, W21, h, lane, WD0, WD1);
+      run_stage<KB2e, false, NP>(L2, W20, W21, h, lane, WD0, WD1, WS2);
       if (stage_prio) __builtin_amdgcn_s_setprio(0);
       STAMP(5);
       __syncthreads();
@@ -1072,11 +1204,21 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
   const size_t lds = (size_t)p.info.lds_bytes;
   const int k2 = p.bits.n_stages == 2 ? p.bits.st[1].k : 0;
+  const int split = p.bits.split;
+#define ARTN_LAUNCH_NP(K2, NPV)                                                                           \
+  {                                                                                                       \
+    auto kern = artn_k_bits<KB1, K2, false, NPV>;                                                         \
+    if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, NPV>>(lds); e != hipSuccess) return e;      \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                                 \
+  }
+  // split-bf16 instantiations exist only where a stage has the >= 3 contracted bits they need
 #define ARTN_LAUNCH(K2)                                                                                   \
   case K2: {                                                                                              \
-    auto kern = artn_k_bits<KB1, K2, false>;                                                              \
-    if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false>>(lds); e != hipSuccess) return e;           \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                                 \
+    if constexpr (KB1 >= 3 || K2 >= 3) {                                                                  \
+      if (split == 3) { ARTN_LAUNCH_NP(K2, 3) break; }                                                    \
+      if (split == 1) { ARTN_LAUNCH_NP(K2, 1) break; }                                                    \
+    }                                                                                                     \
+    ARTN_LAUNCH_NP(K2, 0)                                                                                 \
     break;                                                                                                \
   }
   if (KB1 == 6 && k2 == 0 && p.bits.st[0].k > 6) {
@@ -1096,6 +1238,7 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
     default: return hipErrorInvalidValue;
   }
 #undef ARTN_LAUNCH
+#undef ARTN_LAUNCH_NP
   return hipGetLastError();
 }
 
@@ -1156,7 +1299,7 @@ int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, 
   }
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
   if (p.gen.out_numel == 0) return ARTN_OK;
-  if (d->dtype == ARTN_C64)
+  if (d->dtype != ARTN_C128) // (small steps of the reduced-precision mode run in fp32: they are launch-bound)
     hipLaunchKernelGGL((artn_k_generic<float2, float>), grid, block, 0, st, (const float2 *)A,
                        (const float2 *)B, (float2 *)C, p.gen);
   else

@@ -73,7 +73,7 @@ struct ArtnBitsPlan {
   int32_t blocked;            // 1: a workgroup takes a contiguous range of tiles instead of a grid-stride sequence
   int64_t n_tiles;
   int32_t ksplit;             // 1: 7-8 contracted bits, one 32 x 16 block per tile: the four waves split the chain
-  int32_t pad_;
+  int32_t split;              // MFMA arithmetic: 0 fp32; 3 fp32-grade from three bf16 pieces; 1 plain bf16 operands
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
   ArtnStage st[2];
@@ -111,6 +111,7 @@ struct Tuning {
   int run_max = 4;    // longest contiguous run (log2 elements) the tile is forced to keep
   int swizzle = 1;    // XOR-swizzle stage output regions against LDS bank conflicts
   int stage_prio = 1; // asymmetric MFMA-stage priority between the two workgroups of a CU
+  int split = 0;      // complex64 chains: 0 fp32 MFMA, 3 fp32-grade split-bf16 MFMA
 };
 static inline Tuning &tuning() {
   static Tuning t = [] {
@@ -120,6 +121,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_RUN_MAX")) x.run_max = std::min(6, std::max(1, atoi(e)));
     if (const char *e = getenv("ARTN_SWIZZLE")) x.swizzle = atoi(e) != 0;
     if (const char *e = getenv("ARTN_STAGE_PRIO")) x.stage_prio = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
     return x;
   }();
   return t;
@@ -135,7 +137,7 @@ static inline int ilog2_exact(int64_t v) {
 // Returns 0 or a negative ARTN_E_* with `err` set.
 static inline int validate(const ArtnStepDesc *d, std::string &err) {
   if (!d) { err = "null descriptor"; return ARTN_E_INVALID; }
-  if (d->dtype != ARTN_C64 && d->dtype != ARTN_C128) { err = "unknown dtype"; return ARTN_E_UNSUPPORTED; }
+  if (d->dtype != ARTN_C64 && d->dtype != ARTN_C128 && d->dtype != ARTN_C64_BF16) { err = "unknown dtype"; return ARTN_E_UNSUPPORTED; }
   if (d->n_labels < 0 || d->n_labels > ARTN_MAX_LABELS) { err = "n_labels out of range"; return ARTN_E_INVALID; }
   for (int l = 0; l < d->n_labels; ++l) {
     if (d->extent[l] < 1) { err = "label extent < 1"; return ARTN_E_INVALID; }
@@ -273,7 +275,8 @@ static inline bool chain_axes(const ArtnStepDesc *d2, std::vector<Axis> &ax, std
 
 static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, ArtnPlan &p, int n_cu,
                              int64_t min_tiles) {
-  if (d1->dtype != ARTN_C64 || (d2 && d2->dtype != ARTN_C64)) { p.why_generic = "dtype is not complex64"; return false; }
+  auto c64 = [](int dt) { return dt == ARTN_C64 || dt == ARTN_C64_BF16; };
+  if (!c64(d1->dtype) || (d2 && d2->dtype != d1->dtype)) { p.why_generic = "dtype is not complex64"; return false; }
   const bool fused = d2 != nullptr;
   std::vector<Axis> ax;
   expand_axes(d1, ax);
@@ -578,7 +581,9 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     // sides: the chunk steps of the sparse path) would keep one wave busy; the four waves take a
     // quarter of the chain each and three partial blocks (4 KiB each) are summed through LDS
     b.ksplit = (k1 > 6 && !fused && mt == 5 && b.st[0].wn_log2 == 0) ? 1 : 0;
-    b.pad_ = 0;
+    // arithmetic of the chains: ARTN_C64_BF16 asks for plain bf16 operands; complex64 uses the
+    // split (three bf16 pieces) when tuning().split says so; 7-8 contracted bits stay fp32
+    b.split = k1 > 6 ? 0 : (d1->dtype == ARTN_C64_BF16 ? 1 : tuning().split);
     f.lds_bytes = (int32_t)((8LL << b.r0_bits) + (8LL << b.T_mid) + (8LL << (mt - 5)) + (fused ? (8LL << (m2 - 5)) : 0) + off_tab +
                             (b.ksplit ? 3 * 4096 + 16 : 0));
   }
@@ -613,7 +618,7 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   if (!ok && !make_generic(d, p, err)) return ARTN_E_UNSUPPORTED;
   double na, nb, nc;
   step_cost(d, p.info.flops, na, nb, nc);
-  p.info.bytes = (d->dtype == ARTN_C64 ? 8.0 : 16.0) * (na + nb + nc);
+  p.info.bytes = (d->dtype == ARTN_C128 ? 16.0 : 8.0) * (na + nb + nc);
   return ARTN_OK;
 }
 

@@ -93,6 +93,8 @@ SLICED_WORKLOADS = {
     # name: (fixture, sparse executor?, description)
     "n53": ("n53_m14_sliced.npz", True,
             "Sycamore n53 m14 (first 14 cycles of the bundled m20 circuit), 1 bitstring, 14 sliced bonds"),
+    "n53m20": ("n53_m20_sliced.npz", True,
+               "Sycamore n53 m20 (bundled circuit_n53_m20_s0_e0_pABCDCDAB), 1 bitstring, 29 sliced bonds"),
     "rand2": ("rand_D2_nv260_sliced.npz", False,
               "random 3-regular tensor network, bond dimension 2, 260 tensors, closed, 12 sliced bonds (sc 30)"),
     "rand4": ("rand_D4_nv100.npz", False,
@@ -156,7 +158,8 @@ def bench_sliced(args, A, dev, world, rank, dist):
             "metric": f"contracted TFLOP/s, {args.workload} sliced contraction (8 real FLOP per complex MAC)",
             "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "c64 (fp32 MFMA)", "data": "synthetic",
+            "dtype": ("c64 in memory, bf16 MFMA operands, fp32 accumulate" if args.precision == "bf16"
+                      else "c64 (fp32 MFMA)"), "data": "synthetic",
             "config": {"workload": f"{what}, tests/golden/{fixture}",
                        "slices_per_rank_per_step": per_step, "slices_timed": n_slices,
                        "flops_per_slice": flops_slice,
@@ -180,8 +183,13 @@ def main():
     ap.add_argument("--workload", default="n30", choices=["n30"] + sorted(SLICED_WORKLOADS),
                     help="n30: BASELINE configs[1] (default, the metric's config); n53: configs[3], the "
                          "slice-sharded Sycamore n53 m14 contraction with one RCCL reduce at the end; "
+                         "n53m20: the bundled n53 m20 circuit, per-slice throughput; "
                          "rand2 / rand4: random 3-regular tensor networks of bond dimension 2 (sliced) / 4")
     ap.add_argument("--slices", type=int, default=4, help="sliced workloads: slices per rank per step")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 (default; the metric's arithmetic) or bf16: complex64 in memory, MFMA operands "
+                         "rounded to bfloat16, fp32 accumulation (BASELINE configs[4]'s reduced-precision mode; "
+                         "reported as its own metric, checked by state fidelity)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -200,6 +208,9 @@ def main():
     from artensor_amd import contraction as C
     from artensor_amd.fixtures import load_case
 
+    bf16 = args.precision == "bf16"
+    if bf16:
+        A.precision("bf16").__enter__()   # for the whole run
     if args.workload in SLICED_WORKLOADS:
         return bench_sliced(args, A, dev, world, rank, dist)
     case = load_case(os.path.join(ROOT, "tests", "golden", "n30_dense.npz"))
@@ -228,6 +239,8 @@ def main():
     at = out.reshape(-1)[pos].cpu().numpy()
     want = case.arrays["amps_at_google"]
     rel_err = float((np.abs(at - want) / np.maximum(np.abs(want), 2.0 ** -15)).max())
+    w128, a128 = want.astype(np.complex128), at.astype(np.complex128)
+    fidelity = float(abs(np.vdot(w128, a128)) ** 2 / (np.vdot(w128, w128).real * np.vdot(a128, a128).real))
     del out
 
     prof = KernelTimes()
@@ -281,15 +294,17 @@ def main():
             with open(tfiles[-1]) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         line = {
-            "metric": "contracted TFLOP/s, Sycamore n30 m14 full-amplitude (8 real FLOP per complex MAC)",
+            "metric": "contracted TFLOP/s, Sycamore n30 m14 full-amplitude (8 real FLOP per complex MAC)"
+                      + (", bf16 operands" if bf16 else ""),
             "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "c64 (fp32 MFMA)", "data": "synthetic",
+            "dtype": "c64 in memory, bf16 MFMA operands, fp32 accumulate" if bf16 else "c64 (fp32 MFMA)",
+            "data": "synthetic",
             "config": {"workload": "Sycamore n30 m14 full-amplitude, complex64, no slicing, 180-step scheme "
                                    "(tests/golden/n30_dense.npz)",
                        "flops_per_step": flops_per_step, "parallelism": "replicas" if world > 1 else "single",
                        "frac_mfma_peak": value / world / MFMA_F32_PEAK_TFLOPS,
-                       "max_rel_err_vs_reference": rel_err},
+                       "max_rel_err_vs_reference": rel_err, "fidelity_vs_reference": fidelity},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
@@ -301,6 +316,9 @@ def main():
                 "other_kernels_ms_per_step": sum(v["ms"] for k, v in ks.items() if k != 1) / max(args.steps, 1),
             },
         }
+        if bf16:  # with bf16 operands every big launch is bound by its one pass over HBM
+            line["roofline"].update({"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(case)
         print(json.dumps(line), flush=True)

@@ -34,6 +34,9 @@ extern "C" {
 /* dtypes (arithmetic type of the contraction) */
 #define ARTN_C64 0  /* interleaved (re,im) float32 pairs  -- torch.complex64  */
 #define ARTN_C128 1 /* interleaved (re,im) float64 pairs  -- torch.complex128 */
+#define ARTN_C64_BF16 2 /* complex64 in memory; operands of the big steps rounded to bfloat16 for the
+                           matrix cores, fp32 accumulation: the reduced-precision sampling mode (the
+                           reference has no such path; its results define no parity here) */
 
 /*
  * One pairwise contraction step  C[out labels] = sum_{labels not in C} A[...] * B[...]

@@ -485,10 +485,12 @@ def n53_m14_qsim():
     return N53_M14
 
 
-def case_n53_plan():
-    """n53 m14 (derived), one bitstring, sc_target 30: plan + leaf tensors + slicing indices."""
+def case_n53_plan(which="m14"):
+    """n53 m14 (derived) or the bundled n53 m20, one bitstring, sc_target 30: plan + leaf tensors +
+    slicing indices."""
     bits = ["0" * 53]
-    sim, meta = plan(n53_m14_qsim(), bits, 30)
+    qsim = n53_m14_qsim() if which == "m14" else os.path.join(REF, "examples", "circuits", "circuit_n53_m20_s0_e0_pABCDCDAB.qsim")
+    sim, meta = plan(qsim, bits, 30)
     # With a single bitstring the chunking rule of contraction.py:288-297 (chunks when
     # log2(rows) + rank > sc_target - 2) produces chunks of int(1 / 8) = 0 rows and the
     # reference executor then dies on an empty tensor.  Recompile the scheme from the same
@@ -498,7 +500,8 @@ def case_n53_plan():
     meta["scheme_chunk_threshold"] = 40
     meta["n_slicing"] = len(sim.slicing_indices)
     meta["reference_slice_loop_well_defined"] = bool(slicing_ok(sim))
-    meta["derivation"] = "first 14 cycles of circuit_n53_m20_s0_e0_pABCDCDAB.qsim + its final 1-qubit layer"
+    meta["derivation"] = ("first 14 cycles of circuit_n53_m20_s0_e0_pABCDCDAB.qsim + its final 1-qubit layer" if which == "m14"
+                          else "circuit_n53_m20_s0_e0_pABCDCDAB.qsim as bundled")
     tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
     # The reference computes a sliced bond's dim as its position in tensor_bonds[tid]
     # (simulation.py:62-65), but in the sparse pattern a final-qubit tensor carries a leading
@@ -512,18 +515,18 @@ def case_n53_plan():
             touched += shift != 0
             fixed[bond].append((tid, ind + shift))
     meta["slicing_dims_shifted_for_batch_dim"] = int(touched)
-    save_case(os.path.join(HERE, "n53_m14_sliced.npz"), tensors, sim.scheme, meta, slicing_indices=fixed)
-    print("n53_m14 plan:", len(sim.scheme), "steps,", len(sim.slicing_indices), "sliced bonds, log10 tc/slice",
+    save_case(os.path.join(HERE, f"n53_{which}_sliced.npz"), tensors, sim.scheme, meta, slicing_indices=fixed)
+    print(f"n53_{which} plan:", len(sim.scheme), "steps,", len(sim.slicing_indices), "sliced bonds, log10 tc/slice",
           meta["log10_tc"], "reference loop well defined:", meta["reference_slice_loop_well_defined"])
 
 
-def case_n53_slice0():
+def case_n53_slice0(which="m14"):
     """Reference sparse executor on slice 0 of the n53 plan (CPU, ~half an hour, ~25 GB).
     The slice is applied with the unsliced-index semantics (artensor_amd.apply_slice), which is
     what the reference loop means wherever it is well defined."""
     from artensor_amd.fixtures import load_case
     from artensor_amd.simulation import apply_slice, slice_assignments
-    path = os.path.join(HERE, "n53_m14_sliced.npz")
+    path = os.path.join(HERE, f"n53_{which}_sliced.npz")
     case = load_case(path)
     out = {}
     for s in (0,):
@@ -592,6 +595,8 @@ CASES = {
     "random_bench": case_random_bench,
     "n53_plan": case_n53_plan,
     "n53_slice0": case_n53_slice0,
+    "n53m20_plan": lambda: case_n53_plan("m20"),
+    "n53m20_slice0": lambda: case_n53_slice0("m20"),
     "trees": case_trees,
     "n12_dense": case_n12_dense,
     "n12_sparse5": case_n12_sparse5,

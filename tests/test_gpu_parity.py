@@ -532,3 +532,75 @@ def test_state_vec_n12_and_n30():
     # the state is normalised
     norm2 = sum(float((torch.view_as_real(flat[k::4]) ** 2).sum().item()) for k in range(4))
     assert abs(norm2 - 1.0) < 1e-3
+
+
+def test_n53_m20_slice0():
+    """The bundled Sycamore n53 m20 circuit (BASELINE configs[4] runs it at reduced precision; here
+    complex64): slice 0 of 2^29 against the reference executor's CPU value, plus one more slice
+    with and without the reuse of small intermediates."""
+    case = load_case(os.path.join(GOLDEN, "n53_m20_sliced.npz"))
+    n_b = len(case.slicing_indices)
+    assert n_b == 29 and len(case.scheme) == 454
+    leaves = case.fresh_tensors(device=DEV)
+    runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV)
+    got = runner.run([0]).reshape(-1).cpu().numpy().copy()
+    want = case.arrays["slice0"].reshape(-1)
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    a = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV, slices=[1, 3])
+    b = A.sliced_contraction(leaves, case.scheme, case.slicing_indices, (1,), sparse=True, device=DEV, slices=[1, 3],
+                             reuse_small=False)
+    assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+
+
+def _bf16_round(x):
+    """Round to nearest even onto bfloat16, returned as float32 (complex parts separately)."""
+    def r(f):
+        u = np.ascontiguousarray(f, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+    x = np.asarray(x)
+    return (r(x.real) + 1j * r(x.imag)).astype(np.complex64).reshape(x.shape)
+
+
+def test_bf16_precision_mode(monkeypatch):
+    """precision("bf16"): complex64 in memory, MFMA operands rounded to bfloat16, fp32 accumulation.
+    The reference has no such mode (parity unpinned): single steps and fused pairs are checked
+    against a numpy restatement of exactly that arithmetic, and the n30 amplitudes against the
+    complex64 reference by state fidelity."""
+    from artensor_amd.contraction import contract2
+    monkeypatch.setenv("ARTN_FORCE_BITS", "1")
+    rng = np.random.default_rng(21)
+    for eq, sa, sb in [("abcdefghijklmnop,pcfx->abdeghijklmnox", (2,) * 16, (2, 2, 2, 2)),
+                       ("abcdefghijklmnopq,qhcfaxyz->bdegijklmnopzyx", (2,) * 17, (2,) * 8),
+                       ("zabcdefghijklmn,znkcfxy->zabdeghijlmyx", (3,) + (2,) * 14, (3, 2, 2, 2, 2, 2, 2))]:
+        a, b = crandn(rng, sa), crandn(rng, sb)
+        with A.precision("bf16"):
+            got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
+        want = oracle.einsum_pair(eq, _bf16_round(a).astype(np.complex128), _bf16_round(b).astype(np.complex128))
+        assert rel(got, want) < 2e-6, eq
+        exact = oracle.einsum_pair(eq, a, b)
+        assert 1e-4 < rel(got, exact) < 3e-2   # really reduced precision, and sane
+    eq1, eq2 = "abcdefghijklmnopq,qhcfxyzw->abdegijklmnopwzyx", "abdegijklmnopwzyx,xbkdouv->aegijlmnpwzyuv"
+    a, b1, b2 = crandn(rng, (2,) * 17), crandn(rng, (2,) * 8), crandn(rng, (2,) * 7)
+    with A.precision("bf16"):
+        got = contract2(eq1, gpu(a), gpu(b1), eq2, gpu(b2))
+    assert got is not None
+    mid = oracle.einsum_pair(eq1, _bf16_round(a).astype(np.complex128), _bf16_round(b1).astype(np.complex128))
+    want = oracle.einsum_pair(eq2, _bf16_round(mid.astype(np.complex64)).astype(np.complex128),
+                              _bf16_round(b2).astype(np.complex128))
+    assert rel(got.cpu().numpy(), want) < 5e-5   # (the rounding of the fp32 intermediate can flip on ties)
+    monkeypatch.delenv("ARTN_FORCE_BITS")
+    # whole circuit: fidelity of the bf16 state against the reference amplitudes at Google's bitstrings
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    with A.precision("bf16"):
+        out = A.tensor_contraction(case.fresh_tensors(device=DEV), case.scheme)
+    perm = case.meta["permute_dims"]
+    fpos = np.array([int(b, 2) for b in case.meta["google_bitstrings"]], dtype=np.int64)
+    rpos = np.zeros_like(fpos)
+    for d in range(30):
+        rpos |= ((fpos >> (29 - d)) & 1) << (29 - perm[d])
+    at = out.reshape(-1)[torch.from_numpy(rpos).to(DEV)].cpu().numpy().astype(np.complex128)
+    want = case.arrays["amps_at_google"].astype(np.complex128)
+    fidelity = abs(np.vdot(want, at)) ** 2 / (np.vdot(want, want).real * np.vdot(at, at).real)
+    assert fidelity > 0.99, fidelity
+    assert rel(at, want) > 1e-4   # and it is not the fp32 path
