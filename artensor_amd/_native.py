@@ -71,6 +71,8 @@ _EXPORTS = {
     "artn_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_axpy_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "artn_sum_axis_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_void_p]),
     "artn_absmax_normalize_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                  ctypes.c_void_p]),
 }

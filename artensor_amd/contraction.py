@@ -184,6 +184,33 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None):
     return outer
 
 
+def sum_leading(part, n_rows):
+    """out[c] = sum_r part.reshape(n_rows, -1)[r, c] through artn_sum_axis_c64, as a two-pass tree
+    when there are many rows (the first pass keeps every CU busy, the order of additions is
+    fixed).  `part` must be a contiguous complex64 GPU tensor with an even number of columns."""
+    n_cols = part.numel() // n_rows
+    lib = N.lib()
+    out = torch.empty(n_cols, dtype=part.dtype, device=part.device)
+    with torch.cuda.device(part.device):
+        stream = N.current_stream_ptr(part.device)
+        groups = 1
+        col_tiles = (n_cols // 2 + 63) // 64
+        while groups * col_tiles < 2048 and n_rows % (groups * 2) == 0 and n_rows // (groups * 2) >= 16:
+            groups *= 2
+        if groups > 1:
+            tmp = torch.empty(groups * n_cols, dtype=part.dtype, device=part.device)
+            N.check(lib.artn_sum_axis_c64(part.data_ptr(), tmp.data_ptr(), groups, n_rows // groups, n_cols, stream))
+            N.check(lib.artn_sum_axis_c64(tmp.data_ptr(), out.data_ptr(), 1, groups, n_cols, stream))
+        else:
+            N.check(lib.artn_sum_axis_c64(part.data_ptr(), out.data_ptr(), 1, n_rows, n_cols, stream))
+    return out
+
+
+def _sum_leading_ok(t, n_rows):
+    return (t.dtype == torch.complex64 and t.is_contiguous() and n_rows > 1 and t.numel() % n_rows == 0
+            and (t.numel() // n_rows) % 2 == 0 and t.data_ptr() % 16 == 0)
+
+
 def _split_big_k(la, lb, lo, a, b):
     """More contracted bits than one LDS tile holds (closing steps of the sparse path contract
     15 bonds at once): keep the slowest-varying contracted labels as a temporary batch label,
@@ -196,7 +223,7 @@ def _split_big_k(la, lb, lo, a, b):
         return None
     mid = tuple(outer) + tuple(lo)
     part = contract((la, lb, mid), a, b)
-    return (mid, (), tuple(lo)), part, _one_scalar(a.dtype, a.device)
+    return (mid, (), tuple(lo)), part, _one_scalar(a.dtype, a.device), len(outer)
 
 
 def contract(eq, a, b, out=None):
@@ -208,7 +235,12 @@ def contract(eq, a, b, out=None):
     N.require_gpu(b, "contract")
     split = _split_big_k(la, lb, lo, a, b) if a.is_cuda and b.is_cuda and a.dtype == b.dtype else None
     if split is not None:
-        (la, lb, lo), a, b = split
+        (la, lb, lo), a, b, n_outer = split
+        n_rows = 1
+        for e in a.shape[:n_outer]:
+            n_rows *= e
+        if out is None and _sum_leading_ok(a, n_rows):   # the temporary label leads: a plain column sum
+            return sum_leading(a, n_rows).reshape(a.shape[n_outer:])
     if a.dtype != b.dtype or a.dtype not in _DTYPES:
         raise RuntimeError(f"operands must both be complex64 or complex128, got {a.dtype} and {b.dtype}")
     if a.device != b.device:
@@ -408,7 +440,7 @@ _schedule_cache = {}
 
 class _Op:
     """One launch of a compiled dense scheme: a single step or a fused pair."""
-    __slots__ = ("steps", "i", "j", "j2", "d1", "d2", "out_shape", "info")
+    __slots__ = ("steps", "i", "j", "j2", "d1", "d2", "out_shape", "info", "sum_rows")
 
 
 def _compile_dense(scheme, shapes, dtype):
@@ -423,6 +455,7 @@ def _compile_dense(scheme, shapes, dtype):
         op.steps, op.i, op.j, op.j2, op.d2 = (n,), i, j, None, None
         op.d1, op.out_shape = _descriptor(la, lb, lo, sa, _dense_strides(sa), sb, _dense_strides(sb), dtype)
         op.info = None
+        op.sum_rows = 0
         ops.append(op)
         return op.out_shape
 
@@ -436,6 +469,10 @@ def _compile_dense(scheme, shapes, dtype):
             mid = tuple(outer) + tuple(lo)
             mid_shape = emit(n, i, j, la, lb, mid, shapes[i], shapes[j])
             shapes[i] = emit(n, i, _ONE, mid, (), lo, mid_shape, ())
+            rows = 1
+            for e in mid_shape[:len(outer)]:
+                rows *= e
+            ops[-1].sum_rows = rows   # the temporary label leads `mid`: a column sum (artn_sum_axis_c64)
         else:
             shapes[i] = emit(n, i, j, la, lb, lo, shapes[i], shapes[j])
 
@@ -470,6 +507,7 @@ def _compile_dense(scheme, shapes, dtype):
             continue
         op = _Op()
         op.steps, op.i, op.j, op.j2, op.d1, op.d2, op.out_shape, op.info = (n, m), i, j, j2, d1, d2, out_shape, info
+        op.sum_rows = 0
         shapes[i] = out_shape
         ops.append(op)
     return ops
@@ -525,6 +563,9 @@ def tensor_contraction(tensors, scheme):
         stream = N.current_stream_ptr(device)
         for op in ops:
             a = tensors[op.i]
+            if op.sum_rows and _sum_leading_ok(a, op.sum_rows):
+                tensors[op.i] = sum_leading(a, op.sum_rows).reshape(op.out_shape)
+                continue
             b = _one_scalar(dtype, device) if op.j is _ONE else tensors[op.j]
             out = torch.empty(op.out_shape, dtype=dtype, device=device)
             if profiler is not None:

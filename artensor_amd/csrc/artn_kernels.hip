@@ -311,7 +311,8 @@ __device__ __forceinline__ unsigned swz(unsigned byte_off, const ArtnStage *z) {
 // Per-wave / per-lane constants of one stage, computed once per kernel.
 template <int KB>
 struct StageConst {
-  unsigned lane_in, lane_out, lane_b; // per-lane byte offsets: LDS input tile, LDS output tile, small operand
+  unsigned lane_in, lane_out;         // per-lane byte offsets: LDS input tile, LDS output tile
+  long lane_b;                        // per-lane byte offset into the small operand (only used when fragments are reloaded)
   bool w_valid;
   unsigned kin[KB > 1 ? KB : 2];      // byte offset of K bit b in the LDS input tile
   long kb[KB > 1 ? KB : 2];           // byte stride of K bit b in the small operand
@@ -351,15 +352,15 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
   if (st.nt > 1) L.lane_out += (unsigned)h << (st.n_out_pos[1] + 3);
   const int nloc = j >> 1;
   L.w_valid = (nloc >> L.nt_eff) == 0;
-  L.lane_b = (unsigned)h * (unsigned)st.k_b_stride[hb] * 8u;
+  L.lane_b = (long)h * st.k_b_stride[hb] * 8;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
-    if (b < L.nt_eff && ((nloc >> b) & 1)) L.lane_b += (unsigned)st.n_b_stride[b] * 8u;
+    if (b < L.nt_eff && ((nloc >> b) & 1)) L.lane_b += st.n_b_stride[b] * 8;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     if (b < st.wn_log2 && ((wn >> b) & 1)) {
       L.lane_out += 8u << st.n_out_pos[4 + b];
-      L.lane_b += (unsigned)st.n_b_stride[4 + b] * 8u;
+      L.lane_b += st.n_b_stride[4 + b] * 8;
     }
   }
 #pragma unroll
@@ -1257,6 +1258,41 @@ static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, 
   return hipErrorInvalidValue;
 }
 
+// out[g][c] = sum_r in[g][r][c] over float4 columns (two complex64 each): the sum-out that closes a
+// split-K contraction.  256 threads = 64 columns x 4 row lanes; the lanes' partial sums are added in
+// a fixed order, so results do not depend on the launch shape.
+__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_sum_axis4(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                                   long n_rows, long n_cols4, long col_tiles) {
+  __shared__ float4 part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long g = blockIdx.x / col_tiles, ct = blockIdx.x % col_tiles;
+  const long c = ct * 64 + tx;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < n_cols4) {
+    const float4 *p = in + (g * n_rows) * n_cols4 + c;
+    long r = ty;
+    for (; r + 12 < n_rows; r += 16) { // four independent loads in flight per thread
+      const float4 v0 = p[r * n_cols4], v1 = p[(r + 4) * n_cols4], v2 = p[(r + 8) * n_cols4], v3 = p[(r + 12) * n_cols4];
+      acc.x += (v0.x + v1.x) + (v2.x + v3.x);
+      acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+      acc.z += (v0.z + v1.z) + (v2.z + v3.z);
+      acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; r < n_rows; r += 4) {
+      const float4 v = p[r * n_cols4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < n_cols4) {
+    float4 t = part[0][tx];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) { t.x += part[q][tx].x; t.y += part[q][tx].y; t.z += part[q][tx].z; t.w += part[q][tx].w; }
+    out[g * n_cols4 + c] = t;
+  }
+}
+
 extern "C" {
 
 int artn_abi_version(void) { return ARTN_ABI_VERSION; }
@@ -1389,6 +1425,21 @@ int artn_axpy_c64(void *acc, const void *x, int64_t n, void *stream) {
     const int grid = (int)std::min<long>((n1 + ARTN_WG_THREADS - 1) / ARTN_WG_THREADS, 256L * 8);
     hipLaunchKernelGGL(artn_k_axpy1, dim3(grid), dim3(ARTN_WG_THREADS), 0, st, (float *)acc, (const float *)x, n1);
   }
+  HIP_TRY(hipGetLastError());
+  return ARTN_OK;
+}
+
+int artn_sum_axis_c64(const void *in, void *out, int64_t n_groups, int64_t n_rows, int64_t n_cols, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (n_groups < 0 || n_rows < 1 || n_cols < 0) return fail(ARTN_E_INVALID, "bad extent");
+  if (n_groups == 0 || n_cols == 0) return ARTN_OK;
+  if (!in || !out) return fail(ARTN_E_INVALID, "null pointer");
+  if ((n_cols & 1) || ((((uintptr_t)in | (uintptr_t)out) & 15) != 0))
+    return fail(ARTN_E_UNSUPPORTED, "artn_sum_axis_c64 needs an even column count and 16-byte aligned buffers");
+  const long n4 = n_cols / 2, col_tiles = (n4 + 63) / 64;
+  if (n_groups * col_tiles > (1L << 30)) return fail(ARTN_E_UNSUPPORTED, "too many workgroups");
+  hipLaunchKernelGGL(artn_k_sum_axis4, dim3((unsigned)(n_groups * col_tiles)), dim3(ARTN_WG_THREADS), 0, (hipStream_t)stream,
+                     (const float4 *)in, (float4 *)out, (long)n_rows, n4, col_tiles);
   HIP_TRY(hipGetLastError());
   return ARTN_OK;
 }

@@ -554,14 +554,9 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     int64_t si = 0, so = 0;
     for (int i = 1; i <= 8; ++i) { si += b.in_stride[i]; if (i < b.T_out) so += b.out_stride[i]; }
     const int64_t lim = (int64_t(1) << 28) - 1; // elements: * 8 B < 2^31
-    bool wide = si > lim || so > lim;
-    for (int s = 0; s < b.n_stages; ++s) {
-      int64_t sb = 0;
-      for (int i = 0; i < b.st[s].nt; ++i) sb += b.st[s].n_b_stride[i];
-      for (int i = 0; i < b.st[s].k; ++i) sb += b.st[s].k_b_stride[i];
-      wide = wide || sb > lim;
-    }
-    if (wide) { p.why_generic = "lane offsets exceed 32 bits"; return false; }
+    // (the small operands are addressed with 64-bit offsets: a "small" operand of a split-K
+    // step can itself be gigabytes)
+    if (si > lim || so > lim) { p.why_generic = "lane offsets exceed 32 bits"; return false; }
   }
   if (b.n_tiles < min_tiles) { p.why_generic = "too few tiles to fill the chip"; return false; }
 

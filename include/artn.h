@@ -129,6 +129,13 @@ int artn_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t nro
  * `collect_tensor += ...` of artensor/simulation.py:114 and :210. */
 int artn_axpy_c64(void *acc, const void *x, int64_t n, void *stream);
 
+/* out[g][c] = sum_r in[g][r][c] for complex64 arrays in[n_groups][n_rows][n_cols] (n_cols even,
+ * 16-byte aligned): sums out the leading label(s) of a dense tensor.  Closes a contraction whose
+ * contracted labels exceed one LDS tile: `torch.einsum` at artensor/contraction.py:70 contracts any
+ * number of labels in one call; here the slowest ones become a batch label of artn_contract and are
+ * summed afterwards.  Applied twice (n_rows = R * n_rows') it is a two-pass tree sum. */
+int artn_sum_axis_c64(const void *in, void *out, int64_t n_groups, int64_t n_rows, int64_t n_cols, void *stream);
+
 /* out[0] = max_i |x[i]| over n complex64 elements (float32, device pointer), then
  * x[i] /= out[0]: the running renormalisation of artensor/contraction.py:197-200
  * (`norm_factor = tensors[i].abs().max(); tensors[i] /= norm_factor`). */

@@ -289,6 +289,11 @@ def test_gather_axpy_normalize():
     # out-of-range rows are zero-filled and flagged, never read
     A.contraction.gather_rows(gpu(crandn(rng, (4, 2))), torch.tensor([0, 9]))
     assert int(A.contraction.gather_rows.last_flag.item()) == 1
+    for rows, cols in [(2, 2), (5, 6), (64, 1024), (4096, 130), (131072, 16), (37, 4098)]:
+        t = crandn(rng, (rows, cols))
+        got = A.contraction.sum_leading(gpu(t), rows).cpu().numpy()
+        want = t.astype(np.complex128).sum(axis=0)
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(t).max() * np.sqrt(rows) + 1e-30, (rows, cols)
     for n in (1, 7, 4096, 100003):
         x, y = crandn(rng, (n,)), crandn(rng, (n,))
         acc = gpu(x)
