@@ -434,17 +434,21 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) { // RNE, a in t
   v2f_t v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
-// (a, b) -> NP packed pieces; piece p+1 splits what piece p left over (exact subtraction)
+// (a, b) -> NP packed pieces; piece p+1 splits what piece p left over (exact subtraction).
+// The first piece is rounded to nearest even, so what it leaves has no preferred sign and the
+// dropped piece products do not add up to a bias; the later pieces are cut off (their top 16
+// bits: one v_perm_b32 per pair), which is exact for the last one -- what the first two pieces
+// leave of an fp32 number has at most 8 significant bits.
 template <int NP>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&piece)[NP]) {
+  unsigned d = pack_bf16(a, b);
+  piece[0] = d;
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const unsigned d = pack_bf16(a, b);
+  for (int p = 1; p < NP; ++p) {
+    a -= __builtin_bit_cast(float, p == 1 ? d << 16 : __builtin_bit_cast(unsigned, a) & 0xffff0000u);
+    b -= __builtin_bit_cast(float, p == 1 ? d & 0xffff0000u : __builtin_bit_cast(unsigned, b) & 0xffff0000u);
+    d = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
     piece[p] = d;
-    if (p + 1 < NP) {
-      a -= __builtin_bit_cast(float, d << 16);
-      b -= __builtin_bit_cast(float, d & 0xffff0000u);
-    }
   }
 }
 // Small-operand fragments for the split chain: WS[p][g] = 8 bf16 of piece p for the lane's row
