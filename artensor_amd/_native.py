@@ -64,6 +64,9 @@ _EXPORTS = {
     "artn_last_plan_note": (ctypes.c_char_p, []),
     "artn_contract": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p]),
+    "artn_contract_gather": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                            ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_contract2_query": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepDesc),
                                             ctypes.POINTER(ArtnStepInfo)]),
     "artn_contract2": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p,
@@ -99,6 +102,8 @@ def lib():
         # is the HIP runtime this library binds to -- one runtime per process.
         handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         for name, (res, args) in _EXPORTS.items():
+            if os.environ.get("ARTN_LIB") and not hasattr(handle, name):
+                continue  # diagnostic builds of older revisions (tools/libartn_prev.so) may lack newer entry points
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args

@@ -629,6 +629,59 @@ def _is_identity(idx, rows):
     return hit[1] == rows
 
 
+def contract_gathered(eq, a, rows_a, b, rows_b, out=None):
+    """einsum(eq, a[rows_a], b[rows_b]) without materialising the gathered operands
+    (artn_contract_gather): the first label of every operand that has row indices must be the
+    first label of the result (the shared batch label of the sparse executor, reference
+    contraction.py:149-156, :177-179).  rows_* are the reference's int64 index tensors or None.
+    Returns None when the step does not fit the tiled kernel (the caller gathers instead)."""
+    la, lb, lo = _parse(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
+    if a.dtype != torch.complex64 or b.dtype != torch.complex64 or not lo:
+        return None
+    lab = lo[0]
+    if (rows_a is not None and (not la or la[0] != lab)) or (rows_b is not None and (not lb or lb[0] != lab)):
+        return None
+    n = len(rows_a) if rows_a is not None else len(rows_b)
+    if rows_a is not None and rows_b is not None and len(rows_b) != n:
+        raise RuntimeError("row index lists of the two operands differ in length")
+    a, b = _as_operand(a), _as_operand(b)
+    a_shape = ((n,) + tuple(a.shape[1:])) if rows_a is not None else tuple(a.shape)
+    b_shape = ((n,) + tuple(b.shape[1:])) if rows_b is not None else tuple(b.shape)
+    d, out_shape = _descriptor(la, lb, lo, a_shape, tuple(a.stride()), b_shape, tuple(b.stride()), a.dtype)
+    labels = list(la) + [x for x in lb if x not in la]
+    if out is None:
+        out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
+    elif tuple(out.shape) != out_shape or not out.is_contiguous():
+        raise RuntimeError("out= must be a contiguous tensor of the result shape")
+    if out.numel() == 0:
+        return out
+    ia = _device_index(rows_a, a.device) if rows_a is not None else None
+    ib = _device_index(rows_b, b.device) if rows_b is not None else None
+    flag = _flag_cache.get(a.device)
+    if flag is None:
+        flag = _flag_cache[a.device] = torch.zeros(1, dtype=torch.int32, device=a.device)
+    with torch.cuda.device(a.device):
+        e0 = e1 = None
+        if profiler is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = N.lib().artn_contract_gather(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(), labels.index(lab),
+                                          ia.data_ptr() if ia is not None else None, a.shape[0],
+                                          ib.data_ptr() if ib is not None else None, b.shape[0],
+                                          flag.data_ptr(), N.current_stream_ptr(a.device))
+        if rc == -2:
+            return None
+        N.check(rc)
+        if profiler is not None:
+            e1.record()
+            info = _info_cache.get(id(d))
+            if info is None:
+                info = _info_cache[id(d)] = _query(d)
+            profiler.record(info, e0, e1)
+    gather_rows.last_flag = flag
+    return out
+
+
 def gather_rows(t, idx):
     """t[idx] along dim 0 through artn_gather_rows (reference contraction.py:149-150 etc.).
     An index that selects every row in order returns `t` itself (the reference copies)."""
@@ -696,21 +749,30 @@ def _sparse_step(tensors, step):
         first = None
         r0 = 0
         for k in range(len(batch_i)):
-            gi, gj = gather_rows(src_i, batch_i[k]), gather_rows(src_j, batch_j[k])
             if first is None:
-                ext = dict(zip(la, gi.shape))
-                ext.update(zip(lb, gj.shape))
-                first = torch.empty((sum(rows),) + tuple(ext[x] for x in lo[1:]), dtype=gi.dtype, device=gi.device)
-            contract(eq, gi, gj, out=first[r0:r0 + rows[k]])
+                ext = dict(zip(la, (rows[k],) + tuple(src_i.shape[1:])))
+                ext.update(zip(lb, (rows[k],) + tuple(src_j.shape[1:])))
+                first = torch.empty((sum(rows),) + tuple(ext[x] for x in lo[1:]), dtype=src_i.dtype, device=src_i.device)
+            dst = first[r0:r0 + rows[k]]
+            # rows gathered inside the contraction kernel; two gathers + contraction otherwise
+            if contract_gathered(eq, src_i, batch_i[k], src_j, batch_j[k], out=dst) is None:
+                contract(eq, gather_rows(src_i, batch_i[k]), gather_rows(src_j, batch_j[k]), out=dst)
             r0 += rows[k]
         if step[3]:
             first = first.reshape((-1,) + tuple(step[3][1:]))
         tensors[j] = []
         tensors[i] = first
     elif len(step) > 3 and len(batch_i) == len(batch_j) == 1:
-        tensors[i] = gather_rows(tensors[i], batch_i[0])
-        tensors[j] = gather_rows(tensors[j], batch_j[0])
-        tensors[i] = contract(eq, tensors[i], tensors[j])
+        fused = None
+        if isinstance(tensors[i], torch.Tensor) and tensors[i].numel() >= (1 << 20):
+            fused = contract_gathered(eq, tensors[i], batch_i[0], tensors[j], batch_j[0])
+        if fused is None:
+            tensors[i] = gather_rows(tensors[i], batch_i[0])
+            tensors[j] = gather_rows(tensors[j], batch_j[0])
+            fused = contract(eq, tensors[i], tensors[j])
+        # (the reference leaves the gathered operand in tensors[j]; here it keeps its rows when the
+        #  gather ran inside the kernel -- tensors[j] is consumed by this step either way)
+        tensors[i] = fused
     elif len(step) > 3:
         tensors[i] = contract(eq, tensors[i], tensors[j]).reshape(step[3])
         if len(batch_i) == 1:

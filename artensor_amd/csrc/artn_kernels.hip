@@ -205,6 +205,7 @@ __device__ __forceinline__ long uniform64(long x) {
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x >> 32));
   return (long)(((unsigned long)hi << 32) | lo);
 }
+template <bool GATHER = false>
 __device__ __forceinline__ TileOff tile_offsets(const ArtnBitsPlan &P, const OffTab &T, long tile) {
   long a = 0, b1 = 0, b2 = 0, c = 0;
 #pragma unroll
@@ -221,8 +222,21 @@ __device__ __forceinline__ TileOff tile_offsets(const ArtnBitsPlan &P, const Off
       const long ext = P.outer[d].ext;
       const long x = r % ext;
       r /= ext;
-      t.a += x * P.outer[d].sA;
-      t.b1 += x * P.outer[d].sB1;
+      long xa = x, xb = x;
+      if constexpr (GATHER) { // fused row gather: the operands are read at rows_a[x] / rows_b[x]
+        if (d == P.gather_dim) {
+          if (P.rows_a) {
+            xa = P.rows_a[x];
+            if (xa < 0 || xa >= P.src_rows_a) { xa = 0; if (P.gather_err) *P.gather_err = 1; }
+          }
+          if (P.rows_b) {
+            xb = P.rows_b[x];
+            if (xb < 0 || xb >= P.src_rows_b) { xb = 0; if (P.gather_err) *P.gather_err = 1; }
+          }
+        }
+      }
+      t.a += xa * P.outer[d].sA;
+      t.b1 += xb * P.outer[d].sB1;
       t.b2 += x * P.outer[d].sB2;
       t.c += x * P.outer[d].sC;
     }
@@ -231,9 +245,10 @@ __device__ __forceinline__ TileOff tile_offsets(const ArtnBitsPlan &P, const Off
 }
 
 // offsets(tile + G) from offsets(tile): one 32-byte LDS lookup when the grid is a power of two
+template <bool GATHER = false>
 __device__ __forceinline__ TileOff next_offsets(const ArtnBitsPlan &P, const OffTab &T, const TileOff &cur, long tile,
                                                 long G) {
-  if (T.g_log2 < 0) return tile_offsets(P, T, tile + G);
+  if (T.g_log2 < 0) return tile_offsets<GATHER>(P, T, tile + G);
   const unsigned hi = (unsigned)(tile >> T.g_log2);
   const int c = __builtin_ctz(~hi);
   const long *e = T.delta + c * 4;
@@ -825,7 +840,8 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1
 
 // KB2 == 0: single stage.  BIGK: 7 or 8 contracted bits (KB1 = 6 of them in the chain).
 // NP: 0 = fp32 MFMA chains; 3 / 1 = split-bf16 chains (stages with >= 3 contracted bits).
-template <int KB1, int KB2, bool BIGK, int NP = 0>
+// GATHER: row indices on one outer axis (artn_contract_gather; single stage, fp32 chains).
+template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(const float2 *__restrict__ A,
                                                                   const float2 *__restrict__ B1,
                                                                   const float2 *__restrict__ B2,
@@ -915,10 +931,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     n_tiles = t0 + per < P.n_tiles ? t0 + per : P.n_tiles;
   }
   if (t0 < n_tiles) {
-    off = tile_offsets(P, OT, t0);
+    off = tile_offsets<GATHER>(P, OT, t0);
     copy_in_sync(reinterpret_cast<const char *>(A + off.a), in_hi, in_lane, R0, tid16, n_in_iters);
     if (t0 + G < n_tiles) {
-      noff = tile_offsets(P, OT, t0 + G);
+      noff = tile_offsets<GATHER>(P, OT, t0 + G);
       if (prefetch) issue_loads(v, reinterpret_cast<const char *>(A + noff.a), in_hi, in_lane);
     }
   }
@@ -966,7 +982,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     }
     const long next = tile + G, next2 = tile + 2 * G;
     TileOff n2off = noff;
-    if (next2 < n_tiles) n2off = next_offsets(P, OT, noff, next, G);
+    if (next2 < n_tiles) n2off = next_offsets<GATHER>(P, OT, noff, next, G);
     STAMP(0); // W reload, offsets of the tile after next
     PHASE_MARK(0);
 
@@ -1226,6 +1242,19 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
     ARTN_LAUNCH_NP(K2, 0)                                                                                 \
     break;                                                                                                \
   }
+  if (p.bits.gather_dim >= 0) { // fused row gather: single stage, fp32 chains
+    if (k2 != 0) return hipErrorInvalidValue;
+    if (KB1 == 6 && p.bits.st[0].k > 6) {
+      auto kern = artn_k_bits<(KB1 == 6 ? 6 : 1), 0, true, 0, true>;
+      if (hipError_t e = ensure_lds<artn_k_bits<(KB1 == 6 ? 6 : 1), 0, true, 0, true>>(lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
+    } else {
+      auto kern = artn_k_bits<KB1, 0, false, 0, true>;
+      if (hipError_t e = ensure_lds<artn_k_bits<KB1, 0, false, 0, true>>(lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
+    }
+    return hipGetLastError();
+  }
   if (KB1 == 6 && k2 == 0 && p.bits.st[0].k > 6) {
     auto kern = artn_k_bits<(KB1 == 6 ? 6 : 1), 0, true>;
     if (hipError_t e = ensure_lds<artn_k_bits<(KB1 == 6 ? 6 : 1), 0, true>>(lds); e != hipSuccess) return e;
@@ -1346,6 +1375,28 @@ int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, 
     hipLaunchKernelGGL((artn_k_generic<double2, double>), grid, block, 0, st, (const double2 *)A,
                        (const double2 *)B, (double2 *)C, p.gen);
   HIP_TRY(hipGetLastError());
+  return ARTN_OK;
+}
+
+int artn_contract_gather(const ArtnStepDesc *d, const void *A, const void *B, void *C, int label,
+                         const int64_t *rows_a, int64_t src_rows_a, const int64_t *rows_b, int64_t src_rows_b,
+                         int32_t *err_flag, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (!d || !A || !B || !C) return fail(ARTN_E_INVALID, "null pointer");
+  if (label < 0 || label >= d->n_labels) return fail(ARTN_E_INVALID, "gather label out of range");
+  if (d->stride_c[label] < 0) return fail(ARTN_E_INVALID, "the gathered label must be an output label");
+  if ((rows_a && (d->stride_a[label] < 0 || src_rows_a < 1)) || (rows_b && (d->stride_b[label] < 0 || src_rows_b < 1)))
+    return fail(ARTN_E_INVALID, "row indices for an operand that does not carry the label");
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::make_plan(d, p, err, g_ncu, true, 1, label);
+  if (rc) return fail(rc, err);
+  p.bits.rows_a = rows_a;
+  p.bits.rows_b = rows_b;
+  p.bits.src_rows_a = src_rows_a;
+  p.bits.src_rows_b = src_rows_b;
+  p.bits.gather_err = err_flag;
+  HIP_TRY(launch_bits(p, A, B, nullptr, C, (hipStream_t)stream));
   return ARTN_OK;
 }
 

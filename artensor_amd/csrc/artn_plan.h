@@ -78,6 +78,15 @@ struct ArtnBitsPlan {
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
   ArtnStage st[2];
   ArtnOuterDim outer[ARTN_MAX_OUTER];
+  // fused row gather (artn_contract_gather, read by the GATHER instantiations only): along outer axis
+  // `gather_dim` operand A is read at row rows_a[x] and the small operand at rows_b[x] instead of x
+  // (device pointers, nullptr = x); indices outside [0, src_rows) read row 0 and set *gather_err
+  int32_t gather_dim; // -1: none
+  int32_t pad2_;
+  const int64_t *rows_a;
+  const int64_t *rows_b;
+  int64_t src_rows_a, src_rows_b;
+  int32_t *gather_err;
 };
 
 // Plan of the strided fallback (one thread per C element).
@@ -211,6 +220,7 @@ struct Axis {
   int64_t ext;
   int64_t sA, sB1, sC1, sB2, sC;
   bool bit;
+  bool gathered = false; // the label whose rows are gathered: always one whole outer axis
   bool k1() const { return sA >= 0 && sB1 >= 0 && sC1 < 0; }
   bool m1() const { return sA >= 0 && sB1 < 0 && sC1 >= 0; }
   bool n1() const { return sA < 0 && sB1 >= 0 && sC1 >= 0; }
@@ -219,11 +229,11 @@ struct Axis {
   bool n2() const { return sC1 < 0 && sB2 >= 0 && sC >= 0; } // produced by stage 2
 };
 
-static inline void expand_axes(const ArtnStepDesc *d, std::vector<Axis> &ax) {
+static inline void expand_axes(const ArtnStepDesc *d, std::vector<Axis> &ax, int gather_label = -1) {
   for (int l = 0; l < d->n_labels; ++l) {
     int64_t e = d->extent[l];
-    if (e == 1) continue;
-    int lg = ilog2_exact(e);
+    if (e == 1 && l != gather_label) continue;
+    int lg = l == gather_label ? -1 : ilog2_exact(e);
     int parts = lg > 0 ? lg : 1;
     for (int jb = 0; jb < parts; ++jb) {
       Axis a;
@@ -235,6 +245,7 @@ static inline void expand_axes(const ArtnStepDesc *d, std::vector<Axis> &ax) {
       a.sC1 = d->stride_c[l] >= 0 ? d->stride_c[l] << sh : -1;
       a.sB2 = -1;
       a.sC = a.sC1;
+      a.gathered = l == gather_label;
       ax.push_back(a);
     }
   }
@@ -274,12 +285,13 @@ static inline bool chain_axes(const ArtnStepDesc *d2, std::vector<Axis> &ax, std
 }
 
 static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, ArtnPlan &p, int n_cu,
-                             int64_t min_tiles) {
+                             int64_t min_tiles, int gather_label = -1) {
   auto c64 = [](int dt) { return dt == ARTN_C64 || dt == ARTN_C64_BF16; };
   if (!c64(d1->dtype) || (d2 && d2->dtype != d1->dtype)) { p.why_generic = "dtype is not complex64"; return false; }
   const bool fused = d2 != nullptr;
   std::vector<Axis> ax;
-  expand_axes(d1, ax);
+  expand_axes(d1, ax, gather_label);
+  if (fused && gather_label >= 0) { p.why_generic = "row gather in a fused pair"; return false; }
   if (fused && !chain_axes(d2, ax, p.why_generic)) return false;
 
   // ---- classify
@@ -505,6 +517,11 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   });
   outer.insert(outer.end(), O.begin(), O.end());
   b.n_tiles = 1;
+  b.gather_dim = -1;
+  b.pad2_ = 0;
+  b.rows_a = b.rows_b = nullptr;
+  b.src_rows_a = b.src_rows_b = 0;
+  b.gather_err = nullptr;
   int64_t a_rereads = 1;
   for (int i : outer) {
     const Axis &a = ax[i];
@@ -514,7 +531,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     od.sB1 = a.sB1 >= 0 ? a.sB1 : 0;
     od.sB2 = a.sB2 >= 0 ? a.sB2 : 0;
     od.sC = a.sC >= 0 ? a.sC : 0;
-    od.log2ext = ilog2_exact(a.ext);
+    od.log2ext = a.gathered ? -1 : ilog2_exact(a.ext); // the gathered axis is decoded the slow way, on its own
     od.pad_ = 0;
     b.n_tiles *= a.ext;
     if (a.sA < 0) a_rereads *= a.ext;
@@ -529,6 +546,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
       }
     }
     if (b.n_outer >= ARTN_MAX_OUTER) { p.why_generic = "too many outer axes"; return false; }
+    if (a.gathered) b.gather_dim = b.n_outer;
     b.outer[b.n_outer++] = od;
   }
 
@@ -536,6 +554,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   // operand a function of the tile.  Grid-stride order then changes it at every tile of a
   // workgroup (a reload of up to 256 fragment registers per lane from global memory); in
   // contiguous ranges the batch axes, which are the slowest tile digits, change once per row.
+  if (gather_label >= 0 && b.gather_dim < 0) { p.why_generic = "gathered label is not an outer axis"; return false; }
   b.blocked = 0;
   for (int i = 0; i < b.n_outer; ++i)
     if ((b.outer[i].sA != 0 && b.outer[i].sB1 != 0) || (b.outer[i].sB2 != 0 && b.outer[i].sC != 0 && b.outer[i].sA != 0))
@@ -605,11 +624,12 @@ static inline void step_cost(const ArtnStepDesc *d, double &flops, double &na, d
 // min_tiles: below this many LDS tiles the strided kernel is used instead (a handful of
 // workgroups cannot fill 256 CUs; such steps are launch-latency bound either way).
 static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err, int n_cu = 256,
-                            bool allow_bits = true, int64_t min_tiles = 32) {
+                            bool allow_bits = true, int64_t min_tiles = 32, int gather_label = -1) {
   int rc = validate(d, err);
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
-  bool ok = allow_bits && make_bits(d, nullptr, p, n_cu, min_tiles);
+  bool ok = allow_bits && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
+  if (!ok && gather_label >= 0) { err = "row gather needs the tiled kernel: " + p.why_generic; return ARTN_E_UNSUPPORTED; }
   if (!ok && !make_generic(d, p, err)) return ARTN_E_UNSUPPORTED;
   double na, nb, nc;
   step_cost(d, p.info.flops, na, nb, nc);

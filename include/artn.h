@@ -102,6 +102,20 @@ const char *artn_last_plan_note(void);
 int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *stream);
 
 /*
+ * artn_contract with a fused row gather: along `label` (an output label; the batch label of the
+ * sparse executor) operand A is read at row rows_a[r] and operand B at row rows_b[r] for output row
+ * r (device pointers to int64; NULL = r itself); extent[label] is the number of output rows and
+ * stride_a/b[label] the row strides of the SOURCE tensors, which have src_rows_a/b rows.
+ * Replaces `tensors[i][batch_i[k]]`, `tensors[j][batch_j[k]]` followed by the batched einsum of
+ * artensor/contraction.py:149-156 and :177-179 without materialising the gathered operands.
+ * Out-of-range indices read row 0 and set *err_flag (if non-NULL).  Returns ARTN_E_UNSUPPORTED
+ * when the step does not fit the tiled kernel; callers then gather with artn_gather_rows.
+ */
+int artn_contract_gather(const ArtnStepDesc *d, const void *A, const void *B, void *C, int label,
+                         const int64_t *rows_a, int64_t src_rows_a, const int64_t *rows_b, int64_t src_rows_b,
+                         int32_t *err_flag, void *stream);
+
+/*
  * Two consecutive steps on the same big operand in ONE pass over HBM:
  *     C1 = contract(d1; A, B1);  C = contract(d2; C1, B2)
  * i.e. two successive iterations of the loop at artensor/contraction.py:66-70 whose first

@@ -86,7 +86,12 @@ static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf 
       int64_t ext = P.outer[d].ext, x;
       if (P.outer[d].log2ext >= 0) { x = r & (ext - 1); r >>= P.outer[d].log2ext; }
       else { x = r % ext; r /= ext; }
-      offA += x * P.outer[d].sA; offB1 += x * P.outer[d].sB1; offB2 += x * P.outer[d].sB2; offC += x * P.outer[d].sC;
+      int64_t xa = x, xb = x;
+      if (d == P.gather_dim) { // fused row gather (host pointers here)
+        if (P.rows_a) { xa = P.rows_a[x]; if (xa < 0 || xa >= P.src_rows_a) { xa = 0; if (P.gather_err) *P.gather_err = 1; } }
+        if (P.rows_b) { xb = P.rows_b[x]; if (xb < 0 || xb >= P.src_rows_b) { xb = 0; if (P.gather_err) *P.gather_err = 1; } }
+      }
+      offA += xa * P.outer[d].sA; offB1 += xb * P.outer[d].sB1; offB2 += x * P.outer[d].sB2; offC += x * P.outer[d].sC;
     }
     for (int tid = 0; tid < 256; ++tid) {
       int64_t in_lane = 0;
@@ -146,6 +151,21 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
   if (d->dtype != ARTN_C64) return ARTN_E_UNSUPPORTED;
   if (p.kernel == ARTN_KERNEL_BITS_MFMA) run_bits(p.bits, (const cf *)A, (const cf *)B, nullptr, (cf *)C);
   else run_generic(p.gen, (const cf *)A, (const cf *)B, (cf *)C);
+  return 0;
+}
+
+// artn_contract_gather: row indices are host arrays here.
+extern "C" int artn_emulate_gather(const ArtnStepDesc *d, const void *A, const void *B, void *C, int label,
+                                   const int64_t *rows_a, int64_t src_rows_a, const int64_t *rows_b,
+                                   int64_t src_rows_b, int32_t *err_flag) {
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::make_plan(d, p, err, 256, true, 1, label);
+  if (rc) return rc;
+  p.bits.rows_a = rows_a; p.bits.rows_b = rows_b;
+  p.bits.src_rows_a = src_rows_a; p.bits.src_rows_b = src_rows_b;
+  p.bits.gather_err = err_flag;
+  run_bits(p.bits, (const cf *)A, (const cf *)B, nullptr, (cf *)C);
   return 0;
 }
 

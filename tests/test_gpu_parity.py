@@ -274,6 +274,38 @@ def test_batch_generic_dims_and_edge_cases():
         A.contract("ab,bc->ac", gpu(a[0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]), gpu(crandn(rng, (3, 2))))
 
 
+def test_contract_gathered():
+    """artn_contract_gather against gather + einsum in numpy; ragged row counts; an out-of-range
+    index is flagged; a step the tiled kernel cannot take reports None."""
+    from artensor_amd.contraction import contract_gathered
+    rng = np.random.default_rng(23)
+    for (na, nb, n, free, kb, nn) in [(7, 5, 6, 12, 3, 2), (16, 16, 9, 13, 4, 3), (3, 9, 619, 10, 8, 3), (40, 1, 33, 11, 5, 5)]:
+        la = ["z"] + [chr(65 + x) for x in range(free + kb)]
+        kl = la[1:1 + kb]
+        nl = [chr(97 + x) for x in range(nn)]
+        lb = ["z"] + kl[::-1] + nl
+        lo = ["z"] + [x for x in la[1:] if x not in kl] + nl
+        eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
+        a = crandn(rng, (na,) + (2,) * (len(la) - 1))
+        b = crandn(rng, (nb,) + (2,) * (len(lb) - 1))
+        ra, rb = torch.from_numpy(rng.integers(0, na, size=n)), torch.from_numpy(rng.integers(0, nb, size=n))
+        got = contract_gathered(eq, gpu(a), ra, gpu(b), rb)
+        assert got is not None, eq
+        want = oracle.einsum_pair(eq, a[ra.numpy()], b[rb.numpy()])
+        assert rel(got.cpu().numpy(), want) < STEP_TOL, eq
+        # one operand gathered only
+        got = contract_gathered(eq, gpu(a), ra, gpu(b[rb.numpy()]), None)
+        assert got is not None and rel(got.cpu().numpy(), want) < STEP_TOL
+    A.contraction.gather_rows.last_flag.zero_()
+    bad = torch.tensor([0, 99, 1, 2, 3, 4])
+    contract_gathered("zABCDEFGHIJKL,zLKa->zABCDEFGHIJa", gpu(crandn(rng, (7,) + (2,) * 12)), bad,
+                      gpu(crandn(rng, (6, 2, 2, 2))), None)
+    assert int(A.contraction.gather_rows.last_flag.item()) == 1
+    A.contraction.gather_rows.last_flag.zero_()
+    assert contract_gathered("zab,zbc->zac", gpu(crandn(rng, (4, 2, 2))), torch.tensor([0, 1]),
+                             gpu(crandn(rng, (4, 2, 2))), torch.tensor([1, 1])) is None
+
+
 def test_gather_axpy_normalize():
     rng = np.random.default_rng(9)
     for shape in [(37, 2, 2, 2), (5, 3), (16, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2)]:
