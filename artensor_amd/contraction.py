@@ -184,13 +184,15 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None):
     return outer
 
 
-def sum_leading(part, n_rows):
+def sum_leading(part, n_rows, out=None):
     """out[c] = sum_r part.reshape(n_rows, -1)[r, c] through artn_sum_axis_c64, as a two-pass tree
     when there are many rows (the first pass keeps every CU busy, the order of additions is
     fixed).  `part` must be a contiguous complex64 GPU tensor with an even number of columns."""
     n_cols = part.numel() // n_rows
     lib = N.lib()
-    out = torch.empty(n_cols, dtype=part.dtype, device=part.device)
+    dst = out
+    if out is None or not out.is_contiguous() or out.data_ptr() % 16 or out.numel() != n_cols:
+        out = torch.empty(n_cols, dtype=part.dtype, device=part.device)
     with torch.cuda.device(part.device):
         stream = N.current_stream_ptr(part.device)
         groups = 1
@@ -203,6 +205,9 @@ def sum_leading(part, n_rows):
             N.check(lib.artn_sum_axis_c64(tmp.data_ptr(), out.data_ptr(), 1, groups, n_cols, stream))
         else:
             N.check(lib.artn_sum_axis_c64(part.data_ptr(), out.data_ptr(), 1, n_rows, n_cols, stream))
+    if dst is not None and dst is not out:
+        dst.copy_(out.reshape(dst.shape))
+        return dst
     return out
 
 
@@ -629,7 +634,7 @@ def _is_identity(idx, rows):
     return hit[1] == rows
 
 
-def contract_gathered(eq, a, rows_a, b, rows_b, out=None):
+def contract_gathered(eq, a, rows_a, b, rows_b, out=None, label=None):
     """einsum(eq, a[rows_a], b[rows_b]) without materialising the gathered operands
     (artn_contract_gather): the first label of every operand that has row indices must be the
     first label of the result (the shared batch label of the sparse executor, reference
@@ -638,7 +643,7 @@ def contract_gathered(eq, a, rows_a, b, rows_b, out=None):
     la, lb, lo = _parse(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
     if a.dtype != torch.complex64 or b.dtype != torch.complex64 or not lo:
         return None
-    lab = lo[0]
+    lab = lo[0] if label is None else label
     if (rows_a is not None and (not la or la[0] != lab)) or (rows_b is not None and (not lb or lb[0] != lab)):
         return None
     n = len(rows_a) if rows_a is not None else len(rows_b)
@@ -647,6 +652,22 @@ def contract_gathered(eq, a, rows_a, b, rows_b, out=None):
     a, b = _as_operand(a), _as_operand(b)
     a_shape = ((n,) + tuple(a.shape[1:])) if rows_a is not None else tuple(a.shape)
     b_shape = ((n,) + tuple(b.shape[1:])) if rows_b is not None else tuple(b.shape)
+    outer = _big_k_outer(la, lb, lo, a_shape, tuple(a.stride())) if label is None else None
+    if outer:  # more contracted bits than a tile holds: split-K around the gathered contraction
+        part = contract_gathered((la, lb, tuple(outer) + tuple(lo)), a, rows_a, b, rows_b, label=lab)
+        if part is None:
+            return None
+        n_rows = 1
+        for e in part.shape[:len(outer)]:
+            n_rows *= e
+        if not _sum_leading_ok(part, n_rows):
+            return None
+        res = sum_leading(part, n_rows, out=out.reshape(-1) if out is not None and out.is_contiguous() else None)
+        if out is not None:
+            if res.data_ptr() != out.data_ptr():
+                out.copy_(res.reshape(out.shape))
+            return out
+        return res.reshape(part.shape[len(outer):])
     d, out_shape = _descriptor(la, lb, lo, a_shape, tuple(a.stride()), b_shape, tuple(b.stride()), a.dtype)
     labels = list(la) + [x for x in lb if x not in la]
     if out is None:
