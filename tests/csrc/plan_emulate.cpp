@@ -180,3 +180,31 @@ extern "C" int artn_emulate2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, con
   run_bits(p.bits, (const cf *)A, (const cf *)B1, (const cf *)B2, (cf *)C);
   return 0;
 }
+
+// Diagnostic: LDS cycles per ds_read_b64 of the stage-1 operand reads (1 = conflict free): the 32
+// lanes of a half wave read 8 bytes each, bank = (byte address / 4) mod 64.
+extern "C" int artn_read_conflicts(const ArtnStepDesc *d1, const ArtnStepDesc *d2, int *stage1, int *stage2) {
+  ArtnPlan p;
+  std::string err;
+  int rc = d2 ? artn::make_plan_fused(d1, d2, p, err, 256, 1) : artn::make_plan(d1, p, err, 256, true, 1);
+  if (rc) return rc;
+  if (p.kernel != ARTN_KERNEL_BITS_MFMA) return ARTN_E_UNSUPPORTED;
+  for (int s = 0; s < p.bits.n_stages; ++s) {
+    const ArtnStage &st = p.bits.st[s];
+    const ArtnStage *zin = s == 0 ? nullptr : &p.bits.st[0];
+    int count[32] = {0};
+    bool seen[32][64];
+    memset(seen, 0, sizeof(seen));
+    int worst = 1;
+    for (int j = 0; j < 32; ++j) {
+      int off = 0;
+      for (int b = 0; b < 5; ++b) if ((j >> b) & 1) off += 1 << st.lane_in_pos[b];
+      off = swz(off, zin); // element index (8-byte units)
+      const int slot = off & 31, hi = (off >> 5) & 63;
+      if (!seen[slot][hi]) { seen[slot][hi] = true; count[slot]++; }
+    }
+    for (int b = 0; b < 32; ++b) worst = std::max(worst, count[b]);
+    *(s == 0 ? stage1 : stage2) = worst;
+  }
+  return 0;
+}
