@@ -785,7 +785,9 @@ def _sparse_step(tensors, step):
         tensors[i] = first
     elif len(step) > 3 and len(batch_i) == len(batch_j) == 1:
         fused = None
-        if isinstance(tensors[i], torch.Tensor) and tensors[i].numel() >= (1 << 20):
+        plain = (isinstance(tensors[i], torch.Tensor) and isinstance(tensors[j], torch.Tensor)
+                 and _is_identity(batch_i[0], tensors[i].shape[0]) and _is_identity(batch_j[0], tensors[j].shape[0]))
+        if not plain and isinstance(tensors[i], torch.Tensor) and tensors[i].numel() >= (1 << 20):
             fused = contract_gathered(eq, tensors[i], batch_i[0], tensors[j], batch_j[0])
         if fused is None:
             tensors[i] = gather_rows(tensors[i], batch_i[0])
