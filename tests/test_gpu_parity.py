@@ -388,6 +388,14 @@ def test_random_networks(name):
                                device=DEV).cpu().numpy()
     assert rel(out, want) < 1e-5
     assert rel(out, case.arrays["exact128"]) < 1e-5
+    if case.slicing_indices:
+        # the three ways through the slice loop agree: reuse of small intermediates (default, Gray
+        # order), plain loop, whole slices replayed from a captured HIP graph (dense executor)
+        plain = A.sliced_contraction(case.tensors, case.scheme, case.slicing_indices, want.shape, device=DEV,
+                                     reuse_small=False).cpu().numpy()
+        replay = A.sliced_contraction(case.tensors, case.scheme, case.slicing_indices, want.shape, device=DEV,
+                                      reuse_small=False, graph=True).cpu().numpy()
+        assert rel(plain, want) < 1e-5 and np.array_equal(plain, replay)
 
 
 def test_n30_sparse_10000():
