@@ -649,3 +649,22 @@ def test_bf16_precision_mode(monkeypatch):
     fidelity = abs(np.vdot(want, at)) ** 2 / (np.vdot(want, want).real * np.vdot(at, at).real)
     assert fidelity > 0.99, fidelity
     assert rel(at, want) > 1e-4   # and it is not the fp32 path
+
+
+def test_c_abi_demo_without_python(tmp_path):
+    """examples/abi_demo.cpp: libartn_hip.so driven from plain C++ (hipMalloc'ed buffers, a
+    hipStream_t, label lists) -- no torch, no Python in the process."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "abi_demo")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(ROOT, "artensor_amd")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "abi_demo.cpp"), "-L" + lib_dir, "-lartn_hip",
+                    "-Wl,-rpath," + lib_dir, "-o", exe], check=True, capture_output=True, timeout=300)
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "kernel=1" in run.stdout   # the tiled MFMA kernel, not the strided fallback
