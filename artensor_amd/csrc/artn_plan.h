@@ -555,9 +555,13 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   // workgroup (a reload of up to 256 fragment registers per lane from global memory); in
   // contiguous ranges the batch axes, which are the slowest tile digits, change once per row.
   if (gather_label >= 0 && b.gather_dim < 0) { p.why_generic = "gathered label is not an outer axis"; return false; }
+  // (not when the small operand also has outer free bits: those are the fastest tile digits, in
+  //  grid-stride order a workgroup keeps its value of them -- and its fragments -- while a
+  //  contiguous range would step through them tile by tile)
   b.blocked = 0;
   for (int i = 0; i < b.n_outer; ++i)
-    if ((b.outer[i].sA != 0 && b.outer[i].sB1 != 0) || (b.outer[i].sB2 != 0 && b.outer[i].sC != 0 && b.outer[i].sA != 0))
+    if (((b.outer[i].sA != 0 && b.outer[i].sB1 != 0) || (b.outer[i].sB2 != 0 && b.outer[i].sC != 0 && b.outer[i].sA != 0)) &&
+        a_rereads == 1)
       b.blocked = 1;
 
   // ---- envelope checks
