@@ -196,9 +196,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Self-test knobs (never set by the driver): ARTN_BENCH_BACKEND=gloo with ARTN_BENCH_DEVICE=0 runs
+    # the N > 1 code path with every rank on one GPU, where RCCL cannot
+    backend = os.environ.get("ARTN_BENCH_BACKEND", "nccl")
+    if "ARTN_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ARTN_BENCH_DEVICE"])
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     elif args.gpus > 1:
         sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     dev = torch.device("cuda", local_rank)
