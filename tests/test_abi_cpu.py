@@ -56,6 +56,11 @@ def test_no_cpu_fallback_anywhere():
     assert N.lib().artn_contract(ctypes.byref(d), p, p, p, None) == -4
     assert b"gfx950" in N.lib().artn_last_error()
     assert N.lib().artn_axpy_c64(p, p, 4, None) == -4
+    assert N.lib().artn_sum_axis_c64(p, p, 1, 2, 2, None) == -4
+    assert N.lib().artn_contract_gather(ctypes.byref(d), p, p, p, 0, None, 0, None, 0, None, None) == -4
+    assert N.lib().artn_contract2(ctypes.byref(d), ctypes.byref(d), p, p, p, p, None) == -4
+    assert N.lib().artn_gather_rows(p, p, p, 1, 8, 1, None, None) == -4
+    assert N.lib().artn_absmax_normalize_c64(p, 4, p, None) == -4
 
 
 def test_planner_query_and_errors():
