@@ -738,7 +738,7 @@ def _normalize_inplace(t):
 
 
 def _out_numel(eq, a, b):
-    la, lb, lo = _parse(eq)
+    la, lb, lo = _labels(eq)
     ext = dict(zip(la, a.shape))
     ext.update(zip(lb, b.shape))
     n = 1
@@ -765,7 +765,7 @@ def _sparse_step(tensors, step):
     batch_i, batch_j = step[2]
     if len(batch_i) > 1:
         src_i, src_j = tensors[i], tensors[j]
-        la, lb, lo = _parse(eq)
+        la, lb, lo = _labels(eq)
         rows = [len(x) for x in batch_i]
         first = None
         r0 = 0
@@ -897,12 +897,24 @@ def einsum_eq_convert(ixs, iy):
     return ",".join("".join(m[x] for x in ix) for ix in ixs) + "->" + "".join(m[x] for x in iy)
 
 
-def contraction_scheme(ctree):
+def _equation(ixs, iy, labels):
+    """labels="einsum": the reference's equation string (50-letter alphabet, contraction.py:9-10);
+    labels="tuples": the bond labels themselves as (labels of operand 0, of operand 1, of the
+    result) -- any number of distinct labels per step, understood by every executor here."""
+    if labels == "einsum":
+        return einsum_eq_convert(ixs, iy)
+    if labels == "tuples":
+        return (tuple(ixs[0]), tuple(ixs[1]), tuple(iy))
+    raise RuntimeError(f"labels must be 'einsum' or 'tuples', got {labels!r}")
+
+
+def contraction_scheme(ctree, labels="einsum"):
     """Dense scheme of a contraction tree (reference contraction.py:23-59): depth-first from
     the root, larger-space child first, emitted in reverse; each step is
     ((rep, other), equation) where `rep` is the vertex's representative tensor id (always
     the child with the larger sc, contraction_tree.py:305-314) and the output labels are
-    list(vertex.contain_bonds)."""
+    list(vertex.contain_bonds).  labels="tuples" emits label tuples instead of einsum strings
+    (no 50-symbol limit; not understood by the reference's executor)."""
     ctree.mark_rep_tensor()
     root = ctree.tree[ctree.all_tensors]
     bonds_of = ctree.tn.tensor_bonds
@@ -924,7 +936,7 @@ def contraction_scheme(ctree):
         iy = list(v.contain_bonds)
         if v is root:
             output_bonds = iy
-        scheme.append((pair, einsum_eq_convert(ixs, iy)))
+        scheme.append((pair, _equation(ixs, iy, labels)))
         todo += [v.left, v.right] if v.left.sc > v.right.sc else [v.right, v.left]
     scheme.reverse()
     return scheme, output_bonds
@@ -939,7 +951,7 @@ def _merge_bits(bits_i, bits_j, loc_i, loc_j):
     return "".join(bits_i[loc_i.index(k)] if k in loc_i else bits_j[loc_j.index(k)] for k in range(n))
 
 
-def contraction_scheme_sparse(ctree, bitstrings=None, sc_target=31):
+def contraction_scheme_sparse(ctree, bitstrings=None, sc_target=31, labels="einsum"):
     """Sparse-state scheme (reference contraction.py:208-341).
 
     Walks the tree's DFS order keeping, per live tensor, which final qubits it already
@@ -1062,7 +1074,7 @@ def contraction_scheme_sparse(ctree, bitstrings=None, sc_target=31):
             has_i = 0
             ix_left = bond_i
         iy = iy + tensor_bonds[i]
-        eq = einsum_eq_convert((ix_left, ix_right), iy)
+        eq = _equation((ix_left, ix_right), iy, labels)
         if has_i and has_j:
             next_shape = (len(rows),) + (2,) * len(tensor_bonds[i])
             if chunked:

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from .contraction import _parse, _sparse_step, contract, tensor_contraction, tensor_contraction_sparse
+from .contraction import _labels, _sparse_step, contract, tensor_contraction, tensor_contraction_sparse
 
 __all__ = ["slice_assignments", "rank_slices", "apply_slice", "accumulate", "sliced_contraction",
            "SliceRunner", "TensorNetworkSimulation"]
@@ -102,7 +102,7 @@ def split_scheme(scheme, shapes):
     for n, step in enumerate(scheme):
         i, j = step[0]
         out_shape = None
-        if (isinstance(step[1], str) and i not in tainted and j not in tainted and i in shapes and j in shapes
+        if (i not in tainted and j not in tainted and i in shapes and j in shapes
                 and (len(step) == 2 or (len(step[2][0]) <= 1 and len(step[2][1]) <= 1))):
             out_shape = _small_step_shape(step, shapes[i], shapes[j])
         if out_shape is not None and max(numel(shapes[i]), numel(shapes[j]), numel(out_shape)) <= SMALL_NUMEL:
@@ -124,7 +124,7 @@ def _small_step_shape(step, si, sj):
     both = sparse5 and len(bi) == 1 and len(bj) == 1
     if both:  # branch (B): one row gather per operand, then the batched contraction
         si, sj = (len(bi[0]),) + tuple(si[1:]), (len(bj[0]),) + tuple(sj[1:])
-    la, lb, lo = _parse(step[1])
+    la, lb, lo = _labels(step[1])
     if len(la) != len(si) or len(lb) != len(sj):
         return None
     ext = dict(zip(la, si))

@@ -10,6 +10,7 @@ amplitudes at or above the typical magnitude and 1e-5 of the typical magnitude b
 chaotic circuit: the reference's own complex64 output is 2.9e-5 away from a complex128
 run of the same scheme under that metric, and 1.4e-6 under this one -- measured on n12.)"""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -668,3 +669,25 @@ def test_c_abi_demo_without_python(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "kernel=1" in run.stdout   # the tiled MFMA kernel, not the strided fallback
+
+
+def test_label_tuple_schemes_execute():
+    """Schemes compiled with labels="tuples" (bond labels instead of einsum letters; no 50-symbol
+    limit) through the dense and the sparse executor: the reference's n12 outputs."""
+    import json
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_scheme_compilers import Tree
+    trees = json.load(open(os.path.join(GOLDEN, "trees.json")))
+    case = load_case(os.path.join(GOLDEN, "n12_dense.npz"))
+    scheme, _ = A.contraction_scheme(Tree(trees["n12_dense"]["tree"]), labels="tuples")
+    raw = A.tensor_contraction(case.fresh_tensors(device=DEV), scheme).cpu().numpy()
+    assert rel(raw, case.arrays["raw"]) < 1e-5
+    sp = load_case(os.path.join(GOLDEN, "n12_sparse5.npz"))
+    rec = trees["n12_sparse"]
+    scheme, _, order = A.contraction_scheme_sparse(Tree(rec["tree"]), rec["bitstrings"], sc_target=rec["sc_target"],
+                                                   labels="tuples")
+    out = A.tensor_contraction_sparse(sp.fresh_tensors(device=DEV), scheme).cpu().numpy().reshape(-1)
+    # (the leaf tensors of the sparse pattern do not depend on the bitstring set; this tree was
+    #  compiled for 40 bitstrings, whose amplitudes the reference's state vector holds)
+    want = case.arrays["state_vec"].reshape(-1)[[int(b, 2) for b in order]]
+    assert out.shape == want.shape and amp_rel(out, want, rms=2.0 ** -6) < 5e-5

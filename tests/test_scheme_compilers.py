@@ -127,3 +127,26 @@ def test_compiled_scheme_runs_through_the_oracle(trees):
     raw = oracle.tensor_contraction({i: t.numpy().copy() for i, t in case.tensors.items()}, scheme)
     want = case.arrays["raw"]
     assert np.abs(raw - want).max() / np.abs(want).max() < 5e-6
+
+
+def test_label_tuple_schemes_equal_the_string_schemes(trees):
+    """labels="tuples": the same steps with the bond labels themselves instead of einsum letters (no
+    50-symbol limit): turning each tuple equation back into a string gives the string scheme."""
+    rec = trees["n12_dense"]
+    s_str, out_str = A.contraction_scheme(Tree(rec["tree"]))
+    s_tup, out_tup = A.contraction_scheme(Tree(rec["tree"]), labels="tuples")
+    assert list(out_str) == list(out_tup) and len(s_str) == len(s_tup)
+    for (e1, eq), (e2, tup) in zip(s_str, s_tup):
+        assert e1 == e2 and isinstance(tup, tuple) and len(tup) == 3
+        assert canon(A.einsum_eq_convert((list(tup[0]), list(tup[1])), list(tup[2]))) == canon(eq)
+    for name in ("n12_sparse", "n12_sparse_chunked"):
+        rec = trees[name]
+        a = A.contraction_scheme_sparse(Tree(rec["tree"]), rec["bitstrings"], sc_target=rec["sc_target"])[0]
+        b = A.contraction_scheme_sparse(Tree(rec["tree"]), rec["bitstrings"], sc_target=rec["sc_target"],
+                                        labels="tuples")[0]
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert x[0] == y[0] and len(x) == len(y)
+            assert canon(A.einsum_eq_convert((list(y[1][0]), list(y[1][1])), list(y[1][2]))) == canon(x[1])
+    with pytest.raises(RuntimeError):
+        A.contraction_scheme(Tree(trees["n12_dense"]["tree"]), labels="letters")
