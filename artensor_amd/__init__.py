@@ -30,6 +30,7 @@ from .simulation import (  # noqa: F401
     sliced_contraction,
 )
 
+from .network import tn_contract  # noqa: F401
 from .statevector import state_vec  # noqa: F401
 
 __version__ = "0.1.0"

@@ -691,3 +691,27 @@ def test_label_tuple_schemes_execute():
     #  compiled for 40 bitstrings, whose amplitudes the reference's state vector holds)
     want = case.arrays["state_vec"].reshape(-1)[[int(b, 2) for b in order]]
     assert out.shape == want.shape and amp_rel(out, want, rms=2.0 ** -6) < 5e-5
+
+
+def test_tn_contract_bookkeeping_and_values():
+    """tensor_network.py:207-226 on the device: a 4-tensor ring with a dangling vector, contracted
+    pairwise; bond bookkeeping as the reference leaves it, values against numpy."""
+    import types
+    rng = np.random.default_rng(31)
+    bonds = {0: ["a", "b", "v"], 1: ["b", "c"], 2: ["c", "d", "e"], 3: ["d", "a"], 4: ["v"]}
+    arrs = {k: crandn(rng, (2,) * len(v)) for k, v in bonds.items()}
+    tn = types.SimpleNamespace(tensor_bonds={k: list(v) for k, v in bonds.items()},
+                               bond_tensors={}, tensors={k: gpu(v) for k, v in arrs.items()})
+    for k, v in bonds.items():
+        for b in v:
+            tn.bond_tensors.setdefault(b, set()).add(k)
+    A.tn_contract(tn, 0, 4)      # dangling vector into its neighbour
+    assert tn.tensor_bonds[0] == ["a", "b"] and 4 not in tn.tensors and "v" not in tn.bond_tensors
+    A.tn_contract(tn, 0, 1)      # matrix
+    assert tn.tensor_bonds[0] == ["a", "c"] and tn.bond_tensors["c"] == {0, 2}
+    A.tn_contract(tn, 2, 3)
+    assert tn.tensor_bonds[2] == ["c", "e", "a"]
+    out = A.tn_contract(tn, 2, 0)   # two shared bonds at once
+    assert tn.tensor_bonds == {2: ["e"]} and set(tn.bond_tensors) == {"e"}
+    want = np.einsum("abv,v,bc,cde,da->e", arrs[0], arrs[4], arrs[1], arrs[2], arrs[3])
+    assert rel(out.cpu().numpy(), want) < 1e-5
