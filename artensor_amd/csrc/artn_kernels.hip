@@ -496,6 +496,30 @@ __device__ __forceinline__ void load_w_split(u32x4_t (&WS)[NP][KB >= 3 ? 1 << (K
     for (int g = 0; g < G; ++g) asm volatile("" : "+v"(WS[p][g])); // see load_w
 }
 
+// One plane of bf16 fragments (NP = 1) for the 7-8 bit kernel: row[g] = 8 bf16 for kc = 8g + 4h + u
+template <int KB>
+__device__ __forceinline__ void load_w_plane(u32x4_t (&row)[KB >= 3 ? 1 << (KB - 3) : 1], const char *__restrict__ Bbase,
+                                             const StageConst<KB> &L, int ro) {
+  constexpr int G = KB >= 3 ? 1 << (KB - 3) : 1;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      long ko = 0;
+      if (u & 1) ko += L.kb[0];
+      if (u & 2) ko += L.kb[KB > 1 ? 1 : 0];
+#pragma unroll
+      for (int b = 3; b < KB; ++b)
+        if ((g >> (b - 3)) & 1) ko += L.kb[b];
+      float2 bv = make_float2(0.f, 0.f);
+      if (L.w_valid) bv = *reinterpret_cast<const float2 *>(Bbase + ko + L.lane_b);
+      row[g][u] = pack_bf16(ro ? bv.y : bv.x, ro ? bv.x : -bv.y);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) asm volatile("" : "+v"(row[g])); // see load_w
+}
+
 // One stage on this wave's sub-tiles.  Per sub-tile: a chain of 2^KB MFMAs over the
 // contracted bits, then the scatter of the 32 x 16 complex result into the output region.
 // The chain must never wait on LDS and the scatter must not sit between two chains, so the
@@ -511,6 +535,10 @@ struct StageRun {
   static constexpr int UPS = S / CH;         // units per sub-tile (1, or 2 for KB = 6)
   static constexpr bool SPLIT = NP > 0 && KB >= 3;
   static constexpr int G = KB >= 3 ? 1 << (KB - 3) : 1;
+  // split fragments: [piece][group]; the 7-8 bit kernel runs NP = 1 only and uses the first index
+  // for the looped-over value instead
+  static constexpr int WSD = SPLIT ? (BIGK ? 4 : NP) : 1;
+  static_assert(!(BIGK && NP > 1), "the 7-8 bit kernel has no three-piece split");
   const StageConst<KB> &L;
   float (&W0)[S];
   float (&W1)[S];
@@ -519,7 +547,7 @@ struct StageRun {
   // registers (the instantiation runs one wave per SIMD, so 512 VGPRs are available)
   float (&WH0)[BIGK ? 3 : 1][S];
   float (&WH1)[BIGK ? 3 : 1][S];
-  u32x4_t (&WS)[SPLIT ? NP : 1][G]; // split chain: bf16 pieces of the small operand
+  u32x4_t (&WS)[WSD][G]; // split chain: bf16 pieces of the small operand
 
   // LDS offset of read s of a chain: fp32 chain kc = 2s + h; split chain kc = 8g + 4h + u, s = 4g + u
   __device__ __forceinline__ unsigned ko(int s) const {
@@ -655,6 +683,21 @@ struct StageRun {
   }
   template <int HI, int BASE>
   __device__ __forceinline__ void chain_hi(f32x16 &acc, const v2f_t (&buf)[CH]) const {
+    if constexpr (SPLIT) { // bf16 operands (NP = 1): one MFMA per group of 8 complex kc
+#pragma unroll
+      for (int gg = 0; gg < CH / 4; ++gg) {
+        u32x4_t a;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = pack_bf16(buf[4 * gg + u].x, buf[4 * gg + u].y);
+#ifdef ARTN_ABLATE_MFMA
+        asm volatile("" ::"v"(a), "v"(WS[BIGK ? HI : 0][BASE / 4 + gg]));
+#else
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, WS[BIGK ? HI : 0][BASE / 4 + gg]),
+                                                      __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
+#endif
+      }
+      return;
+    }
     const float(&a0)[S] = w0<HI>();
     const float(&a1)[S] = w1<HI>();
 #pragma unroll
@@ -833,7 +876,7 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1
                                           float (&W1)[1 << (KB - 1)], int h, int lane,
                                           float (&WH0)[BIGK ? 3 : 1][1 << (KB - 1)],
                                           float (&WH1)[BIGK ? 3 : 1][1 << (KB - 1)],
-                                          u32x4_t (&WS)[(NP > 0 && KB >= 3) ? NP : 1][KB >= 3 ? 1 << (KB - 3) : 1]) {
+                                          u32x4_t (&WS)[(NP > 0 && KB >= 3) ? (BIGK ? 4 : NP) : 1][KB >= 3 ? 1 << (KB - 3) : 1]) {
   StageRun<KB, BIGK, NP> r{L, W0, W1, h, lane, WH0, WH1, WS};
   r.run();
 }
@@ -906,7 +949,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   for (int i = 0; i < 16; ++i) out_i_swz[i] = swz(i * (ARTN_WG_THREADS * 16), zout);
   const OffTab OT = build_offset_table(P, offtab, tid);
   float W10[S1], W11[S1], W20[S2], W21[S2]; // (whichever of the fp32 / split fragment sets a stage does not use is dead)
-  u32x4_t WS1[SP1 ? NP : 1][G1], WS2[SP2 ? NP : 1][G2];
+  u32x4_t WS1[SP1 ? (BIGK ? 4 : NP) : 1][G1], WS2[SP2 ? NP : 1][G2];
   float WH0[BIGK ? 3 : 1][S1], WH1[BIGK ? 3 : 1][S1], WD0[1][S2], WD1[1][S2]; // BIGK: fragments of looped-over values 1..3
   long prev_b1 = -1, prev_b2 = -1;
   __syncthreads(); // tables are in LDS
@@ -964,7 +1007,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
         for (int b = 0; b < 2; ++b)
           if ((L1.ksplit_wave >> b) & 1) kb0 += L1.kb_hi[b];
       }
-      if constexpr (SP1) load_w_split<KB1, (SP1 ? NP : 1)>(WS1, Bb, L1, ro);
+      if constexpr (SP1 && BIGK) load_w_plane<KB1>(WS1[0], Bb + kb0, L1, ro);
+      else if constexpr (SP1) load_w_split<KB1, (SP1 ? NP : 1)>(WS1, Bb, L1, ro);
       else load_w<KB1>(W10, W11, Bb + kb0, L1, ro);
       if constexpr (BIGK) { // fragments of the looped-over contracted bits' values 1..3
 #pragma unroll
@@ -975,7 +1019,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 #pragma unroll
             for (int b = 0; b < 2; ++b)
               if ((hi >> b) & 1) kbo += L1.kb_hi[b];
-            load_w<KB1>(WH0[hi - 1], WH1[hi - 1], Bb + kbo, L1, ro);
+            if constexpr (SP1) load_w_plane<KB1>(WS1[SP1 ? hi : 0], Bb + kbo, L1, ro);
+            else load_w<KB1>(WH0[hi - 1], WH1[hi - 1], Bb + kbo, L1, ro);
           }
         }
       }
@@ -1258,6 +1303,12 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
       if (hipError_t e = ensure_lds<artn_k_bits<KB1, 0, false, 0, true>>(lds); e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
     }
+    return hipGetLastError();
+  }
+  if (KB1 == 6 && k2 == 0 && p.bits.st[0].k > 6 && split == 1) { // bf16 operands
+    auto kern = artn_k_bits<(KB1 == 6 ? 6 : 1), 0, true, 1>;
+    if (hipError_t e = ensure_lds<artn_k_bits<(KB1 == 6 ? 6 : 1), 0, true, 1>>(lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
     return hipGetLastError();
   }
   if (KB1 == 6 && k2 == 0 && p.bits.st[0].k > 6) {

@@ -601,7 +601,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     b.ksplit = (k1 > 6 && !fused && mt == 5 && b.st[0].wn_log2 == 0) ? 1 : 0;
     // arithmetic of the chains: ARTN_C64_BF16 asks for plain bf16 operands; complex64 uses the
     // split (three bf16 pieces) when tuning().split says so; 7-8 contracted bits stay fp32
-    b.split = k1 > 6 ? 0 : (d1->dtype == ARTN_C64_BF16 ? 1 : tuning().split);
+    b.split = d1->dtype == ARTN_C64_BF16 ? 1 : (k1 > 6 ? 0 : tuning().split);
     f.lds_bytes = (int32_t)((8LL << b.r0_bits) + (8LL << b.T_mid) + (8LL << (mt - 5)) + (fused ? (8LL << (m2 - 5)) : 0) + off_tab +
                             (b.ksplit ? 3 * 4096 + 16 : 0));
   }

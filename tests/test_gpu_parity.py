@@ -618,7 +618,11 @@ def test_bf16_precision_mode(monkeypatch):
     rng = np.random.default_rng(21)
     for eq, sa, sb in [("abcdefghijklmnop,pcfx->abdeghijklmnox", (2,) * 16, (2, 2, 2, 2)),
                        ("abcdefghijklmnopq,qhcfaxyz->bdegijklmnopzyx", (2,) * 17, (2,) * 8),
-                       ("zabcdefghijklmn,znkcfxy->zabdeghijlmyx", (3,) + (2,) * 14, (3, 2, 2, 2, 2, 2, 2))]:
+                       ("zabcdefghijklmn,znkcfxy->zabdeghijlmyx", (3,) + (2,) * 14, (3, 2, 2, 2, 2, 2, 2)),
+                       # 8 and 7 contracted bits: the one-workgroup-per-CU kernel, and its split over the waves
+                       ("abcdefghijklmnopqrstu,ucfhkmoqxyzw->abdegijlnprstwzyx", (2,) * 21, (2,) * 12),
+                       ("abcdefghijklmnopqrstu,ucfhkmoxyzwv->abdegijlnpqrstvwzyx", (2,) * 21, (2,) * 12),
+                       ("abcdefghijklmnopqrst,tcfhkmoqxy->abdegijlnprsyx", (2,) * 20, (2,) * 10)]:
         a, b = crandn(rng, sa), crandn(rng, sb)
         with A.precision("bf16"):
             got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
