@@ -1085,7 +1085,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 #ifdef ARTN_ABLATE_MEM
           asm volatile("" ::"v"(x[i]), "s"(Cbase), "v"(lo_out));
 #else
-          *reinterpret_cast<f32x4 *>(Cbase + o + lo_out) = x[i];
+          // (results are not read again by this launch)
+          __builtin_nontemporal_store(x[i], reinterpret_cast<f32x4 *>(Cbase + o + lo_out));
 #endif
         }
       }
