@@ -294,11 +294,22 @@ __device__ __forceinline__ f32x4 load_chunk(const char *__restrict__ Abase, long
   return *reinterpret_cast<const f32x4 *>(Abase + off + lane_off);
 #endif
 }
-template <int NV>
+// NT: every A tile is read exactly once by the launch, in full 128-byte runs: non-temporal loads
+// keep the stream from displacing lines that will be used again.  (A compile-time choice: behind
+// a run-time branch the compiler merges the two loads and drops the hint.)
+template <int NV, bool NT = false>
 __device__ __forceinline__ void issue_loads(f32x4 (&v)[NV], const char *__restrict__ Abase, const long (&hi)[4],
                                             unsigned lane_off) {
 #pragma unroll
-  for (int u = 0; u < NV; ++u) v[u] = load_chunk(Abase, chunk_off(hi, u), lane_off);
+  for (int u = 0; u < NV; ++u) {
+#ifndef ARTN_ABLATE_MEM
+    if constexpr (NT) {
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Abase + chunk_off(hi, u) + lane_off));
+      continue;
+    }
+#endif
+    v[u] = load_chunk(Abase, chunk_off(hi, u), lane_off);
+  }
 }
 template <int NV>
 __device__ __forceinline__ void store_lds(const f32x4 (&v)[NV], unsigned ldsb, unsigned tid16) {
@@ -884,7 +895,8 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1
 // KB2 == 0: single stage.  BIGK: 7 or 8 contracted bits (KB1 = 6 of them in the chain).
 // NP: 0 = fp32 MFMA chains; 3 / 1 = split-bf16 chains (stages with >= 3 contracted bits).
 // GATHER: row indices on one outer axis (artn_contract_gather; single stage, fp32 chains).
-template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false>
+// NT: non-temporal loads of the A tiles (see issue_loads).
+template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false, bool NT = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(const float2 *__restrict__ A,
                                                                   const float2 *__restrict__ B1,
                                                                   const float2 *__restrict__ B2,
@@ -983,7 +995,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     copy_in_sync(reinterpret_cast<const char *>(A + off.a), in_hi, in_lane, R0, tid16, n_in_iters);
     if (t0 + G < n_tiles) {
       noff = tile_offsets<GATHER>(P, OT, t0 + G);
-      if (prefetch) issue_loads(v, reinterpret_cast<const char *>(A + noff.a), in_hi, in_lane);
+      if (prefetch) issue_loads<NV, NT>(v, reinterpret_cast<const char *>(A + noff.a), in_hi, in_lane);
     }
   }
   __syncthreads();
@@ -1092,7 +1104,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       }
       PHASE_MARK(5);
       STAMP(7);
-      if (next2 < n_tiles) issue_loads(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
+      if (next2 < n_tiles) issue_loads<NV, NT>(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
       PHASE_MARK(6);
       STAMP(4);
     } else {
@@ -1289,6 +1301,14 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
     if constexpr (KB1 >= 3 || K2 >= 3) {                                                                  \
       if (split == 3) { ARTN_LAUNCH_NP(K2, 3) break; }                                                    \
       if (split == 1) { ARTN_LAUNCH_NP(K2, 1) break; }                                                    \
+    }                                                                                                     \
+    if constexpr (KB1 >= 3 && (K2 == 0 || K2 >= 3)) {                                                     \
+      if (p.bits.nt_loads) { /* the big steps: non-temporal loads of A */                                 \
+        auto kern = artn_k_bits<KB1, K2, false, 0, false, true>;                                          \
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, true>>(lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                             \
+        break;                                                                                            \
+      }                                                                                                   \
     }                                                                                                     \
     ARTN_LAUNCH_NP(K2, 0)                                                                                 \
     break;                                                                                                \

@@ -82,7 +82,7 @@ struct ArtnBitsPlan {
   // `gather_dim` operand A is read at row rows_a[x] and the small operand at rows_b[x] instead of x
   // (device pointers, nullptr = x); indices outside [0, src_rows) read row 0 and set *gather_err
   int32_t gather_dim; // -1: none
-  int32_t pad2_;
+  int32_t nt_loads;   // 1: every A tile is read once, in full 128-byte runs, by a big launch: non-temporal loads
   const int64_t *rows_a;
   const int64_t *rows_b;
   int64_t src_rows_a, src_rows_b;
@@ -121,6 +121,7 @@ struct Tuning {
   int swizzle = 1;    // XOR-swizzle stage output regions against LDS bank conflicts
   int stage_prio = 1; // asymmetric MFMA-stage priority between the two workgroups of a CU
   int split = 0;      // complex64 chains: 0 fp32 MFMA, 3 fp32-grade split-bf16 MFMA
+  int nt = 1;         // non-temporal loads of A tiles that are read once
 };
 static inline Tuning &tuning() {
   static Tuning t = [] {
@@ -130,6 +131,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_RUN_MAX")) x.run_max = std::min(6, std::max(1, atoi(e)));
     if (const char *e = getenv("ARTN_SWIZZLE")) x.swizzle = atoi(e) != 0;
     if (const char *e = getenv("ARTN_STAGE_PRIO")) x.stage_prio = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_NT")) x.nt = atoi(e) != 0;
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
     return x;
   }();
@@ -518,7 +520,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   outer.insert(outer.end(), O.begin(), O.end());
   b.n_tiles = 1;
   b.gather_dim = -1;
-  b.pad2_ = 0;
+  b.nt_loads = 0;
   b.rows_a = b.rows_b = nullptr;
   b.src_rows_a = b.src_rows_b = 0;
   b.gather_err = nullptr;
@@ -555,6 +557,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   // workgroup (a reload of up to 256 fragment registers per lane from global memory); in
   // contiguous ranges the batch axes, which are the slowest tile digits, change once per row.
   if (gather_label >= 0 && b.gather_dim < 0) { p.why_generic = "gathered label is not an outer axis"; return false; }
+  b.nt_loads = (a_rereads == 1 && run_in >= 4 && b.n_tiles >= (1 << 14) && tuning().nt) ? 1 : 0;
   // (not when the small operand also has outer free bits: those are the fastest tile digits, in
   //  grid-stride order a workgroup keeps its value of them -- and its fragments -- while a
   //  contiguous range would step through them tile by tile)
