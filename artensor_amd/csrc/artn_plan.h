@@ -112,8 +112,8 @@ struct ArtnPlan {
 
 namespace artn {
 
-// Development knobs (environment: ARTN_WG_PER_CU, ARTN_TILE_TARGET, ARTN_RUN_MAX, ARTN_SWIZZLE, ARTN_STAGE_PRIO); the
-// defaults are what ships.
+// Development knobs (environment: ARTN_WG_PER_CU, ARTN_TILE_TARGET, ARTN_RUN_MAX, ARTN_SWIZZLE, ARTN_STAGE_PRIO,
+// ARTN_SPLIT, ARTN_NT); the defaults are what ships.
 struct Tuning {
   int wg_per_cu = 2;  // persistent workgroups per CU (grid = CUs * this), capped by LDS
   int tile_target = ARTN_TILE_BITS_TARGET;
