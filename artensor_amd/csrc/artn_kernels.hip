@@ -1300,6 +1300,14 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
   case K2: {                                                                                              \
     if constexpr (KB1 >= 3 || K2 >= 3) {                                                                  \
       if (split == 3) { ARTN_LAUNCH_NP(K2, 3) break; }                                                    \
+      if constexpr (KB1 >= 3 && (K2 == 0 || K2 >= 3)) {                                                   \
+        if (split == 1 && p.bits.nt_loads) { /* bf16 operands: every big launch is HBM-bound */           \
+          auto kern = artn_k_bits<KB1, K2, false, 1, false, true>;                                        \
+          if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 1, false, true>>(lds); e != hipSuccess) return e; \
+          hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                           \
+          break;                                                                                          \
+        }                                                                                                 \
+      }                                                                                                   \
       if (split == 1) { ARTN_LAUNCH_NP(K2, 1) break; }                                                    \
     }                                                                                                     \
     if constexpr (KB1 >= 3 && (K2 == 0 || K2 >= 3)) {                                                     \
