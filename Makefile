@@ -22,6 +22,13 @@ ablate: $(CSRC)/artn_kernels.hip $(CSRC)/artn_plan.h include/artn.h
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MEM -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomem.so
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MEM -DARTN_ABLATE_MFMA -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomem_nomfma.so
 
+# stand-alone HBM copy probes (tile-structured persistent copies; diagnostics only)
+probes: tools/bw_probe tools/bw_probe2
+tools/bw_probe: tools/bw_probe.hip
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) $< -o $@
+tools/bw_probe2: tools/bw_probe2.hip
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) $< -o $@
+
 clean:
 	rm -f $(LIB)
-.PHONY: all clean
+.PHONY: all clean probes stamps phases ablate

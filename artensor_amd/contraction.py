@@ -13,6 +13,8 @@ kernels.  Tree traversal stays in Python on PyTorch-ROCm tensors.  Errors raise
 RuntimeError (the reference prints and sys.exit(1)s, contraction.py:71-74).
 """
 import ctypes
+import threading
+import warnings
 from math import ceil
 
 import numpy as np
@@ -54,18 +56,66 @@ def _labels(eq):
 
 
 _DTYPES = {torch.complex64: N.ARTN_C64, torch.complex128: N.ARTN_C128}
-_desc_cache = {}
+
+
+class _Bounded(dict):
+    """A dict that forgets everything once it holds `limit` entries: the host-side caches below are
+    pure memoisation (descriptors, planner answers, device copies of index tensors), so dropping them
+    costs a recomputation, never a wrong answer."""
+
+    def __init__(self, limit):
+        super().__init__()
+        self.limit = limit
+
+    def __setitem__(self, key, value):
+        if len(self) >= self.limit and key not in self:
+            self.clear()
+        super().__setitem__(key, value)
+
+
+_desc_cache = _Bounded(8192)   # key: labels + shapes + strides of one step
 
 # Optional per-launch timing hook (bench.py / profiling only): an object with
 # .record(info_dict, start_event, end_event); events are recorded on the launch stream.
 profiler = None
-_info_cache = {}
+_info_cache = _Bounded(8192)   # id(descriptor) -> (descriptor, planner answer); the descriptor is held
+                               # so that its id cannot be reused while the entry lives
 
 
 def _query(d):
     info = N.ArtnStepInfo()
     N.check(N.lib().artn_contract_query(ctypes.byref(d), ctypes.byref(info)))
     return {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+
+
+def _step_info_cached(d):
+    hit = _info_cache.get(id(d))
+    if hit is None or hit[0] is not d:
+        hit = _info_cache[id(d)] = (d, _query(d))
+    return hit[1]
+
+
+# A big step that the bit planner declines runs on the strided kernel (one thread per output
+# element): correct, but far from the MFMA kernel's rate.  Say so once per reason.
+GENERIC_WARN_NUMEL = 1 << 20
+_warned_generic = set()
+
+
+def _warn_if_generic(d, numel, what):
+    if numel < GENERIC_WARN_NUMEL:
+        return
+    hit = _info_cache.get(id(d))
+    if hit is not None and hit[0] is d:
+        return                    # already looked at (and warned about, if need be)
+    info = _step_info_cached(d)   # leaves the planner's reason in artn_last_plan_note()
+    if info["kernel"] != N.KERNEL_GENERIC:
+        return
+    note = N.lib().artn_last_plan_note().decode()
+    if note in _warned_generic:
+        return
+    _warned_generic.add(note)
+    warnings.warn(f"artensor_amd: {what} with a {numel}-element operand runs on the strided fallback kernel "
+                  f"(artn_k_generic), not the MFMA kernel: {note}", RuntimeWarning, stacklevel=3)
 
 
 class precision:
@@ -78,25 +128,29 @@ class precision:
     bfloat16 (round to nearest even) and accumulated in fp32 -- the reduced-precision sampling
     mode of BASELINE configs[4].  The reference has no such path: it is defined against this
     package's own complex64 results (tests check state fidelity).  None / "fp32": the default."""
-    _current = None
+    _state = threading.local()   # per thread: a `with precision(...)` in one thread leaves the others alone
 
     def __init__(self, mode):
         if mode not in (None, "fp32", "bf16"):
             raise RuntimeError(f"unknown precision {mode!r} (use None, 'fp32' or 'bf16')")
         self.mode = None if mode == "fp32" else mode
 
+    @staticmethod
+    def current():
+        return getattr(precision._state, "mode", None)
+
     def __enter__(self):
-        self._prev = precision._current
-        precision._current = self.mode
+        self._prev = precision.current()
+        precision._state.mode = self.mode
         return self
 
     def __exit__(self, *exc):
-        precision._current = self._prev
+        precision._state.mode = self._prev
         return False
 
 
 def _descriptor(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype):
-    reduced = precision._current == "bf16" and dtype == torch.complex64
+    reduced = precision.current() == "bf16" and dtype == torch.complex64
     key = (la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype, reduced)
     hit = _desc_cache.get(key)
     if hit is not None:
@@ -260,14 +314,13 @@ def contract(eq, a, b, out=None):
             raise RuntimeError("out= must be a contiguous tensor of the result shape and dtype")
     if out.numel() == 0:
         return out
+    _warn_if_generic(d, max(a.numel(), out.numel()), f"contract({eq!r})" if isinstance(eq, str) else "contract()")
     with torch.cuda.device(a.device):
         if profiler is None:
             N.check(N.lib().artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(),
                                           N.current_stream_ptr(a.device)))
         else:
-            info = _info_cache.get(id(d))
-            if info is None:
-                info = _info_cache[id(d)] = _query(d)
+            info = _step_info_cached(d)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             N.check(N.lib().artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(),
@@ -285,7 +338,7 @@ def _dense_strides(shape):
     return tuple(reversed(st))
 
 
-_pair_cache = {}
+_pair_cache = _Bounded(4096)
 
 
 def _resolve_reshape(numel, shape):
@@ -349,7 +402,8 @@ def contract2(eq1, a, b1, eq2, b2, mid_view=None):
     b1, b2 = _as_operand(b1), _as_operand(b2)
     d1, d2, out_shape = _pair_descriptors(eq1, a, b1, eq2, b2, mid_view)
     key = (id(d1), id(d2))
-    info = _pair_cache.get(key)
+    hit = _pair_cache.get(key)
+    info = hit[2] if hit is not None and hit[0] is d1 and hit[1] is d2 else None
     if info is None:
         q = N.ArtnStepInfo()
         rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
@@ -358,7 +412,7 @@ def contract2(eq1, a, b1, eq2, b2, mid_view=None):
         else:
             N.check(rc)
             info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
-        _pair_cache[key] = info
+        _pair_cache[key] = (d1, d2, info)
     if info is False:
         return None
     out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
@@ -439,8 +493,8 @@ def fusion_schedule(scheme):
     return order
 
 
-_plan_cache = {}
-_schedule_cache = {}
+_plan_cache = _Bounded(64)
+_schedule_cache = _Bounded(64)
 
 
 class _Op:
@@ -462,6 +516,10 @@ def _compile_dense(scheme, shapes, dtype):
         op.info = None
         op.sum_rows = 0
         ops.append(op)
+        numel = 1
+        for e in (sa if len(sa) >= len(op.out_shape) else op.out_shape):
+            numel *= e
+        _warn_if_generic(op.d1, numel, f"tensor_contraction step {n}")
         return op.out_shape
 
     def single(n):
@@ -549,7 +607,7 @@ def tensor_contraction(tensors, scheme):
         shapes[k] = tuple(t.shape)
     if first is None or first.dtype not in _DTYPES:
         raise RuntimeError("tensor_contraction needs complex64 or complex128 GPU tensors")
-    key = (id(scheme), first.dtype, precision._current, tuple(sorted(shapes.items())), N.lib().artn_contract2_query is not None,
+    key = (id(scheme), first.dtype, precision.current(), tuple(sorted(shapes.items())), N.lib().artn_contract2_query is not None,
            bool(__import__("os").environ.get("ARTN_NO_FUSE")))
     hit = _plan_cache.get(key)
     if hit is None or hit[0] is not scheme:
@@ -557,8 +615,6 @@ def tensor_contraction(tensors, scheme):
             ops = _compile_dense(scheme, shapes, first.dtype)
         except KeyError as e:
             raise RuntimeError(f"scheme refers to tensor id {e} that was not supplied") from e
-        if len(_plan_cache) > 64:
-            _plan_cache.clear()
         hit = _plan_cache[key] = (scheme, ops)
     ops = hit[1]
     lib = N.lib()
@@ -598,25 +654,61 @@ def tensor_contraction(tensors, scheme):
 # ----------------------------------------------------------------------------------------
 # sparse-state executor
 # ----------------------------------------------------------------------------------------
-_index_cache = {}
+_index_cache = _Bounded(4096)
+_flag_cache = {}      # device -> sticky int32 out-of-range flag written by the gather kernels
+_flags_used = set()   # devices whose flag some launch since the last check may have set
 
 
-def _device_index(idx, device):
+def _device_index(idx, device, src_rows=None):
     """int64 row indices of a scheme step (CPU tensors built at reference
-    contraction.py:249-283) cached on the device: the scheme is reused for every slice."""
-    key = (id(idx), str(device))
+    contraction.py:249-283) cached on the device: the scheme is reused for every slice.
+
+    With `src_rows` the indices are validated ONCE on the host against the operand they select
+    from, with the reference's semantics (`tensors[i][idx]`, contraction.py:149-150, :177-178,
+    :187): an index outside [-src_rows, src_rows) raises (the reference dies with IndexError there,
+    contraction.py:192-195), a negative one counts from the end."""
+    key = (id(idx), str(device), src_rows)
     hit = _index_cache.get(key)
     if hit is not None and hit[0] is idx:
         return hit[1]
-    dev = torch.as_tensor(idx, dtype=torch.int64).to(device).contiguous()
-    if len(_index_cache) > 4096:
-        _index_cache.clear()
+    host = torch.as_tensor(idx, dtype=torch.int64).reshape(-1).cpu()
+    if src_rows is not None and host.numel():
+        lo, hi = int(host.min()), int(host.max())
+        if lo < -src_rows or hi >= src_rows:
+            raise RuntimeError(f"row index out of range: indices span [{lo}, {hi}] but the operand has {src_rows} rows "
+                               "(IndexError in the reference, contraction.py:192-195)")
+        if lo < 0:
+            host = torch.where(host < 0, host + src_rows, host)
+    dev = host.to(device).contiguous()
     _index_cache[key] = (idx, dev)
     return dev
 
 
-_identity_cache = {}
-_flag_cache = {}
+def _flag(device):
+    flag = _flag_cache.get(device)
+    if flag is None:
+        flag = _flag_cache[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return flag
+
+
+def check_gather_flag(what="gather"):
+    """Read (one sync per device) and clear the sticky out-of-range flag of the gather kernels; raise
+    if any launch since the last check saw a row index outside its operand.  Host validation in
+    _device_index catches bad schemes before launch; this is the device's own word, read once per
+    scheme by the executors rather than after every launch."""
+    bad = []
+    for device in list(_flags_used):
+        flag = _flag_cache[device]
+        if int(flag.item()) != 0:
+            flag.zero_()
+            bad.append(str(device))
+    _flags_used.clear()
+    if bad:
+        raise RuntimeError(f"{what}: a row gather read an index outside its operand on {', '.join(bad)} "
+                           "(the reference raises IndexError, contraction.py:192-195)")
+
+
+_identity_cache = _Bounded(4096)
 
 
 def _is_identity(idx, rows):
@@ -628,13 +720,11 @@ def _is_identity(idx, rows):
         flat = torch.as_tensor(idx, dtype=torch.int64).reshape(-1).cpu()
         n = flat.numel()
         ident = n if bool(torch.equal(flat, torch.arange(n, dtype=torch.int64))) else -1
-        if len(_identity_cache) > 4096:
-            _identity_cache.clear()
         hit = _identity_cache[key] = (idx, ident)
     return hit[1] == rows
 
 
-def contract_gathered(eq, a, rows_a, b, rows_b, out=None, label=None):
+def contract_gathered(eq, a, rows_a, b, rows_b, out=None, label=None, _validate=True):
     """einsum(eq, a[rows_a], b[rows_b]) without materialising the gathered operands
     (artn_contract_gather): the first label of every operand that has row indices must be the
     first label of the result (the shared batch label of the sparse executor, reference
@@ -654,7 +744,7 @@ def contract_gathered(eq, a, rows_a, b, rows_b, out=None, label=None):
     b_shape = ((n,) + tuple(b.shape[1:])) if rows_b is not None else tuple(b.shape)
     outer = _big_k_outer(la, lb, lo, a_shape, tuple(a.stride())) if label is None else None
     if outer:  # more contracted bits than a tile holds: split-K around the gathered contraction
-        part = contract_gathered((la, lb, tuple(outer) + tuple(lo)), a, rows_a, b, rows_b, label=lab)
+        part = contract_gathered((la, lb, tuple(outer) + tuple(lo)), a, rows_a, b, rows_b, label=lab, _validate=_validate)
         if part is None:
             return None
         n_rows = 1
@@ -676,11 +766,9 @@ def contract_gathered(eq, a, rows_a, b, rows_b, out=None, label=None):
         raise RuntimeError("out= must be a contiguous tensor of the result shape")
     if out.numel() == 0:
         return out
-    ia = _device_index(rows_a, a.device) if rows_a is not None else None
-    ib = _device_index(rows_b, b.device) if rows_b is not None else None
-    flag = _flag_cache.get(a.device)
-    if flag is None:
-        flag = _flag_cache[a.device] = torch.zeros(1, dtype=torch.int32, device=a.device)
+    ia = _device_index(rows_a, a.device, a.shape[0] if _validate else None) if rows_a is not None else None
+    ib = _device_index(rows_b, b.device, b.shape[0] if _validate else None) if rows_b is not None else None
+    flag = _flag(a.device)
     with torch.cuda.device(a.device):
         e0 = e1 = None
         if profiler is not None:
@@ -695,34 +783,32 @@ def contract_gathered(eq, a, rows_a, b, rows_b, out=None, label=None):
         N.check(rc)
         if profiler is not None:
             e1.record()
-            info = _info_cache.get(id(d))
-            if info is None:
-                info = _info_cache[id(d)] = _query(d)
-            profiler.record(info, e0, e1)
-    gather_rows.last_flag = flag
+            profiler.record(_step_info_cached(d), e0, e1)
+    _flags_used.add(a.device)
     return out
 
 
-def gather_rows(t, idx):
+def gather_rows(t, idx, _validate=True):
     """t[idx] along dim 0 through artn_gather_rows (reference contraction.py:149-150 etc.).
-    An index that selects every row in order returns `t` itself (the reference copies)."""
+    An index that selects every row in order returns `t` itself (the reference copies).
+    Indices are validated once per index tensor on the host (out of range raises, negative wraps:
+    the reference's indexing semantics); the kernel additionally zero-fills and flags any row it
+    could not read (check_gather_flag)."""
     N.require_gpu(t, "gather_rows")
     if t.dim() > 0 and _is_identity(idx, t.shape[0]):
         return t
     t = t.contiguous()
-    dev_idx = _device_index(idx, t.device)
+    dev_idx = _device_index(idx, t.device, t.shape[0] if _validate and t.dim() > 0 else None)
     nrows = dev_idx.numel()
     out = torch.empty((nrows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     if out.numel() == 0:
         return out
     row_bytes = (t.numel() // t.shape[0]) * t.element_size()
-    flag = _flag_cache.get(t.device)   # sticky out-of-range flag, one per device
-    if flag is None:
-        flag = _flag_cache[t.device] = torch.zeros(1, dtype=torch.int32, device=t.device)
+    flag = _flag(t.device)   # sticky out-of-range flag, one per device
     with torch.cuda.device(t.device):
         N.check(N.lib().artn_gather_rows(t.data_ptr(), dev_idx.data_ptr(), out.data_ptr(), nrows, row_bytes,
                                          t.shape[0], flag.data_ptr(), N.current_stream_ptr(t.device)))
-    gather_rows.last_flag = flag  # checked lazily by callers that can afford a sync
+    _flags_used.add(t.device)
     return out
 
 
@@ -806,6 +892,9 @@ def _sparse_step(tensors, step):
         tensors[j] = []
 
 
+_defer = threading.local()   # .flag_check: the slice loop reads the gather flag once, after its last slice
+
+
 def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=False):
     """Run a sparse-state scheme (reference contraction.py:132-205); the four branches are
     keyed exactly like the reference:
@@ -825,8 +914,6 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
     key = id(scheme)
     hit = _schedule_cache.get(key)
     if hit is None or hit[0] is not scheme:
-        if len(_schedule_cache) > 64:
-            _schedule_cache.clear()
         hit = _schedule_cache[key] = (scheme, fusion_schedule(scheme))
     factor = None
     last = scheme[-1][0][0]
@@ -846,6 +933,8 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
         for n in range(len(scheme)):
             one(n)
             normalize(scheme[n][0][0])
+        if _flags_used and not getattr(_defer, "flag_check", False):
+            check_gather_flag("tensor_contraction_sparse")
         return factor.reshape(()).to(tensors[last].dtype), tensors[last]
 
     for entry in hit[1]:
@@ -879,6 +968,10 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
             tensors[s1[0][0]] = fused
             tensors[s1[0][1]] = []
             tensors[s2[0][1]] = []
+    # abort-on-failure semantics of the reference (contraction.py:192-195) for the one failure the
+    # kernels cannot raise themselves: one flag read per scheme (the slice loop defers it to its end)
+    if _flags_used and not getattr(_defer, "flag_check", False):
+        check_gather_flag("tensor_contraction_sparse")
     return tensors[last]
 
 

@@ -1472,6 +1472,9 @@ int artn_contract_gather(const ArtnStepDesc *d, const void *A, const void *B, vo
   if (d->stride_c[label] < 0) return fail(ARTN_E_INVALID, "the gathered label must be an output label");
   if ((rows_a && (d->stride_a[label] < 0 || src_rows_a < 1)) || (rows_b && (d->stride_b[label] < 0 || src_rows_b < 1)))
     return fail(ARTN_E_INVALID, "row indices for an operand that does not carry the label");
+  // the tiled kernel moves 16-byte lanes (artn_contract falls back to the strided kernel instead;
+  // there is no strided gather, so the caller gathers explicitly)
+  if ((((uintptr_t)A | (uintptr_t)C) & 15) != 0) return fail(ARTN_E_UNSUPPORTED, "row gather needs 16-byte aligned operands");
   ArtnPlan p;
   std::string err;
   int rc = artn::make_plan(d, p, err, g_ncu, true, 1, label);

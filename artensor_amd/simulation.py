@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import _native as N
+from . import contraction as _C
 from .contraction import _labels, _sparse_step, contract, tensor_contraction, tensor_contraction_sparse
 
 __all__ = ["slice_assignments", "rank_slices", "apply_slice", "accumulate", "sliced_contraction",
@@ -90,7 +91,9 @@ def split_scheme(scheme, shapes):
     scheme once the results of the small steps are supplied as tensors).  `shapes` maps tensor
     id -> leaf shape."""
     shapes = dict(shapes)
-    tainted = set()
+    tainted = set()      # ids written by a main step: what they hold is not a small tensor any more
+    main_reads = set()   # ids a main step reads as its second operand: a later step that overwrites one
+                         # must stay behind that main step (the executors' semantics are sequential)
     small, main = [], []
 
     def numel(sh):
@@ -102,7 +105,7 @@ def split_scheme(scheme, shapes):
     for n, step in enumerate(scheme):
         i, j = step[0]
         out_shape = None
-        if (i not in tainted and j not in tainted and i in shapes and j in shapes
+        if (i not in tainted and j not in tainted and i not in main_reads and i in shapes and j in shapes
                 and (len(step) == 2 or (len(step[2][0]) <= 1 and len(step[2][1]) <= 1))):
             out_shape = _small_step_shape(step, shapes[i], shapes[j])
         if out_shape is not None and max(numel(shapes[i]), numel(shapes[j]), numel(out_shape)) <= SMALL_NUMEL:
@@ -111,6 +114,7 @@ def split_scheme(scheme, shapes):
         else:
             main.append(step)
             tainted.add(i)
+            main_reads.add(j)
             shapes.pop(i, None)
     return small, main, shapes
 
@@ -163,7 +167,19 @@ class SliceRunner:
     """
 
     def __init__(self, tensors, scheme, slicing_indices, out_shape, sparse=False, dtype=torch.complex64,
-                 device="cuda", graph=False, reuse_small=True, _execute=None, _accumulate=None):
+                 device="cuda", graph=False, reuse_small=True):
+        self._setup(tensors, scheme, slicing_indices, out_shape, sparse, dtype, device, graph, reuse_small, None, None)
+
+    @classmethod
+    def _with_seams(cls, tensors, scheme, slicing_indices, out_shape, sparse, dtype, device, execute, accumulate):
+        """Test seam (tests/test_distributed.py): a runner whose executor / accumulator are injected, so
+        the sharding and reduction logic can run on CPU boxes.  Never used by the product path."""
+        self = cls.__new__(cls)
+        self._setup(tensors, scheme, slicing_indices, out_shape, sparse, dtype, device, False, False, execute, accumulate)
+        return self
+
+    def _setup(self, tensors, scheme, slicing_indices, out_shape, sparse, dtype, device, graph, reuse_small,
+               _execute, _accumulate):
         self.execute = _execute or (tensor_contraction_sparse if sparse else tensor_contraction)
         self.add = _accumulate or accumulate
         self.scheme = scheme
@@ -244,7 +260,20 @@ class SliceRunner:
         self.add(self.collect, res.reshape(self.collect.shape))
 
     def run(self, slices):
-        """Contract the given slice numbers and add them to `self.collect` (returned)."""
+        """Contract the given slice numbers and add them to `self.collect` (returned).  The gather
+        kernels' out-of-range flag is read once, after the last slice (one sync per call, not per
+        slice), and raises RuntimeError -- the reference aborts on the first bad step."""
+        prev = getattr(_C._defer, "flag_check", False)
+        _C._defer.flag_check = True
+        try:
+            self._run(slices)
+        finally:
+            _C._defer.flag_check = prev
+        if _C._flags_used and not prev:
+            _C.check_gather_flag("SliceRunner.run")
+        return self.collect
+
+    def _run(self, slices):
         for s in slices:
             cfg = slice_assignments(self.n_bonds, s)
             if self.reuse_small:
@@ -277,7 +306,7 @@ class SliceRunner:
 
 def sliced_contraction(tensors, scheme, slicing_indices, out_shape, sparse=False, permute_dims=None,
                        dtype=torch.complex64, device="cuda", group=None, slices=None, reduce="all",
-                       graph=False, reuse_small=True, runner=None, _execute=None, _accumulate=None):
+                       graph=False, reuse_small=True, runner=None):
     """The slice loop (reference simulation.py:101-116) on one rank of `group`.
 
     tensors         leaf tensors (dict or list) already on `device` or movable to it
@@ -289,19 +318,22 @@ def sliced_contraction(tensors, scheme, slicing_indices, out_shape, sparse=False
                     in Gray-code order
     graph           True: replay whole slices from a captured HIP graph instead
     runner          a SliceRunner to reuse across calls (its accumulator is zeroed first)
-    _execute/_accumulate   test seams: the world_size-2 gloo tests of the sharding and
-                    reduction logic run on CPU boxes and inject a CPU executor; the
-                    product path never sets them (defaults are the HIP kernels)
     """
+    if runner is None:
+        runner = SliceRunner(tensors, scheme, slicing_indices, out_shape, sparse=sparse, dtype=dtype, device=device,
+                             graph=graph, reuse_small=reuse_small)
+    else:
+        runner.collect.zero_()
+    return _shard_and_reduce(runner, permute_dims, group, slices, reduce)
+
+
+def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce="all"):
+    """Sharding + the single reduction of sliced_contraction around a ready SliceRunner (also the entry
+    of the CPU tests, which hand in a runner built by SliceRunner._with_seams)."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
     rank = dist.get_rank(group) if distributed else 0
     world = dist.get_world_size(group) if distributed else 1
-    if runner is None:
-        runner = SliceRunner(tensors, scheme, slicing_indices, out_shape, sparse=sparse, dtype=dtype, device=device,
-                             graph=graph, reuse_small=reuse_small, _execute=_execute, _accumulate=_accumulate)
-    else:
-        runner.collect.zero_()
     if slices is None:
         slices = rank_slices(2 ** runner.n_bonds, rank, world, gray=runner.reuse_small)
     collect = runner.run(slices)

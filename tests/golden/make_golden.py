@@ -543,6 +543,81 @@ def case_n53_slice0(which="m14"):
     save_case(path, case.tensors, case.scheme, meta, arrays=out, slicing_indices=case.slicing_indices)
 
 
+def n53_batch_bitstrings(n_open=16, count=1024, seed=53):
+    """BASELINE configs[4] ("big-batch sampling"): `count` distinct bitstrings that agree on 53 - n_open
+    closed qubits (all '0') and vary on n_open randomly placed open ones -- a strict subset of the
+    2^n_open product, so the sparse compiler has to emit row selects / gathered steps."""
+    rng = np.random.RandomState(seed)
+    open_pos = np.sort(rng.choice(53, size=n_open, replace=False))
+    seen, bits = set(), []
+    while len(bits) < count:
+        x = int(rng.randint(0, 2 ** n_open))
+        if x in seen:
+            continue
+        seen.add(x)
+        s = ["0"] * 53
+        for k, p in enumerate(open_pos):
+            s[p] = str((x >> k) & 1)
+        bits.append("".join(s))
+    return bits, [int(p) for p in open_pos]
+
+
+def case_n53m20_batch_plan(sc_target=30):
+    """The bundled n53 m20 circuit with a batch of 1 024 correlated bitstrings (configs[4]): plan,
+    leaf tensors, sparse scheme with its index tensors, slicing indices."""
+    bits, open_pos = n53_batch_bitstrings()
+    sim, meta = plan(N53_M20, bits, sc_target)
+    kinds = dict(A=0, B=0, C=0, C_select=0, D=0)
+    for st in sim.scheme:
+        if len(st[2][0]) > 1:
+            kinds["A"] += 1
+        elif len(st) > 3 and len(st[2][0]) == len(st[2][1]) == 1:
+            kinds["B"] += 1
+        elif len(st) > 3:
+            kinds["C"] += 1
+            kinds["C_select"] += len(st[2][0]) == 1
+        else:
+            kinds["D"] += 1
+    meta["branches"] = kinds
+    meta["open_qubits"] = open_pos
+    meta["n_slicing"] = len(sim.slicing_indices)
+    meta["reference_slice_loop_well_defined"] = bool(slicing_ok(sim))
+    meta["derivation"] = "circuit_n53_m20_s0_e0_pABCDCDAB.qsim as bundled; 1024 bitstrings over 16 open qubits"
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    fixed, touched = {}, 0   # see case_n53_plan: dims of the actual (batch-carrying) tensors
+    for bond, lst in sim.slicing_indices.items():
+        fixed[bond] = []
+        for tid, ind in lst:
+            shift = tensors[tid].dim() - len(sim.tensor_bonds[tid])
+            touched += shift != 0
+            fixed[bond].append((tid, ind + shift))
+    meta["slicing_dims_shifted_for_batch_dim"] = int(touched)
+    save_case(os.path.join(HERE, "n53_m20_batch.npz"), tensors, sim.scheme, meta, slicing_indices=fixed)
+    print("n53_m20_batch plan:", len(sim.scheme), "steps,", len(sim.slicing_indices), "sliced bonds, log10 tc/slice",
+          meta["log10_tc"], "sc", meta["sc"], "branches", kinds, flush=True)
+
+
+def case_n53m20_batch_slice0():
+    """Reference sparse executor (contraction.py:132-205) on slice 0 of the big-batch plan, torch-CPU."""
+    from artensor_amd.fixtures import load_case
+    from artensor_amd.simulation import apply_slice, slice_assignments
+    path = os.path.join(HERE, "n53_m20_batch.npz")
+    case = load_case(path)
+    cfg = slice_assignments(len(case.slicing_indices), 0)
+    sliced = apply_slice(case.fresh_tensors(), case.slicing_indices, cfg)
+    t0 = time.time()
+    res = tensor_contraction_sparse(sliced, case.scheme)
+    dt = time.time() - t0
+    print("n53 m20 batch slice 0:", tuple(res.shape), f"{dt:.0f} s", flush=True)
+    meta = case.meta
+    for k in ("tensor_ids", "steps", "slicing_indices"):
+        meta.pop(k, None)
+    meta["reference_cpu_seconds_per_slice"] = dt
+    meta["reference_cpu_threads"] = torch.get_num_threads()
+    save_case(path, case.tensors, case.scheme, meta, arrays=dict(slice0=res.reshape(-1).numpy().copy()),
+              slicing_indices=case.slicing_indices)
+
+
 def case_random_bench():
     """Benchmark-scale random tensor networks (SURVEY 8d input 2: 3-regular graphs, seed 0, leaves
     complex(randn, randn) / D^1.5, planned by the reference's find_order, trials 4, iters 5):
@@ -597,6 +672,8 @@ CASES = {
     "n53_slice0": case_n53_slice0,
     "n53m20_plan": lambda: case_n53_plan("m20"),
     "n53m20_slice0": lambda: case_n53_slice0("m20"),
+    "n53m20_batch_plan": case_n53m20_batch_plan,
+    "n53m20_batch_slice0": case_n53m20_batch_slice0,
     "trees": case_trees,
     "n12_dense": case_n12_dense,
     "n12_sparse5": case_n12_sparse5,

@@ -89,3 +89,45 @@ def test_label_tuples_lift_the_alphabet_limit():
     assert info["flops"] == 8.0 * 2.0 ** 60
     with pytest.raises(RuntimeError, match="alphabet"):
         A.einsum_eq_convert(([list(la)], [list(lb)])[0] + [list(lb)], list(lo))
+
+
+def test_row_indices_are_validated_on_the_host_with_the_reference_semantics():
+    """tensors[i][idx] in the reference (contraction.py:149-150, :177-178, :187) raises IndexError for
+    an index outside [-rows, rows) and wraps negative ones; _device_index does both once per index
+    tensor, before anything is launched."""
+    from artensor_amd import contraction as C
+    ok = torch.tensor([0, 3, -1, -4, 2])
+    dev = C._device_index(ok, "cpu", 4)
+    assert dev.tolist() == [0, 3, 3, 0, 2]
+    assert C._device_index(ok, "cpu", 4) is dev                 # cached per (index tensor, rows)
+    with pytest.raises(RuntimeError, match="row index out of range"):
+        C._device_index(torch.tensor([0, 4]), "cpu", 4)
+    with pytest.raises(RuntimeError, match="row index out of range"):
+        C._device_index(torch.tensor([-5]), "cpu", 4)
+    assert C._device_index(torch.tensor([7, 9]), "cpu", None).tolist() == [7, 9]   # unvalidated (kernel flag tests)
+
+
+def test_precision_is_thread_local_and_caches_are_bounded():
+    import threading
+    from artensor_amd import contraction as C
+    seen = {}
+
+    def other():
+        seen["before"] = C.precision.current()
+        with C.precision("bf16"):
+            seen["inside"] = C.precision.current()
+        seen["after"] = C.precision.current()
+
+    with C.precision("bf16"):
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        assert C.precision.current() == "bf16"
+    assert C.precision.current() is None
+    assert seen == {"before": None, "inside": "bf16", "after": None}
+    b = C._Bounded(3)
+    for k in range(10):
+        b[k] = k
+        assert len(b) <= 3
+    assert b[9] == 9
+    assert isinstance(C._desc_cache, C._Bounded) and isinstance(C._plan_cache, C._Bounded)

@@ -1,7 +1,9 @@
 """The N > 1 path on CPU: slice sharding + the single reduce of artensor_amd.sliced_contraction
-with world_size 2 over gloo.  The HIP executors cannot run here, so the test injects the CPU
-oracle through the function's test seams; what is exercised is the product's slice
-assignment, per-tensor slice application, accumulation order and the collective."""
+with world_size 2 over gloo.  The HIP executors cannot run here, so the test builds its runner with
+SliceRunner._with_seams (CPU oracle as executor) and enters below the public signature at
+_shard_and_reduce; what is exercised is the product's slice assignment, per-tensor slice
+application, accumulation order and the collective.  The same path with the real HIP executors
+and two processes on one GPU is tests/test_gpu_parity.py::test_two_process_sliced_contraction."""
 import os
 import socket
 import sys
@@ -50,9 +52,10 @@ def _worker(rank, world, port, name, reduce, out_dir):
         case = load_case(os.path.join(GOLDEN, name + ".npz"))
         want = case.arrays["final"]
         sparse = case.meta.get("pattern") == "sparse"
-        out = A.sliced_contraction(case.tensors, case.scheme, case.slicing_indices, want.shape, sparse=sparse,
-                                   device="cpu", reduce=reduce, _execute=_oracle_execute(sparse),
-                                   _accumulate=_cpu_add)
+        from artensor_amd import simulation as S
+        runner = S.SliceRunner._with_seams(case.tensors, case.scheme, case.slicing_indices, want.shape, sparse,
+                                           torch.complex64, "cpu", _oracle_execute(sparse), _cpu_add)
+        out = S._shard_and_reduce(runner, reduce=reduce)
         np.save(os.path.join(out_dir, f"{name}_{reduce}_{rank}.npy"), out.numpy())
     finally:
         dist.destroy_process_group()

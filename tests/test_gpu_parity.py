@@ -297,12 +297,23 @@ def test_contract_gathered():
         # one operand gathered only
         got = contract_gathered(eq, gpu(a), ra, gpu(b[rb.numpy()]), None)
         assert got is not None and rel(got.cpu().numpy(), want) < STEP_TOL
-    A.contraction.gather_rows.last_flag.zero_()
+    # an index outside the operand: refused on the host (the reference raises IndexError) ...
     bad = torch.tensor([0, 99, 1, 2, 3, 4])
-    contract_gathered("zABCDEFGHIJKL,zLKa->zABCDEFGHIJa", gpu(crandn(rng, (7,) + (2,) * 12)), bad,
-                      gpu(crandn(rng, (6, 2, 2, 2))), None)
-    assert int(A.contraction.gather_rows.last_flag.item()) == 1
-    A.contraction.gather_rows.last_flag.zero_()
+    big, small = gpu(crandn(rng, (7,) + (2,) * 12)), gpu(crandn(rng, (6, 2, 2, 2)))
+    with pytest.raises(RuntimeError, match="row index out of range"):
+        contract_gathered("zABCDEFGHIJKL,zLKa->zABCDEFGHIJa", big, bad, small, None)
+    # ... and, should it ever reach the kernel, flagged there and raised by the next flag check
+    A.contraction.check_gather_flag()
+    contract_gathered("zABCDEFGHIJKL,zLKa->zABCDEFGHIJa", big, bad, small, None, _validate=False)
+    with pytest.raises(RuntimeError, match="outside its operand"):
+        A.contraction.check_gather_flag("test")
+    A.contraction.check_gather_flag()   # cleared
+    # negative indices count from the end, as in the reference's tensors[i][idx]
+    neg = torch.tensor([-1, 0, -7, 3])
+    a_np, b_np = crandn(rng, (7,) + (2,) * 12), crandn(rng, (4, 2, 2, 2))
+    got = contract_gathered("zABCDEFGHIJKL,zLKa->zABCDEFGHIJa", gpu(a_np), neg, gpu(b_np), None)
+    want = oracle.einsum_pair("zABCDEFGHIJKL,zLKa->zABCDEFGHIJa", a_np[neg.numpy()], b_np)
+    assert rel(got.cpu().numpy(), want) < STEP_TOL
     assert contract_gathered("zab,zbc->zac", gpu(crandn(rng, (4, 2, 2))), torch.tensor([0, 1]),
                              gpu(crandn(rng, (4, 2, 2))), torch.tensor([1, 1])) is None
 
@@ -319,9 +330,16 @@ def test_gather_axpy_normalize():
     assert np.array_equal(A.contraction.gather_rows(gpu(t), torch.arange(5)).cpu().numpy(), t[:5])
     empty = A.contraction.gather_rows(gpu(crandn(rng, (4, 2))), torch.zeros(0, dtype=torch.int64))
     assert empty.shape == (0, 2)
-    # out-of-range rows are zero-filled and flagged, never read
-    A.contraction.gather_rows(gpu(crandn(rng, (4, 2))), torch.tensor([0, 9]))
-    assert int(A.contraction.gather_rows.last_flag.item()) == 1
+    # out-of-range rows: refused on the host; in the kernel zero-filled and flagged, never read
+    with pytest.raises(RuntimeError, match="row index out of range"):
+        A.contraction.gather_rows(gpu(crandn(rng, (4, 2))), torch.tensor([0, 9]))
+    A.contraction.check_gather_flag()
+    z = A.contraction.gather_rows(gpu(crandn(rng, (4, 2))), torch.tensor([0, 9]), _validate=False)
+    assert np.all(z.cpu().numpy()[1] == 0)
+    with pytest.raises(RuntimeError, match="outside its operand"):
+        A.contraction.check_gather_flag("test")
+    t4 = crandn(rng, (4, 2))
+    assert np.array_equal(A.contraction.gather_rows(gpu(t4), torch.tensor([-1, 0, -4])).cpu().numpy(), t4[[-1, 0, -4]])
     for rows, cols in [(2, 2), (5, 6), (64, 1024), (4096, 130), (131072, 16), (37, 4098)]:
         t = crandn(rng, (rows, cols))
         got = A.contraction.sum_leading(gpu(t), rows).cpu().numpy()

@@ -75,3 +75,36 @@ def test_split_scheme_small_then_main_equals_whole(name, limit, monkeypatch):
         assert not main  # n12: every step is small
     else:
         assert small and main
+
+
+def test_split_scheme_keeps_a_reused_operand_behind_the_main_step_that_reads_it():
+    """a main step (X, Y) followed by a small step that overwrites Y.  The executors'
+    semantics are sequential (reference contraction.py:66-70), so the small step may not be hoisted in
+    front of the main step that still has to read the old Y."""
+    rng = np.random.default_rng(5)
+
+    def t(*shape):
+        return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+
+    leaves = {0: t(2, 2, 2, 2), 1: t(2, 2), 2: t(2, 2), 3: t(2, 2)}
+    scheme = [((0, 1), "abcd,de->abce"),   # main (operand 0 is "big" under the limit below); reads Y = 1
+              ((1, 2), "de,ef->df"),       # small, but overwrites Y after the main step read it
+              ((0, 1), "abce,ef->abcf"),   # main again, reads the NEW Y
+              ((0, 3), "abcf,fa->bc")]
+    import artensor_amd.simulation as S2
+    old = S2.SMALL_NUMEL
+    S2.SMALL_NUMEL = 8
+    try:
+        small, main, _ = S.split_scheme(scheme, {k: v.shape for k, v in leaves.items()})
+    finally:
+        S2.SMALL_NUMEL = old
+    assert small == []                      # step 1 stays behind step 0
+    assert main == scheme
+    whole = oracle.tensor_contraction(dict(leaves), scheme)
+    cur = dict(leaves)
+    for n in small:
+        scratch = {scheme[n][0][0]: cur[scheme[n][0][0]], scheme[n][0][1]: cur[scheme[n][0][1]]}
+        oracle.tensor_contraction(scratch, [scheme[n]])
+        cur[scheme[n][0][0]] = scratch[scheme[n][0][0]]
+    got = oracle.tensor_contraction(cur, main)
+    assert np.allclose(got, whole)
