@@ -6,8 +6,12 @@ Drop-in for the hot path of Fanerst/artensor:
     from artensor_amd import contraction_scheme, contraction_scheme_sparse   # scheme compilers
     from artensor_amd import TensorNetworkSimulation, sliced_contraction     # slice loop, multi-GPU
 
-Planning (AbstractTensorNetwork / ContractionTree / find_order / GreedyOrderFinder) is not
-part of this package: the engine consumes the planner's products unchanged.
+    from artensor_amd import tensor_network_contraction, quantum_circuit_simulation   # one-call API
+
+Planning (AbstractTensorNetwork / ContractionTree / find_order / GreedyOrderFinder, the circuit parser)
+is not part of this package: the engine consumes the planner's products unchanged; the one-call API and
+TensorNetworkSimulation.from_circuit_file / prepare_contraction forward the planning half to the
+reference's front end (the installed `artensor` package, or `planner=`).
 """
 from .contraction import (  # noqa: F401
     contract,
@@ -25,9 +29,11 @@ from .simulation import (  # noqa: F401
     TensorNetworkSimulation,
     accumulate,
     apply_slice,
+    quantum_circuit_simulation,
     rank_slices,
     slice_assignments,
     sliced_contraction,
+    tensor_network_contraction,
 )
 
 from .network import tn_contract  # noqa: F401

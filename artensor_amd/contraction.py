@@ -509,7 +509,7 @@ def _compile_dense(scheme, shapes, dtype):
     fuse_ok = dtype == torch.complex64
     ops = []
 
-    def emit(n, i, j, la, lb, lo, sa, sb):
+    def emit(n, i, j, la, lb, lo, sa, sb, warn=True):
         op = _Op()
         op.steps, op.i, op.j, op.j2, op.d2 = (n,), i, j, None, None
         op.d1, op.out_shape = _descriptor(la, lb, lo, sa, _dense_strides(sa), sb, _dense_strides(sb), dtype)
@@ -519,7 +519,8 @@ def _compile_dense(scheme, shapes, dtype):
         numel = 1
         for e in (sa if len(sa) >= len(op.out_shape) else op.out_shape):
             numel *= e
-        _warn_if_generic(op.d1, numel, f"tensor_contraction step {n}")
+        if warn:
+            _warn_if_generic(op.d1, numel, f"tensor_contraction step {n}")
         return op.out_shape
 
     def single(n):
@@ -531,7 +532,7 @@ def _compile_dense(scheme, shapes, dtype):
             # split-K through a temporary batch label, then sum it out (see _split_big_k)
             mid = tuple(outer) + tuple(lo)
             mid_shape = emit(n, i, j, la, lb, mid, shapes[i], shapes[j])
-            shapes[i] = emit(n, i, _ONE, mid, (), lo, mid_shape, ())
+            shapes[i] = emit(n, i, _ONE, mid, (), lo, mid_shape, (), warn=False)   # runs as artn_sum_axis_c64
             rows = 1
             for e in mid_shape[:len(outer)]:
                 rows *= e

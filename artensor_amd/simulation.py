@@ -18,7 +18,7 @@ from . import contraction as _C
 from .contraction import _labels, _sparse_step, contract, tensor_contraction, tensor_contraction_sparse
 
 __all__ = ["slice_assignments", "rank_slices", "apply_slice", "accumulate", "sliced_contraction",
-           "SliceRunner", "TensorNetworkSimulation"]
+           "SliceRunner", "TensorNetworkSimulation", "tensor_network_contraction", "quantum_circuit_simulation"]
 
 
 def slice_assignments(n_bonds, s):
@@ -348,6 +348,56 @@ def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce
     return collect
 
 
+def _planner(planner=None):
+    """The planning front end (circuit parser, simplifier, order finder, contraction tree): the
+    reference package itself -- `north_star` keeps it untouched -- or any module with the same names."""
+    if planner is not None:
+        return planner
+    try:
+        import artensor
+    except ImportError as e:
+        raise RuntimeError("planning stays with the reference's front end: install Fanerst/artensor next to "
+                           "artensor_amd, or pass planner=<module with the same API>") from e
+    return artensor
+
+
+def _bond_owners(tensor_bonds):
+    owners = {}
+    for tid, bonds in tensor_bonds.items():
+        for b in bonds:
+            owners.setdefault(b, []).append(tid)
+    return owners
+
+
+def _slicing_indices(slicing_bonds, tensor_bonds, tensors):
+    """bond -> [(tensor id, dim)], dims of the ACTUAL leaf tensors.  The reference takes the bond's
+    position in tensor_bonds[tid] (simulation.py:60-65, :176-178); in the sparse pattern a final-qubit
+    leaf carries a leading batch dim that tensor_bonds does not list, so its select() would hit the
+    batch dim there -- the offset is added here."""
+    owners = _bond_owners(tensor_bonds)
+    out = {}
+    for bond in slicing_bonds:
+        out[bond] = [(tid, tensor_bonds[tid].index(bond) + tensors[tid].dim() - len(tensor_bonds[tid]))
+                     for tid in owners.get(bond, [])]
+    return out
+
+
+def _output_permutation(output_bonds, tensor_bonds, final_qubits, sparse):
+    """Dims of the raw result -> final-qubit order (reference simulation.py:68-77, :186-195)."""
+    if len(output_bonds) == 0:
+        return None
+    owners = _bond_owners(tensor_bonds)
+    fq = list(final_qubits)
+    where = []
+    for b in output_bonds:
+        tids = owners[b]
+        if len(tids) != 1 or tids[0] not in fq:
+            raise RuntimeError(f"output bond {b!r} is not a dangling bond of a final-qubit tensor")
+        where.append(fq.index(tids[0]))
+    perm = [int(x) for x in np.argsort(where)]
+    return [0] + [d + 1 for d in perm] if sparse else perm
+
+
 class TensorNetworkSimulation:
     """Execution half of the reference class of the same name (simulation.py:33-148).
 
@@ -374,6 +424,54 @@ class TensorNetworkSimulation:
         return cls(sim.tensors, sim.scheme, sim.slicing_indices, sim.output_bonds, sim.pattern,
                    getattr(sim, "bitstrings_sorted", None), getattr(sim, "permute_dims", None))
 
+    # ---- the reference's own constructors and planning calls, forwarded to its front end -------------
+    @classmethod
+    def _from_front(cls, front):
+        self = cls(front.tensors, [], {}, [], front.pattern)
+        self._front = front
+        for name in ("tensor_bonds", "bond_dims", "final_qubits", "bitstrings", "max_bitstrings"):
+            setattr(self, name, getattr(front, name))
+        return self
+
+    @classmethod
+    def from_circuit_file(cls, circuit_filename, bitstrings=[], planner=None):
+        """Reference simulation.py:120-133: the circuit is parsed and simplified by the front end."""
+        return cls._from_front(_planner(planner).TensorNetworkSimulation.from_circuit_file(circuit_filename, bitstrings))
+
+    @classmethod
+    def from_tn_circuit(cls, circ, bitstrings=[], planner=None):
+        """Reference simulation.py:135-148."""
+        return cls._from_front(_planner(planner).TensorNetworkSimulation.from_tn_circuit(circ, bitstrings))
+
+    def prepare_contraction(self, sc_target=30, **planner_args):
+        """Reference simulation.py:47-77: the order finder runs in the front end (its keyword arguments
+        pass through); the scheme is then compiled by this package (`update_scheme`), slicing indices
+        are taken on the actual leaf tensors and the output permutation is recomputed from the tree."""
+        front = getattr(self, "_front", None)
+        if front is None:
+            raise RuntimeError("prepare_contraction needs an object built by from_circuit_file / from_tn_circuit")
+        front.prepare_contraction(sc_target=sc_target, **planner_args)
+        self.ctree = front.ctree
+        self.slicing_indices = _slicing_indices(list(front.slicing_indices.keys()), front.tensor_bonds, front.tensors)
+        self.update_scheme(sc_target, self.bitstrings)
+        perm = _output_permutation(self.output_bonds, front.tensor_bonds, front.final_qubits, self.pattern == "sparse")
+        if perm is not None:
+            self.permute_dims = perm
+        return self
+
+    def update_scheme(self, sc_target=30, bitstrings=[]):
+        """Reference simulation.py:79-88, with this package's compilers."""
+        from copy import deepcopy
+        from .contraction import contraction_scheme, contraction_scheme_sparse
+        if self.pattern == "normal":
+            self.scheme, self.output_bonds = contraction_scheme(deepcopy(self.ctree))
+        else:
+            self.scheme, self.output_bonds, self.bitstrings_sorted = contraction_scheme_sparse(
+                deepcopy(self.ctree), bitstrings, sc_target=sc_target)
+            if len(self.bitstrings_sorted) > self.max_bitstrings:
+                raise RuntimeError("more output rows than distinct bitstrings")
+        self.output_bonds = list(self.output_bonds)
+
     @classmethod
     def from_case(cls, case):
         m = case.meta
@@ -389,3 +487,49 @@ class TensorNetworkSimulation:
         permute = getattr(self, "permute_dims", None) if len(self.output_bonds) > 0 else None
         return sliced_contraction(src, self.scheme, self.slicing_indices, shape, sparse=self.pattern == "sparse",
                                   permute_dims=permute, dtype=dtype, device=device, group=group, reduce=reduce)
+
+
+def tensor_network_contraction(tensors, tensor_bonds, bond_dims, final_qubits, bitstrings=[], sc_target=31,
+                               trial_num=8, alpha=0.0, dtype=torch.complex64, device="cuda", planner=None,
+                               group=None, reduce="all"):
+    """One-call API of the reference (simulation.py:151-213), same arguments and return value
+    `(tensor, bitstrings)`.  Simplification and order finding run in the reference's front end
+    (`planner`, default: the installed `artensor` package) with the reference's own settings
+    (simulation.py:160-165: trials=trial_num, iters=50, betas 3..21 in 61 steps, start_seed 0); scheme
+    compilation, the slice loop and every contraction run here.  `group`/`reduce`: slices are sharded
+    over the ranks of a torch.distributed group with one reduction at the end (see sliced_contraction)."""
+    from copy import deepcopy
+    from .contraction import contraction_scheme, contraction_scheme_sparse
+    P = _planner(planner)
+    distinct = len(np.unique(bitstrings)) if len(bitstrings) else 0
+    sparse = distinct > 0
+    max_bitstrings = distinct if sparse else 1
+    net = P.NumericalTensorNetwork(tensors, tensor_bonds, bond_dims, final_qubits)
+    bonds_of, final_ids = net._simplify("sparse" if sparse else "normal")
+    order, slicing_bonds, ctree = P.find_order(
+        deepcopy(bonds_of), deepcopy(net.bond_dims), final_ids, 0, max_bitstrings, sc_target=sc_target,
+        trials=trial_num, iters=50, betas=np.linspace(3.0, 21.0, 61), start_seed=0, alpha=alpha)
+    leaves = {new: net.tensors[old] for new, old in enumerate(net.tensors.keys())}
+    slicing = _slicing_indices(slicing_bonds, bonds_of, leaves)
+    if sparse:
+        scheme, output_bonds, bitstrings = contraction_scheme_sparse(ctree, bitstrings, sc_target=sc_target)
+        if len(bitstrings) != max_bitstrings:
+            raise RuntimeError("the compiled scheme does not produce one row per distinct bitstring")
+        shape = [max_bitstrings] + [2] * len(output_bonds)
+    else:
+        scheme, output_bonds = contraction_scheme(ctree)
+        shape = [2] * len(output_bonds)
+    perm = _output_permutation(list(output_bonds), bonds_of, final_ids, sparse)
+    out = sliced_contraction(leaves, scheme, slicing, shape, sparse=sparse, permute_dims=perm, dtype=dtype,
+                             device=device, group=group, reduce=reduce)
+    return out, bitstrings
+
+
+def quantum_circuit_simulation(circuit_filename, bitstrings=[], sc_target=31, trial_num=8, alpha=0.0,
+                               dtype=torch.complex64, device="cuda", planner=None):
+    """Reference simulation.py:216-225: parse a qsim-format circuit with the front end's
+    TensorNetworkCircuit, then tensor_network_contraction."""
+    circ = _planner(planner).TensorNetworkCircuit(circuit_filename)
+    tensors, tensor_bonds, bond_dims, final_qubits = circ.to_numerical_tn()
+    return tensor_network_contraction(tensors, tensor_bonds, bond_dims, final_qubits, bitstrings, sc_target,
+                                      trial_num, alpha, dtype, device, planner=planner)
