@@ -29,6 +29,8 @@ from .simulation import (  # noqa: F401
     TensorNetworkSimulation,
     accumulate,
     apply_slice,
+    partition_output,
+    partitioned_contraction,
     quantum_circuit_simulation,
     rank_slices,
     slice_assignments,

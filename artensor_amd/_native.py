@@ -13,7 +13,7 @@ import torch
 
 ARTN_MAX_LABELS = 96
 ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
-KERNEL_GENERIC, KERNEL_BITS_MFMA = 0, 1
+KERNEL_GENERIC, KERNEL_BITS_MFMA, KERNEL_GEMM_MFMA = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARTN_LIB") or os.path.join(_HERE, "libartn_hip.so")  # ARTN_LIB: diagnostic builds

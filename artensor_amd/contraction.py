@@ -193,7 +193,9 @@ def _as_operand(t):
     return t
 
 
-MAX_TILE_K_BITS = 8  # contracted bits one LDS tile of the MFMA kernel can hold
+MAX_TILE_K_BITS = 8   # contracted bits one LDS tile of the state-streaming kernel can hold
+SPLIT_K_MIN_TILES = 512   # the GEMM kernel loops over any number of contracted bits inside a workgroup;
+                          # contracted labels are turned into a batch label only to get this many tiles
 
 
 _ONE = object()  # operand id of the scalar 1 in a compiled sum-out op
@@ -208,10 +210,16 @@ def _one_scalar(dtype, device):
     return t
 
 
-def _big_k_outer(la, lb, lo, a_shape, a_stride=None):
-    """Contracted labels to turn into a temporary batch label when a step contracts more bits
-    than one LDS tile holds: the slowest-varying ones of A, until MAX_TILE_K_BITS remain.
-    None when the step does not need / allow it."""
+def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None):
+    """Contracted labels to turn into a temporary batch label (split-K with the partial results in
+    HBM, summed afterwards), or None.
+
+    A step that contracts more bits than one LDS tile of the state-streaming kernel holds runs on the
+    two-operand GEMM kernel, which walks all contracted bits inside the workgroup -- no split needed
+    unless the result is so small that its tiles cannot fill the chip (closing steps: two 2^30
+    tensors contracted to 2^10 amplitudes); then the slowest-varying contracted labels of A are
+    split off until SPLIT_K_MIN_TILES workgroups have work.  Where the planner does not give the
+    step to the GEMM kernel the old rule applies: split until MAX_TILE_K_BITS remain."""
     numel = 1
     for e in a_shape:
         numel *= e
@@ -228,10 +236,24 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None):
         bits += e.bit_length() - 1
     if bits <= MAX_TILE_K_BITS:
         return None
+    keep = MAX_TILE_K_BITS
+    if b_shape is not None:
+        d, out_shape = _descriptor(tuple(la), tuple(lb), tuple(lo), tuple(a_shape), tuple(a_stride), tuple(b_shape),
+                                   tuple(b_stride if b_stride is not None else _dense_strides(tuple(b_shape))),
+                                   torch.complex64)
+        info = _step_info_cached(d)
+        if info["kernel"] == N.KERNEL_GEMM_MFMA:
+            want = 0   # bits to split off for parallelism
+            tiles = max(1, info["n_tiles"])
+            while (tiles << want) < SPLIT_K_MIN_TILES and bits - want > 6:
+                want += 1
+            if want == 0:
+                return None
+            keep = bits - want
     ka.sort(reverse=True)  # highest A stride first
     outer = []
     for _, x in ka:
-        if bits <= MAX_TILE_K_BITS:
+        if bits <= keep:
             break
         outer.append(x)
         bits -= a_shape[la.index(x)].bit_length() - 1
@@ -277,7 +299,7 @@ def _split_big_k(la, lb, lo, a, b):
     in HBM.  Returns None when the step does not need / allow it."""
     if a.dtype != torch.complex64:
         return None
-    outer = _big_k_outer(la, lb, lo, tuple(a.shape), tuple(a.stride()))
+    outer = _big_k_outer(la, lb, lo, tuple(a.shape), tuple(a.stride()), tuple(b.shape), tuple(b.stride()))
     if not outer:
         return None
     mid = tuple(outer) + tuple(lo)
@@ -526,7 +548,7 @@ def _compile_dense(scheme, shapes, dtype):
     def single(n):
         (i, j), eq = scheme[n][0], scheme[n][1]
         la, lb, lo = _labels(eq)
-        outer = _big_k_outer(la, lb, lo, shapes[i]) if dtype == torch.complex64 else None
+        outer = _big_k_outer(la, lb, lo, shapes[i], None, shapes[j]) if dtype == torch.complex64 else None
         if outer:
             # more contracted bits than one LDS tile holds (big x big steps of random networks):
             # split-K through a temporary batch label, then sum it out (see _split_big_k)

@@ -1,0 +1,347 @@
+// artn_gemm_kernel.h -- the two-operand LDS GEMM of libartn_hip.so (included by artn_kernels.hip).
+//
+// artn_k_bits streams ONE big operand and keeps the small one in registers; that stops paying
+// when a step contracts 7+ bits (the fragments fill the register file, one workgroup per CU) or
+// when the second operand is itself big (big x big steps of sliced circuits and random networks:
+// the reference's torch.einsum at artensor/contraction.py:70,179,190 takes any pair of operands).
+// Here both operands go through LDS:
+//
+//   workgroup  = a C tile of 2^mt x 2^nt elements (mt <= 7, nt <= 7), 4 waves in a wm x wn grid,
+//                each wave MB x NB MFMA blocks of 32 rows (m) x 16 complex columns (n);
+//   chunk      = 2^4 values of the contracted index: the [16][2^mt] piece of the first operand and
+//                the [16][2^nt] piece of the second are copied global -> registers -> LDS with
+//                16-byte lanes (element pairs along each operand's stride-1 bit), double buffered:
+//                the loads of chunk c+1 are in flight while chunk c is multiplied;
+//   k loop     = the remaining contracted bits, walked in Gray-code order (one stride added or
+//                subtracted per chunk), accumulators in registers throughout;
+//   epilogue   = accumulators -> LDS in C order (XOR-swizzled like artn_k_bits' stage output) ->
+//                16-byte coalesced stores, in passes of 2^13 elements.
+//
+// Arithmetic as in artn_k_bits: interleaved complex64 times the real block form of the other
+// operand on v_mfma_f32_32x32x2_f32, 8 real FLOP per complex multiply-add, fp32 throughout.
+// Lane roles of one MFMA pair (k pair s of a chunk, kc = 2s + h):
+//   W side (MFMA A operand): row i = lane&31 = 2*n_in_block + ro, value from B image [kc][n]
+//   X side (MFMA B operand): column j = lane&31 = m_in_block,     value from A image [kc][m]
+//   accumulator register r of lane (j, h): n_in_block = ((r>>1)&1) + 2h + 4(r>>2), ro = r&1.
+
+template <typename PlanT>
+__device__ __forceinline__ unsigned swz_gemm(unsigned elem_off, const PlanT &P) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < P.swz_n && ((elem_off >> P.swz_src[i]) & 1)) elem_off ^= 1u << P.swz_dst[i];
+  return elem_off;
+}
+
+// BF = true (ARTN_C64_BF16, the reduced-precision sampling mode): operands are rounded to bfloat16
+// (round to nearest even) when they enter LDS, chunks are 2^5 contracted values, and the images hold per
+// row and per 4 consecutive contracted values the 8 bf16 -- (re, im) x 4 -- that one lane feeds to
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate): image[kc >> 2][row][kc & 3], 16 bytes per lane
+// read.  Lane half h carries contracted bit 2: kc = 8t + 4h + u.  The W side turns its raw (re, im)
+// pairs into (re, -im) or (im, re) per output parity with one v_perm + one v_xor per pair.
+// Accumulation stays fp32.
+
+__device__ __forceinline__ void lds_write4(unsigned a, unsigned v) {
+  *(__attribute__((address_space(3))) unsigned *)(unsigned long)a = v;
+}
+
+template <int MB, int NB, bool BF = false>
+__global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                                                 float2 *__restrict__ C, const ArtnGemmPlan P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((unsigned)(unsigned long)(lds_byte_t *)smem != 0) __builtin_trap(); // LDS is addressed by raw byte offsets
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5, ro = j & 1;
+  const int mt = P.mt, nt = P.nt;
+  // both images are [16][2^7] whatever mt / nt (ARTN_GEMM_PITCH_LOG2): LDS offsets of the MFMA loop are immediates
+  // (fp32: [16][128] x 8 B; bf16: [8][128][4] x 4 B -- 16 KiB either way)
+  constexpr unsigned a_bytes = 8u << (ARTN_GEMM_PITCH_LOG2 + ARTN_GEMM_KC), b_bytes = a_bytes, stage_bytes = a_bytes + b_bytes;
+  constexpr unsigned ROW2 = 16u << ARTN_GEMM_PITCH_LOG2; // fp32: bytes between k pairs (two image rows)
+  constexpr int NVA = BF ? 8 : 4;                        // 16-byte global loads per thread and chunk, first operand
+  const int epi_bits = P.tc_bits < ARTN_GEMM_EPI_BITS ? P.tc_bits : ARTN_GEMM_EPI_BITS;
+  const unsigned epi_bytes = 8u << epi_bits;
+  const unsigned tab_base = 2 * stage_bytes > epi_bytes ? 2 * stage_bytes : epi_bytes;
+  long *offtab = reinterpret_cast<long *>(smem + tab_base);
+  long *kotab = offtab + 512 + 128;
+  if (tid < P.n_ko) {
+    kotab[2 * tid] = P.ko_sA[tid] * 8;
+    kotab[2 * tid + 1] = P.ko_sB[tid] * 8;
+  }
+  const OffTab OT = build_offset_table(P, offtab, tid);
+
+  // ---- copy threads: 16-byte chunk c = tid + 256 * u of an image, chunk bits 1.. -> strides
+  const int a_cb = P.ta_bits - 1, b_cb = P.tb_bits - 1;      // chunk-index bits
+  const int a_iters = a_cb > 8 ? 1 << (a_cb - 8) : 1, b_iters = b_cb > 8 ? 1 << (b_cb - 8) : 1;
+  const bool a_act = a_cb >= 8 || tid < (1 << a_cb), b_act = b_cb >= 8 || tid < (1 << b_cb);
+  unsigned a_gl = 0, a_ll = 0, b_gl = 0, b_ll = 0;
+#pragma unroll
+  for (int b = 1; b <= 8; ++b) {
+    if ((tid >> (b - 1)) & 1) {
+      if (b < P.ta_bits) { a_gl += (unsigned)P.a_stride[b] * 8u; a_ll += (unsigned)P.a_lds[b]; }
+      if (b < P.tb_bits) { b_gl += (unsigned)P.b_stride[b] * 8u; b_ll += (unsigned)P.b_lds[b]; }
+    }
+  }
+  long a_gi[3], b_gi[2];
+  unsigned a_li[3], b_li[2];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    a_gi[b] = 9 + b < P.ta_bits ? P.a_stride[9 + b] * 8 : 0;
+    a_li[b] = 9 + b < P.ta_bits ? (unsigned)P.a_lds[9 + b] : 0u;
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    b_gi[b] = 9 + b < P.tb_bits ? P.b_stride[9 + b] * 8 : 0;
+    b_li[b] = 9 + b < P.tb_bits ? (unsigned)P.b_lds[9 + b] : 0u;
+  }
+  const unsigned a_pair = (unsigned)P.a_lds[0], b_pair = (unsigned)P.b_lds[0]; // LDS bytes between the two elements of a lane load
+
+  // ---- MFMA lanes
+  const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
+  const bool w_active = wm < (1 << P.wm_log2);
+  const int n_in = j >> 1;
+  const bool w_valid = nt >= 4 || n_in < (1 << nt);
+  constexpr unsigned EB = BF ? 16u : 8u; // bytes per (row, k pair | k quad) slot
+  const unsigned lane_x = (((unsigned)h << ARTN_GEMM_PITCH_LOG2) + (unsigned)(wm * MB * 32 + j)) * EB;
+  const unsigned lane_w = a_bytes + (((unsigned)h << ARTN_GEMM_PITCH_LOG2) + (unsigned)(wn * NB * 16) + (unsigned)(w_valid ? n_in : 0)) * EB;
+  const unsigned w_sel = ro ? 0x01000302u : 0x03020100u, w_sign = ro ? 0u : 0x80000000u; // bf16 W side: (im, re) / (re, -im)
+
+  // ---- epilogue offsets (elements of the C-ordered result image, swizzled; fields are disjoint: XOR)
+  auto m_off = [&](int m_local) {
+    unsigned o = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i < mt && ((m_local >> i) & 1)) o |= 1u << P.m_pos[i];
+    return o;
+  };
+  auto n_off = [&](int n_local) {
+    unsigned o = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i < nt && ((n_local >> i) & 1)) o |= 1u << P.n_pos[i];
+    return o;
+  };
+  const unsigned lane_c = swz_gemm(m_off(wm * MB * 32 + j) | n_off(wn * NB * 16 + 2 * h), P);
+  unsigned c_mb[MB], c_nb[NB];
+#pragma unroll
+  for (int q = 0; q < MB; ++q) c_mb[q] = swz_gemm(m_off(q * 32), P);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) c_nb[q] = swz_gemm(n_off(q * 16), P);
+  const unsigned c_b0 = swz_gemm(n_off(1), P), c_q0 = swz_gemm(n_off(4), P), c_q1 = swz_gemm(n_off(8), P);
+  const int n_lim = nt >= 4 ? 16 : 1 << nt; // valid n_in_block values
+  // copy-out threads
+  const int o_cb = epi_bits - 1;
+  const int o_iters = o_cb > 8 ? 1 << (o_cb - 8) : 1;
+  const bool o_act = o_cb >= 8 || tid < (1 << o_cb);
+  unsigned o_gl = 0;
+#pragma unroll
+  for (int b = 1; b <= 8; ++b)
+    if (((tid >> (b - 1)) & 1) && b < P.tc_bits) o_gl += (unsigned)P.out_stride[b] * 8u;
+  long o_gi[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) o_gi[b] = 9 + b < epi_bits ? P.out_stride[9 + b] * 8 : 0;
+  const int n_pass = 1 << (P.tc_bits - epi_bits);
+  const long pass_stride = P.tc_bits > epi_bits ? P.out_stride[epi_bits] * 8 : 0;
+  const unsigned o_ll = swz_gemm((unsigned)tid * 2u, P) * 8u;
+
+  f32x4 va[NVA], vb[4];
+  auto issue = [&](const char *__restrict__ Ab, const char *__restrict__ Bb) {
+#pragma unroll
+    for (int u = 0; u < NVA; ++u) {
+      if (u < a_iters && a_act) {
+        const long o = ((u & 1) ? a_gi[0] : 0) + ((u & 2) ? a_gi[1] : 0) + ((u & 4) ? a_gi[2] : 0);
+        va[u] = *reinterpret_cast<const f32x4 *>(Ab + o + a_gl);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u < b_iters && b_act) {
+        const long o = ((u & 1) ? b_gi[0] : 0) + ((u & 2) ? b_gi[1] : 0);
+        vb[u] = *reinterpret_cast<const f32x4 *>(Bb + o + b_gl);
+      }
+    }
+  };
+  auto put = [&](unsigned d, unsigned pair, const f32x4 &v) {
+    if constexpr (BF) {
+      const unsigned p0 = pack_bf16(v[0], v[1]), p1 = pack_bf16(v[2], v[3]);
+      if (pair == 4u) *(lds_u2_t *)(unsigned long)d = u2_t{p0, p1};
+      else { lds_write4(d, p0); lds_write4(d + pair, p1); }
+    } else {
+      if (pair == 8u) lds_write16(d, v);
+      else { lds_write8(d, v2f_t{v[0], v[1]}); lds_write8(d + pair, v2f_t{v[2], v[3]}); }
+    }
+  };
+  auto fill = [&](unsigned buf) {
+#pragma unroll
+    for (int u = 0; u < NVA; ++u)
+      if (u < a_iters && a_act)
+        put(buf + a_ll + ((u & 1) ? a_li[0] : 0u) + ((u & 2) ? a_li[1] : 0u) + ((u & 4) ? a_li[2] : 0u), a_pair, va[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < b_iters && b_act)
+        put(buf + a_bytes + b_ll + ((u & 1) ? b_li[0] : 0u) + ((u & 2) ? b_li[1] : 0u), b_pair, vb[u]);
+  };
+
+  long t0 = blockIdx.x;
+  const long G = gridDim.x, n_tiles = P.n_tiles;
+  if ((G & 7) == 0) t0 = (long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3); // XCD-contiguous tile ranges
+  const int n_chunks = 1 << P.n_ko;
+  __syncthreads(); // tables are in LDS
+  TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
+  const char *Ac = reinterpret_cast<const char *>(A), *Bc = reinterpret_cast<const char *>(B);
+  if (t0 < n_tiles) {
+    off = tile_offsets<false>(P, OT, t0);
+    issue(Ac + off.a * 8, Bc + off.b1 * 8);
+    fill(0u);
+  }
+  __syncthreads();
+  unsigned cur = 0;
+  for (long tile = t0; tile < n_tiles; tile += G) {
+    const bool more_tiles = tile + G < n_tiles;
+    if (more_tiles) noff = next_offsets<false>(P, OT, off, tile, G);
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    long ka = 0, kb = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+      const bool last = c + 1 == n_chunks;
+      bool have_next = true;
+      if (!last) { // Gray code: chunk c+1 differs from chunk c in one looped bit
+        const int bit = __builtin_ctz((unsigned)(c + 1));
+        const unsigned gn = (unsigned)(c + 1) ^ ((unsigned)(c + 1) >> 1);
+        const long sa = kotab[2 * bit], sb = kotab[2 * bit + 1];
+        if ((gn >> bit) & 1) { ka += sa; kb += sb; } else { ka -= sa; kb -= sb; }
+        ka = uniform64(ka);
+        kb = uniform64(kb);
+        issue(Ac + off.a * 8 + ka, Bc + off.b1 * 8 + kb);
+      } else {
+        have_next = more_tiles;
+        if (have_next) issue(Ac + noff.a * 8, Bc + noff.b1 * 8);
+      }
+      // ---- multiply chunk `cur`
+      if (w_active) {
+        const unsigned base = cur * stage_bytes;
+        const unsigned xa = base + lane_x, wa = base + lane_w;
+        if constexpr (BF) {
+          // 4 groups of 8 contracted values; operands of group t+1 are read under the MFMAs of group t
+          u32x4_t X[2][MB], Wr[2][NB];
+          auto load_ops = [&](int t, u32x4_t (&x)[MB], u32x4_t (&w)[NB]) {
+#pragma unroll
+            for (int a = 0; a < MB; ++a) x[a] = __builtin_bit_cast(u32x4_t, lds_read16(xa + (unsigned)t * 4096u + (unsigned)a * 512u));
+#pragma unroll
+            for (int b = 0; b < NB; ++b) w[b] = __builtin_bit_cast(u32x4_t, lds_read16(wa + (unsigned)t * 4096u + (unsigned)b * 256u));
+          };
+          load_ops(0, X[0], Wr[0]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (t + 1 < 4) load_ops(t + 1, X[(t + 1) & 1], Wr[(t + 1) & 1]);
+            u32x4_t W[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const unsigned d = Wr[t & 1][b][e];
+                W[b][e] = w_valid ? (__builtin_amdgcn_perm(d, d, w_sel) ^ w_sign) : 0u;
+              }
+#pragma unroll
+            for (int a = 0; a < MB; ++a)
+#pragma unroll
+              for (int b = 0; b < NB; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, W[b]),
+                                                                   __builtin_bit_cast(bf16x8_t, X[t & 1][a]), acc[a][b], 0, 0, 0);
+          }
+        } else {
+          v2f_t X[2][MB], Wr[2][NB];
+          auto load_ops = [&](int s, v2f_t (&x)[MB], v2f_t (&w)[NB]) {
+#pragma unroll
+            for (int a = 0; a < MB; ++a) x[a] = lds_read8(xa + (unsigned)s * ROW2 + (unsigned)a * 256u);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) w[b] = lds_read8(wa + (unsigned)s * ROW2 + (unsigned)b * 128u);
+          };
+          load_ops(0, X[0], Wr[0]);
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            if (s + 1 < 8) load_ops(s + 1, X[(s + 1) & 1], Wr[(s + 1) & 1]);
+            float W0[NB], W1[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              const v2f_t bv = Wr[s & 1][b];
+              W0[b] = w_valid ? (ro ? bv.y : bv.x) : 0.f;
+              W1[b] = w_valid ? (ro ? bv.x : -bv.y) : 0.f;
+            }
+#pragma unroll
+            for (int a = 0; a < MB; ++a)
+#pragma unroll
+              for (int b = 0; b < NB; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[b], X[s & 1][a].x, acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[b], X[s & 1][a].y, acc[a][b], 0, 0, 0);
+              }
+          }
+        }
+      }
+      if (!last) {
+        fill((cur ^ 1u) * stage_bytes);
+        __syncthreads();
+        cur ^= 1u;
+      }
+    }
+    // ---- epilogue: accumulators -> C-ordered LDS image -> global, 2^13 elements per pass
+    char *Cb = reinterpret_cast<char *>(C) + off.c * 8;
+    for (int pass = 0; pass < n_pass; ++pass) {
+      __syncthreads(); // chunk buffers / previous pass are no longer read
+      unsigned lc = lane_c; // (opaque: 64 hoisted scatter addresses per lane would cost the accumulators their registers)
+      OPAQUE_V(lc);
+      if (w_active) {
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int b0 = 0; b0 < 2; ++b0) {
+                const int n_loc = b0 + 2 * h + 4 * q;
+                const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ (b0 ? c_b0 : 0u) ^ ((q & 1) ? c_q0 : 0u) ^ ((q >> 1) ? c_q1 : 0u);
+                if (n_loc < n_lim && (int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
+                  lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{acc[a][b][4 * q + 2 * b0], acc[a][b][4 * q + 2 * b0 + 1]});
+              }
+      }
+      __syncthreads();
+      char *Cp = Cb + pass * pass_stride;
+      // (a swizzle source may be the pass bit itself: its image under the swizzle belongs to every address of the pass)
+      unsigned oll = o_ll ^ ((swz_gemm((unsigned)pass << ARTN_GEMM_EPI_BITS, P) & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u), ogl = o_gl;
+      OPAQUE_V(oll);
+      OPAQUE_V(ogl);
+      for (int i0 = 0; i0 < o_iters; i0 += 4) {
+        f32x4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u;
+          if (i < o_iters && o_act) x[u] = lds_read16(oll ^ (swz_gemm((unsigned)i * 512u, P) * 8u));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u;
+          if (i < o_iters && o_act) {
+            long o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              if ((i >> b) & 1) o += o_gi[b];
+            *reinterpret_cast<f32x4 *>(Cp + o + ogl) = x[u];
+          }
+        }
+      }
+    }
+    __syncthreads(); // the result image has been read; the chunk buffers are free again
+    if (more_tiles) {
+      fill(0u);
+      __syncthreads();
+    }
+    cur = 0;
+    off = noff;
+  }
+}

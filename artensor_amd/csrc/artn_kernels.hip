@@ -132,7 +132,8 @@ struct OffTab {
   int first_generic;
   int g_log2;        // log2 of the grid size if it is a power of two inside the prefix, else -1
 };
-__device__ __forceinline__ OffTab build_offset_table(const ArtnBitsPlan &P, long *tab, int tid) {
+template <typename PlanT>
+__device__ __forceinline__ OffTab build_offset_table(const PlanT &P, long *tab, int tid) {
   OffTab T;
   int bits = 0, d = 0;
   for (; d < P.n_outer && P.outer[d].log2ext >= 0; ++d) bits += P.outer[d].log2ext;
@@ -205,8 +206,8 @@ __device__ __forceinline__ long uniform64(long x) {
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x >> 32));
   return (long)(((unsigned long)hi << 32) | lo);
 }
-template <bool GATHER = false>
-__device__ __forceinline__ TileOff tile_offsets(const ArtnBitsPlan &P, const OffTab &T, long tile) {
+template <bool GATHER = false, typename PlanT = ArtnBitsPlan>
+__device__ __forceinline__ TileOff tile_offsets(const PlanT &P, const OffTab &T, long tile) {
   long a = 0, b1 = 0, b2 = 0, c = 0;
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
@@ -245,8 +246,8 @@ __device__ __forceinline__ TileOff tile_offsets(const ArtnBitsPlan &P, const Off
 }
 
 // offsets(tile + G) from offsets(tile): one 32-byte LDS lookup when the grid is a power of two
-template <bool GATHER = false>
-__device__ __forceinline__ TileOff next_offsets(const ArtnBitsPlan &P, const OffTab &T, const TileOff &cur, long tile,
+template <bool GATHER = false, typename PlanT = ArtnBitsPlan>
+__device__ __forceinline__ TileOff next_offsets(const PlanT &P, const OffTab &T, const TileOff &cur, long tile,
                                                 long G) {
   if (T.g_log2 < 0) return tile_offsets<GATHER>(P, T, tile + G);
   const unsigned hi = (unsigned)(tile >> T.g_log2);
@@ -1136,6 +1137,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   STAMP_FLUSH
 }
 
+#include "artn_gemm_kernel.h"
+
 // ----------------------------------------------------------------------------------------
 // strided fallback: one thread per C element
 // ----------------------------------------------------------------------------------------
@@ -1365,6 +1368,10 @@ static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, 
                               hipStream_t st) {
   const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2;
   float2 *c = (float2 *)C;
+#ifdef ARTN_DEV_FEW // development builds only: one family of artn_k_bits instantiations (compiles in seconds)
+  if (p.bits.st[0].k == 4) return launch_bits_k2<4>(p, a, b1, b2, c, st);
+  return hipErrorInvalidValue;
+#else
   switch (std::min(p.bits.st[0].k, 6)) {
     case 1: return launch_bits_k2<1>(p, a, b1, b2, c, st);
     case 2: return launch_bits_k2<2>(p, a, b1, b2, c, st);
@@ -1373,6 +1380,48 @@ static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, 
     case 5: return launch_bits_k2<5>(p, a, b1, b2, c, st);
     case 6: return launch_bits_k2<6>(p, a, b1, b2, c, st);
   }
+  return hipErrorInvalidValue;
+#endif
+}
+
+static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, void *C, hipStream_t st) {
+  const ArtnGemmPlan &g = p.gemm;
+  const float2 *a = (const float2 *)(g.swapped ? B : A), *b = (const float2 *)(g.swapped ? A : B);
+  float2 *c = (float2 *)C;
+  dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
+  const size_t lds = (size_t)p.info.lds_bytes;
+#define ARTN_GEMM_LAUNCH(MBV, NBV)                                                                   \
+  {                                                                                                  \
+    auto kern = artn_k_gemm<MBV, NBV>;                                                               \
+    if (hipError_t e = ensure_lds<artn_k_gemm<MBV, NBV>>(lds); e != hipSuccess) return e;            \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
+    return hipGetLastError();                                                                        \
+  }
+#define ARTN_GEMM_LAUNCH_BF(MBV, NBV)                                                                \
+  {                                                                                                  \
+    auto kern = artn_k_gemm<MBV, NBV, true>;                                                         \
+    if (hipError_t e = ensure_lds<artn_k_gemm<MBV, NBV, true>>(lds); e != hipSuccess) return e;      \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
+    return hipGetLastError();                                                                        \
+  }
+  const int key = g.mb_log2 * 4 + g.nb_log2;
+  if (g.split) {
+    switch (key) {
+      case 0: ARTN_GEMM_LAUNCH_BF(1, 1)
+      case 1: ARTN_GEMM_LAUNCH_BF(1, 2)
+      case 5: ARTN_GEMM_LAUNCH_BF(2, 2)
+    }
+    return hipErrorInvalidValue;
+  }
+  switch (key) {
+    case 0: ARTN_GEMM_LAUNCH(1, 1)
+    case 1: ARTN_GEMM_LAUNCH(1, 2)
+    case 2: ARTN_GEMM_LAUNCH(1, 4)
+    case 5: ARTN_GEMM_LAUNCH(2, 2)
+    case 6: ARTN_GEMM_LAUNCH(2, 4)
+  }
+#undef ARTN_GEMM_LAUNCH
+#undef ARTN_GEMM_LAUNCH_BF
   return hipErrorInvalidValue;
 }
 
@@ -1446,9 +1495,17 @@ int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, 
   const int64_t min_tiles = env_flag("ARTN_FORCE_BITS") ? 1 : 32;
   int rc = artn::make_plan(d, p, err, g_ncu, !no_bits, min_tiles);
   if (rc) return fail(rc, err);
+  if (p.kernel == ARTN_KERNEL_GEMM_MFMA && (((uintptr_t)B) & 15) != 0) { // the GEMM kernel moves both operands in 16-byte lanes
+    rc = artn::make_plan(d, p, err, g_ncu, !no_bits, min_tiles, -1, false);
+    if (rc) return fail(rc, err);
+  }
   hipStream_t st = (hipStream_t)stream;
   if (p.kernel == ARTN_KERNEL_BITS_MFMA) {
     HIP_TRY(launch_bits(p, A, B, nullptr, C, st));
+    return ARTN_OK;
+  }
+  if (p.kernel == ARTN_KERNEL_GEMM_MFMA) {
+    HIP_TRY(launch_gemm(p, A, B, C, st));
     return ARTN_OK;
   }
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);

@@ -102,9 +102,53 @@ struct ArtnGenericPlan {
   int64_t red_ext[ARTN_GEN_MAX_RED], red_sA[ARTN_GEN_MAX_RED], red_sB[ARTN_GEN_MAX_RED];
 };
 
+// Launch plan of the two-operand LDS GEMM (artn_k_gemm): both operands are staged through LDS in
+// chunks of 2^kc contracted values, the remaining contracted bits are looped over inside the
+// kernel with the accumulators in registers, the result tile leaves through LDS in C order.
+// For steps whose contracted set or second operand is too big for the state-streaming kernel above
+// (7+ contracted bits; big x big steps of sliced circuits and random networks).
+#define ARTN_GEMM_MAX_KO 40
+#define ARTN_GEMM_KC 4           /* contracted bits per LDS chunk */
+#define ARTN_GEMM_EPI_BITS 13    /* the result tile leaves in passes of 2^13 elements (64 KiB) */
+#define ARTN_GEMM_PITCH_LOG2 7   /* rows of both LDS images are 2^7 elements apart whatever mt / nt: every
+                                    LDS read of the MFMA loop has a compile-time offset */
+struct ArtnGemmPlan {
+  int32_t mt, nt, kc;        // tile: free bits of the first / second operand, contracted bits per chunk
+  int32_t n_ko;              // contracted bits looped over inside the kernel (2^n_ko chunks per tile)
+  int32_t swapped;           // 1: the kernel's first operand is the caller's B (it has the free bits to tile)
+  int32_t mb_log2, nb_log2;  // 32-row / 16-column MFMA blocks per wave
+  int32_t wm_log2, wn_log2;  // waves along m / along n (idle waves when the sum is < 2)
+  int32_t split;             // 0 fp32 MFMA; 1 bf16 operands (ARTN_C64_BF16)
+  int32_t n_outer;
+  int32_t blocked;           // (always 0; kept so the tile-offset helpers serve both plans)
+  int64_t n_tiles;
+  // global -> LDS: bit b of a chunk's element index, elements ordered by stride in the operand
+  // (bit 0 = the operand's stride-1 bit: a thread moves elements 2c, 2c+1 with one 16-byte load)
+  int32_t ta_bits, tb_bits;  // mt + kc, nt + kc
+  int64_t a_stride[12], b_stride[12]; // -> element stride in the operand
+  int32_t a_lds[12], b_lds[12];       // -> byte offset in the LDS image (fp32: [kc][2^7 rows] x 8 B; bf16: [kc >> 2][2^7 rows][kc & 3] x 4 B)
+  int64_t ko_sA[ARTN_GEMM_MAX_KO], ko_sB[ARTN_GEMM_MAX_KO]; // looped contracted bit -> element strides
+  // epilogue: the result tile in C order
+  int32_t tc_bits;           // mt + nt
+  int32_t pad0_;
+  int64_t out_stride[14];    // C-tile-local bit -> C element stride
+  int32_t m_pos[8], n_pos[8]; // m_local / n_local bit -> C-tile-local position
+  int32_t swz_n, swz_src[4], swz_dst[4]; // XOR swizzle of the LDS result image (as ArtnStage::swz_*)
+  int32_t pad1_[3];
+  ArtnOuterDim outer[ARTN_MAX_OUTER];
+  // (unused by this kernel; present so tile_offsets<> compiles for both plan types)
+  int32_t gather_dim;
+  int32_t pad2_;
+  const int64_t *rows_a;
+  const int64_t *rows_b;
+  int64_t src_rows_a, src_rows_b;
+  int32_t *gather_err;
+};
+
 struct ArtnPlan {
   int kernel; // ARTN_KERNEL_*
   ArtnBitsPlan bits;
+  ArtnGemmPlan gemm;
   ArtnGenericPlan gen;
   ArtnStepInfo info;
   std::string why_generic;
@@ -122,6 +166,7 @@ struct Tuning {
   int stage_prio = 1; // asymmetric MFMA-stage priority between the two workgroups of a CU
   int split = 0;      // complex64 chains: 0 fp32 MFMA, 3 fp32-grade split-bf16 MFMA
   int nt = 1;         // non-temporal loads of A tiles that are read once
+  int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
 };
 static inline Tuning &tuning() {
   static Tuning t = [] {
@@ -132,6 +177,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_SWIZZLE")) x.swizzle = atoi(e) != 0;
     if (const char *e = getenv("ARTN_STAGE_PRIO")) x.stage_prio = atoi(e) != 0;
     if (const char *e = getenv("ARTN_NT")) x.nt = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
     return x;
   }();
@@ -616,6 +662,266 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   return true;
 }
 
+
+// ----------------------------------------------------------------------------------------
+// two-operand LDS GEMM planner (artn_k_gemm)
+// ----------------------------------------------------------------------------------------
+// Bits of one step: K (contracted), M (first operand and C), N (second operand and C); everything
+// else (batch axes, non power-of-two free axes) is enumerated by the tile index.  A workgroup owns a
+// C tile of 2^mt x 2^nt elements and walks the contracted index in chunks of 2^kc: per chunk the
+// [2^kc][2^mt] piece of the first operand and the [2^kc][2^nt] piece of the second are copied to LDS
+// (16-byte lanes, runs as long as the low address bits of each operand allow), every wave multiplies
+// its 32-row x 16-column MFMA blocks, accumulators stay in registers across all chunks.
+static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles, bool only_if_preferred) {
+  if (d->dtype != ARTN_C64 && d->dtype != ARTN_C64_BF16) { p.why_generic = "dtype is not complex64"; return false; }
+  std::vector<Axis> ax;
+  expand_axes(d, ax);
+  std::vector<int> K, M, N, O;
+  for (int i = 0; i < (int)ax.size(); ++i) {
+    const Axis &a = ax[i];
+    if (a.k1()) {
+      if (!a.bit) { p.why_generic = "contracted label with a non power-of-two extent"; return false; }
+      K.push_back(i);
+    } else if (a.m1()) {
+      (a.bit ? M : O).push_back(i);
+    } else if (a.n1()) {
+      (a.bit ? N : O).push_back(i);
+    } else if (a.h1()) {
+      O.push_back(i);
+    } else {
+      p.why_generic = "label summed out of a single operand";
+      return false;
+    }
+  }
+  const int k = (int)K.size();
+  const bool bf16 = d->dtype == ARTN_C64_BF16;
+  const int kc = bf16 ? ARTN_GEMM_KC + 1 : ARTN_GEMM_KC; // bf16 MFMAs take 8 contracted values each: chunks of 32
+  if (k < kc) { p.why_generic = "fewer contracted bits than one LDS chunk of the GEMM kernel"; return false; }
+  if (k - kc > ARTN_GEMM_MAX_KO) { p.why_generic = "too many contracted bits"; return false; }
+  if (only_if_preferred) {
+    int64_t nb = 1;
+    for (int i = 0; i < (int)ax.size(); ++i) if (ax[i].sB1 >= 0 && (ax[i].k1() || ax[i].n1())) nb *= ax[i].ext;
+    int64_t na = 1;
+    for (int i = 0; i < (int)ax.size(); ++i) if (ax[i].sA >= 0 && (ax[i].k1() || ax[i].m1())) na *= ax[i].ext;
+    const bool big_second = std::min(na, nb) >= (int64_t(1) << 15);
+    // measured on n53 / sparse-state steps: with 7-8 contracted bits the GEMM kernel wins once both
+    // operands bring 6+ free bits (128 x 64 tiles and up); with fewer, the second operand fits the
+    // registers of the state-streaming kernel and one pass of it is faster
+    const int free_small = (int)std::min(M.size(), N.size());
+    if (!(k > 8 || (k > 6 && free_small >= 6) || big_second)) { p.why_generic = "state-streaming kernel preferred"; return false; }
+  }
+  // the first operand supplies the 32-row MFMA blocks: it needs 5 free bits
+  const bool swapped = M.size() < 5 && N.size() >= 5;
+  if (swapped) {
+    for (auto &a : ax) std::swap(a.sA, a.sB1);
+    std::swap(M, N);
+  }
+  const int m = (int)M.size(), n = (int)N.size();
+  if (m < 5) { p.why_generic = "too few free bits for an MFMA tile"; return false; }
+
+  auto in_set = [](const std::vector<int> &v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+  auto has_unit = [&](const std::vector<int> &s1, const std::vector<int> &s2, int which) {
+    for (const std::vector<int> *s : {&s1, &s2})
+      for (int i : *s) {
+        const int64_t st = which == 0 ? ax[i].sA : which == 1 ? ax[i].sB1 : ax[i].sC;
+        if (st == 1) return true;
+      }
+    return false;
+  };
+  if (!has_unit(K, M, 0) || !has_unit(K, N, 1) || !has_unit(M, N, 2)) {
+    p.why_generic = "no contiguous 16-byte run at the bottom of an operand";
+    return false;
+  }
+  // ---- forced tile members: the bits inside the contiguous runs of A, B and C (2^r elements)
+  int ra = 4, rb = 4, rc = 4;
+  std::vector<int> Kf, Mf, Nf;
+  for (;;) {
+    Kf.clear(); Mf.clear(); Nf.clear();
+    const int64_t la = int64_t(1) << ra, lb = int64_t(1) << rb, lc = int64_t(1) << rc;
+    for (int i : K) if (ax[i].sA < la || ax[i].sB1 < lb) Kf.push_back(i);
+    for (int i : M) if (ax[i].sA < la || ax[i].sC < lc) Mf.push_back(i);
+    for (int i : N) if (ax[i].sB1 < lb || ax[i].sC < lc) Nf.push_back(i);
+    int *shrink = nullptr;
+    if ((int)Kf.size() > kc) shrink = rb >= ra ? &rb : &ra;
+    else if ((int)Mf.size() > 7) shrink = rc >= ra ? &rc : &ra;
+    else if ((int)Nf.size() > 7) shrink = rc >= rb ? &rc : &rb;
+    if (!shrink) break;
+    if (*shrink <= 1) { p.why_generic = "forced tile bits exceed the GEMM tile"; return false; }
+    --*shrink;
+  }
+  auto byA = [&](int x, int y) { return ax[x].sA < ax[y].sA; };
+  auto byB = [&](int x, int y) { return ax[x].sB1 < ax[y].sB1; };
+  auto byC = [&](int x, int y) { return ax[x].sC < ax[y].sC; };
+  std::sort(K.begin(), K.end(), byA);
+  std::sort(M.begin(), M.end(), byA);
+  std::sort(N.begin(), N.end(), byB);
+  int64_t outer_ext = 1;
+  for (int i : O) outer_ext *= ax[i].ext;
+  // (bf16: 128 x 64 tiles at most -- twice the chunk depth has to fit the same prefetch registers)
+  int mt = std::min(m, 7), nt = std::min(n, bf16 ? 6 : 7);
+  if ((int)Nf.size() > nt) { p.why_generic = "forced tile bits exceed the bf16 GEMM tile"; return false; }
+  // too few tiles to fill the chip: smaller tiles (down to what the runs force)
+  while (((int64_t(1) << (m - mt + n - nt)) * outer_ext) < n_cu) {
+    if (mt >= nt + 1 && mt > 5 && mt > (int)Mf.size()) --mt;
+    else if (nt > 4 && nt > (int)Nf.size()) --nt;
+    else if (mt > 5 && mt > (int)Mf.size()) --mt;
+    else break;
+  }
+  std::vector<int> Kc(Kf), Mt(Mf), Nt(Nf);
+  for (int i : K) { if ((int)Kc.size() >= kc) break; if (!in_set(Kc, i)) Kc.push_back(i); }
+  for (int i : M) { if ((int)Mt.size() >= mt) break; if (!in_set(Mt, i)) Mt.push_back(i); }
+  for (int i : N) { if ((int)Nt.size() >= nt) break; if (!in_set(Nt, i)) Nt.push_back(i); }
+  mt = (int)Mt.size(); nt = (int)Nt.size();
+  if (mt < 5) { p.why_generic = "too few free bits for an MFMA tile"; return false; }
+
+  ArtnGemmPlan &g = p.gemm;
+  memset(&g, 0, sizeof(g));
+  g.mt = mt; g.nt = nt; g.kc = kc; g.n_ko = k - kc; g.swapped = swapped ? 1 : 0;
+  g.split = bf16 ? 1 : 0;
+  g.gather_dim = -1;
+  // ---- waves: blocks per wave from the allowed instantiations (1,1) (1,2) (2,2) (1,4) (2,4)
+  {
+    const int mbl = mt - 5, nbl = std::max(nt - 4, 0);
+    int best = 1 << 30;
+    for (int wm = 0; wm <= std::min(2, mbl); ++wm) {
+      const int wn = std::min(2 - wm, nbl);
+      const int MB = mbl - wm, NB = nbl - wn;
+      const bool allowed = (MB == 0 && NB <= 2) || (MB == 1 && (NB == 1 || NB == 2));
+      if (!allowed) continue;
+      const int cost = (1 << MB) + (1 << NB) + 8 * (2 - wm - wn);
+      if (cost < best) { best = cost; g.wm_log2 = wm; g.wn_log2 = wn; g.mb_log2 = MB; g.nb_log2 = NB; }
+    }
+    if (best == (1 << 30)) { p.why_generic = "internal: no wave layout for the GEMM tile"; return false; }
+  }
+  // ---- LDS images: [kc value][m_local] and [kc value][n_local].  Local bit order = stride order in the
+  //      operand: the copy lanes (lowest-stride bits of a chunk) then write neighbouring rows and
+  //      chunk values -- ordered by C stride instead, a bf16 step ran 8x slower on LDS bank conflicts
+  std::sort(Kc.begin(), Kc.end(), byA);
+  std::sort(Mt.begin(), Mt.end(), byA);
+  std::sort(Nt.begin(), Nt.end(), byB);
+  auto pos = [](const std::vector<int> &v, int axis) { return (int)(std::find(v.begin(), v.end(), axis) - v.begin()); };
+  std::vector<int> tA(Kc), tB(Kc), tC(Mt);
+  tA.insert(tA.end(), Mt.begin(), Mt.end());
+  tB.insert(tB.end(), Nt.begin(), Nt.end());
+  tC.insert(tC.end(), Nt.begin(), Nt.end());
+  std::sort(tA.begin(), tA.end(), byA);
+  std::sort(tB.begin(), tB.end(), byB);
+  std::sort(tC.begin(), tC.end(), byC);
+  g.ta_bits = mt + kc; g.tb_bits = nt + kc; g.tc_bits = mt + nt;
+  // byte offset of (row bit i | chunk bit q) in an image: fp32 [kc][128 rows] x 8 B; bf16 [kc >> 2][128 rows][kc & 3] x 4 B
+  auto lds_row = [&](int i) { return bf16 ? 16 << i : 8 << i; };
+  auto lds_kc = [&](int q) { return bf16 ? (q < 2 ? 4 << q : (16 << ARTN_GEMM_PITCH_LOG2) << (q - 2)) : (8 << ARTN_GEMM_PITCH_LOG2) << q; };
+  for (int b = 0; b < g.ta_bits; ++b) {
+    g.a_stride[b] = ax[tA[b]].sA;
+    g.a_lds[b] = in_set(Mt, tA[b]) ? lds_row(pos(Mt, tA[b])) : lds_kc(pos(Kc, tA[b]));
+  }
+  for (int b = 0; b < g.tb_bits; ++b) {
+    g.b_stride[b] = ax[tB[b]].sB1;
+    g.b_lds[b] = in_set(Nt, tB[b]) ? lds_row(pos(Nt, tB[b])) : lds_kc(pos(Kc, tB[b]));
+  }
+  if (g.a_stride[0] != 1 || g.b_stride[0] != 1) { p.why_generic = "internal: operand run broken"; return false; }
+  for (int b = 0; b < g.tc_bits; ++b) g.out_stride[b] = ax[tC[b]].sC;
+  if (g.tc_bits > 0 && g.out_stride[0] != 1) { p.why_generic = "internal: output run broken"; return false; }
+  for (int i = 0; i < mt; ++i) g.m_pos[i] = pos(tC, Mt[i]);
+  for (int i = 0; i < nt; ++i) g.n_pos[i] = pos(tC, Nt[i]);
+  // looped contracted bits, lowest A stride first
+  {
+    int q = 0;
+    for (int i : K) if (!in_set(Kc, i)) { g.ko_sA[q] = ax[i].sA; g.ko_sB[q] = ax[i].sB1; ++q; }
+  }
+  // result-image swizzle: the 16 lanes of a ds_write_b64 group differ in m_local bits 0..3
+  {
+    bool taken[4] = {true, false, false, false};
+    for (int i = 0; i < 4; ++i) if (g.m_pos[i] < 4) taken[g.m_pos[i]] = true;
+    // n_local bit 0 is written by the same lane in two instructions, it may share a window position;
+    // positions held by other low tile bits stay usable as XOR targets (the map stays a bijection)
+    for (int i = 0; i < 4 && tuning().swizzle; ++i) {
+      if (g.m_pos[i] < 4) continue;
+      int f = -1;
+      for (int c = 1; c < 4; ++c) if (!taken[c]) { f = c; break; }
+      if (f < 0) break;
+      taken[f] = true;
+      g.swz_src[g.swz_n] = g.m_pos[i];
+      g.swz_dst[g.swz_n] = f;
+      ++g.swz_n;
+    }
+  }
+  // ---- outer axes: N-outer fastest (tiles sharing an A row block run together), M-outer, the rest
+  std::vector<int> outer;
+  for (int i : N) if (!in_set(Nt, i)) outer.push_back(i);
+  for (int i : M) if (!in_set(Mt, i)) outer.push_back(i);
+  std::sort(O.begin(), O.end(), [&](int x, int y) {
+    auto key = [&](int z) { return ax[z].sA >= 0 ? ax[z].sA : ax[z].sB1; };
+    return key(x) < key(y);
+  });
+  outer.insert(outer.end(), O.begin(), O.end());
+  g.n_tiles = 1;
+  int64_t a_rereads = 1;
+  for (int i : outer) {
+    const Axis &a = ax[i];
+    ArtnOuterDim od;
+    od.ext = a.ext;
+    od.sA = a.sA >= 0 ? a.sA : 0;
+    od.sB1 = a.sB1 >= 0 ? a.sB1 : 0;
+    od.sB2 = 0;
+    od.sC = a.sC >= 0 ? a.sC : 0;
+    od.log2ext = ilog2_exact(a.ext);
+    od.pad_ = 0;
+    g.n_tiles *= a.ext;
+    if (a.sA < 0) a_rereads *= a.ext;
+    if (g.n_outer > 0) {
+      ArtnOuterDim &pr = g.outer[g.n_outer - 1];
+      auto okf = [&](int64_t ps, int64_t ns) { return (ps == 0 && ns == 0) || (ps != 0 && ns == ps * pr.ext); };
+      if (pr.log2ext >= 0 && od.log2ext >= 0 && okf(pr.sA, od.sA) && okf(pr.sB1, od.sB1) && okf(pr.sC, od.sC) &&
+          pr.log2ext + od.log2ext < 31) {
+        pr.ext *= od.ext;
+        pr.log2ext += od.log2ext;
+        continue;
+      }
+    }
+    if (g.n_outer >= ARTN_MAX_OUTER) { p.why_generic = "too many outer axes"; return false; }
+    g.outer[g.n_outer++] = od;
+  }
+  // ---- envelope: 16-byte lanes, 32-bit per-lane offsets
+  for (int b = 1; b < g.ta_bits; ++b) if (g.a_stride[b] & 1) { p.why_generic = "odd A stride"; return false; }
+  for (int b = 1; b < g.tb_bits; ++b) if (g.b_stride[b] & 1) { p.why_generic = "odd B stride"; return false; }
+  for (int b = 1; b < g.tc_bits; ++b) if (g.out_stride[b] & 1) { p.why_generic = "odd C stride"; return false; }
+  for (int i = 0; i < g.n_outer; ++i)
+    if ((g.outer[i].sA & 1) || (g.outer[i].sB1 & 1) || (g.outer[i].sC & 1)) { p.why_generic = "odd outer stride"; return false; }
+  for (int q = 0; q < g.n_ko; ++q) if ((g.ko_sA[q] & 1) || (g.ko_sB[q] & 1)) { p.why_generic = "odd contracted stride"; return false; }
+  {
+    int64_t sa = 0, sb = 0, sc = 0;
+    for (int b = 1; b <= 8; ++b) {
+      if (b < g.ta_bits) sa += g.a_stride[b];
+      if (b < g.tb_bits) sb += g.b_stride[b];
+      if (b < g.tc_bits) sc += g.out_stride[b];
+    }
+    const int64_t lim = (int64_t(1) << 28) - 1;
+    if (sa > lim || sb > lim || sc > lim) { p.why_generic = "lane offsets exceed 32 bits"; return false; }
+  }
+  {
+    int pow2_bits = 0;
+    for (int i = 0; i < g.n_outer && g.outer[i].log2ext >= 0; ++i) pow2_bits += g.outer[i].log2ext;
+    if (pow2_bits > 32) { p.why_generic = "more than 2^32 tiles"; return false; }
+  }
+  if (g.n_tiles < min_tiles && !(k > 8)) { p.why_generic = "too few tiles to fill the chip"; return false; }
+
+  p.kernel = ARTN_KERNEL_GEMM_MFMA;
+  ArtnStepInfo &f = p.info;
+  f.kernel = ARTN_KERNEL_GEMM_MFMA;
+  f.k_bits = k; f.m_tile_bits = mt; f.n_tile_bits = nt;
+  f.tile_in_bits = g.ta_bits; f.tile_out_bits = g.tc_bits;
+  f.run_in_bits = ra; f.run_out_bits = rc;
+  const int64_t stage = 2 * (8LL << (ARTN_GEMM_PITCH_LOG2 + ARTN_GEMM_KC));
+  const int64_t epi = 8LL << std::min(g.tc_bits, ARTN_GEMM_EPI_BITS);
+  f.lds_bytes = (int32_t)(std::max(2 * stage, epi) + 512LL * 8 + 32 * 32 + 16LL * ARTN_GEMM_MAX_KO);
+  f.n_tiles = g.n_tiles;
+  f.a_rereads = a_rereads;
+  const int wg_per_cu = std::max(1, std::min(2, (160 * 1024) / f.lds_bytes));
+  f.grid = (int32_t)std::min<int64_t>(g.n_tiles, (int64_t)n_cu * wg_per_cu);
+  return true;
+}
+
 static inline void step_cost(const ArtnStepDesc *d, double &flops, double &na, double &nb, double &nc) {
   double prod = 1;
   na = nb = nc = 1;
@@ -631,11 +937,19 @@ static inline void step_cost(const ArtnStepDesc *d, double &flops, double &na, d
 // min_tiles: below this many LDS tiles the strided kernel is used instead (a handful of
 // workgroups cannot fill 256 CUs; such steps are launch-latency bound either way).
 static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err, int n_cu = 256,
-                            bool allow_bits = true, int64_t min_tiles = 32, int gather_label = -1) {
+                            bool allow_bits = true, int64_t min_tiles = 32, int gather_label = -1, bool allow_gemm = true) {
   int rc = validate(d, err);
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
-  bool ok = allow_bits && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
+  bool ok = false;
+  allow_gemm = allow_gemm && allow_bits && gather_label < 0 && tuning().gemm;
+  if (allow_gemm) ok = make_gemm(d, p, n_cu, min_tiles, tuning().gemm < 2);
+  if (!ok) ok = allow_bits && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
+  if (!ok && allow_gemm) { // what the state-streaming kernel declines
+    const std::string why = p.why_generic;
+    ok = make_gemm(d, p, n_cu, min_tiles, false);
+    if (!ok) p.why_generic = why + "; GEMM kernel: " + p.why_generic;
+  }
   if (!ok && gather_label >= 0) { err = "row gather needs the tiled kernel: " + p.why_generic; return ARTN_E_UNSUPPORTED; }
   if (!ok && !make_generic(d, p, err)) return ARTN_E_UNSUPPORTED;
   double na, nb, nc;

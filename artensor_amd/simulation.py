@@ -18,7 +18,8 @@ from . import contraction as _C
 from .contraction import _labels, _sparse_step, contract, tensor_contraction, tensor_contraction_sparse
 
 __all__ = ["slice_assignments", "rank_slices", "apply_slice", "accumulate", "sliced_contraction",
-           "SliceRunner", "TensorNetworkSimulation", "tensor_network_contraction", "quantum_circuit_simulation"]
+           "SliceRunner", "TensorNetworkSimulation", "tensor_network_contraction", "quantum_circuit_simulation",
+           "partition_output", "partitioned_contraction"]
 
 
 def slice_assignments(n_bonds, s):
@@ -346,6 +347,108 @@ def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce
     if permute_dims is not None and len(permute_dims) > 0:
         collect = collect.permute(tuple(permute_dims))
     return collect
+
+
+# ----------------------------------------------------------------------------------------
+# output-qubit partitioning of an unsliced dense contraction (build-side extension)
+# ----------------------------------------------------------------------------------------
+def _step_cost(labels, ext):
+    n = 8.0
+    for x in labels:
+        n *= ext[x]
+    return n
+
+
+def partition_output(scheme, leaf_shapes, n_fix):
+    """Fix `n_fix` dims of the FINAL result of a dense scheme to constants, at the leaves.
+
+    The reference can only shard a contraction over sliced inner bonds, which for a dense
+    full-amplitude output ends in a sum of whole output tensors (simulation.py:107-114; SURVEY 8e: an
+    8 GiB all-reduce for n30).  An output label, though, is a dangling bond of one leaf tensor that
+    every step merely carries along: selecting one value of it AT THE LEAF gives the same scheme with
+    that label dropped everywhere, whose result is one slab of the full output -- 2^n_fix independent
+    contractions with disjoint results and no exchange at all.
+
+    Returns (new_scheme, selects, fixed_dims): `new_scheme` in the format of `scheme` (einsum strings
+    or label tuples) with the chosen labels removed from every step; `selects` = [(leaf id, leaf dim)]
+    in the order of `fixed_dims`, the dims of the original final result they fix (value v of select q
+    <-> index v along fixed_dims[q]).  Dims are chosen greedily by how much work fixing them removes
+    (labels that join the state early are carried by every big step)."""
+    from .contraction import _labels
+    prov = {k: [frozenset([(k, d)]) for d in range(len(sh))] for k, sh in leaf_shapes.items()}
+    ext0 = {(k, d): e for k, sh in leaf_shapes.items() for d, e in enumerate(sh)}
+    steps = []
+    for (i, j), eq in (st[:2] for st in scheme):
+        la, lb, lo = _labels(eq)
+        org = {}
+        for x, o in zip(la, prov[i]):
+            org[x] = o
+        for x, o in zip(lb, prov[j]):
+            org[x] = org[x] | o if x in org else o
+        steps.append((i, j, la, lb, lo, org))
+        prov[i] = [org[x] for x in lo]
+    final_id = scheme[-1][0][0]
+    final = prov[final_id]
+
+    def total_cost(fixed):
+        c = 0.0
+        for i, j, la, lb, lo, org in steps:
+            n = 8.0
+            for x in dict.fromkeys(la + lb):
+                if org[x] & fixed:
+                    continue
+                n *= ext0[next(iter(org[x]))]
+            c += n
+        return c
+
+    fixed, fixed_dims = frozenset(), []
+    for _ in range(n_fix):
+        best = None
+        for d, o in enumerate(final):
+            if d in fixed_dims or len(o) != 1:
+                continue
+            c = total_cost(fixed | o)
+            if best is None or c < best[0] or (c == best[0] and d < best[1]):
+                best = (c, d, o)
+        if best is None:
+            raise RuntimeError("not enough single-leaf output labels to partition over")
+        fixed = fixed | best[2]
+        fixed_dims.append(best[1])
+    selects = [next(iter(final[d])) for d in fixed_dims]
+    new_scheme = []
+    for (i, j, la, lb, lo, org), st in zip(steps, scheme):
+        keep = lambda labs: tuple(x for x in labs if not (org[x] & fixed))
+        ka, kb, ko = keep(la), keep(lb), keep(lo)
+        eq = ("".join(ka) + "," + "".join(kb) + "->" + "".join(ko)) if isinstance(st[1], str) else (ka, kb, ko)
+        new_scheme.append(((i, j), eq))
+    return new_scheme, selects, fixed_dims
+
+
+_partition_cache = {}
+
+
+def partitioned_contraction(tensors, scheme, n_fix, part, device="cuda", dtype=torch.complex64):
+    """Slab `part` (0 <= part < 2^n_fix) of the result of a dense scheme: the output dims chosen by
+    partition_output fixed to the bits of `part` (MSB = first fixed dim).  Returns
+    (slab, fixed_dims, values); slab has the result's remaining dims in order."""
+    key = (id(scheme), n_fix)
+    hit = _partition_cache.get(key)
+    items = list(tensors.items()) if isinstance(tensors, dict) else list(enumerate(tensors))
+    if hit is None or hit[0] is not scheme:
+        shapes = {k: tuple(t.shape) for k, t in items}
+        hit = _partition_cache[key] = (scheme,) + partition_output(scheme, shapes, n_fix)
+    _, new_scheme, selects, fixed_dims = hit
+    values = slice_assignments(n_fix, part)
+    per_leaf = {}
+    for (leaf, dim), v in zip(selects, values):
+        per_leaf.setdefault(leaf, {})[dim] = v
+    leaves = {}
+    for k, t in items:
+        t = t.to(dtype).to(device)
+        if k in per_leaf:
+            t = t[tuple(per_leaf[k].get(d, slice(None)) for d in range(t.dim()))].contiguous()
+        leaves[k] = t
+    return tensor_contraction(leaves, new_scheme), fixed_dims, values
 
 
 def _planner(planner=None):

@@ -65,6 +65,7 @@ typedef struct ArtnStepDesc {
 /* What the planner decided for a step (filled on the host, no GPU needed). */
 #define ARTN_KERNEL_GENERIC 0 /* one thread per output element, strided loops       */
 #define ARTN_KERNEL_BITS_MFMA 1 /* LDS-tiled bit-permuted complex GEMM on fp32 MFMA */
+#define ARTN_KERNEL_GEMM_MFMA 2 /* two-operand LDS GEMM on fp32 MFMA, contracted bits looped in-kernel */
 typedef struct ArtnStepInfo {
   int32_t kernel;       /* ARTN_KERNEL_*                                        */
   int32_t k_bits;       /* contracted bits handled inside a tile                */

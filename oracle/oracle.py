@@ -178,3 +178,42 @@ def scheme_flops(tensors, scheme):
         total += f
         shapes[i] = tuple(dim[x] for x in lo)
     return total, per_step
+
+
+def tensor_contraction_torch_cpu(tensors, scheme, budget_s=None, threads=None):
+    """The reference's dense executor as it runs on a CPU: `tensors[i] = torch.einsum(eq, tensors[i],
+    tensors[j])` for every step (/root/reference/artensor/contraction.py:62-76), on torch-CPU tensors.
+    This is the CPU baseline SURVEY 8d specifies (bench.py's cpu_baseline leg); nothing else calls it.
+
+    budget_s: stop after the first step that ends past this many seconds (a bounded sample of a big
+    scheme).  Returns dict(result (None if stopped early), steps_done, flops_done, flops_total,
+    seconds, threads)."""
+    import time
+    import torch
+    if threads:
+        torch.set_num_threads(int(threads))
+    ts = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in
+          (tensors.items() if isinstance(tensors, dict) else enumerate(tensors))}
+    shapes = {k: tuple(t.shape) for k, t in ts.items()}
+    per_step = []
+    for (i, j), eq in scheme:
+        a, b, out = parse_eq(eq)
+        ext = dict(zip(a, shapes[i]))
+        ext.update(zip(b, shapes[j]))
+        f = 8.0
+        for x in ext.values():
+            f *= x
+        per_step.append(f)
+        shapes[i] = tuple(ext[x] for x in out)
+    done_f, done_n = 0.0, 0
+    t0 = time.perf_counter()
+    for n, ((i, j), eq) in enumerate(scheme):
+        ts[i] = torch.einsum(eq, ts[i], ts[j])
+        done_f += per_step[n]
+        done_n += 1
+        if budget_s is not None and time.perf_counter() - t0 > budget_s and n + 1 < len(scheme):
+            break
+    dt = time.perf_counter() - t0
+    whole = done_n == len(scheme)
+    return dict(result=ts[scheme[-1][0][0]] if whole else None, steps_done=done_n, flops_done=done_f,
+                flops_total=float(sum(per_step)), seconds=dt, threads=torch.get_num_threads())

@@ -127,6 +127,160 @@ static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf 
   }
 }
 
+
+// ---- artn_k_gemm (artn_gemm_kernel.h), replayed thread by thread from the same ArtnGemmPlan ---------
+static unsigned swzg(unsigned off, const ArtnGemmPlan &P) {
+  for (int i = 0; i < P.swz_n; ++i)
+    if ((off >> P.swz_src[i]) & 1) off ^= 1u << P.swz_dst[i];
+  return off;
+}
+
+static float bf16r(float x) { // round to nearest even, as v_cvt_pk_bf16_f32 (finite inputs)
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  u &= 0xFFFF0000u;
+  float y;
+  memcpy(&y, &u, 4);
+  return y;
+}
+
+static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
+  const cf *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
+  const int mt = P.mt, nt = P.nt, MB = 1 << P.mb_log2, NB = 1 << P.nb_log2;
+  const int epi_bits = std::min(P.tc_bits, ARTN_GEMM_EPI_BITS);
+  const int PL = ARTN_GEMM_PITCH_LOG2;
+  const int EB = P.split ? 4 : 8; // bytes per image element (bf16 pairs / fp32 pairs)
+  std::vector<cf> imgA((size_t)(16 << PL) * 8 / EB), imgB((size_t)(16 << PL) * 8 / EB), res((size_t)1 << epi_bits);
+  const int n_chunks = 1 << P.n_ko;
+  for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
+    int64_t r = tile, offA = 0, offB = 0, offC = 0;
+    for (int d = 0; d < P.n_outer; ++d) {
+      int64_t ext = P.outer[d].ext, x;
+      if (P.outer[d].log2ext >= 0) { x = r & (ext - 1); r >>= P.outer[d].log2ext; }
+      else { x = r % ext; r /= ext; }
+      offA += x * P.outer[d].sA; offB += x * P.outer[d].sB1; offC += x * P.outer[d].sC;
+    }
+    // accumulators of every (wave, block, lane, register)
+    std::vector<float> acc((size_t)4 * MB * NB * 64 * 16, 0.f);
+    auto ACC = [&](int wave, int a, int b, int lane, int rr) -> float & {
+      return acc[((((size_t)wave * MB + a) * NB + b) * 64 + lane) * 16 + rr];
+    };
+    int64_t ka = 0, kb = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+      if (c > 0) { // Gray code step from chunk c-1 to chunk c
+        const int bit = __builtin_ctz((unsigned)c);
+        const unsigned gn = (unsigned)c ^ ((unsigned)c >> 1);
+        if ((gn >> bit) & 1) { ka += P.ko_sA[bit]; kb += P.ko_sB[bit]; } else { ka -= P.ko_sA[bit]; kb -= P.ko_sB[bit]; }
+      }
+      // global -> LDS images, one 16-byte chunk (two elements) per thread and iteration
+      for (int which = 0; which < 2; ++which) {
+        const int bits = which ? P.tb_bits : P.ta_bits;
+        const int64_t *gs = which ? P.b_stride : P.a_stride;
+        const int32_t *ls = which ? P.b_lds : P.a_lds;
+        cf *img = which ? imgB.data() : imgA.data();
+        const cf *src = which ? B + offB + kb : A + offA + ka;
+        const int cb = bits - 1, iters = cb > 8 ? 1 << (cb - 8) : 1;
+        for (int tid = 0; tid < 256; ++tid) {
+          if (!(cb >= 8 || tid < (1 << cb))) continue;
+          for (int u = 0; u < iters; ++u) {
+            const int chunk = tid + 256 * u;
+            int64_t g = 0; int l = 0;
+            for (int b = 1; b < bits; ++b) if ((chunk >> (b - 1)) & 1) { g += gs[b]; l += ls[b]; }
+            cf e0 = src[g], e1 = src[g + 1];
+            if (P.split) { e0 = cf(bf16r(e0.real()), bf16r(e0.imag())); e1 = cf(bf16r(e1.real()), bf16r(e1.imag())); }
+            img[l / EB] = e0;
+            img[(l + ls[0]) / EB] = e1;
+          }
+        }
+      }
+      // MFMA pairs
+      for (int wave = 0; wave < 4; ++wave) {
+        const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
+        if (wm >= (1 << P.wm_log2)) continue;
+        if (P.split) { // v_mfma_f32_32x32x16_bf16 groups: kc = 8t + 4h + u, image [kc >> 2][row][kc & 3]
+          for (int t = 0; t < 4; ++t)
+            for (int a = 0; a < MB; ++a)
+              for (int b = 0; b < NB; ++b)
+                for (int lane = 0; lane < 64; ++lane)
+                  for (int rr = 0; rr < 16; ++rr) {
+                    const int i = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5), jj = lane & 31;
+                    const int n_in = i >> 1, ro = i & 1;
+                    if (!(nt >= 4 || n_in < (1 << nt))) continue;
+                    float sum = 0.f;
+                    for (int kk = 0; kk < 8; ++kk) {
+                      const int kc = 8 * t + kk;
+                      const cf xv = imgA[((size_t)((kc >> 2) << PL) + (wm * MB + a) * 32 + jj) * 4 + (kc & 3)];
+                      const cf bv = imgB[((size_t)((kc >> 2) << PL) + (wn * NB + b) * 16 + n_in) * 4 + (kc & 3)];
+                      const float w0 = ro ? bv.imag() : bv.real(), w1 = ro ? bv.real() : -bv.imag();
+                      sum += w0 * xv.real() + w1 * xv.imag();
+                    }
+                    ACC(wave, a, b, lane, rr) += sum;
+                  }
+          continue;
+        }
+        for (int s = 0; s < 8; ++s)
+          for (int a = 0; a < MB; ++a)
+            for (int b = 0; b < NB; ++b) {
+              float W0[64], W1[64], ax[64], ay[64];
+              for (int lane = 0; lane < 64; ++lane) {
+                const int j = lane & 31, h = lane >> 5, ro = j & 1, n_in = j >> 1;
+                const bool w_valid = nt >= 4 || n_in < (1 << nt);
+                const cf xv = imgA[((size_t)(2 * s + h) << PL) + (wm * MB + a) * 32 + j];
+                cf bv(0.f, 0.f);
+                if (w_valid) bv = imgB[((size_t)(2 * s + h) << PL) + (wn * NB + b) * 16 + n_in];
+                W0[lane] = ro ? bv.imag() : bv.real();
+                W1[lane] = ro ? bv.real() : -bv.imag();
+                ax[lane] = xv.real(); ay[lane] = xv.imag();
+              }
+              for (int phase = 0; phase < 2; ++phase) {
+                const float *Wp = phase ? W1 : W0, *ap = phase ? ay : ax;
+                for (int lane = 0; lane < 64; ++lane)
+                  for (int rr = 0; rr < 16; ++rr) {
+                    const int i = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5), jj = lane & 31;
+                    for (int kk = 0; kk < 2; ++kk) ACC(wave, a, b, lane, rr) += Wp[i + 32 * kk] * ap[jj + 32 * kk];
+                  }
+              }
+            }
+      }
+    }
+    // epilogue
+    auto m_off = [&](int m_local) { unsigned o = 0; for (int i = 0; i < mt; ++i) if ((m_local >> i) & 1) o |= 1u << P.m_pos[i]; return o; };
+    auto n_off = [&](int n_local) { unsigned o = 0; for (int i = 0; i < nt; ++i) if ((n_local >> i) & 1) o |= 1u << P.n_pos[i]; return o; };
+    const int n_lim = nt >= 4 ? 16 : 1 << nt;
+    const int n_pass = 1 << (P.tc_bits - epi_bits);
+    for (int pass = 0; pass < n_pass; ++pass) {
+      for (auto &x : res) x = cf(-777.f, -777.f);
+      for (int wave = 0; wave < 4; ++wave) {
+        const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
+        if (wm >= (1 << P.wm_log2)) continue;
+        for (int a = 0; a < MB; ++a) for (int b = 0; b < NB; ++b) for (int lane = 0; lane < 64; ++lane)
+          for (int q = 0; q < 4; ++q) for (int b0 = 0; b0 < 2; ++b0) {
+            const int j = lane & 31, h = lane >> 5;
+            const int n_loc = b0 + 2 * h + 4 * q;
+            if (n_loc >= n_lim) continue;
+            const unsigned pos = swzg(m_off((wm * MB + a) * 32 + j) | n_off((wn * NB + b) * 16 + n_loc), P);
+            if ((int)(pos >> ARTN_GEMM_EPI_BITS) != pass) continue;
+            res[pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)] = cf(ACC(wave, a, b, lane, 4 * q + 2 * b0), ACC(wave, a, b, lane, 4 * q + 2 * b0 + 1));
+          }
+      }
+      const int cb = epi_bits - 1, iters = cb > 8 ? 1 << (cb - 8) : 1;
+      const int64_t pass_off = P.tc_bits > epi_bits ? pass * P.out_stride[epi_bits] : 0;
+      for (int tid = 0; tid < 256; ++tid) {
+        if (!(cb >= 8 || tid < (1 << cb))) continue;
+        for (int i = 0; i < iters; ++i) {
+          const int chunk = tid + 256 * i;
+          int64_t g = 0;
+          for (int b = 1; b < epi_bits; ++b) if ((chunk >> (b - 1)) & 1) g += P.out_stride[b];
+          const unsigned l = swzg(((unsigned)pass << ARTN_GEMM_EPI_BITS) | 2u * (unsigned)chunk, P) & ((1u << ARTN_GEMM_EPI_BITS) - 1u);
+          C[offC + pass_off + g] = res[l];
+          C[offC + pass_off + g + 1] = res[l + 1];
+        }
+      }
+    }
+  }
+}
+
 static void run_generic(const ArtnGenericPlan &G, const cf *A, const cf *B, cf *C) {
   for (int64_t idx = 0; idx < G.out_numel; ++idx) {
     int64_t r = idx, oa = 0, ob = 0;
@@ -148,9 +302,24 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
   int rc = artn::make_plan(d, p, err, 256, !force_generic, 1);
   if (rc) return rc;
   if (kernel_used) *kernel_used = p.kernel;
-  if (d->dtype != ARTN_C64) return ARTN_E_UNSUPPORTED;
+  if (d->dtype != ARTN_C64 && !(d->dtype == ARTN_C64_BF16 && p.kernel == ARTN_KERNEL_GEMM_MFMA)) return ARTN_E_UNSUPPORTED;
   if (p.kernel == ARTN_KERNEL_BITS_MFMA) run_bits(p.bits, (const cf *)A, (const cf *)B, nullptr, (cf *)C);
+  else if (p.kernel == ARTN_KERNEL_GEMM_MFMA) run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);
   else run_generic(p.gen, (const cf *)A, (const cf *)B, (cf *)C);
+  return 0;
+}
+
+// Force the two-operand GEMM plan (whatever the planner would prefer); ARTN_E_UNSUPPORTED if it declines.
+extern "C" int artn_emulate_gemm(const ArtnStepDesc *d, const void *A, const void *B, void *C, ArtnStepInfo *info) {
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::validate(d, err);
+  if (rc) return rc;
+  memset(&p.info, 0, sizeof(p.info));
+  const char *e = getenv("ARTN_EMU_NCU"); // 1: never shrink tiles for want of workgroups (covers the big-tile layouts)
+  if (!artn::make_gemm(d, p, e ? atoi(e) : 256, 1, false)) return ARTN_E_UNSUPPORTED;
+  if (info) *info = p.info;
+  run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);
   return 0;
 }
 

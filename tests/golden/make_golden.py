@@ -618,6 +618,35 @@ def case_n53m20_batch_slice0():
               slicing_indices=case.slicing_indices)
 
 
+def case_c128_spread():
+    """The reference's own complex64-vs-complex128 spread (its executors run in both dtypes on the same
+    leaf tensors and schemes): the yardstick for the strict per-amplitude tolerance of SURVEY 8c
+    (relative error on |amp| >= 1e-3 rms).  Stores the complex128 results next to the complex64 ones
+    in tests/golden/c128_spread.npz plus both error figures per case."""
+    from artensor_amd.fixtures import load_case
+    out, meta = {}, {}
+
+    def figures(got, want):
+        got, want = np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)
+        rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+        loose = float(np.abs(got - want).max() / max(float(np.abs(want).max()), rms))
+        sel = np.abs(want) >= 1e-3 * rms
+        strict = float((np.abs(got - want)[sel] / np.abs(want)[sel]).max())
+        return dict(loose=loose, strict=strict, n=int(sel.sum()))
+
+    for name, sparse in (("n12_dense", False), ("n12_sparse5", True), ("n30_sparse100", True)):
+        case = load_case(os.path.join(HERE, name + ".npz"))
+        fn = tensor_contraction_sparse if sparse else tensor_contraction
+        t0 = time.time()
+        r64 = fn(case.fresh_tensors(dtype=torch.complex64), case.scheme).reshape(-1)
+        r128 = fn(case.fresh_tensors(dtype=torch.complex128), case.scheme).reshape(-1)
+        out[name + "_c128"] = r128.numpy()
+        meta[name] = figures(r64.numpy(), r128.numpy())
+        print(name, meta[name], f"{time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "c128_spread.npz"),
+                        meta=np.frombuffer(__import__("json").dumps(meta).encode(), dtype=np.uint8), **out)
+
+
 def case_random_bench():
     """Benchmark-scale random tensor networks (SURVEY 8d input 2: 3-regular graphs, seed 0, leaves
     complex(randn, randn) / D^1.5, planned by the reference's find_order, trials 4, iters 5):
@@ -672,6 +701,7 @@ CASES = {
     "n53_slice0": case_n53_slice0,
     "n53m20_plan": lambda: case_n53_plan("m20"),
     "n53m20_slice0": lambda: case_n53_slice0("m20"),
+    "c128_spread": case_c128_spread,
     "n53m20_batch_plan": case_n53m20_batch_plan,
     "n53m20_batch_slice0": case_n53m20_batch_slice0,
     "trees": case_trees,

@@ -8,9 +8,11 @@ import pytest
 from artensor_amd import step_info
 from artensor_amd.fixtures import load_case
 from oracle import oracle
-from helpers import GOLDEN, crandn, dense_scheme_shapes, emulate, shrink_step
+from helpers import GOLDEN, crandn, dense_scheme_shapes, emulate, emulate_gemm, shrink_step
 
 KERNEL_BITS = 1
+KERNEL_GEMM = 2
+MFMA_KERNELS = (KERNEL_BITS, KERNEL_GEMM)
 
 
 def check(eq, a_shape, b_shape, seed=0, expect_bits=None):
@@ -22,7 +24,7 @@ def check(eq, a_shape, b_shape, seed=0, expect_bits=None):
     err = np.abs(got - want).max() / np.abs(want).max()
     assert err < 1e-5, (eq, err)
     if expect_bits is not None:
-        assert (used == KERNEL_BITS) == expect_bits, (eq, used)
+        assert (used in MFMA_KERNELS) == expect_bits, (eq, used)
     return used
 
 
@@ -36,10 +38,11 @@ def test_n30_big_steps_surrogates():
     for n, (eq, sa, sb) in big:
         eq2, sa2, sb2 = shrink_step(eq, sa, sb, max_log2=16)
         used = check(eq2, sa2, sb2, seed=n)
-        n_bits += used == KERNEL_BITS
-        # and the full-size step must be planned onto the MFMA kernel
+        n_bits += used in MFMA_KERNELS
+        # and the full-size step must be planned onto an MFMA kernel (the growth steps whose second
+        # operand is itself big go to the two-operand GEMM kernel when they run unfused)
         info = step_info(eq, sa, sb)
-        assert info["kernel"] == KERNEL_BITS, (n, eq, info)
+        assert info["kernel"] in MFMA_KERNELS, (n, eq, info)
         assert info["lds_bytes"] <= 72 * 1024
     assert n_bits >= 20  # the surrogates themselves mostly take the MFMA plan
 
@@ -242,3 +245,87 @@ def test_fused_row_gather_emulated():
         assert rc == 0, rc
         assert flag.value == 0
         assert np.abs(out - want).max() / np.abs(want).max() < 1e-5, eq
+
+
+def _random_gemm_step(rng, m, n, k, batch=0):
+    ml = [f"m{x}" for x in range(m)]
+    kl = [f"k{x}" for x in range(k)]
+    nl = [f"n{x}" for x in range(n)]
+    la, lb, lo = ml + kl, kl + nl, ml + nl
+    rng.shuffle(la), rng.shuffle(lb), rng.shuffle(lo)
+    sa, sb = [2] * len(la), [2] * len(lb)
+    if batch:
+        la, lb, lo = ["z"] + la, ["z"] + lb, ["z"] + lo
+        sa, sb = [batch] + sa, [batch] + sb
+    return (tuple(la), tuple(lb), tuple(lo)), tuple(sa), tuple(sb)
+
+
+def _einsum128(eq, a, b):
+    import string
+    la, lb, lo = eq
+    labels = list(dict.fromkeys(list(la) + list(lb)))
+    mp = {x: string.ascii_letters[i] for i, x in enumerate(labels)}
+    return np.einsum("".join(mp[x] for x in la) + "," + "".join(mp[x] for x in lb) + "->" + "".join(mp[x] for x in lo),
+                     a.astype(np.complex128), b.astype(np.complex128))
+
+
+@pytest.mark.parametrize("m,n,k,batch", [(7, 7, 4, 0), (7, 7, 6, 0), (8, 7, 5, 0), (9, 3, 8, 0), (6, 6, 4, 3), (5, 4, 9, 0),
+                                         (10, 0, 5, 0), (3, 9, 6, 0), (7, 5, 7, 2), (6, 7, 5, 0), (8, 2, 10, 0)])
+def test_gemm_plan_emulated(monkeypatch, m, n, k, batch):
+    """The two-operand GEMM kernel replayed thread by thread from its plan (global -> LDS images, MFMA
+    lane maps, Gray-code walk over the looped contracted bits, C-ordered swizzled result image in one
+    or two passes, copy-out): random bit permutations, full 128 x 128 tiles (ARTN_EMU_NCU=1 keeps the
+    planner from shrinking tiles for want of workgroups), tiles with fewer than 16 columns, operands
+    exchanged (m < 5), a ragged batch axis."""
+    monkeypatch.setenv("ARTN_EMU_NCU", "1")
+    rng = np.random.default_rng(100 * m + 10 * n + k)
+    eq, sa, sb = _random_gemm_step(rng, m, n, k, batch)
+    a, b = crandn(rng, sa), crandn(rng, sb)
+    got, info = emulate_gemm(eq, a, b)
+    assert got is not None and info["kernel"] == KERNEL_GEMM
+    want = _einsum128(eq, a, b)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (eq, info)
+    if m >= 7 and n >= 7:
+        assert info["tile_out_bits"] == 14   # two epilogue passes covered
+
+
+@pytest.mark.parametrize("m,n,k", [(7, 7, 5), (7, 6, 6), (8, 3, 7), (5, 4, 9), (3, 9, 6)])
+def test_gemm_plan_emulated_bf16(monkeypatch, m, n, k):
+    """bf16 operand mode of the GEMM kernel (chunks of 32 contracted values, [kc >> 2][row][kc & 3] images)
+    against a complex128 einsum of the bf16-rounded operands: only fp32 accumulation order differs."""
+    import torch
+    monkeypatch.setenv("ARTN_EMU_NCU", "1")
+    rng = np.random.default_rng(7 * m + n + 31 * k)
+    eq, sa, sb = _random_gemm_step(rng, m, n, k)
+    a, b = crandn(rng, sa), crandn(rng, sb)
+
+    def bf(x):
+        r = torch.view_as_real(torch.from_numpy(np.ascontiguousarray(x))).to(torch.bfloat16).to(torch.float32)
+        return torch.view_as_complex(r.contiguous()).numpy()
+
+    got, info = emulate_gemm(eq, a, b, bf16=True)
+    assert got is not None and info["kernel"] == KERNEL_GEMM and info["n_tile_bits"] <= 6
+    want = _einsum128(eq, bf(a), bf(b))
+    assert np.abs(got - want).max() / np.abs(want).max() < 2e-6, (eq, info)
+
+
+def test_planner_routes_big_contractions_to_the_gemm_kernel():
+    # 15 contracted bits between two big operands (the n53 m20 big-batch step): one launch, no split-K
+    la = tuple(f"m{x}" for x in range(15)) + tuple(f"k{x}" for x in range(15))
+    lb = tuple(f"k{x}" for x in range(15)) + tuple(f"n{x}" for x in range(14))
+    lo = tuple(f"m{x}" for x in range(15)) + tuple(f"n{x}" for x in range(14))
+    info = step_info((la, lb, lo), (2,) * 30, (2,) * 29)
+    assert info["kernel"] == KERNEL_GEMM and info["k_bits"] == 15 and info["m_tile_bits"] == 7 and info["n_tile_bits"] == 7
+    from artensor_amd.contraction import _big_k_outer
+    assert _big_k_outer(la, lb, lo, (2,) * 30, None, (2,) * 29) is None
+    # a closing step (two 2^26 tensors down to 2^10 amplitudes): contracted labels are split off only
+    # until enough workgroups have work
+    la = tuple(f"m{x}" for x in range(5)) + tuple(f"k{x}" for x in range(21))
+    lb = tuple(f"k{x}" for x in range(21)) + tuple(f"n{x}" for x in range(5))
+    lo = la[:5] + lb[21:]
+    outer = _big_k_outer(la, lb, lo, (2,) * 26, None, (2,) * 26)
+    assert outer is not None and 1 <= len(outer) <= 10
+    # small second operand, 5 contracted bits: stays on the state-streaming kernel
+    info = step_info("ABCDEFGHIJKLMNOPQRST,DHKOSwxyz->ABCEFGIJLMNPQRTwxyz", (2,) * 20, (2,) * 9)
+    assert info["kernel"] == KERNEL_BITS

@@ -25,7 +25,7 @@ class Prof:
     def record(s, info, e0, e1): s.rows.append((info, e0, e1))
 p = Prof(); C.profiler = p; one(3); torch.cuda.synchronize(); C.profiler = None
 rows = sorted(((e0.elapsed_time(e1), info) for info, e0, e1 in p.rows), key=lambda r: -r[0])
-tot = sum(r[0] for r in rows); big = sum(r[0] for r in rows if r[1]["kernel"] == 1)
+tot = sum(r[0] for r in rows); big = sum(r[0] for r in rows if r[1]["kernel"] in (1, 2))
 print(f"per slice wall {dt*1e3:.1f} ms; apply_slice {ds*1e3:.2f} ms; contract launches {len(rows)}: {tot:.1f} ms in kernels ({big:.1f} ms MFMA kernel)")
 for ms, info in rows[:int(os.environ.get("TOP", "10"))]:
     print(f"   {ms:6.2f} ms kernel={info['kernel']} k={info['k_bits']}+{info['k2_bits']} T={info['tile_in_bits']}/{info['tile_out_bits']} tiles={info['n_tiles']} GF={info['flops']/1e9:.0f} -> {info['flops']/ms/1e9:.1f} TF/s  {info.get('note','')}")

@@ -19,7 +19,7 @@ for reuse in (False, True):
     t0 = time.perf_counter(); r.run(order[2:10]); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8
     p = Prof(); C.profiler = p; r.run(order[10:11]); torch.cuda.synchronize(); C.profiler = None
     rows = sorted(((e0.elapsed_time(e1), info) for info, e0, e1 in p.rows), key=lambda x: -x[0])
-    tot = sum(x[0] for x in rows); big = sum(x[0] for x in rows if x[1]["kernel"] == 1)
+    tot = sum(x[0] for x in rows); big = sum(x[0] for x in rows if x[1]["kernel"] in (1, 2))
     print(f"reuse_small={reuse}: {dt*1e3:.2f} ms per slice; launches {len(rows)}, {tot:.1f} ms in contract kernels ({big:.1f} MFMA)")
     for ms, info in rows[:int(os.environ.get("TOP", "14"))]:
         print(f"   {ms:6.2f} ms kernel={info['kernel']} k={info['k_bits']}+{info['k2_bits']} T={info['tile_in_bits']}/{info['tile_out_bits']} tiles={info['n_tiles']} GF={info['flops']/1e9:.0f} -> {info['flops']/ms/1e9:.1f} TF/s")
