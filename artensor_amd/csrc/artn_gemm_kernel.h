@@ -13,7 +13,11 @@
 //                16-byte lanes (element pairs along each operand's stride-1 bit), double buffered:
 //                the loads of chunk c+1 are in flight while chunk c is multiplied;
 //   k loop     = the remaining contracted bits, walked in Gray-code order (one stride added or
-//                subtracted per chunk), accumulators in registers throughout;
+//                subtracted per chunk), accumulators in registers; every 2^12 contracted values the
+//                partial sum is flushed into the C tile (read-add-write through the epilogue) and
+//                the registers restart from zero: one chain of 2^15 fp32 additions put the n53 m20
+//                big-batch slice 1.2e-5 of the typical amplitude from the reference, chains of 2^10
+//                5.9e-6 (what the other 453 steps leave) at 4 % more time; 2^12 costs 1 %;
 //   epilogue   = accumulators -> LDS in C order (XOR-swizzled like artn_k_bits' stage output) ->
 //                16-byte coalesced stores, in passes of 2^13 elements.
 //
@@ -186,6 +190,9 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
   const long G = gridDim.x, n_tiles = P.n_tiles;
   if ((G & 7) == 0) t0 = (long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3); // XCD-contiguous tile ranges
   const int n_chunks = 1 << P.n_ko;
+  // chunks per partial sum - 1: 2^12 contracted values in fp32; bf16 operands carry 2^-9 of rounding each, the
+  // length of the fp32 chain does not matter there
+  const int flush_mask = BF ? 0x7fffffff : (1 << (ARTN_GEMM_FLUSH_LOG2 - ARTN_GEMM_KC)) - 1;
   __syncthreads(); // tables are in LDS
   TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
   const char *Ac = reinterpret_cast<const char *>(A), *Bc = reinterpret_cast<const char *>(B);
@@ -283,65 +290,80 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
           }
         }
       }
-      if (!last) {
+      const bool flush = last || ((c + 1) & flush_mask) == 0;
+      if (!flush) {
         fill((cur ^ 1u) * stage_bytes);
         __syncthreads();
         cur ^= 1u;
+        continue;
       }
-    }
-    // ---- epilogue: accumulators -> C-ordered LDS image -> global, 2^13 elements per pass
-    char *Cb = reinterpret_cast<char *>(C) + off.c * 8;
-    for (int pass = 0; pass < n_pass; ++pass) {
-      __syncthreads(); // chunk buffers / previous pass are no longer read
-      unsigned lc = lane_c; // (opaque: 64 hoisted scatter addresses per lane would cost the accumulators their registers)
-      OPAQUE_V(lc);
-      if (w_active) {
+      // ---- epilogue: accumulators -> C-ordered LDS image -> global, 2^13 elements per pass; a later partial
+      //      sum of the same tile is added to what the earlier ones left in C
+      const bool accumulate = c > flush_mask;
+      char *Cb = reinterpret_cast<char *>(C) + off.c * 8;
+      for (int pass = 0; pass < n_pass; ++pass) {
+        __syncthreads(); // chunk buffers / previous pass are no longer read
+        unsigned lc = lane_c; // (opaque: 64 hoisted scatter addresses per lane would cost the accumulators their registers)
+        OPAQUE_V(lc);
+        if (w_active) {
+#pragma unroll
+          for (int a = 0; a < MB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b0 = 0; b0 < 2; ++b0) {
+                  const int n_loc = b0 + 2 * h + 4 * q;
+                  const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ (b0 ? c_b0 : 0u) ^ ((q & 1) ? c_q0 : 0u) ^ ((q >> 1) ? c_q1 : 0u);
+                  if (n_loc < n_lim && (int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
+                    lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{acc[a][b][4 * q + 2 * b0], acc[a][b][4 * q + 2 * b0 + 1]});
+                }
+        }
+        __syncthreads();
+        char *Cp = Cb + pass * pass_stride;
+        // (a swizzle source may be the pass bit itself: its image under the swizzle belongs to every address of the pass)
+        unsigned oll = o_ll ^ ((swz_gemm((unsigned)pass << ARTN_GEMM_EPI_BITS, P) & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u), ogl = o_gl;
+        OPAQUE_V(oll);
+        OPAQUE_V(ogl);
+        for (int i0 = 0; i0 < o_iters; i0 += 4) {
+          f32x4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i < o_iters && o_act) x[u] = lds_read16(oll ^ (swz_gemm((unsigned)i * 512u, P) * 8u));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i < o_iters && o_act) {
+              long o = 0;
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+                if ((i >> b) & 1) o += o_gi[b];
+              f32x4 *dst = reinterpret_cast<f32x4 *>(Cp + o + ogl);
+              // (this thread wrote the same 16 bytes at the previous flush, long ago; read them past the L1)
+              if (accumulate) x[u] += __builtin_nontemporal_load(dst);
+              *dst = x[u];
+            }
+          }
+        }
+      }
+      __syncthreads(); // the result image has been read; the chunk buffers are free again
+      if (have_next) {
+        fill(0u);
+        __syncthreads();
+      }
+      cur = 0;
+      if (!last) {
 #pragma unroll
         for (int a = 0; a < MB; ++a)
 #pragma unroll
           for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int b0 = 0; b0 < 2; ++b0) {
-                const int n_loc = b0 + 2 * h + 4 * q;
-                const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ (b0 ? c_b0 : 0u) ^ ((q & 1) ? c_q0 : 0u) ^ ((q >> 1) ? c_q1 : 0u);
-                if (n_loc < n_lim && (int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
-                  lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{acc[a][b][4 * q + 2 * b0], acc[a][b][4 * q + 2 * b0 + 1]});
-              }
-      }
-      __syncthreads();
-      char *Cp = Cb + pass * pass_stride;
-      // (a swizzle source may be the pass bit itself: its image under the swizzle belongs to every address of the pass)
-      unsigned oll = o_ll ^ ((swz_gemm((unsigned)pass << ARTN_GEMM_EPI_BITS, P) & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u), ogl = o_gl;
-      OPAQUE_V(oll);
-      OPAQUE_V(ogl);
-      for (int i0 = 0; i0 < o_iters; i0 += 4) {
-        f32x4 x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u;
-          if (i < o_iters && o_act) x[u] = lds_read16(oll ^ (swz_gemm((unsigned)i * 512u, P) * 8u));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u;
-          if (i < o_iters && o_act) {
-            long o = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              if ((i >> b) & 1) o += o_gi[b];
-            *reinterpret_cast<f32x4 *>(Cp + o + ogl) = x[u];
-          }
-        }
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
       }
     }
-    __syncthreads(); // the result image has been read; the chunk buffers are free again
-    if (more_tiles) {
-      fill(0u);
-      __syncthreads();
-    }
-    cur = 0;
     off = noff;
   }
 }

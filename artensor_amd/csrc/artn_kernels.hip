@@ -1008,7 +1008,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   // issue priority of ONE of the two (the one whose waves sit in the odd wave slots) during
   // its MFMA stages only breaks the symmetry: its chains never wait, the other workgroup's
   // chains fill the pipe while it copies, and the pair locks into alternation (offset 0.48).
-  const bool stage_prio = P.stage_prio && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1); // HW_ID.wave_id bit 0
+  const bool stage_prio = (P.stage_prio == 1 || P.stage_prio == 3) && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1); // HW_ID.wave_id bit 0
+  // experiment (ARTN_STAGE_PRIO=2/3): the COPY phases of every workgroup run at raised priority instead, so their few
+  // instructions never queue behind the co-resident workgroup's MFMA stream (3: on top of the asymmetric stage priority)
+  const bool copy_prio = P.stage_prio >= 2;
   STAMP_DECL
   for (long tile = t0; tile < n_tiles; tile += G) {
     if (off.b1 != prev_b1) {
@@ -1067,6 +1070,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     }
     STAMP(6); // barriers after the stages
     PHASE_MARK(2);
+    if (copy_prio) __builtin_amdgcn_s_setprio(3);
 
     unsigned lo_in = in_lane, lo_out = out_lane, t16 = tid16, t16o = tid16_out;
     OPAQUE_V(lo_in);
@@ -1128,6 +1132,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       if (KB2 > 0) __syncthreads();
       if (next < n_tiles) copy_in_sync(reinterpret_cast<const char *>(A + noff.a), in_hi, lo_in, R0, t16, n_in_iters);
     }
+    if (copy_prio) __builtin_amdgcn_s_setprio(0);
     __syncthreads(); // R0 holds the next tile; every wave is done with the result region
     PHASE_MARK(7);
     STAMP(3);

@@ -109,6 +109,7 @@ struct ArtnGenericPlan {
 // (7+ contracted bits; big x big steps of sliced circuits and random networks).
 #define ARTN_GEMM_MAX_KO 40
 #define ARTN_GEMM_KC 4           /* contracted bits per LDS chunk */
+#define ARTN_GEMM_FLUSH_LOG2 12   /* fp32: partial sums leave the registers every 2^12 contracted values */
 #define ARTN_GEMM_EPI_BITS 13    /* the result tile leaves in passes of 2^13 elements (64 KiB) */
 #define ARTN_GEMM_PITCH_LOG2 7   /* rows of both LDS images are 2^7 elements apart whatever mt / nt: every
                                     LDS read of the MFMA loop has a compile-time offset */
@@ -175,7 +176,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_TILE_TARGET")) x.tile_target = std::min(ARTN_TILE_BITS_MAX, std::max(9, atoi(e)));
     if (const char *e = getenv("ARTN_RUN_MAX")) x.run_max = std::min(6, std::max(1, atoi(e)));
     if (const char *e = getenv("ARTN_SWIZZLE")) x.swizzle = atoi(e) != 0;
-    if (const char *e = getenv("ARTN_STAGE_PRIO")) x.stage_prio = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_STAGE_PRIO")) x.stage_prio = std::min(3, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_NT")) x.nt = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }

@@ -166,6 +166,43 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
     auto ACC = [&](int wave, int a, int b, int lane, int rr) -> float & {
       return acc[((((size_t)wave * MB + a) * NB + b) * 64 + lane) * 16 + rr];
     };
+    // epilogue: every 2^10 contracted values and at the end (the later partial sums are added to C)
+    auto flush_tile = [&](bool accumulate) {
+    auto m_off = [&](int m_local) { unsigned o = 0; for (int i = 0; i < mt; ++i) if ((m_local >> i) & 1) o |= 1u << P.m_pos[i]; return o; };
+    auto n_off = [&](int n_local) { unsigned o = 0; for (int i = 0; i < nt; ++i) if ((n_local >> i) & 1) o |= 1u << P.n_pos[i]; return o; };
+    const int n_lim = nt >= 4 ? 16 : 1 << nt;
+    const int n_pass = 1 << (P.tc_bits - epi_bits);
+    for (int pass = 0; pass < n_pass; ++pass) {
+      for (auto &x : res) x = cf(-777.f, -777.f);
+      for (int wave = 0; wave < 4; ++wave) {
+        const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
+        if (wm >= (1 << P.wm_log2)) continue;
+        for (int a = 0; a < MB; ++a) for (int b = 0; b < NB; ++b) for (int lane = 0; lane < 64; ++lane)
+          for (int q = 0; q < 4; ++q) for (int b0 = 0; b0 < 2; ++b0) {
+            const int j = lane & 31, h = lane >> 5;
+            const int n_loc = b0 + 2 * h + 4 * q;
+            if (n_loc >= n_lim) continue;
+            const unsigned pos = swzg(m_off((wm * MB + a) * 32 + j) | n_off((wn * NB + b) * 16 + n_loc), P);
+            if ((int)(pos >> ARTN_GEMM_EPI_BITS) != pass) continue;
+            res[pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)] = cf(ACC(wave, a, b, lane, 4 * q + 2 * b0), ACC(wave, a, b, lane, 4 * q + 2 * b0 + 1));
+          }
+      }
+      const int cb = epi_bits - 1, iters = cb > 8 ? 1 << (cb - 8) : 1;
+      const int64_t pass_off = P.tc_bits > epi_bits ? pass * P.out_stride[epi_bits] : 0;
+      for (int tid = 0; tid < 256; ++tid) {
+        if (!(cb >= 8 || tid < (1 << cb))) continue;
+        for (int i = 0; i < iters; ++i) {
+          const int chunk = tid + 256 * i;
+          int64_t g = 0;
+          for (int b = 1; b < epi_bits; ++b) if ((chunk >> (b - 1)) & 1) g += P.out_stride[b];
+          const unsigned l = swzg(((unsigned)pass << ARTN_GEMM_EPI_BITS) | 2u * (unsigned)chunk, P) & ((1u << ARTN_GEMM_EPI_BITS) - 1u);
+          if (accumulate) { C[offC + pass_off + g] += res[l]; C[offC + pass_off + g + 1] += res[l + 1]; }
+          else { C[offC + pass_off + g] = res[l]; C[offC + pass_off + g + 1] = res[l + 1]; }
+        }
+      }
+    }
+    };
+    const int flush_mask = P.split ? 0x7fffffff : (1 << (ARTN_GEMM_FLUSH_LOG2 - ARTN_GEMM_KC)) - 1;
     int64_t ka = 0, kb = 0;
     for (int c = 0; c < n_chunks; ++c) {
       if (c > 0) { // Gray code step from chunk c-1 to chunk c
@@ -243,39 +280,9 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
               }
             }
       }
-    }
-    // epilogue
-    auto m_off = [&](int m_local) { unsigned o = 0; for (int i = 0; i < mt; ++i) if ((m_local >> i) & 1) o |= 1u << P.m_pos[i]; return o; };
-    auto n_off = [&](int n_local) { unsigned o = 0; for (int i = 0; i < nt; ++i) if ((n_local >> i) & 1) o |= 1u << P.n_pos[i]; return o; };
-    const int n_lim = nt >= 4 ? 16 : 1 << nt;
-    const int n_pass = 1 << (P.tc_bits - epi_bits);
-    for (int pass = 0; pass < n_pass; ++pass) {
-      for (auto &x : res) x = cf(-777.f, -777.f);
-      for (int wave = 0; wave < 4; ++wave) {
-        const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
-        if (wm >= (1 << P.wm_log2)) continue;
-        for (int a = 0; a < MB; ++a) for (int b = 0; b < NB; ++b) for (int lane = 0; lane < 64; ++lane)
-          for (int q = 0; q < 4; ++q) for (int b0 = 0; b0 < 2; ++b0) {
-            const int j = lane & 31, h = lane >> 5;
-            const int n_loc = b0 + 2 * h + 4 * q;
-            if (n_loc >= n_lim) continue;
-            const unsigned pos = swzg(m_off((wm * MB + a) * 32 + j) | n_off((wn * NB + b) * 16 + n_loc), P);
-            if ((int)(pos >> ARTN_GEMM_EPI_BITS) != pass) continue;
-            res[pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)] = cf(ACC(wave, a, b, lane, 4 * q + 2 * b0), ACC(wave, a, b, lane, 4 * q + 2 * b0 + 1));
-          }
-      }
-      const int cb = epi_bits - 1, iters = cb > 8 ? 1 << (cb - 8) : 1;
-      const int64_t pass_off = P.tc_bits > epi_bits ? pass * P.out_stride[epi_bits] : 0;
-      for (int tid = 0; tid < 256; ++tid) {
-        if (!(cb >= 8 || tid < (1 << cb))) continue;
-        for (int i = 0; i < iters; ++i) {
-          const int chunk = tid + 256 * i;
-          int64_t g = 0;
-          for (int b = 1; b < epi_bits; ++b) if ((chunk >> (b - 1)) & 1) g += P.out_stride[b];
-          const unsigned l = swzg(((unsigned)pass << ARTN_GEMM_EPI_BITS) | 2u * (unsigned)chunk, P) & ((1u << ARTN_GEMM_EPI_BITS) - 1u);
-          C[offC + pass_off + g] = res[l];
-          C[offC + pass_off + g + 1] = res[l + 1];
-        }
+      if (c + 1 == n_chunks || ((c + 1) & flush_mask) == 0) {
+        flush_tile(c > flush_mask);
+        std::fill(acc.begin(), acc.end(), 0.f);
       }
     }
   }

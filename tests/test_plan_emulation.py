@@ -270,13 +270,14 @@ def _einsum128(eq, a, b):
 
 
 @pytest.mark.parametrize("m,n,k,batch", [(7, 7, 4, 0), (7, 7, 6, 0), (8, 7, 5, 0), (9, 3, 8, 0), (6, 6, 4, 3), (5, 4, 9, 0),
-                                         (10, 0, 5, 0), (3, 9, 6, 0), (7, 5, 7, 2), (6, 7, 5, 0), (8, 2, 10, 0)])
+                                         (10, 0, 5, 0), (3, 9, 6, 0), (7, 5, 7, 2), (6, 7, 5, 0), (8, 2, 10, 0), (5, 3, 13, 0)])
 def test_gemm_plan_emulated(monkeypatch, m, n, k, batch):
     """The two-operand GEMM kernel replayed thread by thread from its plan (global -> LDS images, MFMA
     lane maps, Gray-code walk over the looped contracted bits, C-ordered swizzled result image in one
     or two passes, copy-out): random bit permutations, full 128 x 128 tiles (ARTN_EMU_NCU=1 keeps the
     planner from shrinking tiles for want of workgroups), tiles with fewer than 16 columns, operands
-    exchanged (m < 5), a ragged batch axis."""
+    exchanged (m < 5), a ragged batch axis, and more than 2^12 contracted values (partial sums flushed
+    into C and added up there)."""
     monkeypatch.setenv("ARTN_EMU_NCU", "1")
     rng = np.random.default_rng(100 * m + 10 * n + k)
     eq, sa, sb = _random_gemm_step(rng, m, n, k, batch)
@@ -290,7 +291,7 @@ def test_gemm_plan_emulated(monkeypatch, m, n, k, batch):
         assert info["tile_out_bits"] == 14   # two epilogue passes covered
 
 
-@pytest.mark.parametrize("m,n,k", [(7, 7, 5), (7, 6, 6), (8, 3, 7), (5, 4, 9), (3, 9, 6)])
+@pytest.mark.parametrize("m,n,k", [(7, 7, 5), (7, 6, 6), (8, 3, 7), (5, 4, 9), (3, 9, 6), (5, 3, 11)])
 def test_gemm_plan_emulated_bf16(monkeypatch, m, n, k):
     """bf16 operand mode of the GEMM kernel (chunks of 32 contracted values, [kc >> 2][row][kc & 3] images)
     against a complex128 einsum of the bf16-rounded operands: only fp32 accumulation order differs."""
