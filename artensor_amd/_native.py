@@ -12,6 +12,7 @@ import threading
 import torch
 
 ARTN_MAX_LABELS = 96
+ARTN_PROGRAM_MAX_EXT = 256
 ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
 KERNEL_GENERIC, KERNEL_BITS_MFMA, KERNEL_GEMM_MFMA = 0, 1, 2
 
@@ -71,6 +72,11 @@ _EXPORTS = {
                                             ctypes.POINTER(ArtnStepInfo)]),
     "artn_contract2": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "artn_program_record_bytes": (ctypes.c_int64, []),
+    "artn_program_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
+    "artn_program_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                        ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_axpy_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),

@@ -524,12 +524,170 @@ class _Op:
     __slots__ = ("steps", "i", "j", "j2", "d1", "d2", "out_shape", "info", "sum_rows")
 
 
+
+# ----------------------------------------------------------------------------------------
+# the launch-latency tail of a dense scheme as ONE launch (artn_program_*)
+# ----------------------------------------------------------------------------------------
+PROGRAM_MAX_NUMEL = 1 << 14   # operands and result of a step that goes into the small-step program
+PROGRAM_MIN_STEPS = 4         # not worth a program below this many steps
+KERNEL_PROGRAM = 3            # profiler label of the program launch (not a planner kernel id)
+
+
+class _Program:
+    """Compiled small steps of a dense scheme: device image per device, workspace layout, which tensor
+    ids it reads from the caller (`ext_ids`, in kernel-argument order) and which results it leaves
+    (`outputs`: id -> (workspace byte offset, shape))."""
+    __slots__ = ("host_image", "host_groups", "n_groups", "n_steps", "ext_ids", "ws_bytes", "outputs", "dev", "flops")
+
+    def device_copy(self, device):
+        hit = self.dev.get(device)
+        if hit is None:
+            hit = self.dev[device] = (self.host_image.to(device), self.host_groups.to(device))
+        return hit
+
+
+def _plan_small_program(scheme, shapes, dtype):
+    """Split a dense scheme into the steps that only combine small, leaf-derived tensors -- compiled into
+    a one-launch program -- and the rest, in scheme order.  Returns (program or None, indices of the
+    remaining steps).  Sequential semantics are kept: a step joins the program only if neither operand
+    was produced by a remaining step and its target is not still to be read by an earlier remaining step."""
+    every = list(range(len(scheme)))
+    if dtype != torch.complex64 or len(scheme) < PROGRAM_MIN_STEPS or __import__("os").environ.get("ARTN_NO_PROGRAM", "0") not in ("", "0"):
+        return None, every
+    cur = dict(shapes)
+    tainted, main_reads, small, main = set(), set(), [], []
+
+    def numel(sh):
+        n = 1
+        for e in sh:
+            n *= e
+        return n
+
+    recs = {}
+    for n, step in enumerate(scheme):
+        (i, j), eq = step[0], step[1]
+        la, lb, lo = _labels(eq)
+        ok = (i not in tainted and j not in tainted and i not in main_reads and i in cur and j in cur and i != j
+              and len(la) == len(cur[i]) and len(lb) == len(cur[j]))
+        out_shape = None
+        if ok:
+            ext = dict(zip(la, cur[i]))
+            ext.update(zip(lb, cur[j]))
+            out_shape = tuple(ext[x] for x in lo)
+            ok = 0 < max(numel(cur[i]), numel(cur[j]), numel(out_shape)) <= PROGRAM_MAX_NUMEL and numel(out_shape) > 0
+        if ok:
+            recs[n] = (la, lb, lo, cur[i], cur[j], out_shape)
+            small.append(n)
+            cur[i] = out_shape
+        else:
+            main.append(n)
+            tainted.add(i)
+            main_reads.add(j)
+            cur.pop(i, None)
+    if len(small) < PROGRAM_MIN_STEPS:
+        return None, every
+    # groups = connected components of the small steps (steps of different groups share no tensor)
+    parent = {}
+
+    def find(x):
+        while parent.setdefault(x, x) != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    for n in small:
+        i, j = scheme[n][0]
+        parent[find(i)] = find(j)
+    order, seen = [], {}
+    for n in small:
+        r = find(scheme[n][0][0])
+        if r not in seen:
+            seen[r] = len(seen)
+    small_sorted = sorted(small, key=lambda n: (seen[find(scheme[n][0][0])], n))
+    group_start = [0]
+    for k in range(1, len(small_sorted)):
+        if find(scheme[small_sorted[k]][0][0]) != find(scheme[small_sorted[k - 1]][0][0]):
+            group_start.append(k)
+    group_start.append(len(small_sorted))
+    # locations: leaves are external pointers, results live in the workspace
+    loc, ext_ids, ws = {}, [], 0
+    la_, lb_, lc_, descs, flops = [], [], [], [], 0.0
+    where = {}
+    for n in small_sorted:
+        i, j = scheme[n][0]
+        la, lb, lo, sa, sb, so = recs[n]
+        for t in (i, j):
+            if t not in loc:
+                loc[t] = -(len(ext_ids) + 1)
+                ext_ids.append(t)
+        d, _ = _descriptor(la, lb, lo, sa, _dense_strides(sa), sb, _dense_strides(sb), torch.complex64)
+        descs.append(d)
+        la_.append(loc[i])
+        lb_.append(loc[j])
+        lc_.append(ws)
+        loc[i] = ws
+        where[i] = (ws, so)
+        ws += (numel(so) * 8 + 15) // 16 * 16
+        f = 8.0
+        for x in dict.fromkeys(la + lb):
+            f *= dict(zip(la, sa)).get(x) or dict(zip(lb, sb))[x]
+        flops += f
+    if len(ext_ids) > N.ARTN_PROGRAM_MAX_EXT:
+        return None, every
+    lib = N.lib()
+    rec_bytes = int(lib.artn_program_record_bytes())
+    image = torch.zeros(len(small_sorted) * rec_bytes, dtype=torch.uint8)
+    arr = (ctypes.POINTER(N.ArtnStepDesc) * len(descs))(*[ctypes.pointer(d) for d in descs])
+    i64 = lambda v: (ctypes.c_int64 * len(v))(*v)
+    rc = lib.artn_program_build(len(descs), arr, i64(la_), i64(lb_), i64(lc_), image.data_ptr())
+    if rc == -2:
+        return None, every
+    N.check(rc)
+    prog = _Program()
+    prog.host_image, prog.host_groups = image, torch.tensor(group_start, dtype=torch.int32)
+    prog.n_groups, prog.n_steps, prog.ext_ids, prog.ws_bytes = len(group_start) - 1, len(small_sorted), ext_ids, max(ws, 16)
+    # results a remaining step reads, or the scheme's own result
+    needed = set()
+    for n in main:
+        needed.update(scheme[n][0])
+    needed.add(scheme[-1][0][0])
+    prog.outputs = {t: v for t, v in where.items() if t in needed}
+    prog.dev, prog.flops = {}, flops
+    return prog, main
+
+
+def _run_program(prog, tensors, dtype, device, stream):
+    image, groups = prog.device_copy(device)
+    ws = torch.empty(prog.ws_bytes, dtype=torch.uint8, device=device)
+    ext = (ctypes.c_void_p * len(prog.ext_ids))(*[tensors[t].data_ptr() for t in prog.ext_ids])
+    if profiler is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    N.check(N.lib().artn_program_run(image.data_ptr(), groups.data_ptr(), prog.n_groups, ext, len(prog.ext_ids),
+                                     ws.data_ptr(), stream))
+    if profiler is not None:
+        e1.record()
+        profiler.record({"kernel": KERNEL_PROGRAM, "flops": prog.flops, "bytes": 0.0, "k_bits": 0, "k2_bits": 0, "m_tile_bits": 0,
+                         "n_tile_bits": 0, "tile_in_bits": 0, "tile_out_bits": 0, "n_tiles": prog.n_steps, "a_rereads": 1}, e0, e1)
+    for t, (off, shape) in prog.outputs.items():
+        n = 8
+        for e in shape:
+            n *= e
+        tensors[t] = ws[off:off + n].view(torch.complex64).reshape(shape)
+
+
 def _compile_dense(scheme, shapes, dtype):
-    """Resolve a dense scheme once: execution order, fused pairs (host-only planner queries),
-    descriptors and result shapes.  Everything the per-call loop needs except pointers."""
+    """Resolve a dense scheme once: the small-step program, execution order of the rest, fused pairs
+    (host-only planner queries), descriptors and result shapes.  Everything the per-call loop needs
+    except pointers.  Returns (program or None, launch list)."""
     shapes = dict(shapes)
     fuse_ok = dtype == torch.complex64
     ops = []
+    prog, main_idx = _plan_small_program(scheme, shapes, dtype)
+    in_prog = set(range(len(scheme))) - set(main_idx)
+    if prog is not None:
+        for t, (off, shape) in prog.outputs.items():
+            shapes[t] = shape
 
     def emit(n, i, j, la, lb, lo, sa, sb, warn=True):
         op = _Op()
@@ -562,11 +720,19 @@ def _compile_dense(scheme, shapes, dtype):
         else:
             shapes[i] = emit(n, i, j, la, lb, lo, shapes[i], shapes[j])
 
+    # (the pairing is decided on the whole scheme, as if there were no program: steps the program has
+    #  taken are simply skipped -- they ran before everything else)
     for entry in fusion_schedule(scheme):
         if entry[0] == "one":
-            single(entry[1])
+            if entry[1] not in in_prog:
+                single(entry[1])
             continue
         n, m = entry[1], entry[2]
+        if n in in_prog or m in in_prog:
+            for q in (n, m):
+                if q not in in_prog:
+                    single(q)
+            continue
         (i, j), eq1 = scheme[n][0], scheme[n][1]
         (_, j2), eq2 = scheme[m][0], scheme[m][1]
         numel = 1
@@ -596,7 +762,7 @@ def _compile_dense(scheme, shapes, dtype):
         op.sum_rows = 0
         shapes[i] = out_shape
         ops.append(op)
-    return ops
+    return prog, ops
 
 
 def tensor_contraction(tensors, scheme):
@@ -635,16 +801,18 @@ def tensor_contraction(tensors, scheme):
     hit = _plan_cache.get(key)
     if hit is None or hit[0] is not scheme:
         try:
-            ops = _compile_dense(scheme, shapes, first.dtype)
+            prog, ops = _compile_dense(scheme, shapes, first.dtype)
         except KeyError as e:
             raise RuntimeError(f"scheme refers to tensor id {e} that was not supplied") from e
-        hit = _plan_cache[key] = (scheme, ops)
-    ops = hit[1]
+        hit = _plan_cache[key] = (scheme, ops, prog)
+    ops, prog = hit[1], hit[2]
     lib = N.lib()
     dtype, device = first.dtype, first.device
     byref = ctypes.byref
     with torch.cuda.device(device):
         stream = N.current_stream_ptr(device)
+        if prog is not None:   # every step that only combines small leaf-derived tensors: one launch
+            _run_program(prog, tensors, dtype, device, stream)
         for op in ops:
             a = tensors[op.i]
             if op.sum_rows and _sum_leading_ok(a, op.sum_rows):

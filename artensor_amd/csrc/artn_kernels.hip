@@ -1183,6 +1183,99 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_generic(const T2 *__re
   }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// small-step programs: the launch-latency tail of a scheme in one launch
+// ----------------------------------------------------------------------------------------
+#define ARTN_PROG_MAX_OUT 24
+#define ARTN_PROG_MAX_RED 12
+#define ARTN_PROG_MAX_REDN 2048
+struct ArtnProgStep {
+  int32_t n_out, n_red, out_numel, red_numel;
+  int32_t a_numel, b_numel; // elements of the (dense) operands
+  int64_t loc_a, loc_b, loc_c; // >= 0: workspace byte offset; < 0: external pointer -(loc + 1)
+  int32_t out_ext[ARTN_PROG_MAX_OUT], out_lg[ARTN_PROG_MAX_OUT], out_sA[ARTN_PROG_MAX_OUT], out_sB[ARTN_PROG_MAX_OUT];
+  int32_t red_ext[ARTN_PROG_MAX_RED], red_lg[ARTN_PROG_MAX_RED], red_sA[ARTN_PROG_MAX_RED], red_sB[ARTN_PROG_MAX_RED];
+};
+struct ArtnExtPtrs {
+  const void *p[ARTN_PROGRAM_MAX_EXT];
+};
+// One workgroup per group of steps; 1024 threads.  Per step: both operands are copied into LDS when they
+// fit (the usual case: tensors of a few thousand elements), the reduction offsets are tabulated in LDS
+// once, then every thread takes output elements tid, tid + 1024, ... with the reduction loop unrolled
+// four times on independent accumulators (the loads of four terms are in flight together).  Extents
+// that are powers of two (every axis of a circuit) are decoded with shifts.  Global writes of one step
+// are read by the next after a workgroup barrier (same CU: its L1 sees its own stores).
+#define ARTN_PROG_LDS_ELEMS 6144
+template <typename PA, typename PB>
+__device__ __forceinline__ void prog_reduce(PA A, PB B, int oa, int ob, const int2 *red_tab, int red_numel, float &re, float &im) {
+  float r0 = 0.f, i0 = 0.f, r1 = 0.f, i1 = 0.f;
+  int q = 0;
+  for (; q + 4 <= red_numel; q += 4) {
+    const int2 t0 = red_tab[q], t1 = red_tab[q + 1], t2 = red_tab[q + 2], t3 = red_tab[q + 3];
+    const float2 a0 = A[oa + t0.x], b0 = B[ob + t0.y], a1 = A[oa + t1.x], b1 = B[ob + t1.y];
+    const float2 a2 = A[oa + t2.x], b2 = B[ob + t2.y], a3 = A[oa + t3.x], b3 = B[ob + t3.y];
+    r0 += a0.x * b0.x - a0.y * b0.y; i0 += a0.x * b0.y + a0.y * b0.x;
+    r1 += a1.x * b1.x - a1.y * b1.y; i1 += a1.x * b1.y + a1.y * b1.x;
+    r0 += a2.x * b2.x - a2.y * b2.y; i0 += a2.x * b2.y + a2.y * b2.x;
+    r1 += a3.x * b3.x - a3.y * b3.y; i1 += a3.x * b3.y + a3.y * b3.x;
+  }
+  for (; q < red_numel; ++q) {
+    const int2 t = red_tab[q];
+    const float2 a = A[oa + t.x], b = B[ob + t.y];
+    r0 += a.x * b.x - a.y * b.y; i0 += a.x * b.y + a.y * b.x;
+  }
+  re = r0 + r1;
+  im = i0 + i1;
+}
+__global__ __launch_bounds__(1024) void artn_k_program(const ArtnProgStep *__restrict__ image, const int32_t *__restrict__ group_start,
+                                                       const ArtnExtPtrs ext, char *__restrict__ ws) {
+  __shared__ int2 red_tab[ARTN_PROG_MAX_REDN];
+  __shared__ float2 opnd[ARTN_PROG_LDS_ELEMS];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  for (int s = group_start[g]; s < group_start[g + 1]; ++s) {
+    const ArtnProgStep &R = image[s];
+    const float2 *A = reinterpret_cast<const float2 *>(R.loc_a >= 0 ? ws + R.loc_a : (const char *)ext.p[-(R.loc_a + 1)]);
+    const float2 *B = reinterpret_cast<const float2 *>(R.loc_b >= 0 ? ws + R.loc_b : (const char *)ext.p[-(R.loc_b + 1)]);
+    float2 *Cc = reinterpret_cast<float2 *>(ws + R.loc_c);
+    const int n_red = R.n_red, n_out = R.n_out, red_numel = R.red_numel, out_numel = R.out_numel;
+    const int a_numel = R.a_numel, b_numel = R.b_numel;
+    const bool in_lds = a_numel + b_numel <= ARTN_PROG_LDS_ELEMS;
+    if (in_lds) {
+      for (int e = tid; e < a_numel; e += 1024) opnd[e] = A[e];
+      for (int e = tid; e < b_numel; e += 1024) opnd[a_numel + e] = B[e];
+    }
+    for (int q = tid; q < red_numel; q += 1024) {
+      int rr = q, ka = 0, kb = 0;
+      for (int d = 0; d < n_red; ++d) {
+        const int e = R.red_ext[d], lg = R.red_lg[d];
+        const int x = lg >= 0 ? rr & (e - 1) : rr % e;
+        rr = lg >= 0 ? rr >> lg : rr / e;
+        ka += x * R.red_sA[d];
+        kb += x * R.red_sB[d];
+      }
+      red_tab[q] = make_int2(ka, kb);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < out_numel; idx += 1024) {
+      int r = idx, oa = 0, ob = 0;
+      for (int d = 0; d < n_out; ++d) {
+        const int e = R.out_ext[d], lg = R.out_lg[d];
+        const int x = lg >= 0 ? r & (e - 1) : r % e;
+        r = lg >= 0 ? r >> lg : r / e;
+        oa += x * R.out_sA[d];
+        ob += x * R.out_sB[d];
+      }
+      float re, im;
+      if (in_lds) prog_reduce(opnd, opnd + a_numel, oa, ob, red_tab, red_numel, re, im);
+      else prog_reduce(A, B, oa, ob, red_tab, red_numel, re, im);
+      Cc[idx] = make_float2(re, im);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 // ----------------------------------------------------------------------------------------
 // row gather / slice accumulate / renormalise
 // ----------------------------------------------------------------------------------------
@@ -1592,6 +1685,77 @@ int artn_debug_read_stamps(unsigned long long *host, int n_waves) {
   return ARTN_OK;
 }
 #endif
+
+int64_t artn_program_record_bytes(void) { return (int64_t)sizeof(ArtnProgStep); }
+
+int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const int64_t *loc_a, const int64_t *loc_b,
+                       const int64_t *loc_c, void *host_image) {
+  if (n_steps < 0 || !descs || !loc_a || !loc_b || !loc_c || !host_image) return fail(ARTN_E_INVALID, "null argument");
+  ArtnProgStep *img = (ArtnProgStep *)host_image;
+  for (int s = 0; s < n_steps; ++s) {
+    const ArtnStepDesc *d = descs[s];
+    std::string err;
+    int rc = artn::validate(d, err);
+    if (rc) return fail(rc, err);
+    if (d->dtype != ARTN_C64 && d->dtype != ARTN_C64_BF16) return fail(ARTN_E_UNSUPPORTED, "small-step programs are complex64");
+    ArtnPlan p;
+    if (!artn::make_generic(d, p, err)) return fail(ARTN_E_UNSUPPORTED, err);
+    const ArtnGenericPlan &g = p.gen;
+    if (g.n_out > ARTN_PROG_MAX_OUT || g.n_red > ARTN_PROG_MAX_RED || g.red_numel > ARTN_PROG_MAX_REDN ||
+        g.out_numel >= (1LL << 30) || loc_c[s] < 0)
+      return fail(ARTN_E_UNSUPPORTED, "step does not fit a small-step record");
+    ArtnProgStep &r = img[s];
+    memset(&r, 0, sizeof(r));
+    r.n_out = g.n_out; r.n_red = g.n_red; r.out_numel = (int32_t)g.out_numel; r.red_numel = (int32_t)g.red_numel;
+    r.loc_a = loc_a[s]; r.loc_b = loc_b[s]; r.loc_c = loc_c[s];
+    {
+      double f, na, nb, nc;
+      artn::step_cost(d, f, na, nb, nc);
+      if (na >= (double)(1 << 30) || nb >= (double)(1 << 30)) return fail(ARTN_E_UNSUPPORTED, "operand too large for a small-step record");
+      r.a_numel = (int32_t)na; r.b_numel = (int32_t)nb;
+      // the LDS copy takes the operands as dense arrays of that many elements
+      for (int which = 0; which < 2; ++which) {
+        std::vector<std::pair<int64_t, int64_t>> v;
+        for (int l = 0; l < d->n_labels; ++l) {
+          const int64_t st = which ? d->stride_b[l] : d->stride_a[l];
+          if (st >= 0 && d->extent[l] > 1) v.push_back({st, d->extent[l]});
+        }
+        std::sort(v.begin(), v.end());
+        int64_t expect = 1;
+        for (auto &pr : v) {
+          if (pr.first != expect) return fail(ARTN_E_UNSUPPORTED, "small-step programs take dense operands");
+          expect *= pr.second;
+        }
+      }
+    }
+    for (int i = 0; i < g.n_out; ++i) {
+      if (g.out_sA[i] >= (1LL << 30) || g.out_sB[i] >= (1LL << 30)) return fail(ARTN_E_UNSUPPORTED, "stride too large for a small-step record");
+      r.out_ext[i] = (int32_t)g.out_ext[i]; r.out_sA[i] = (int32_t)g.out_sA[i]; r.out_sB[i] = (int32_t)g.out_sB[i];
+      r.out_lg[i] = artn::ilog2_exact(g.out_ext[i]);
+    }
+    for (int i = 0; i < g.n_red; ++i) {
+      if (g.red_sA[i] >= (1LL << 30) || g.red_sB[i] >= (1LL << 30)) return fail(ARTN_E_UNSUPPORTED, "stride too large for a small-step record");
+      r.red_ext[i] = (int32_t)g.red_ext[i]; r.red_sA[i] = (int32_t)g.red_sA[i]; r.red_sB[i] = (int32_t)g.red_sB[i];
+      r.red_lg[i] = artn::ilog2_exact(g.red_ext[i]);
+    }
+  }
+  return ARTN_OK;
+}
+
+int artn_program_run(const void *dev_image, const int32_t *dev_group_start, int32_t n_groups, const void *const *ext,
+                     int32_t n_ext, void *workspace, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (n_groups < 0 || n_ext < 0 || n_ext > ARTN_PROGRAM_MAX_EXT) return fail(ARTN_E_INVALID, "bad group or pointer count");
+  if (n_groups == 0) return ARTN_OK;
+  if (!dev_image || !dev_group_start || !workspace || (n_ext && !ext)) return fail(ARTN_E_INVALID, "null pointer");
+  ArtnExtPtrs e;
+  memset(&e, 0, sizeof(e));
+  for (int i = 0; i < n_ext; ++i) e.p[i] = ext[i];
+  hipLaunchKernelGGL(artn_k_program, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, (const ArtnProgStep *)dev_image,
+                     dev_group_start, e, (char *)workspace);
+  HIP_TRY(hipGetLastError());
+  return ARTN_OK;
+}
 
 int artn_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t nrows, int64_t row_bytes,
                      int64_t src_rows, int32_t *err_flag, void *stream) {

@@ -140,6 +140,30 @@ int artn_contract2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A
 int artn_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t nrows,
                      int64_t row_bytes, int64_t src_rows, int32_t *err_flag, void *stream);
 
+/*
+ * Small-step programs.  A circuit scheme is a few big steps plus hundreds of tiny ones (rank <= 16
+ * operands) that are pure launch latency when issued one by one -- on the CPU the reference spends
+ * 35-65 us per torch.einsum call on them (artensor/contraction.py:66-70; its whole n12 run is that).
+ * Here the tiny steps of a scheme are compiled ONCE into a device-resident step list ("image") and
+ * executed by ONE launch: workgroup g runs the steps of group g in order (steps of different groups
+ * must be independent), every intermediate lives in a caller-provided workspace.
+ *
+ *   artn_program_record_bytes()  size of one step record of the image
+ *   artn_program_build(...)      host only: fills `host_image` (n_steps records) from the step
+ *                                descriptors; operand k of step s is at workspace byte offset loc >= 0, or is
+ *                                external pointer number -(loc + 1) when loc < 0.  Steps must be
+ *                                complex64 with dense operands; returns ARTN_E_UNSUPPORTED when a step
+ *                                does not fit a record (the caller then issues artn_contract per step).
+ *   artn_program_run(...)        enqueue: `dev_image` / `dev_group_start` (n_groups + 1 int32) are the
+ *                                device copies, `ext` a HOST array of n_ext (<= 256) device pointers.
+ */
+#define ARTN_PROGRAM_MAX_EXT 256
+int64_t artn_program_record_bytes(void);
+int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const int64_t *loc_a, const int64_t *loc_b,
+                       const int64_t *loc_c, void *host_image);
+int artn_program_run(const void *dev_image, const int32_t *dev_group_start, int32_t n_groups, const void *const *ext,
+                     int32_t n_ext, void *workspace, void *stream);
+
 /* acc[i] += x[i], i < n complex64 elements: the slice accumulation
  * `collect_tensor += ...` of artensor/simulation.py:114 and :210. */
 int artn_axpy_c64(void *acc, const void *x, int64_t n, void *stream);

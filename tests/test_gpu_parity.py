@@ -418,6 +418,29 @@ def test_sparse_schemes(name):
         assert (np.abs(out - g) / np.abs(g)).max() < 1e-3
 
 
+def test_small_step_program(monkeypatch):
+    """The launch-latency tail of a dense scheme as ONE launch (artn_program_*): n12 is 68 tiny steps and
+    nothing else; with the program switched off the same scheme goes step by step through artn_contract.
+    Both must give the reference's amplitudes, and the program must actually be in use by default."""
+    from artensor_amd import contraction as C
+    case = load_case(os.path.join(GOLDEN, "n12_dense.npz"))
+    shapes = {k: tuple(t.shape) for k, t in case.tensors.items()}
+    prog, main = C._plan_small_program(case.scheme, shapes, torch.complex64)
+    assert prog is not None and prog.n_steps == 68 and main == []
+    a = A.tensor_contraction(case.fresh_tensors(device=DEV), case.scheme).cpu().numpy()
+    monkeypatch.setenv("ARTN_NO_PROGRAM", "1")
+    C._plan_cache.clear()
+    b = A.tensor_contraction(case.fresh_tensors(device=DEV), case.scheme).cpu().numpy()
+    monkeypatch.delenv("ARTN_NO_PROGRAM")
+    C._plan_cache.clear()
+    assert amp_rel(a, case.arrays["raw"]) < 1e-5 and amp_rel(b, case.arrays["raw"]) < 1e-5
+    assert amp_rel(a, b) < 2e-6
+    # a network with bond dimension 3 (non power-of-two extents are decoded with divisions)
+    case = load_case(os.path.join(GOLDEN, "rand_D3_open.npz"))
+    out = A.tensor_contraction(case.fresh_tensors(device=DEV), case.scheme).cpu().numpy()
+    assert rel(out, case.arrays["final"]) < 1e-5
+
+
 def test_sparse_scientific_notation():
     case = load_case(os.path.join(GOLDEN, "n12_sparse5_scinot.npz"))
     factor, out = A.tensor_contraction_sparse(case.fresh_tensors(device=DEV), case.scheme, scientific_notation=True)

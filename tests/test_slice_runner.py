@@ -108,3 +108,35 @@ def test_split_scheme_keeps_a_reused_operand_behind_the_main_step_that_reads_it(
         cur[scheme[n][0][0]] = scratch[scheme[n][0][0]]
     got = oracle.tensor_contraction(cur, main)
     assert np.allclose(got, whole)
+
+
+@pytest.mark.parametrize("name,limit", [("n12_dense", 1 << 14), ("n12_dense", 64), ("rand_D2_closed", 1 << 14), ("rand_D4_closed", 256)])
+def test_small_step_program_plan_keeps_sequential_semantics(name, limit, monkeypatch):
+    """contraction._plan_small_program hoists the steps that only combine small leaf-derived tensors into a
+    one-launch program (groups = independent components).  Running those steps in program order and then
+    the remaining steps in scheme order must equal the scheme run step by step (CPU oracle as executor)."""
+    from artensor_amd import contraction as C
+    monkeypatch.setattr(C, "PROGRAM_MAX_NUMEL", limit)
+    case = load_case(os.path.join(GOLDEN, name + ".npz"))
+    if case.slicing_indices:
+        pytest.skip("unsliced cases only")
+    leaves = {k: t.numpy().copy() for k, t in case.tensors.items()}
+    shapes = {k: v.shape for k, v in leaves.items()}
+    prog, main = C._plan_small_program(case.scheme, shapes, torch.complex64)
+    whole = oracle.tensor_contraction(dict(leaves), case.scheme)
+    if prog is None:
+        assert main == list(range(len(case.scheme)))
+        return
+    assert prog.n_steps + len(main) == len(case.scheme)
+    assert len(prog.ext_ids) == len(set(prog.ext_ids)) <= 256
+    groups = prog.host_groups.tolist()
+    assert groups[0] == 0 and groups[-1] == prog.n_steps and sorted(groups) == groups
+    # replay: the program's steps are the scheme's small steps sorted by (group, index); recover that order
+    small = [n for n in range(len(case.scheme)) if n not in set(main)]
+    cur = dict(leaves)
+    for n in small:   # scheme order is a valid order inside every group
+        oracle.tensor_contraction(cur, [case.scheme[n]])
+    for t, (off, shape) in prog.outputs.items():   # what the program leaves for the remaining steps
+        assert tuple(cur[t].shape) == tuple(shape) and off % 16 == 0
+    got = oracle.tensor_contraction(cur, [case.scheme[n] for n in main]) if main else cur[case.scheme[-1][0][0]]
+    assert np.abs(np.asarray(got) - np.asarray(whole)).max() <= 1e-6 * max(np.abs(whole).max(), 1e-30)
