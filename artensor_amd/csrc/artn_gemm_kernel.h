@@ -48,7 +48,13 @@ __device__ __forceinline__ void lds_write4(unsigned a, unsigned v) {
   *(__attribute__((address_space(3))) unsigned *)(unsigned long)a = v;
 }
 
-template <int MB, int NB, bool BF = false>
+// M3 = true (fp32 only, tiles with 32+ columns): the complex product as THREE real products instead of four
+// (the "3M" scheme of BLAS xGEMM3M): T1 = A_re B_re, T2 = A_im B_im, T3 = (A_re + A_im)(B_re + B_im);
+// C_re = T1 - T2, C_im = T3 - T1 - T2.  An MFMA block is then 32 rows (m) x 32 complex columns (n) with three
+// accumulators, three MFMAs per pair of contracted values instead of four for the same 32 x 32 outputs:
+// 6 real FLOP per complex multiply-add on the matrix pipe, the other 2 become one add per operand element
+// and three per result.  NB counts 32-column blocks in this mode.
+template <int MB, int NB, bool BF = false, bool M3 = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *__restrict__ A, const float2 *__restrict__ B,
                                                                  float2 *__restrict__ C, const ArtnGemmPlan P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -103,11 +109,12 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
   // ---- MFMA lanes
   const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
   const bool w_active = wm < (1 << P.wm_log2);
-  const int n_in = j >> 1;
-  const bool w_valid = nt >= 4 || n_in < (1 << nt);
+  const int n_in = M3 ? j : j >> 1;
+  const bool w_valid = M3 || nt >= 4 || n_in < (1 << nt);
+  constexpr int NBW = M3 ? 32 : 16; // complex columns per MFMA block
   constexpr unsigned EB = BF ? 16u : 8u; // bytes per (row, k pair | k quad) slot
   const unsigned lane_x = (((unsigned)h << ARTN_GEMM_PITCH_LOG2) + (unsigned)(wm * MB * 32 + j)) * EB;
-  const unsigned lane_w = a_bytes + (((unsigned)h << ARTN_GEMM_PITCH_LOG2) + (unsigned)(wn * NB * 16) + (unsigned)(w_valid ? n_in : 0)) * EB;
+  const unsigned lane_w = a_bytes + (((unsigned)h << ARTN_GEMM_PITCH_LOG2) + (unsigned)(wn * NB * NBW) + (unsigned)(w_valid ? n_in : 0)) * EB;
   const unsigned w_sel = ro ? 0x01000302u : 0x03020100u, w_sign = ro ? 0u : 0x80000000u; // bf16 W side: (im, re) / (re, -im)
 
   // ---- epilogue offsets (elements of the C-ordered result image, swizzled; fields are disjoint: XOR)
@@ -125,13 +132,15 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
       if (i < nt && ((n_local >> i) & 1)) o |= 1u << P.n_pos[i];
     return o;
   };
-  const unsigned lane_c = swz_gemm(m_off(wm * MB * 32 + j) | n_off(wn * NB * 16 + 2 * h), P);
+  // (accumulator rows: 4M  n_in_block = b0 + 2h + 4q;  3M  n_in_block = (r & 3) + 4h + 8(r >> 2))
+  const unsigned lane_c = swz_gemm(m_off(wm * MB * 32 + j) | n_off(wn * NB * NBW + (M3 ? 4 : 2) * h), P);
   unsigned c_mb[MB], c_nb[NB];
 #pragma unroll
   for (int q = 0; q < MB; ++q) c_mb[q] = swz_gemm(m_off(q * 32), P);
 #pragma unroll
-  for (int q = 0; q < NB; ++q) c_nb[q] = swz_gemm(n_off(q * 16), P);
-  const unsigned c_b0 = swz_gemm(n_off(1), P), c_q0 = swz_gemm(n_off(4), P), c_q1 = swz_gemm(n_off(8), P);
+  for (int q = 0; q < NB; ++q) c_nb[q] = swz_gemm(n_off(q * NBW), P);
+  const unsigned c_b0 = swz_gemm(n_off(1), P), c_q0 = swz_gemm(n_off(M3 ? 8 : 4), P), c_q1 = swz_gemm(n_off(M3 ? 16 : 8), P);
+  const unsigned c_b1 = swz_gemm(n_off(2), P); // 3M: row bit 1
   const int n_lim = nt >= 4 ? 16 : 1 << nt; // valid n_in_block values
   // copy-out threads
   const int o_cb = epi_bits - 1;
@@ -206,11 +215,12 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
   for (long tile = t0; tile < n_tiles; tile += G) {
     const bool more_tiles = tile + G < n_tiles;
     if (more_tiles) noff = next_offsets<false>(P, OT, off, tile, G);
-    f32x16 acc[MB][NB];
+    constexpr int NACC = M3 ? 3 : 1;
+    f32x16 acc[MB][NB * NACC];
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+      for (int b = 0; b < NB * NACC; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     long ka = 0, kb = 0;
@@ -273,6 +283,22 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
 #pragma unroll
           for (int s = 0; s < 8; ++s) {
             if (s + 1 < 8) load_ops(s + 1, X[(s + 1) & 1], Wr[(s + 1) & 1]);
+            if constexpr (M3) {
+              float xs[MB], wsum[NB];
+#pragma unroll
+              for (int a = 0; a < MB; ++a) xs[a] = X[s & 1][a].x + X[s & 1][a].y;
+#pragma unroll
+              for (int b = 0; b < NB; ++b) wsum[b] = Wr[s & 1][b].x + Wr[s & 1][b].y;
+#pragma unroll
+              for (int a = 0; a < MB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                  acc[a][3 * b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].x, X[s & 1][a].x, acc[a][3 * b], 0, 0, 0);
+                  acc[a][3 * b + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].y, X[s & 1][a].y, acc[a][3 * b + 1], 0, 0, 0);
+                  acc[a][3 * b + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wsum[b], xs[a], acc[a][3 * b + 2], 0, 0, 0);
+                }
+              continue;
+            }
             float W0[NB], W1[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -305,7 +331,21 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
         __syncthreads(); // chunk buffers / previous pass are no longer read
         unsigned lc = lane_c; // (opaque: 64 hoisted scatter addresses per lane would cost the accumulators their registers)
         OPAQUE_V(lc);
-        if (w_active) {
+        if constexpr (M3) {
+          if (w_active) {
+#pragma unroll
+            for (int a = 0; a < MB; ++a)
+#pragma unroll
+              for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ ((r & 1) ? c_b0 : 0u) ^ ((r & 2) ? c_b1 : 0u) ^ ((r & 4) ? c_q0 : 0u) ^ ((r & 8) ? c_q1 : 0u);
+                  const float t1 = acc[a][3 * b][r], t2 = acc[a][3 * b + 1][r], t3 = acc[a][3 * b + 2][r];
+                  if ((int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
+                    lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{t1 - t2, t3 - t1 - t2});
+                }
+          }
+        } else if (w_active) {
 #pragma unroll
           for (int a = 0; a < MB; ++a)
 #pragma unroll
@@ -359,7 +399,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
 #pragma unroll
         for (int a = 0; a < MB; ++a)
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
+          for (int b = 0; b < NB * NACC; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
       }

@@ -1502,7 +1502,22 @@ static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, v
     hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
     return hipGetLastError();                                                                        \
   }
+#define ARTN_GEMM_LAUNCH_M3(MBV, NBV)                                                                \
+  {                                                                                                  \
+    auto kern = artn_k_gemm<MBV, NBV, false, true>;                                                  \
+    if (hipError_t e = ensure_lds<artn_k_gemm<MBV, NBV, false, true>>(lds); e != hipSuccess) return e; \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
+    return hipGetLastError();                                                                        \
+  }
   const int key = g.mb_log2 * 4 + g.nb_log2;
+  if (g.m3) {
+    switch (key) {
+      case 0: ARTN_GEMM_LAUNCH_M3(1, 1)
+      case 1: ARTN_GEMM_LAUNCH_M3(1, 2)
+      case 4: ARTN_GEMM_LAUNCH_M3(2, 1)
+    }
+    return hipErrorInvalidValue;
+  }
   if (g.split) {
     switch (key) {
       case 0: ARTN_GEMM_LAUNCH_BF(1, 1)
@@ -1520,6 +1535,7 @@ static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, v
   }
 #undef ARTN_GEMM_LAUNCH
 #undef ARTN_GEMM_LAUNCH_BF
+#undef ARTN_GEMM_LAUNCH_M3
   return hipErrorInvalidValue;
 }
 

@@ -131,7 +131,7 @@ struct ArtnGemmPlan {
   int64_t ko_sA[ARTN_GEMM_MAX_KO], ko_sB[ARTN_GEMM_MAX_KO]; // looped contracted bit -> element strides
   // epilogue: the result tile in C order
   int32_t tc_bits;           // mt + nt
-  int32_t pad0_;
+  int32_t m3;                // 1: three real products per complex product (blocks of 32 columns; nb_log2 counts those)
   int64_t out_stride[14];    // C-tile-local bit -> C element stride
   int32_t m_pos[8], n_pos[8]; // m_local / n_local bit -> C-tile-local position
   int32_t swz_n, swz_src[4], swz_dst[4]; // XOR swizzle of the LDS result image (as ArtnStage::swz_*)
@@ -168,6 +168,7 @@ struct Tuning {
   int split = 0;      // complex64 chains: 0 fp32 MFMA, 3 fp32-grade split-bf16 MFMA
   int nt = 1;         // non-temporal loads of A tiles that are read once
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
+  int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
 };
 static inline Tuning &tuning() {
   static Tuning t = [] {
@@ -179,6 +180,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_STAGE_PRIO")) x.stage_prio = std::min(3, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_NT")) x.nt = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
+    if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
     return x;
   }();
@@ -673,7 +675,8 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
 // [2^kc][2^mt] piece of the first operand and the [2^kc][2^nt] piece of the second are copied to LDS
 // (16-byte lanes, runs as long as the low address bits of each operand allow), every wave multiplies
 // its 32-row x 16-column MFMA blocks, accumulators stay in registers across all chunks.
-static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles, bool only_if_preferred) {
+static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles, bool only_if_preferred,
+                             int use_3m = -1 /* -1: as tuning() says */) {
   if (d->dtype != ARTN_C64 && d->dtype != ARTN_C64_BF16) { p.why_generic = "dtype is not complex64"; return false; }
   std::vector<Axis> ax;
   expand_axes(d, ax);
@@ -758,9 +761,14 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   std::sort(N.begin(), N.end(), byB);
   int64_t outer_ext = 1;
   for (int i : O) outer_ext *= ax[i].ext;
-  // (bf16: 128 x 64 tiles at most -- twice the chunk depth has to fit the same prefetch registers)
-  int mt = std::min(m, 7), nt = std::min(n, bf16 ? 6 : 7);
-  if ((int)Nf.size() > nt) { p.why_generic = "forced tile bits exceed the bf16 GEMM tile"; return false; }
+  // (bf16: 128 x 64 tiles at most -- twice the chunk depth has to fit the same prefetch registers; so does
+  //  the 3M arithmetic, whose 32 x 32 blocks carry three accumulators)
+  const bool want_m3 = !bf16 && (use_3m < 0 ? tuning().gemm_3m != 0 : use_3m != 0) && n >= 5;
+  int mt = std::min(m, 7), nt = std::min(n, (bf16 || want_m3) ? 6 : 7);
+  if ((int)Nf.size() > nt) {
+    if (bf16) { p.why_generic = "forced tile bits exceed the bf16 GEMM tile"; return false; }
+    nt = std::min(n, 7); // (3M gives way)
+  }
   // too few tiles to fill the chip: smaller tiles (down to what the runs force)
   while (((int64_t(1) << (m - mt + n - nt)) * outer_ext) < n_cu) {
     if (mt >= nt + 1 && mt > 5 && mt > (int)Mf.size()) --mt;
@@ -780,8 +788,21 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   g.mt = mt; g.nt = nt; g.kc = kc; g.n_ko = k - kc; g.swapped = swapped ? 1 : 0;
   g.split = bf16 ? 1 : 0;
   g.gather_dim = -1;
-  // ---- waves: blocks per wave from the allowed instantiations (1,1) (1,2) (2,2) (1,4) (2,4)
-  {
+  // ---- waves: blocks per wave from the allowed instantiations (1,1) (1,2) (2,2) (1,4) (2,4); 3M: (1,1) (1,2) (2,1)
+  g.m3 = (want_m3 && nt >= 5 && nt <= 6) ? 1 : 0;
+  if (g.m3) {
+    const int mbl = mt - 5, nbl = nt - 5;
+    int best = 1 << 30;
+    for (int wm = 0; wm <= std::min(2, mbl); ++wm) {
+      const int wn = std::min(2 - wm, nbl);
+      const int MB = mbl - wm, NB = nbl - wn;
+      if (MB + NB > 1) continue;
+      const int cost = (1 << MB) + (1 << NB) + 8 * (2 - wm - wn);
+      if (cost < best) { best = cost; g.wm_log2 = wm; g.wn_log2 = wn; g.mb_log2 = MB; g.nb_log2 = NB; }
+    }
+    if (best == (1 << 30)) g.m3 = 0;
+  }
+  if (!g.m3) {
     const int mbl = mt - 5, nbl = std::max(nt - 4, 0);
     int best = 1 << 30;
     for (int wm = 0; wm <= std::min(2, mbl); ++wm) {

@@ -162,10 +162,12 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
       offA += x * P.outer[d].sA; offB += x * P.outer[d].sB1; offC += x * P.outer[d].sC;
     }
     // accumulators of every (wave, block, lane, register)
-    std::vector<float> acc((size_t)4 * MB * NB * 64 * 16, 0.f);
-    auto ACC = [&](int wave, int a, int b, int lane, int rr) -> float & {
-      return acc[((((size_t)wave * MB + a) * NB + b) * 64 + lane) * 16 + rr];
+    const int NACC = P.m3 ? 3 : 1, NBW = P.m3 ? 32 : 16;
+    std::vector<float> acc((size_t)4 * MB * NB * NACC * 64 * 16, 0.f);
+    auto ACC3 = [&](int wave, int a, int b, int t, int lane, int rr) -> float & {
+      return acc[(((((size_t)wave * MB + a) * NB + b) * NACC + t) * 64 + lane) * 16 + rr];
     };
+    auto ACC = [&](int wave, int a, int b, int lane, int rr) -> float & { return ACC3(wave, a, b, 0, lane, rr); };
     // epilogue: every 2^10 contracted values and at the end (the later partial sums are added to C)
     auto flush_tile = [&](bool accumulate) {
     auto m_off = [&](int m_local) { unsigned o = 0; for (int i = 0; i < mt; ++i) if ((m_local >> i) & 1) o |= 1u << P.m_pos[i]; return o; };
@@ -177,6 +179,18 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
       for (int wave = 0; wave < 4; ++wave) {
         const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
         if (wm >= (1 << P.wm_log2)) continue;
+        if (P.m3) {
+          for (int a = 0; a < MB; ++a) for (int b = 0; b < NB; ++b) for (int lane = 0; lane < 64; ++lane)
+            for (int rr = 0; rr < 16; ++rr) {
+              const int j = lane & 31, h = lane >> 5;
+              const int n_loc = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+              const unsigned pos = swzg(m_off((wm * MB + a) * 32 + j) | n_off((wn * NB + b) * 32 + n_loc), P);
+              if ((int)(pos >> ARTN_GEMM_EPI_BITS) != pass) continue;
+              const float t1 = ACC3(wave, a, b, 0, lane, rr), t2 = ACC3(wave, a, b, 1, lane, rr), t3 = ACC3(wave, a, b, 2, lane, rr);
+              res[pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)] = cf(t1 - t2, t3 - t1 - t2);
+            }
+          continue;
+        }
         for (int a = 0; a < MB; ++a) for (int b = 0; b < NB; ++b) for (int lane = 0; lane < 64; ++lane)
           for (int q = 0; q < 4; ++q) for (int b0 = 0; b0 < 2; ++b0) {
             const int j = lane & 31, h = lane >> 5;
@@ -235,6 +249,23 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
       for (int wave = 0; wave < 4; ++wave) {
         const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
         if (wm >= (1 << P.wm_log2)) continue;
+        if (P.m3) { // three real products: T1 = A_re B_re, T2 = A_im B_im, T3 = (A_re + A_im)(B_re + B_im); rows = 32 columns n
+          for (int s = 0; s < 8; ++s)
+            for (int a = 0; a < MB; ++a)
+              for (int b = 0; b < NB; ++b)
+                for (int lane = 0; lane < 64; ++lane)
+                  for (int rr = 0; rr < 16; ++rr) {
+                    const int i = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5), jj = lane & 31;
+                    for (int kk = 0; kk < 2; ++kk) {
+                      const cf xv = imgA[((size_t)(2 * s + kk) << PL) + (wm * MB + a) * 32 + jj];
+                      const cf bv = imgB[((size_t)(2 * s + kk) << PL) + (wn * NB + b) * 32 + i];
+                      ACC3(wave, a, b, 0, lane, rr) += bv.real() * xv.real();
+                      ACC3(wave, a, b, 1, lane, rr) += bv.imag() * xv.imag();
+                      ACC3(wave, a, b, 2, lane, rr) += (bv.real() + bv.imag()) * (xv.real() + xv.imag());
+                    }
+                  }
+          continue;
+        }
         if (P.split) { // v_mfma_f32_32x32x16_bf16 groups: kc = 8t + 4h + u, image [kc >> 2][row][kc & 3]
           for (int t = 0; t < 4; ++t)
             for (int a = 0; a < MB; ++a)
@@ -317,14 +348,14 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
 }
 
 // Force the two-operand GEMM plan (whatever the planner would prefer); ARTN_E_UNSUPPORTED if it declines.
-extern "C" int artn_emulate_gemm(const ArtnStepDesc *d, const void *A, const void *B, void *C, ArtnStepInfo *info) {
+extern "C" int artn_emulate_gemm(const ArtnStepDesc *d, const void *A, const void *B, void *C, ArtnStepInfo *info, int use_3m) {
   ArtnPlan p;
   std::string err;
   int rc = artn::validate(d, err);
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
   const char *e = getenv("ARTN_EMU_NCU"); // 1: never shrink tiles for want of workgroups (covers the big-tile layouts)
-  if (!artn::make_gemm(d, p, e ? atoi(e) : 256, 1, false)) return ARTN_E_UNSUPPORTED;
+  if (!artn::make_gemm(d, p, e ? atoi(e) : 256, 1, false, use_3m)) return ARTN_E_UNSUPPORTED;
   if (info) *info = p.info;
   run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);
   return 0;

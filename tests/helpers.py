@@ -88,7 +88,7 @@ def emulate(eq, a, b, force_generic=False):
     return out, used.value
 
 
-def emulate_gemm(eq, a, b, bf16=False):
+def emulate_gemm(eq, a, b, bf16=False, m3=-1):
     """One step through the emulation of the two-operand GEMM kernel (plan forced); returns
     (result, planner info) or (None, None) when the GEMM planner declines the step."""
     import torch
@@ -104,7 +104,7 @@ def emulate_gemm(eq, a, b, bf16=False):
     emu = emulator()
     emu.artn_emulate_gemm.restype = ctypes.c_int
     rc = emu.artn_emulate_gemm(ctypes.byref(d), a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
-                               out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info))
+                               out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info), ctypes.c_int(m3))
     if rc == -2:
         return None, None
     assert rc == 0, rc

@@ -269,26 +269,28 @@ def _einsum128(eq, a, b):
                      a.astype(np.complex128), b.astype(np.complex128))
 
 
+@pytest.mark.parametrize("m3", [0, 1])
 @pytest.mark.parametrize("m,n,k,batch", [(7, 7, 4, 0), (7, 7, 6, 0), (8, 7, 5, 0), (9, 3, 8, 0), (6, 6, 4, 3), (5, 4, 9, 0),
                                          (10, 0, 5, 0), (3, 9, 6, 0), (7, 5, 7, 2), (6, 7, 5, 0), (8, 2, 10, 0), (5, 3, 13, 0)])
-def test_gemm_plan_emulated(monkeypatch, m, n, k, batch):
+def test_gemm_plan_emulated(monkeypatch, m, n, k, batch, m3):
     """The two-operand GEMM kernel replayed thread by thread from its plan (global -> LDS images, MFMA
     lane maps, Gray-code walk over the looped contracted bits, C-ordered swizzled result image in one
     or two passes, copy-out): random bit permutations, full 128 x 128 tiles (ARTN_EMU_NCU=1 keeps the
     planner from shrinking tiles for want of workgroups), tiles with fewer than 16 columns, operands
     exchanged (m < 5), a ragged batch axis, and more than 2^12 contracted values (partial sums flushed
-    into C and added up there)."""
+    into C and added up there); with four real products per complex product and with three (m3: 32-column
+    blocks, T1 / T2 / T3 accumulators, combined in the epilogue)."""
     monkeypatch.setenv("ARTN_EMU_NCU", "1")
     rng = np.random.default_rng(100 * m + 10 * n + k)
     eq, sa, sb = _random_gemm_step(rng, m, n, k, batch)
     a, b = crandn(rng, sa), crandn(rng, sb)
-    got, info = emulate_gemm(eq, a, b)
+    got, info = emulate_gemm(eq, a, b, m3=m3)
     assert got is not None and info["kernel"] == KERNEL_GEMM
     want = _einsum128(eq, a, b)
     assert got.shape == want.shape
     assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (eq, info)
     if m >= 7 and n >= 7:
-        assert info["tile_out_bits"] == 14   # two epilogue passes covered
+        assert info["tile_out_bits"] == (13 if m3 else 14)   # 4M: two epilogue passes covered; 3M: 128 x 64 tiles
 
 
 @pytest.mark.parametrize("m,n,k", [(7, 7, 5), (7, 6, 6), (8, 3, 7), (5, 4, 9), (3, 9, 6), (5, 3, 11)])

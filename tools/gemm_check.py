@@ -106,7 +106,7 @@ for st in steps:
     seen.add(key)
     info = A.step_info((la, lb, lo), st["a_shape"], st["b_shape"])
     kb = sum(1 for x in la if x in lb and x not in lo)
-    if kb < 7 and info["kernel"] != 2:
+    if kb < int(os.environ.get("MINK", "7")) and info["kernel"] != 2:
         continue
     a, b = rnd(st["a_shape"]), rnd(st["b_shape"])
     ms = timed(lambda: A.contract((la, lb, lo), a, b))
