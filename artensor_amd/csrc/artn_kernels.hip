@@ -344,6 +344,8 @@ struct StageConst {
   unsigned kin[KB > 1 ? KB : 2];      // byte offset of K bit b in the LDS input tile
   long kb[KB > 1 ? KB : 2];           // byte stride of K bit b in the small operand
   unsigned o0, o2, o3;                // byte offsets of N bits 0, 2, 3 in the LDS output tile
+  unsigned o1, o4;                    // 3M stages: N bits 1 and 4 (accumulator row = (r & 3) + 4h + 8(r >> 2))
+  bool m3;                            // three real products per complex product (ArtnStage::m3)
   int k_hi;                           // contracted bits beyond the chain (0..2), looped over
   unsigned kin_hi[2];
   long kb_hi[2];
@@ -355,7 +357,7 @@ struct StageConst {
 // zin: stage whose output region this stage reads (nullptr: the unswizzled copy-in region).
 // hb: the contracted bit carried by the lane half h (0 for the fp32 chain: kc = 2s + h; 2 for the
 // split-bf16 chain, whose MFMA takes 8 complex kc per instruction: kc = 8g + 4h + u).
-template <int KB>
+template <int KB, bool M3 = false>
 __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const ArtnStage *zin, int j, int h, int wave,
                                                       unsigned tab, unsigned in_base, unsigned out_base, int hb = 0) {
   StageConst<KB> L;
@@ -376,18 +378,21 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
       L.lane_out += 8u << st.lane_out_pos[b];
     }
   }
-  if (st.nt > 1) L.lane_out += (unsigned)h << (st.n_out_pos[1] + 3);
-  const int nloc = j >> 1;
-  L.w_valid = (nloc >> L.nt_eff) == 0;
+  L.m3 = M3 && (KB == 5 || KB == 6); // (the planner launches the M3 instantiation only when every such stage asks for it)
+  if (L.m3) L.lane_out += (unsigned)h << (st.n_out_pos[2] + 3);
+  else if (st.nt > 1) L.lane_out += (unsigned)h << (st.n_out_pos[1] + 3);
+  const int nloc = L.m3 ? j : j >> 1;
+  L.w_valid = L.m3 || (nloc >> L.nt_eff) == 0;
   L.lane_b = (long)h * st.k_b_stride[hb] * 8;
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
-    if (b < L.nt_eff && ((nloc >> b) & 1)) L.lane_b += st.n_b_stride[b] * 8;
+  for (int b = 0; b < 5; ++b)
+    if (b < (L.m3 ? 5 : L.nt_eff) && ((nloc >> b) & 1)) L.lane_b += st.n_b_stride[b] * 8;
+  const int nb0 = L.m3 ? 5 : 4; // first column bit dealt to the waves
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    if (b < st.wn_log2 && ((wn >> b) & 1)) {
-      L.lane_out += 8u << st.n_out_pos[4 + b];
-      L.lane_b += st.n_b_stride[4 + b] * 8;
+    if (b < st.wn_log2 && ((wn >> b) & 1) && nb0 + b < 6) {
+      L.lane_out += 8u << st.n_out_pos[nb0 + b];
+      L.lane_b += st.n_b_stride[nb0 + b] * 8;
     }
   }
 #pragma unroll
@@ -404,6 +409,8 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
   L.o0 = st.nt > 0 ? swz(8u << st.n_out_pos[0], &st) : 0;
   L.o2 = st.nt > 2 ? swz(8u << st.n_out_pos[2], &st) : 0;
   L.o3 = st.nt > 3 ? swz(8u << st.n_out_pos[3], &st) : 0;
+  L.o1 = st.nt > 1 ? swz(8u << st.n_out_pos[1], &st) : 0;
+  L.o4 = st.nt > 4 ? swz(8u << st.n_out_pos[4], &st) : 0;
   // region bases are multiples of the region size: XOR-ing them in equals adding them
   L.lane_in = swz(L.lane_in, zin) ^ in_base;
   L.lane_out = swz(L.lane_out, &st) ^ out_base;
@@ -446,6 +453,26 @@ __device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1
   // unconditional vmcnt(0) there, which drains the next tile's prefetched loads every tile.
 #pragma unroll
   for (int s = 0; s < S; ++s) asm volatile("" : "+v"(W0[s]), "+v"(W1[s]));
+}
+
+// 3M stages: row n = lane&31 of the small operand, (re, im, re + im) of B[kc = 2s + h][n]
+template <int KB>
+__device__ __forceinline__ void load_w3(float (&W0)[1 << (KB - 1)], float (&W1)[1 << (KB - 1)], float (&W2)[1 << (KB - 1)],
+                                        const char *__restrict__ Bbase, const StageConst<KB> &L) {
+  constexpr int S = 1 << (KB - 1);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    long ko = 0;
+#pragma unroll
+    for (int b = 1; b < KB; ++b)
+      if ((s >> (b - 1)) & 1) ko += L.kb[b];
+    const float2 bv = *reinterpret_cast<const float2 *>(Bbase + ko + L.lane_b);
+    W0[s] = bv.x;
+    W1[s] = bv.y;
+    W2[s] = bv.x + bv.y;
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) asm volatile("" : "+v"(W0[s]), "+v"(W1[s]), "+v"(W2[s])); // see load_w
 }
 
 // Split-bf16 arithmetic.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA.  An
@@ -540,7 +567,7 @@ __device__ __forceinline__ void load_w_plane(u32x4_t (&row)[KB >= 3 ? 1 << (KB -
 //     into the other half of a ping-pong register buffer;
 //   * accumulators ping-pong too: the scatter of sub-tile i is issued after the first MFMA
 //     pair of sub-tile i+1, so the LDS writes drain under that chain.
-template <int KB, bool BIGK, int NP = 0>
+template <int KB, bool BIGK, int NP = 0, bool M3 = false>
 struct StageRun {
   static constexpr int S = 1 << (KB - 1);
   static constexpr int CH = S < 16 ? S : 16; // chain steps per unit
@@ -551,9 +578,11 @@ struct StageRun {
   // for the looped-over value instead
   static constexpr int WSD = SPLIT ? (BIGK ? 4 : NP) : 1;
   static_assert(!(BIGK && NP > 1), "the 7-8 bit kernel has no three-piece split");
+  static constexpr bool CAN3M = M3 && (KB == 5 || KB == 6) && !BIGK && NP == 0;
   const StageConst<KB> &L;
   float (&W0)[S];
   float (&W1)[S];
+  float (&W2)[CAN3M ? S : 1]; // 3M stages: re + im of the small operand
   int h, lane;
   // 7-8 contracted bits (BIGK): fragments for every value of the looped-over bits, all in
   // registers (the instantiation runs one wave per SIMD, so 512 VGPRs are available)
@@ -819,7 +848,78 @@ struct StageRun {
     }
   }
 
+  // 3M stage (ArtnStage::m3): the complex product from THREE real products -- T1 = A_re B_re, T2 = A_im B_im,
+  // T3 = (A_re + A_im)(B_re + B_im); C_re = T1 - T2, C_im = T3 - T1 - T2 -- on MFMA blocks of 32 rows (columns m
+  // of the tile) x 32 complex columns n: three accumulators, 3 MFMAs per pair of contracted values where the
+  // 4M chains of two waves need 4 for the same 32 x 32 outputs.  One wave owns a whole 32-column sub-tile.
+  __device__ __forceinline__ void scatter3(const f32x16 &t1, const f32x16 &t2, const f32x16 &t3, unsigned lo) const {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned o = lo ^ ((r & 1) ? L.o0 : 0u) ^ ((r & 2) ? L.o1 : 0u) ^ ((r & 4) ? L.o3 : 0u) ^ ((r & 8) ? L.o4 : 0u);
+      lds_write8(o, v2f_t{t1[r] - t2[r], t3[r] - t1[r] - t2[r]});
+    }
+  }
+  // operands in half units of 8 chain steps (16 VGPRs each): the second half is read under the MFMAs of the
+  // first, the first half of the next sub-tile under those of the second
+  template <int BASE>
+  __device__ __forceinline__ void load_half(v2f_t (&buf)[8], unsigned li) const {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) buf[s] = lds_read8(li ^ ko(BASE + s));
+  }
+  template <int BASE>
+  __device__ __forceinline__ void chain3(f32x16 &t1, f32x16 &t2, f32x16 &t3, const v2f_t (&buf)[8]) const {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float xs = buf[s].x + buf[s].y;
+#ifdef ARTN_ABLATE_MFMA
+      asm volatile("" ::"v"(buf[s].x), "v"(buf[s].y), "v"(xs), "v"(W0[BASE + s]), "v"(W1[BASE + s]), "v"(W2[CAN3M ? BASE + s : 0]));
+#else
+      t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[BASE + s], buf[s].x, t1, 0, 0, 0);
+      t2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[BASE + s], buf[s].y, t2, 0, 0, 0);
+      t3 = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[CAN3M ? BASE + s : 0], xs, t3, 0, 0, 0);
+#endif
+    }
+  }
+  __device__ __forceinline__ void run3() const {
+    constexpr int NU = S / 8; // half units per sub-tile: 2 (5 contracted bits) or 4 (6)
+    int msub = L.wm;
+    if (msub >= L.msubs) return;
+    v2f_t bA[8], bB[8];
+    u2_t mo = lds_read_u2(L.msub_tab + msub * 8);
+    load_half<0>(bA, L.lane_in ^ mo.x);
+    for (;;) {
+      const unsigned li = L.lane_in ^ mo.x, lo = L.lane_out ^ mo.y;
+      const int nmsub = msub + L.wm_count;
+      const bool more = nmsub < L.msubs;
+      u2_t mo_n = mo;
+      if (more) mo_n = lds_read_u2(L.msub_tab + nmsub * 8);
+      f32x16 t1, t2, t3;
+      zero(t1); zero(t2); zero(t3);
+      load_half<8>(bB, li);
+      chain3<0>(t1, t2, t3, bA);
+      if constexpr (NU == 2) {
+        if (more) load_half<0>(bA, L.lane_in ^ mo_n.x);
+        chain3<8>(t1, t2, t3, bB);
+      } else {
+        load_half<(NU == 4 ? 16 : 0)>(bA, li);
+        chain3<8>(t1, t2, t3, bB);
+        load_half<(NU == 4 ? 24 : 0)>(bB, li);
+        chain3<(NU == 4 ? 16 : 0)>(t1, t2, t3, bA);
+        if (more) load_half<0>(bA, L.lane_in ^ mo_n.x);
+        chain3<(NU == 4 ? 24 : 0)>(t1, t2, t3, bB);
+      }
+      scatter3(t1, t2, t3, lo);
+      if (!more) return;
+      msub = nmsub;
+      mo = mo_n;
+    }
+  }
+
   __device__ __forceinline__ void run() const {
+    if constexpr (CAN3M) {
+      run3();
+      return;
+    }
     if constexpr (BIGK) { // 7 or 8 contracted bits: only instantiated for the single-stage KB = 6 kernel
       if (L.ksplit_wave >= 0) { run_ksplit(lane); return; }
       if (L.k_hi > 0) { run_big_k(); return; }
@@ -883,13 +983,14 @@ struct StageRun {
   }
 };
 
-template <int KB, bool BIGK, int NP>
+template <int KB, bool BIGK, int NP, bool M3>
 __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1 << (KB - 1)],
-                                          float (&W1)[1 << (KB - 1)], int h, int lane,
+                                          float (&W1)[1 << (KB - 1)], float (&W2)[(M3 && (KB == 5 || KB == 6) && !BIGK && NP == 0) ? 1 << (KB - 1) : 1],
+                                          int h, int lane,
                                           float (&WH0)[BIGK ? 3 : 1][1 << (KB - 1)],
                                           float (&WH1)[BIGK ? 3 : 1][1 << (KB - 1)],
                                           u32x4_t (&WS)[(NP > 0 && KB >= 3) ? (BIGK ? 4 : NP) : 1][KB >= 3 ? 1 << (KB - 3) : 1]) {
-  StageRun<KB, BIGK, NP> r{L, W0, W1, h, lane, WH0, WH1, WS};
+  StageRun<KB, BIGK, NP, M3> r{L, W0, W1, W2, h, lane, WH0, WH1, WS};
   r.run();
 }
 
@@ -897,7 +998,8 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1
 // NP: 0 = fp32 MFMA chains; 3 / 1 = split-bf16 chains (stages with >= 3 contracted bits).
 // GATHER: row indices on one outer axis (artn_contract_gather; single stage, fp32 chains).
 // NT: non-temporal loads of the A tiles (see issue_loads).
-template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false, bool NT = false>
+// M3: every stage with 5 contracted bits runs the 3M arithmetic (StageRun::run3; fp32 chains only).
+template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false, bool NT = false, bool M3 = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(const float2 *__restrict__ A,
                                                                   const float2 *__restrict__ B1,
                                                                   const float2 *__restrict__ B2,
@@ -948,12 +1050,12 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   const unsigned tab1_a = regions_end, tab2_a = tab1_a + (8u << (P.st[0].m_bits - 5));
   constexpr bool SP1 = NP > 0 && KB1 >= 3, SP2 = NP > 0 && KB2 >= 3;
   constexpr int G1 = KB1 >= 3 ? 1 << (KB1 - 3) : 1, G2 = KB2e >= 3 ? 1 << (KB2e - 3) : 1;
-  StageConst<KB1> L1 = stage_const<KB1>(P.st[0], nullptr, j, h, wave, tab1_a, R0, R1, SP1 ? 2 : 0);
+  StageConst<KB1> L1 = stage_const<KB1, M3>(P.st[0], nullptr, j, h, wave, tab1_a, R0, R1, SP1 ? 2 : 0);
   if (BIGK && P.ksplit) {
     L1.ksplit_wave = wave;
     L1.ksplit_scratch = (regions_end + (8u << (P.st[0].m_bits - 5)) + (512u * 8u + 32u * 32u) + 15u) & ~15u;
   }
-  const StageConst<KB2e> L2 = stage_const<KB2e>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2_a, R1, R0, SP2 ? 2 : 0);
+  const StageConst<KB2e> L2 = stage_const<KB2e, M3>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2_a, R1, R0, SP2 ? 2 : 0);
   // copy-out reads the last stage's (swizzled) output region
   const ArtnStage *zout = &P.st[KB2 > 0 ? 1 : 0];
   const unsigned tid16_out = swz(tid16, zout);
@@ -962,6 +1064,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   for (int i = 0; i < 16; ++i) out_i_swz[i] = swz(i * (ARTN_WG_THREADS * 16), zout);
   const OffTab OT = build_offset_table(P, offtab, tid);
   float W10[S1], W11[S1], W20[S2], W21[S2]; // (whichever of the fp32 / split fragment sets a stage does not use is dead)
+  constexpr bool C31 = M3 && (KB1 == 5 || KB1 == 6) && !BIGK && NP == 0, C32 = M3 && (KB2 == 5 || KB2 == 6) && NP == 0;
+  float W12[C31 ? S1 : 1], W22[C32 ? S2 : 1]; // 3M stages: re + im fragments
   u32x4_t WS1[SP1 ? (BIGK ? 4 : NP) : 1][G1], WS2[SP2 ? NP : 1][G2];
   float WH0[BIGK ? 3 : 1][S1], WH1[BIGK ? 3 : 1][S1], WD0[1][S2], WD1[1][S2]; // BIGK: fragments of looped-over values 1..3
   long prev_b1 = -1, prev_b2 = -1;
@@ -1025,6 +1129,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       }
       if constexpr (SP1 && BIGK) load_w_plane<KB1>(WS1[0], Bb + kb0, L1, ro);
       else if constexpr (SP1) load_w_split<KB1, (SP1 ? NP : 1)>(WS1, Bb, L1, ro);
+      else if constexpr (C31) load_w3<KB1>(W10, W11, W12, Bb, L1);
       else load_w<KB1>(W10, W11, Bb + kb0, L1, ro);
       if constexpr (BIGK) { // fragments of the looped-over contracted bits' values 1..3
 #pragma unroll
@@ -1044,6 +1149,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     if (KB2 > 0 && off.b2 != prev_b2) {
       prev_b2 = off.b2;
       if constexpr (SP2) load_w_split<KB2e, (SP2 ? NP : 1)>(WS2, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
+      else if constexpr (C32) load_w3<KB2e>(W20, W21, W22, reinterpret_cast<const char *>(B2 + off.b2), L2);
       else load_w<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
     }
     const long next = tile + G, next2 = tile + 2 * G;
@@ -1054,7 +1160,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
     if (stage_prio) __builtin_amdgcn_s_setprio(2);
-    run_stage<KB1, BIGK, NP>(L1, W10, W11, h, lane, WH0, WH1, WS1);
+    run_stage<KB1, BIGK, NP, M3>(L1, W10, W11, W12, h, lane, WH0, WH1, WS1);
     if (stage_prio && KB2 == 0) __builtin_amdgcn_s_setprio(0);
     PHASE_MARK(1);
     STAMP(5);
@@ -1062,7 +1168,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     unsigned outr = R1;
     if (KB2 > 0) {
       STAMP(6);
-      run_stage<KB2e, false, NP>(L2, W20, W21, h, lane, WD0, WD1, WS2);
+      run_stage<KB2e, false, NP, M3>(L2, W20, W21, W22, h, lane, WD0, WD1, WS2);
       if (stage_prio) __builtin_amdgcn_s_setprio(0);
       STAMP(5);
       __syncthreads();
@@ -1410,6 +1516,20 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
         }                                                                                                 \
       }                                                                                                   \
       if (split == 1) { ARTN_LAUNCH_NP(K2, 1) break; }                                                    \
+    }                                                                                                     \
+    if constexpr ((KB1 == 5 || KB1 == 6 || K2 == 5 || K2 == 6) && !((KB1 >= 5 && K2 >= 5) && KB1 + K2 > 10)) {      \
+      if (p.bits.m3 && p.bits.nt_loads) { /* three real products per complex product in the 5-bit stages */ \
+        auto kern = artn_k_bits<KB1, K2, false, 0, false, true, true>;                                    \
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, true, true>>(lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                             \
+        break;                                                                                            \
+      }                                                                                                   \
+      if (p.bits.m3) {                                                                                    \
+        auto kern = artn_k_bits<KB1, K2, false, 0, false, false, true>;                                   \
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, false, true>>(lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                             \
+        break;                                                                                            \
+      }                                                                                                   \
     }                                                                                                     \
     if constexpr (KB1 >= 3 && (K2 == 0 || K2 >= 3)) {                                                     \
       if (p.bits.nt_loads) { /* the big steps: non-temporal loads of A */                                 \

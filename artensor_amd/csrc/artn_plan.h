@@ -59,7 +59,8 @@ struct ArtnStage {
   // above the 128-byte bank window (tile-local position >= 4) they are folded into a free
   // position 1..3 so the group spreads over the banks (at most 2-way conflicts remain).
   int32_t swz_n, swz_src[3], swz_dst[3];
-  int32_t pad_;
+  int32_t m3; // 1: three real products per complex product (5 contracted bits, 32+ columns: a wave owns 32-column
+              // sub-tiles; wn_log2 = nt - 5; lane half h carries column bit 2)
 };
 
 // Launch plan of the LDS-tiled bit-permuted complex GEMM (kernel argument, POD).
@@ -72,6 +73,8 @@ struct ArtnBitsPlan {
   int32_t stage_prio;         // 1: one of the two co-resident workgroups runs its MFMA stages at s_setprio 2
   int32_t blocked;            // 1: a workgroup takes a contiguous range of tiles instead of a grid-stride sequence
   int64_t n_tiles;
+  int32_t m3;                 // 1: every stage with 5 contracted bits runs the 3M arithmetic (ArtnStage::m3): the M3 instantiation
+  int32_t pad_m3_;
   int32_t ksplit;             // 1: 7-8 contracted bits, one 32 x 16 block per tile: the four waves split the chain
   int32_t split;              // MFMA arithmetic: 0 fp32; 3 fp32-grade from three bf16 pieces; 1 plain bf16 operands
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
@@ -169,6 +172,7 @@ struct Tuning {
   int nt = 1;         // non-temporal loads of A tiles that are read once
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
   int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
+  int bits_3m = 1;    // state-streaming kernel, fp32 stages with 5 contracted bits and 32+ columns: the same
 };
 static inline Tuning &tuning() {
   static Tuning t = [] {
@@ -181,6 +185,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_NT")) x.nt = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
     return x;
   }();
@@ -521,12 +526,16 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   for (int i = 0; i < run_out; ++i)
     if (b.out_stride[i] != (int64_t(1) << i)) { p.why_generic = "internal: output run broken"; return false; }
 
+  // (not for the split-bf16 arithmetic, whose chains are built differently)
+  const bool use_3m = tuning().bits_3m && d1->dtype == ARTN_C64 && tuning().split == 0;
   auto fill_stage = [&](ArtnStage &s, const std::vector<int> &Kx, const std::vector<int> &Mx,
                         const std::vector<int> &Nx, const std::vector<int> &tile_in,
                         const std::vector<int> &tile_out, bool second) {
     s.k = (int)Kx.size();
     s.nt = (int)Nx.size();
     s.wn_log2 = std::max(0, s.nt - 4);
+    s.m3 = (use_3m && (s.k == 5 || s.k == 6) && s.nt >= 5 && gather_label < 0 && (int)K1.size() <= 6) ? 1 : 0;
+    if (s.m3) s.wn_log2 = s.nt - 5;
     s.m_bits = (int)Mx.size();
     std::vector<int> Ms(Mx);
     std::sort(Ms.begin(), Ms.end(), [&](int x, int y) { return pos(tile_in, x) < pos(tile_in, y); });
@@ -554,6 +563,24 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     std::vector<int> M2t;
     for (int i : tmid) if (!in_set(K2, i)) M2t.push_back(i);
     fill_stage(b.st[1], K2, M2t, N2t, tmid, tout, true);
+  }
+  // the 3M kernels are separate instantiations in which EVERY 5- or 6-bit stage runs three products: all or
+  // none, and only while the fragments of both stages fit the register file next to three accumulators
+  {
+    bool any = false, all = true;
+    int frag = 0;
+    for (int q = 0; q < b.n_stages; ++q) {
+      const bool wide = b.st[q].k == 5 || b.st[q].k == 6;
+      if (wide) { any = any || b.st[q].m3; all = all && b.st[q].m3; }
+      frag += (wide ? 3 : 2) << (std::min(b.st[q].k, 6) - 1);
+    }
+    if (frag > 116) all = false; // 6+4: 112 registers of fragments; 6+5 (144) spills
+    // (a fused pair with a 6-bit 3M stage compiles with 16-48 spilled registers: only on request)
+    if (b.n_stages == 2 && (b.st[0].k == 6 || b.st[1].k == 6) && tuning().bits_3m < 2) all = false;
+    b.m3 = (any && all) ? 1 : 0;
+    if (!b.m3)
+      for (int q = 0; q < b.n_stages; ++q)
+        if (b.st[q].m3) { b.st[q].m3 = 0; b.st[q].wn_log2 = std::max(0, b.st[q].nt - 4); }
   }
 
   // ---- outer axes: N-outer fastest (tiles sharing an A tile run together), then M-outer by A
@@ -709,10 +736,11 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
     for (int i = 0; i < (int)ax.size(); ++i) if (ax[i].sA >= 0 && (ax[i].k1() || ax[i].m1())) na *= ax[i].ext;
     const bool big_second = std::min(na, nb) >= (int64_t(1) << 15);
     // measured on n53 / sparse-state steps: with 7-8 contracted bits the GEMM kernel wins once both
-    // operands bring 6+ free bits (128 x 64 tiles and up); with fewer, the second operand fits the
-    // registers of the state-streaming kernel and one pass of it is faster
+    // operands bring 5+ free bits (32-column blocks: three real products per complex product; 89 against
+    // 81 TFLOP/s on a 2^30 x 2^12 step); with fewer, or with up to 6 contracted bits, one pass of the
+    // state-streaming kernel with the second operand in registers is faster (107 against 96 at 6 bits)
     const int free_small = (int)std::min(M.size(), N.size());
-    if (!(k > 8 || (k > 6 && free_small >= 6) || big_second)) { p.why_generic = "state-streaming kernel preferred"; return false; }
+    if (!(k > 8 || (k > 6 && free_small >= 5) || big_second)) { p.why_generic = "state-streaming kernel preferred"; return false; }
   }
   // the first operand supplies the 32-row MFMA blocks: it needs 5 free bits
   const bool swapped = M.size() < 5 && N.size() >= 5;

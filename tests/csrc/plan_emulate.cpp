@@ -30,6 +30,45 @@ static void run_stage(const ArtnStage &st, const ArtnStage *zin, const cf *in, c
       int oi = 0, oo = 0;
       for (int b = 0; b < st.m_bits - 5; ++b)
         if ((msub >> b) & 1) { oi += 1 << st.msub_in_pos[b]; oo += 1 << st.msub_out_pos[b]; }
+      if (st.m3) { // three real products per complex product: rows = 32 columns n of the small operand
+        std::vector<float> t1(64 * 16, 0.f), t2(64 * 16, 0.f), t3(64 * 16, 0.f);
+        int lane_out3[64];
+        for (int s = 0; s < S; ++s) {
+          int ko = 0; int64_t kbo = 0;
+          for (int b = 1; b < KB; ++b) if ((s >> (b - 1)) & 1) { ko += 1 << st.k_in_pos[b]; kbo += st.k_b_stride[b]; }
+          float wre[64], wim[64], ax[64], ay[64];
+          for (int lane = 0; lane < 64; ++lane) {
+            const int j = lane & 31, h = lane >> 5;
+            int li = h << st.k_in_pos[0], lo = h << st.n_out_pos[2];
+            for (int b = 0; b < 5; ++b) if ((j >> b) & 1) { li += 1 << st.lane_in_pos[b]; lo += 1 << st.lane_out_pos[b]; }
+            int64_t lb = (int64_t)h * st.k_b_stride[0];
+            for (int b = 0; b < 5; ++b) if ((j >> b) & 1) lb += st.n_b_stride[b];
+            for (int b = 0; b < st.wn_log2; ++b) if ((wn >> b) & 1) { lo += 1 << st.n_out_pos[5 + b]; lb += st.n_b_stride[5 + b]; }
+            lane_out3[lane] = lo;
+            const cf bv = B[offB + lb + kbo];
+            wre[lane] = bv.real(); wim[lane] = bv.imag();
+            const cf a = in[swz(li + oi + ko, zin)];
+            ax[lane] = a.real(); ay[lane] = a.imag();
+          }
+          for (int lane = 0; lane < 64; ++lane)
+            for (int rr = 0; rr < 16; ++rr) {
+              const int i = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5), jj = lane & 31;
+              for (int kk = 0; kk < 2; ++kk) {
+                t1[lane * 16 + rr] += wre[i + 32 * kk] * ax[jj + 32 * kk];
+                t2[lane * 16 + rr] += wim[i + 32 * kk] * ay[jj + 32 * kk];
+                t3[lane * 16 + rr] += (wre[i + 32 * kk] + wim[i + 32 * kk]) * (ax[jj + 32 * kk] + ay[jj + 32 * kk]);
+              }
+            }
+        }
+        for (int lane = 0; lane < 64; ++lane)
+          for (int rr = 0; rr < 16; ++rr) {
+            const int o = lane_out3[lane] + oo + ((rr & 1) << st.n_out_pos[0]) + (((rr >> 1) & 1) << st.n_out_pos[1]) +
+                          (((rr >> 2) & 1) << st.n_out_pos[3]) + (((rr >> 3) & 1) << st.n_out_pos[4]);
+            const float a1 = t1[lane * 16 + rr], a2 = t2[lane * 16 + rr], a3 = t3[lane * 16 + rr];
+            out[swz(o, &st)] = cf(a1 - a2, a3 - a1 - a2);
+          }
+        continue;
+      }
       float acc[64][16];
       for (auto &r : acc) for (float &x : r) x = 0.f;
       int lane_out[64];
