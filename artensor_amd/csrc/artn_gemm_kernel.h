@@ -256,6 +256,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             if (t + 1 < 4) load_ops(t + 1, X[(t + 1) & 1], Wr[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
             u32x4_t W[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b)
@@ -283,6 +284,9 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
 #pragma unroll
           for (int s = 0; s < 8; ++s) {
             if (s + 1 < 8) load_ops(s + 1, X[(s + 1) & 1], Wr[(s + 1) & 1]);
+            // (left alone, the scheduler sinks these reads to just above their first use and waits for them there:
+            //  every step then exposes an LDS round trip; pinned here they fly under this step's MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (M3) {
               float xs[MB], wsum[NB];
 #pragma unroll
