@@ -107,8 +107,13 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
   const unsigned a_pair = (unsigned)P.a_lds[0], b_pair = (unsigned)P.b_lds[0]; // LDS bytes between the two elements of a lane load
 
   // ---- MFMA lanes
-  const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
-  const bool w_active = wm < (1 << P.wm_log2);
+  // waves: wn x wm grid of blocks; what is left of the four (tiles with fewer than 4 blocks) splits the contracted
+  // values of every chunk: wave wk takes k pairs wk, wk + WK, ...
+  const int wn = wave & ((1 << P.wn_log2) - 1), wm = (wave >> P.wn_log2) & ((1 << P.wm_log2) - 1);
+  // (only single-block waves ever share a block: the other instantiations carry none of this)
+  constexpr bool CAN_SPLIT = MB == 1 && NB == 1;
+  const int wk = CAN_SPLIT ? wave >> (P.wn_log2 + P.wm_log2) : 0, WK = CAN_SPLIT ? 1 << P.wk_log2 : 1;
+  constexpr bool w_active = true;
   const int n_in = M3 ? j : j >> 1;
   const bool w_valid = M3 || nt >= 4 || n_in < (1 << nt);
   constexpr int NBW = M3 ? 32 : 16; // complex columns per MFMA block
@@ -252,6 +257,24 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
 #pragma unroll
             for (int b = 0; b < NB; ++b) w[b] = __builtin_bit_cast(u32x4_t, lds_read16(wa + (unsigned)t * 4096u + (unsigned)b * 256u));
           };
+          if (CAN_SPLIT && WK > 1) {
+            for (int t = wk; t < 4; t += WK) {
+              load_ops(t, X[0], Wr[0]);
+#pragma unroll
+              for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const unsigned d = Wr[0][b][e];
+                  Wr[0][b][e] = w_valid ? (__builtin_amdgcn_perm(d, d, w_sel) ^ w_sign) : 0u;
+                }
+#pragma unroll
+              for (int a = 0; a < MB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                  acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Wr[0][b]),
+                                                                     __builtin_bit_cast(bf16x8_t, X[0][a]), acc[a][b], 0, 0, 0);
+            }
+          } else {
           load_ops(0, X[0], Wr[0]);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -272,7 +295,31 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, W[b]),
                                                                    __builtin_bit_cast(bf16x8_t, X[t & 1][a]), acc[a][b], 0, 0, 0);
           }
+          } // (WK == 1)
         } else {
+          if (CAN_SPLIT && WK > 1) { // the waves of a block split the chunk (small tiles: no operand pipelining)
+            for (int s = wk; s < 8; s += WK) {
+              v2f_t x[MB], w[NB];
+#pragma unroll
+              for (int a = 0; a < MB; ++a) x[a] = lds_read8(xa + (unsigned)s * ROW2 + (unsigned)a * 256u);
+#pragma unroll
+              for (int b = 0; b < NB; ++b) w[b] = lds_read8(wa + (unsigned)s * ROW2 + (unsigned)b * (NBW * 8u));
+#pragma unroll
+              for (int a = 0; a < MB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                  if constexpr (M3) {
+                    acc[a][3 * b] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[b].x, x[a].x, acc[a][3 * b], 0, 0, 0);
+                    acc[a][3 * b + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[b].y, x[a].y, acc[a][3 * b + 1], 0, 0, 0);
+                    acc[a][3 * b + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[b].x + w[b].y, x[a].x + x[a].y, acc[a][3 * b + 2], 0, 0, 0);
+                  } else {
+                    const float w0 = w_valid ? (ro ? w[b].y : w[b].x) : 0.f, w1 = w_valid ? (ro ? w[b].x : -w[b].y) : 0.f;
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x[a].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x[a].y, acc[a][b], 0, 0, 0);
+                  }
+                }
+            }
+          } else {
           v2f_t X[2][MB], Wr[2][NB];
           auto load_ops = [&](int s, v2f_t (&x)[MB], v2f_t (&w)[NB]) {
 #pragma unroll
@@ -318,6 +365,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[b], X[s & 1][a].y, acc[a][b], 0, 0, 0);
               }
           }
+          } // (WK == 1)
         }
       }
       const bool flush = last || ((c + 1) & flush_mask) == 0;
@@ -331,12 +379,14 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
       //      sum of the same tile is added to what the earlier ones left in C
       const bool accumulate = c > flush_mask;
       char *Cb = reinterpret_cast<char *>(C) + off.c * 8;
-      for (int pass = 0; pass < n_pass; ++pass) {
-        __syncthreads(); // chunk buffers / previous pass are no longer read
+      for (int pass = 0; pass < n_pass; ++pass)
+       for (int round = 0; round < WK; ++round) { // waves that split a block add their partial blocks one after the other
+        __syncthreads(); // chunk buffers / previous pass / previous round are no longer in use
         unsigned lc = lane_c; // (opaque: 64 hoisted scatter addresses per lane would cost the accumulators their registers)
         OPAQUE_V(lc);
+        const bool mine = wk == round, add = round > 0;
         if constexpr (M3) {
-          if (w_active) {
+          if (mine) {
 #pragma unroll
             for (int a = 0; a < MB; ++a)
 #pragma unroll
@@ -345,11 +395,15 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
                 for (int r = 0; r < 16; ++r) {
                   const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ ((r & 1) ? c_b0 : 0u) ^ ((r & 2) ? c_b1 : 0u) ^ ((r & 4) ? c_q0 : 0u) ^ ((r & 8) ? c_q1 : 0u);
                   const float t1 = acc[a][3 * b][r], t2 = acc[a][3 * b + 1][r], t3 = acc[a][3 * b + 2][r];
-                  if ((int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
-                    lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{t1 - t2, t3 - t1 - t2});
+                  if ((int)(pos >> ARTN_GEMM_EPI_BITS) == pass) {
+                    const unsigned ad = (pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u;
+                    v2f_t val = {t1 - t2, t3 - t1 - t2};
+                    if (add) val += lds_read8(ad);
+                    lds_write8(ad, val);
+                  }
                 }
           }
-        } else if (w_active) {
+        } else if (mine) {
 #pragma unroll
           for (int a = 0; a < MB; ++a)
 #pragma unroll
@@ -360,10 +414,15 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
                 for (int b0 = 0; b0 < 2; ++b0) {
                   const int n_loc = b0 + 2 * h + 4 * q;
                   const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ (b0 ? c_b0 : 0u) ^ ((q & 1) ? c_q0 : 0u) ^ ((q >> 1) ? c_q1 : 0u);
-                  if (n_loc < n_lim && (int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
-                    lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{acc[a][b][4 * q + 2 * b0], acc[a][b][4 * q + 2 * b0 + 1]});
+                  if (n_loc < n_lim && (int)(pos >> ARTN_GEMM_EPI_BITS) == pass) {
+                    const unsigned ad = (pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u;
+                    v2f_t val = {acc[a][b][4 * q + 2 * b0], acc[a][b][4 * q + 2 * b0 + 1]};
+                    if (add) val += lds_read8(ad);
+                    lds_write8(ad, val);
+                  }
                 }
         }
+        if (round + 1 < WK) continue;
         __syncthreads();
         char *Cp = Cb + pass * pass_stride;
         // (a swizzle source may be the pass bit itself: its image under the swizzle belongs to every address of the pass)

@@ -138,7 +138,9 @@ struct ArtnGemmPlan {
   int64_t out_stride[14];    // C-tile-local bit -> C element stride
   int32_t m_pos[8], n_pos[8]; // m_local / n_local bit -> C-tile-local position
   int32_t swz_n, swz_src[4], swz_dst[4]; // XOR swizzle of the LDS result image (as ArtnStage::swz_*)
-  int32_t pad1_[3];
+  int32_t wk_log2;           // tiles with fewer than 4 MFMA blocks: 2^wk_log2 waves share a block and split each chunk's
+                             // contracted values between them (partial blocks are added up in the LDS result image)
+  int32_t pad1_[2];
   ArtnOuterDim outer[ARTN_MAX_OUTER];
   // (unused by this kernel; present so tile_offsets<> compiles for both plan types)
   int32_t gather_dim;
@@ -843,6 +845,7 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
     }
     if (best == (1 << 30)) { p.why_generic = "internal: no wave layout for the GEMM tile"; return false; }
   }
+  g.wk_log2 = 2 - g.wm_log2 - g.wn_log2;
   // ---- LDS images: [kc value][m_local] and [kc value][n_local].  Local bit order = stride order in the
   //      operand: the copy lanes (lowest-stride bits of a chunk) then write neighbouring rows and
   //      chunk values -- ordered by C stride instead, a bf16 step ran 8x slower on LDS bank conflicts

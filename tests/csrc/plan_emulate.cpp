@@ -215,9 +215,9 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
     const int n_pass = 1 << (P.tc_bits - epi_bits);
     for (int pass = 0; pass < n_pass; ++pass) {
       for (auto &x : res) x = cf(-777.f, -777.f);
-      for (int wave = 0; wave < 4; ++wave) {
-        const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
-        if (wm >= (1 << P.wm_log2)) continue;
+      for (int wave = 0; wave < 4; ++wave) { // (wave order = ascending wk: the first partial block is stored, the others added)
+        const int wn = wave & ((1 << P.wn_log2) - 1), wm = (wave >> P.wn_log2) & ((1 << P.wm_log2) - 1);
+        const bool add = (wave >> (P.wn_log2 + P.wm_log2)) > 0;
         if (P.m3) {
           for (int a = 0; a < MB; ++a) for (int b = 0; b < NB; ++b) for (int lane = 0; lane < 64; ++lane)
             for (int rr = 0; rr < 16; ++rr) {
@@ -226,7 +226,8 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
               const unsigned pos = swzg(m_off((wm * MB + a) * 32 + j) | n_off((wn * NB + b) * 32 + n_loc), P);
               if ((int)(pos >> ARTN_GEMM_EPI_BITS) != pass) continue;
               const float t1 = ACC3(wave, a, b, 0, lane, rr), t2 = ACC3(wave, a, b, 1, lane, rr), t3 = ACC3(wave, a, b, 2, lane, rr);
-              res[pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)] = cf(t1 - t2, t3 - t1 - t2);
+              cf &dst = res[pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)];
+              dst = add ? dst + cf(t1 - t2, t3 - t1 - t2) : cf(t1 - t2, t3 - t1 - t2);
             }
           continue;
         }
@@ -237,7 +238,9 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
             if (n_loc >= n_lim) continue;
             const unsigned pos = swzg(m_off((wm * MB + a) * 32 + j) | n_off((wn * NB + b) * 16 + n_loc), P);
             if ((int)(pos >> ARTN_GEMM_EPI_BITS) != pass) continue;
-            res[pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)] = cf(ACC(wave, a, b, lane, 4 * q + 2 * b0), ACC(wave, a, b, lane, 4 * q + 2 * b0 + 1));
+            cf &dst = res[pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)];
+            const cf val(ACC(wave, a, b, lane, 4 * q + 2 * b0), ACC(wave, a, b, lane, 4 * q + 2 * b0 + 1));
+            dst = add ? dst + val : val;
           }
       }
       const int cb = epi_bits - 1, iters = cb > 8 ? 1 << (cb - 8) : 1;
@@ -286,10 +289,10 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
       }
       // MFMA pairs
       for (int wave = 0; wave < 4; ++wave) {
-        const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
-        if (wm >= (1 << P.wm_log2)) continue;
+        const int wn = wave & ((1 << P.wn_log2) - 1), wm = (wave >> P.wn_log2) & ((1 << P.wm_log2) - 1);
+        const int wk = wave >> (P.wn_log2 + P.wm_log2), WK = 1 << P.wk_log2; // waves sharing a block split the chunk
         if (P.m3) { // three real products: T1 = A_re B_re, T2 = A_im B_im, T3 = (A_re + A_im)(B_re + B_im); rows = 32 columns n
-          for (int s = 0; s < 8; ++s)
+          for (int s = wk; s < 8; s += WK)
             for (int a = 0; a < MB; ++a)
               for (int b = 0; b < NB; ++b)
                 for (int lane = 0; lane < 64; ++lane)
@@ -306,7 +309,7 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
           continue;
         }
         if (P.split) { // v_mfma_f32_32x32x16_bf16 groups: kc = 8t + 4h + u, image [kc >> 2][row][kc & 3]
-          for (int t = 0; t < 4; ++t)
+          for (int t = wk; t < 4; t += WK)
             for (int a = 0; a < MB; ++a)
               for (int b = 0; b < NB; ++b)
                 for (int lane = 0; lane < 64; ++lane)
@@ -326,7 +329,7 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
                   }
           continue;
         }
-        for (int s = 0; s < 8; ++s)
+        for (int s = wk; s < 8; s += WK)
           for (int a = 0; a < MB; ++a)
             for (int b = 0; b < NB; ++b) {
               float W0[64], W1[64], ax[64], ay[64];
