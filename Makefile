@@ -6,18 +6,18 @@ LIB := artensor_amd/libartn_hip.so
 
 all: $(LIB)
 
-$(LIB): $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_plan.h include/artn.h
+$(LIB): $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_plan.h include/artn.h
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Iinclude -I$(CSRC) $< -o $@
 
 # diagnostic build with in-kernel phase stamps (never loaded by the product; tools/stamps.py)
-stamps: $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_plan.h include/artn.h
+stamps: $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_plan.h include/artn.h
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_STAMPS -Iinclude -I$(CSRC) $< -o tools/libartn_hip_stamps.so
 
-phases: $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_plan.h include/artn.h
+phases: $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_plan.h include/artn.h
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_PHASES -Iinclude -I$(CSRC) $< -o tools/libartn_hip_phases.so
 
 # timing-only ablations (wrong results by construction; never loaded by the product)
-ablate: $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_plan.h include/artn.h
+ablate: $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_plan.h include/artn.h
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MFMA -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomfma.so
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MEM -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomem.so
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MEM -DARTN_ABLATE_MFMA -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomem_nomfma.so

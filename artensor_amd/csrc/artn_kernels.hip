@@ -1249,6 +1249,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 }
 
 #include "artn_gemm_kernel.h"
+#include "artn_gemm128_kernel.h"
 
 // ----------------------------------------------------------------------------------------
 // strided fallback: one thread per C element
@@ -1628,6 +1629,24 @@ static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, v
     if (hipError_t e = ensure_lds<artn_k_gemm<MBV, NBV, false, true>>(lds); e != hipSuccess) return e; \
     hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
     return hipGetLastError();                                                                        \
+  }
+  if (g.split == 2) { // complex128 on v_mfma_f64_16x16x4_f64
+    const double2 *a2 = (const double2 *)(g.swapped ? B : A), *b2 = (const double2 *)(g.swapped ? A : B);
+    double2 *c2 = (double2 *)C;
+#define ARTN_GEMM128_LAUNCH(NBV)                                                                     \
+  {                                                                                                  \
+    auto kern = artn_k_gemm128<NBV>;                                                                 \
+    if (hipError_t e = ensure_lds<artn_k_gemm128<NBV>>(lds); e != hipSuccess) return e;              \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a2, b2, c2, g);                                   \
+    return hipGetLastError();                                                                        \
+  }
+    switch (g.nb_log2) {
+      case 0: ARTN_GEMM128_LAUNCH(1)
+      case 1: ARTN_GEMM128_LAUNCH(2)
+      case 2: ARTN_GEMM128_LAUNCH(4)
+    }
+#undef ARTN_GEMM128_LAUNCH
+    return hipErrorInvalidValue;
   }
   const int key = g.mb_log2 * 4 + g.nb_log2;
   if (g.m3) {

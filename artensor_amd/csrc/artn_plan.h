@@ -975,6 +975,176 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   return true;
 }
 
+
+// ----------------------------------------------------------------------------------------
+// complex128 on v_mfma_f64_16x16x4_f64 (artn_k_gemm128): the same two-operand LDS GEMM with 16-byte
+// elements -- one element per copy lane, chunks of 2^3 contracted values, MFMA blocks of 16 rows (m) x 8
+// complex columns (n), two row blocks x 2^nb column blocks per wave.  ArtnGemmPlan is shared: split = 2.
+// ----------------------------------------------------------------------------------------
+#define ARTN_GEMM128_KC 3
+#define ARTN_GEMM128_EPI_BITS 12 /* result passes of 2^12 elements (64 KiB) */
+static inline bool make_gemm128(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles) {
+  if (d->dtype != ARTN_C128) { p.why_generic = "dtype is not complex128"; return false; }
+  std::vector<Axis> ax;
+  expand_axes(d, ax);
+  std::vector<int> K, M, N, O;
+  for (int i = 0; i < (int)ax.size(); ++i) {
+    const Axis &a = ax[i];
+    if (a.k1()) {
+      if (!a.bit) { p.why_generic = "contracted label with a non power-of-two extent"; return false; }
+      K.push_back(i);
+    } else if (a.m1()) (a.bit ? M : O).push_back(i);
+    else if (a.n1()) (a.bit ? N : O).push_back(i);
+    else if (a.h1()) O.push_back(i);
+    else { p.why_generic = "label summed out of a single operand"; return false; }
+  }
+  const int k = (int)K.size(), kc = ARTN_GEMM128_KC;
+  if (k < kc) { p.why_generic = "fewer contracted bits than one LDS chunk of the complex128 GEMM kernel"; return false; }
+  if (k - kc > ARTN_GEMM_MAX_KO) { p.why_generic = "too many contracted bits"; return false; }
+  const bool swapped = M.size() < 5 && N.size() >= 5;
+  if (swapped) {
+    for (auto &a : ax) std::swap(a.sA, a.sB1);
+    std::swap(M, N);
+  }
+  const int m = (int)M.size(), n = (int)N.size();
+  if (m < 5) { p.why_generic = "too few free bits for an MFMA tile"; return false; }
+  auto in_set = [](const std::vector<int> &v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+  auto byA = [&](int x, int y) { return ax[x].sA < ax[y].sA; };
+  auto byB = [&](int x, int y) { return ax[x].sB1 < ax[y].sB1; };
+  auto byC = [&](int x, int y) { return ax[x].sC < ax[y].sC; };
+  std::sort(K.begin(), K.end(), byA);
+  std::sort(M.begin(), M.end(), byA);
+  std::sort(N.begin(), N.end(), byB);
+  // wave grid / blocks: mt = 5 + wm, nt = 3 + nb + wn (wm + wn <= 2): the biggest tile the free bits allow
+  int best_size = -1, wm_b = 0, wn_b = 0, nb_b = 0;
+  for (int wm = 0; wm <= 2; ++wm)
+    for (int wn = 0; wm + wn <= 2; ++wn)
+      for (int nb = 0; nb <= 2; ++nb) {
+        const int mt = 5 + wm, nt = 3 + nb + wn;
+        if (mt > m || (nt > n && !(wn == 0 && nb == 0))) continue;
+        const int size = mt + std::min(nt, n) + (wm + wn == 2 ? 1 : 0);
+        if (size > best_size) { best_size = size; wm_b = wm; wn_b = wn; nb_b = nb; }
+      }
+  int mt = 5 + wm_b, nt = std::min(3 + nb_b + wn_b, n);
+  // contiguous runs: the low-stride bits of A, B and C belong in the tile (2^r elements of 16 bytes)
+  int ra = 3, rb = 3, rc = 3;
+  std::vector<int> Kf, Mf, Nf;
+  for (;;) {
+    Kf.clear(); Mf.clear(); Nf.clear();
+    const int64_t la = int64_t(1) << ra, lb = int64_t(1) << rb, lc = int64_t(1) << rc;
+    for (int i : K) if (ax[i].sA < la || ax[i].sB1 < lb) Kf.push_back(i);
+    for (int i : M) if (ax[i].sA < la || ax[i].sC < lc) Mf.push_back(i);
+    for (int i : N) if (ax[i].sB1 < lb || ax[i].sC < lc) Nf.push_back(i);
+    int *shrink = nullptr;
+    if ((int)Kf.size() > kc) shrink = rb >= ra ? &rb : &ra;
+    else if ((int)Mf.size() > mt) shrink = rc >= ra ? &rc : &ra;
+    else if ((int)Nf.size() > nt) shrink = rc >= rb ? &rc : &rb;
+    if (!shrink) break;
+    if (*shrink <= 0) { p.why_generic = "forced tile bits exceed the complex128 GEMM tile"; return false; }
+    --*shrink;
+  }
+  std::vector<int> Kc(Kf), Mt(Mf), Nt(Nf);
+  for (int i : K) { if ((int)Kc.size() >= kc) break; if (!in_set(Kc, i)) Kc.push_back(i); }
+  for (int i : M) { if ((int)Mt.size() >= mt) break; if (!in_set(Mt, i)) Mt.push_back(i); }
+  for (int i : N) { if ((int)Nt.size() >= nt) break; if (!in_set(Nt, i)) Nt.push_back(i); }
+  if ((int)Mt.size() != mt || (int)Nt.size() != nt) { p.why_generic = "internal: complex128 tile"; return false; }
+  ArtnGemmPlan &g = p.gemm;
+  memset(&g, 0, sizeof(g));
+  g.mt = mt; g.nt = nt; g.kc = kc; g.n_ko = k - kc; g.swapped = swapped ? 1 : 0;
+  g.split = 2; g.gather_dim = -1;
+  g.wm_log2 = wm_b; g.wn_log2 = wn_b; g.mb_log2 = 1; g.nb_log2 = nb_b;
+  std::sort(Kc.begin(), Kc.end(), byA);
+  std::sort(Mt.begin(), Mt.end(), byA);
+  std::sort(Nt.begin(), Nt.end(), byB);
+  auto pos = [](const std::vector<int> &v, int axis) { return (int)(std::find(v.begin(), v.end(), axis) - v.begin()); };
+  std::vector<int> tA(Kc), tB(Kc), tC(Mt);
+  tA.insert(tA.end(), Mt.begin(), Mt.end());
+  tB.insert(tB.end(), Nt.begin(), Nt.end());
+  tC.insert(tC.end(), Nt.begin(), Nt.end());
+  std::sort(tA.begin(), tA.end(), byA);
+  std::sort(tB.begin(), tB.end(), byB);
+  std::sort(tC.begin(), tC.end(), byC);
+  g.ta_bits = mt + kc; g.tb_bits = nt + kc; g.tc_bits = mt + nt;
+  auto lds_row = [&](int i) { return 16 << i; };
+  auto lds_kc = [&](int q) { return (16 << ARTN_GEMM_PITCH_LOG2) << q; };
+  for (int b = 0; b < g.ta_bits; ++b) { g.a_stride[b] = ax[tA[b]].sA; g.a_lds[b] = in_set(Mt, tA[b]) ? lds_row(pos(Mt, tA[b])) : lds_kc(pos(Kc, tA[b])); }
+  for (int b = 0; b < g.tb_bits; ++b) { g.b_stride[b] = ax[tB[b]].sB1; g.b_lds[b] = in_set(Nt, tB[b]) ? lds_row(pos(Nt, tB[b])) : lds_kc(pos(Kc, tB[b])); }
+  for (int b = 0; b < g.tc_bits; ++b) g.out_stride[b] = ax[tC[b]].sC;
+  for (int i = 0; i < mt; ++i) g.m_pos[i] = pos(tC, Mt[i]);
+  for (int i = 0; i < nt; ++i) g.n_pos[i] = pos(tC, Nt[i]);
+  { int q = 0; for (int i : K) if (!in_set(Kc, i)) { g.ko_sA[q] = ax[i].sA; g.ko_sB[q] = ax[i].sB1; ++q; } }
+  // result-image swizzle: the 16 lanes of a ds_write_b64 group are the 16 rows of an MFMA block (m_local bits 0..3);
+  // elements are 16 bytes: fold row bits that sit above the 128-byte window (position >= 3) into free positions 0..2
+  {
+    bool taken[3] = {false, false, false};
+    for (int i = 0; i < 4; ++i) if (g.m_pos[i] < 3) taken[g.m_pos[i]] = true;
+    for (int i = 0; i < 4 && tuning().swizzle; ++i) {
+      if (g.m_pos[i] < 3) continue;
+      int f = -1;
+      for (int c = 0; c < 3; ++c) if (!taken[c]) { f = c; break; }
+      if (f < 0) break;
+      taken[f] = true;
+      g.swz_src[g.swz_n] = g.m_pos[i]; g.swz_dst[g.swz_n] = f; ++g.swz_n;
+    }
+  }
+  std::vector<int> outer;
+  for (int i : N) if (!in_set(Nt, i)) outer.push_back(i);
+  for (int i : M) if (!in_set(Mt, i)) outer.push_back(i);
+  std::sort(O.begin(), O.end(), [&](int x, int y) {
+    auto key = [&](int z) { return ax[z].sA >= 0 ? ax[z].sA : ax[z].sB1; };
+    return key(x) < key(y);
+  });
+  outer.insert(outer.end(), O.begin(), O.end());
+  g.n_tiles = 1;
+  int64_t a_rereads = 1;
+  for (int i : outer) {
+    const Axis &a = ax[i];
+    ArtnOuterDim od;
+    od.ext = a.ext; od.sA = a.sA >= 0 ? a.sA : 0; od.sB1 = a.sB1 >= 0 ? a.sB1 : 0; od.sB2 = 0; od.sC = a.sC >= 0 ? a.sC : 0;
+    od.log2ext = ilog2_exact(a.ext); od.pad_ = 0;
+    g.n_tiles *= a.ext;
+    if (a.sA < 0) a_rereads *= a.ext;
+    if (g.n_outer > 0) {
+      ArtnOuterDim &pr = g.outer[g.n_outer - 1];
+      auto okf = [&](int64_t ps, int64_t ns) { return (ps == 0 && ns == 0) || (ps != 0 && ns == ps * pr.ext); };
+      if (pr.log2ext >= 0 && od.log2ext >= 0 && okf(pr.sA, od.sA) && okf(pr.sB1, od.sB1) && okf(pr.sC, od.sC) && pr.log2ext + od.log2ext < 31) {
+        pr.ext *= od.ext; pr.log2ext += od.log2ext;
+        continue;
+      }
+    }
+    if (g.n_outer >= ARTN_MAX_OUTER) { p.why_generic = "too many outer axes"; return false; }
+    g.outer[g.n_outer++] = od;
+  }
+  {
+    int64_t sa = 0, sb = 0, sc = 0;
+    for (int b = 0; b < 8; ++b) {
+      if (b < g.ta_bits) sa += g.a_stride[b];
+      if (b < g.tb_bits) sb += g.b_stride[b];
+      if (b < g.tc_bits) sc += g.out_stride[b];
+    }
+    const int64_t lim = (int64_t(1) << 27) - 1; // elements of 16 bytes: < 2^31 bytes
+    if (sa > lim || sb > lim || sc > lim) { p.why_generic = "lane offsets exceed 32 bits"; return false; }
+    int pow2_bits = 0;
+    for (int i = 0; i < g.n_outer && g.outer[i].log2ext >= 0; ++i) pow2_bits += g.outer[i].log2ext;
+    if (pow2_bits > 32) { p.why_generic = "more than 2^32 tiles"; return false; }
+  }
+  if (g.n_tiles < min_tiles && k <= 8) { p.why_generic = "too few tiles to fill the chip"; return false; }
+  p.kernel = ARTN_KERNEL_GEMM_MFMA;
+  ArtnStepInfo &f = p.info;
+  f.kernel = ARTN_KERNEL_GEMM_MFMA;
+  f.k_bits = k; f.m_tile_bits = mt; f.n_tile_bits = nt;
+  f.tile_in_bits = g.ta_bits; f.tile_out_bits = g.tc_bits;
+  f.run_in_bits = ra; f.run_out_bits = rc;
+  const int64_t stage = 2 * (16LL << (ARTN_GEMM_PITCH_LOG2 + kc));
+  const int64_t epi = 16LL << std::min(g.tc_bits, ARTN_GEMM128_EPI_BITS);
+  f.lds_bytes = (int32_t)(std::max(2 * stage, epi) + 512LL * 8 + 32 * 32 + 16LL * ARTN_GEMM_MAX_KO);
+  f.n_tiles = g.n_tiles;
+  f.a_rereads = a_rereads;
+  const int wg_per_cu = std::max(1, std::min(2, (160 * 1024) / f.lds_bytes));
+  f.grid = (int32_t)std::min<int64_t>(g.n_tiles, (int64_t)n_cu * wg_per_cu);
+  return true;
+}
+
 static inline void step_cost(const ArtnStepDesc *d, double &flops, double &na, double &nb, double &nc) {
   double prod = 1;
   na = nb = nc = 1;
@@ -995,9 +1165,11 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
   bool ok = false;
-  allow_gemm = allow_gemm && allow_bits && gather_label < 0 && tuning().gemm;
+  if (d->dtype == ARTN_C128 && allow_bits && allow_gemm && gather_label < 0 && tuning().gemm)
+    ok = make_gemm128(d, p, n_cu, min_tiles); // complex128: the f64 MFMA GEMM kernel or the strided kernel
+  allow_gemm = allow_gemm && allow_bits && gather_label < 0 && tuning().gemm && d->dtype != ARTN_C128 && !ok;
   if (allow_gemm) ok = make_gemm(d, p, n_cu, min_tiles, tuning().gemm < 2);
-  if (!ok) ok = allow_bits && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
+  if (!ok && d->dtype != ARTN_C128) ok = allow_bits && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
   if (!ok && allow_gemm) { // what the state-streaming kernel declines
     const std::string why = p.why_generic;
     ok = make_gemm(d, p, n_cu, min_tiles, false);

@@ -361,6 +361,109 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
   }
 }
 
+
+// ---- artn_k_gemm128 (complex128 on v_mfma_f64_16x16x4_f64), replayed from the same plan --------------------
+typedef std::complex<double> cd;
+static void run_gemm128(const ArtnGemmPlan &P, const cd *A0, const cd *B0, cd *C) {
+  const cd *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
+  const int mt = P.mt, nt = P.nt, MB = 2, NB = 1 << P.nb_log2, PL = ARTN_GEMM_PITCH_LOG2;
+  const int epi_bits = std::min(P.tc_bits, ARTN_GEMM128_EPI_BITS);
+  std::vector<cd> imgA((size_t)8 << PL), imgB((size_t)8 << PL), res((size_t)1 << epi_bits);
+  const int n_chunks = 1 << P.n_ko;
+  for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
+    int64_t r = tile, offA = 0, offB = 0, offC = 0;
+    for (int d = 0; d < P.n_outer; ++d) {
+      int64_t ext = P.outer[d].ext, x;
+      if (P.outer[d].log2ext >= 0) { x = r & (ext - 1); r >>= P.outer[d].log2ext; }
+      else { x = r % ext; r /= ext; }
+      offA += x * P.outer[d].sA; offB += x * P.outer[d].sB1; offC += x * P.outer[d].sC;
+    }
+    std::vector<double> acc((size_t)4 * MB * NB * 64 * 4, 0.0);
+    auto ACC = [&](int wave, int a, int b, int lane, int rr) -> double & { return acc[((((size_t)wave * MB + a) * NB + b) * 64 + lane) * 4 + rr]; };
+    int64_t ka = 0, kb = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+      if (c > 0) {
+        const int bit = __builtin_ctz((unsigned)c);
+        const unsigned gn = (unsigned)c ^ ((unsigned)c >> 1);
+        if ((gn >> bit) & 1) { ka += P.ko_sA[bit]; kb += P.ko_sB[bit]; } else { ka -= P.ko_sA[bit]; kb -= P.ko_sB[bit]; }
+      }
+      for (int which = 0; which < 2; ++which) {
+        const int bits = which ? P.tb_bits : P.ta_bits;
+        const int64_t *gs = which ? P.b_stride : P.a_stride;
+        const int32_t *ls = which ? P.b_lds : P.a_lds;
+        cd *img = which ? imgB.data() : imgA.data();
+        const cd *src = which ? B + offB + kb : A + offA + ka;
+        const int iters = bits > 8 ? 1 << (bits - 8) : 1;
+        for (int tid = 0; tid < 256; ++tid) {
+          if (!(bits >= 8 || tid < (1 << bits))) continue;
+          for (int u = 0; u < iters; ++u) {
+            const int e = tid + 256 * u;
+            int64_t g = 0; int l = 0;
+            for (int b = 0; b < bits; ++b) if ((e >> b) & 1) { g += gs[b]; l += ls[b]; }
+            img[l / 16] = src[g];
+          }
+        }
+      }
+      for (int wave = 0; wave < 4; ++wave) {
+        const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
+        if (wm >= (1 << P.wm_log2)) continue;
+        for (int s = 0; s < 4; ++s)
+          for (int a = 0; a < MB; ++a)
+            for (int b = 0; b < NB; ++b) {
+              double Wv[64], Xv[64];
+              for (int lane = 0; lane < 64; ++lane) {
+                const int j = lane & 15, g = lane >> 4, ro = j & 1, p = g & 1, n_in = j >> 1;
+                const bool w_valid = nt >= 3 || n_in < (1 << nt);
+                const cd xv = imgA[((size_t)(2 * s + (g >> 1)) << PL) + (wm * MB + a) * 16 + j];
+                cd bv(0.0, 0.0);
+                if (w_valid) bv = imgB[((size_t)(2 * s + (g >> 1)) << PL) + (wn * NB + b) * 8 + n_in];
+                Xv[lane] = p ? xv.imag() : xv.real();
+                const double comp = (ro ^ p) ? bv.imag() : bv.real();
+                Wv[lane] = (ro == 0 && p == 1) ? -comp : comp;
+              }
+              for (int lane = 0; lane < 64; ++lane)
+                for (int rr = 0; rr < 4; ++rr) {
+                  const int i = (lane >> 4) + 4 * rr, jj = lane & 15; // guide: f64 C/D map
+                  for (int kk = 0; kk < 4; ++kk) ACC(wave, a, b, lane, rr) += Wv[i + 16 * kk] * Xv[jj + 16 * kk];
+                }
+            }
+      }
+    }
+    auto m_off = [&](int m_local) { unsigned o = 0; for (int i = 0; i < mt; ++i) if ((m_local >> i) & 1) o |= 1u << P.m_pos[i]; return o; };
+    auto n_off = [&](int n_local) { unsigned o = 0; for (int i = 0; i < nt; ++i) if ((n_local >> i) & 1) o |= 1u << P.n_pos[i]; return o; };
+    const int n_lim = nt >= 3 ? 8 : 1 << nt;
+    const int n_pass = 1 << (P.tc_bits - epi_bits);
+    for (int pass = 0; pass < n_pass; ++pass) {
+      std::vector<double> img((size_t)2 << epi_bits, -777.0);
+      for (int wave = 0; wave < 4; ++wave) {
+        const int wn = wave & ((1 << P.wn_log2) - 1), wm = wave >> P.wn_log2;
+        if (wm >= (1 << P.wm_log2)) continue;
+        for (int a = 0; a < MB; ++a) for (int b = 0; b < NB; ++b) for (int lane = 0; lane < 64; ++lane)
+          for (int rr = 0; rr < 4; ++rr) {
+            const int j = lane & 15, g = lane >> 4;
+            const int n_loc = (g >> 1) + 2 * rr;
+            if (n_loc >= n_lim) continue;
+            const unsigned pos = swzg(m_off((wm * MB + a) * 16 + j) | n_off((wn * NB + b) * 8 + n_loc), P);
+            if ((int)(pos >> ARTN_GEMM128_EPI_BITS) != pass) continue;
+            img[2 * (size_t)(pos & ((1u << ARTN_GEMM128_EPI_BITS) - 1u)) + (g & 1)] = ACC(wave, a, b, lane, rr);
+          }
+      }
+      const int iters = epi_bits > 8 ? 1 << (epi_bits - 8) : 1;
+      const int64_t pass_off = P.tc_bits > epi_bits ? pass * P.out_stride[epi_bits] : 0;
+      for (int tid = 0; tid < 256; ++tid) {
+        if (!(epi_bits >= 8 || tid < (1 << epi_bits))) continue;
+        for (int i = 0; i < iters; ++i) {
+          const int e = tid + 256 * i;
+          int64_t g = 0;
+          for (int b = 0; b < epi_bits; ++b) if ((e >> b) & 1) g += P.out_stride[b];
+          const unsigned l = swzg(((unsigned)pass << ARTN_GEMM128_EPI_BITS) | (unsigned)e, P) & ((1u << ARTN_GEMM128_EPI_BITS) - 1u);
+          C[offC + pass_off + g] = cd(img[2 * (size_t)l], img[2 * (size_t)l + 1]);
+        }
+      }
+    }
+  }
+}
+
 static void run_generic(const ArtnGenericPlan &G, const cf *A, const cf *B, cf *C) {
   for (int64_t idx = 0; idx < G.out_numel; ++idx) {
     int64_t r = idx, oa = 0, ob = 0;
@@ -382,6 +485,11 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
   int rc = artn::make_plan(d, p, err, 256, !force_generic, 1);
   if (rc) return rc;
   if (kernel_used) *kernel_used = p.kernel;
+  if (d->dtype == ARTN_C128) {
+    if (p.kernel != ARTN_KERNEL_GEMM_MFMA) return ARTN_E_UNSUPPORTED;
+    run_gemm128(p.gemm, (const cd *)A, (const cd *)B, (cd *)C);
+    return 0;
+  }
   if (d->dtype != ARTN_C64 && !(d->dtype == ARTN_C64_BF16 && p.kernel == ARTN_KERNEL_GEMM_MFMA)) return ARTN_E_UNSUPPORTED;
   if (p.kernel == ARTN_KERNEL_BITS_MFMA) run_bits(p.bits, (const cf *)A, (const cf *)B, nullptr, (cf *)C);
   else if (p.kernel == ARTN_KERNEL_GEMM_MFMA) run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);

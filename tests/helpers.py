@@ -63,7 +63,8 @@ def emulator():
     so = os.path.join(build, "libplan_emulate.so")
     src = os.path.join(ROOT, "tests", "csrc", "plan_emulate.cpp")
     deps = [src, os.path.join(ROOT, "artensor_amd", "csrc", "artn_plan.h"), os.path.join(ROOT, "include", "artn.h"),
-            os.path.join(ROOT, "artensor_amd", "csrc", "artn_gemm_kernel.h")]
+            os.path.join(ROOT, "artensor_amd", "csrc", "artn_gemm_kernel.h"),
+            os.path.join(ROOT, "artensor_amd", "csrc", "artn_gemm128_kernel.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "artensor_amd", "csrc"), src, "-o", so])
@@ -84,6 +85,25 @@ def emulate(eq, a, b, force_generic=False):
     used = ctypes.c_int(-1)
     rc = emulator().artn_emulate(ctypes.byref(d), a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
                                  out.ctypes.data_as(ctypes.c_void_p), int(force_generic), ctypes.byref(used))
+    assert rc == 0, rc
+    return out, used.value
+
+
+def emulate128(eq, a, b):
+    """One complex128 step through the emulation of artn_k_gemm128; (result, kernel id) or (None, kernel id) when
+    the planner gives the step to the strided kernel."""
+    import torch
+    from artensor_amd import contraction as C
+    la, lb, lo = C._labels(eq)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    d, out_shape = C._descriptor(la, lb, lo, tuple(ta.shape), tuple(ta.stride()), tuple(tb.shape), tuple(tb.stride()),
+                                 torch.complex128)
+    out = np.zeros(out_shape, dtype=np.complex128)
+    used = ctypes.c_int(-1)
+    rc = emulator().artn_emulate(ctypes.byref(d), a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                                 out.ctypes.data_as(ctypes.c_void_p), 0, ctypes.byref(used))
+    if rc == -2:
+        return None, used.value
     assert rc == 0, rc
     return out, used.value
 

@@ -766,6 +766,39 @@ def test_gemm_kernel_steps(m, n, k, batch):
     assert rel(got16, got) > 1e-4   # really the reduced-precision arithmetic
 
 
+def test_complex128_on_the_matrix_cores():
+    """dtype=torch.complex128 (reference simulation.py:90 takes any dtype): the 28 big steps of the n30 scheme as
+    surrogates (state operand truncated to 2^20) on v_mfma_f64_16x16x4_f64, parity 1e-12 against a complex128
+    einsum; random GEMM-shaped steps with many contracted bits and a ragged batch axis; the whole n12 scheme."""
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    big = [(n, s) for n, s in enumerate(steps) if np.prod(s[1]) >= 2 ** 20]
+    assert len(big) == 28
+    on_mfma = 0
+    for n, (eq, sa, sb) in big:
+        eq2, sa2, sb2 = shrink_step(eq, sa, sb, max_log2=20)
+        rng = np.random.default_rng(n)
+        a = rng.standard_normal(sa2) + 1j * rng.standard_normal(sa2)
+        b = rng.standard_normal(sb2) + 1j * rng.standard_normal(sb2)
+        info = A.step_info(eq2, sa2, sb2, dtype=torch.complex128)
+        on_mfma += info["kernel"] == N.KERNEL_GEMM_MFMA
+        got = A.contract(eq2, gpu(a), gpu(b)).cpu().numpy()
+        want = torch.einsum(eq2, torch.from_numpy(a), torch.from_numpy(b)).numpy()
+        assert got.dtype == np.complex128 and rel(got, want) < 1e-12, (n, eq2)
+    assert on_mfma >= 26
+    rng = np.random.default_rng(5)
+    for (m, n_, k, batch) in [(11, 10, 9, 0), (12, 3, 5, 0), (9, 9, 12, 0), (8, 7, 4, 5), (4, 12, 6, 0)]:
+        eq, sa, sb = _random_gemm_step(rng, m, n_, k, batch)
+        a = rng.standard_normal(sa) + 1j * rng.standard_normal(sa)
+        b = rng.standard_normal(sb) + 1j * rng.standard_normal(sb)
+        assert A.step_info(eq, sa, sb, dtype=torch.complex128)["kernel"] == N.KERNEL_GEMM_MFMA
+        assert rel(A.contract(eq, gpu(a), gpu(b)).cpu().numpy(), _einsum128(eq, a, b)) < 1e-12, eq
+    case = load_case(os.path.join(GOLDEN, "n12_dense.npz"))
+    raw = A.tensor_contraction(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme).cpu().numpy()
+    meta, arrays = c128_spread()
+    assert raw.dtype == np.complex128 and amp_rel(raw.reshape(-1), arrays["n12_dense_c128"]) < 1e-12
+
+
 def test_gemm_kernel_strided_operands_and_split_k():
     """Operands that are views (the slice loop hands in selected leaves), and a closing step whose result
     is too small to fill the chip: contracted labels become a batch label (split-K) and are summed."""

@@ -8,7 +8,7 @@ import pytest
 from artensor_amd import step_info
 from artensor_amd.fixtures import load_case
 from oracle import oracle
-from helpers import GOLDEN, crandn, dense_scheme_shapes, emulate, emulate_gemm, shrink_step
+from helpers import GOLDEN, crandn, dense_scheme_shapes, emulate, emulate128, emulate_gemm, shrink_step
 
 KERNEL_BITS = 1
 KERNEL_GEMM = 2
@@ -332,3 +332,31 @@ def test_planner_routes_big_contractions_to_the_gemm_kernel():
     # small second operand, 5 contracted bits: stays on the state-streaming kernel
     info = step_info("ABCDEFGHIJKLMNOPQRST,DHKOSwxyz->ABCEFGIJLMNPQRTwxyz", (2,) * 20, (2,) * 9)
     assert info["kernel"] == KERNEL_BITS
+
+
+@pytest.mark.parametrize("m,n,k,batch", [(7, 5, 3, 0), (6, 6, 4, 0), (5, 7, 5, 0), (7, 3, 6, 0), (8, 2, 3, 0), (9, 0, 4, 0),
+                                         (3, 8, 5, 0), (6, 7, 7, 0), (6, 5, 4, 3), (8, 8, 3, 0)])
+def test_complex128_gemm_plan_emulated(monkeypatch, m, n, k, batch):
+    """complex128 on v_mfma_f64_16x16x4_f64 (artn_k_gemm128): 16-byte elements, one per copy lane, 16 x 8 MFMA
+    blocks with the f64 C/D lane map, 2^12-element epilogue passes -- replayed thread by thread in double."""
+    monkeypatch.setenv("ARTN_FORCE_BITS", "1")
+    rng = np.random.default_rng(50 * m + 5 * n + k)
+    eq, sa, sb = _random_gemm_step(rng, m, n, k, batch)
+    a = rng.standard_normal(sa) + 1j * rng.standard_normal(sa)
+    b = rng.standard_normal(sb) + 1j * rng.standard_normal(sb)
+    got, used = emulate128(eq, a, b)
+    assert got is not None and used == KERNEL_GEMM
+    want = _einsum128(eq, a, b)
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-13, eq
+
+
+def test_complex128_big_steps_of_n30_plan_onto_the_matrix_cores():
+    """Every big step of the n30 scheme is given to the f64 MFMA kernel when the tensors are complex128
+    (round 1: the strided one-thread-per-element kernel)."""
+    import torch
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    big = [s for s in steps if np.prod(s[1]) >= 2 ** 20]
+    for eq, sa, sb in big:
+        info = step_info(eq, sa, sb, dtype=torch.complex128)
+        assert info["kernel"] == KERNEL_GEMM, (eq, info)
