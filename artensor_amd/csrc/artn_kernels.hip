@@ -457,7 +457,7 @@ __device__ __forceinline__ void load_w(float (&W0)[1 << (KB - 1)], float (&W1)[1
 
 // 3M stages: row n = lane&31 of the small operand, (re, im, re + im) of B[kc = 2s + h][n]
 template <int KB>
-__device__ __forceinline__ void load_w3(float (&W0)[1 << (KB - 1)], float (&W1)[1 << (KB - 1)], float (&W2)[1 << (KB - 1)],
+__device__ __forceinline__ void load_w3(float (&W0)[1 << (KB - 1)], float (&W1)[1 << (KB - 1)], float (&W2)[1],
                                         const char *__restrict__ Bbase, const StageConst<KB> &L) {
   constexpr int S = 1 << (KB - 1);
 #pragma unroll
@@ -469,10 +469,10 @@ __device__ __forceinline__ void load_w3(float (&W0)[1 << (KB - 1)], float (&W1)[
     const float2 bv = *reinterpret_cast<const float2 *>(Bbase + ko + L.lane_b);
     W0[s] = bv.x;
     W1[s] = bv.y;
-    W2[s] = bv.x + bv.y;
   }
+  (void)W2;
 #pragma unroll
-  for (int s = 0; s < S; ++s) asm volatile("" : "+v"(W0[s]), "+v"(W1[s]), "+v"(W2[s])); // see load_w
+  for (int s = 0; s < S; ++s) asm volatile("" : "+v"(W0[s]), "+v"(W1[s])); // see load_w
 }
 
 // Split-bf16 arithmetic.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA.  An
@@ -582,7 +582,7 @@ struct StageRun {
   const StageConst<KB> &L;
   float (&W0)[S];
   float (&W1)[S];
-  float (&W2)[CAN3M ? S : 1]; // 3M stages: re + im of the small operand
+  float (&W2)[1]; // (unused: the 3M sum fragment is formed on the fly)
   int h, lane;
   // 7-8 contracted bits (BIGK): fragments for every value of the looped-over bits, all in
   // registers (the instantiation runs one wave per SIMD, so 512 VGPRs are available)
@@ -872,11 +872,14 @@ struct StageRun {
     for (int s = 0; s < 8; ++s) {
       const float xs = buf[s].x + buf[s].y;
 #ifdef ARTN_ABLATE_MFMA
-      asm volatile("" ::"v"(buf[s].x), "v"(buf[s].y), "v"(xs), "v"(W0[BASE + s]), "v"(W1[BASE + s]), "v"(W2[CAN3M ? BASE + s : 0]));
+      // (re + im of the small operand is one v_add per MFMA triple: cheaper than 16-32 more fragment registers)
+      const float ws = W0[BASE + s] + W1[BASE + s];
+      asm volatile("" ::"v"(buf[s].x), "v"(buf[s].y), "v"(xs), "v"(W0[BASE + s]), "v"(W1[BASE + s]), "v"(ws));
 #else
+      const float ws = W0[BASE + s] + W1[BASE + s];
       t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[BASE + s], buf[s].x, t1, 0, 0, 0);
       t2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[BASE + s], buf[s].y, t2, 0, 0, 0);
-      t3 = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[CAN3M ? BASE + s : 0], xs, t3, 0, 0, 0);
+      t3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs, t3, 0, 0, 0);
 #endif
     }
   }
@@ -985,7 +988,7 @@ struct StageRun {
 
 template <int KB, bool BIGK, int NP, bool M3>
 __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1 << (KB - 1)],
-                                          float (&W1)[1 << (KB - 1)], float (&W2)[(M3 && (KB == 5 || KB == 6) && !BIGK && NP == 0) ? 1 << (KB - 1) : 1],
+                                          float (&W1)[1 << (KB - 1)], float (&W2)[1],
                                           int h, int lane,
                                           float (&WH0)[BIGK ? 3 : 1][1 << (KB - 1)],
                                           float (&WH1)[BIGK ? 3 : 1][1 << (KB - 1)],
@@ -1065,7 +1068,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   const OffTab OT = build_offset_table(P, offtab, tid);
   float W10[S1], W11[S1], W20[S2], W21[S2]; // (whichever of the fp32 / split fragment sets a stage does not use is dead)
   constexpr bool C31 = M3 && (KB1 == 5 || KB1 == 6) && !BIGK && NP == 0, C32 = M3 && (KB2 == 5 || KB2 == 6) && NP == 0;
-  float W12[C31 ? S1 : 1], W22[C32 ? S2 : 1]; // 3M stages: re + im fragments
+  float W12[1], W22[1]; // (unused)
   u32x4_t WS1[SP1 ? (BIGK ? 4 : NP) : 1][G1], WS2[SP2 ? NP : 1][G2];
   float WH0[BIGK ? 3 : 1][S1], WH1[BIGK ? 3 : 1][S1], WD0[1][S2], WD1[1][S2]; // BIGK: fragments of looped-over values 1..3
   long prev_b1 = -1, prev_b2 = -1;

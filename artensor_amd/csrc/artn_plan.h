@@ -174,7 +174,8 @@ struct Tuning {
   int nt = 1;         // non-temporal loads of A tiles that are read once
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
   int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
-  int bits_3m = 1;    // state-streaming kernel, fp32 stages with 5 contracted bits and 32+ columns: the same
+  int bits_3m = 2;    // state-streaming kernel, fp32 stages with 5/6 contracted bits and 32+ columns: the same
+                      // (1: not in fused pairs that hold a 6-bit stage, 0: never)
 };
 static inline Tuning &tuning() {
   static Tuning t = [] {
@@ -574,10 +575,11 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     for (int q = 0; q < b.n_stages; ++q) {
       const bool wide = b.st[q].k == 5 || b.st[q].k == 6;
       if (wide) { any = any || b.st[q].m3; all = all && b.st[q].m3; }
-      frag += (wide ? 3 : 2) << (std::min(b.st[q].k, 6) - 1);
+      frag += 2 << (std::min(b.st[q].k, 6) - 1);
     }
-    if (frag > 116) all = false; // 6+4: 112 registers of fragments; 6+5 (144) spills
-    // (a fused pair with a 6-bit 3M stage compiles with 16-48 spilled registers: only on request)
+    if (frag > 80) all = false; // fragments of both stages next to three accumulators: 6+4 (80) fits, 6+5 (96) spills
+    // (a fused pair with a 6-bit 3M stage compiles with 8 spilled registers and still wins: 6+4 pairs of n30
+    //  6.98 -> 5.98 ms; ARTN_BITS_3M=1 excludes them)
     if (b.n_stages == 2 && (b.st[0].k == 6 || b.st[1].k == 6) && tuning().bits_3m < 2) all = false;
     b.m3 = (any && all) ? 1 : 0;
     if (!b.m3)
