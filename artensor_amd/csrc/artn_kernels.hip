@@ -859,37 +859,49 @@ struct StageRun {
       lds_write8(o, v2f_t{t1[r] - t2[r], t3[r] - t1[r] - t2[r]});
     }
   }
-  // operands in half units of 8 chain steps (16 VGPRs each): the second half is read under the MFMAs of the
-  // first, the first half of the next sub-tile under those of the second
+  // operands in units of U3 chain steps (2 VGPRs each), ping-pong: the next unit -- of this sub-tile or the first of
+  // the next one -- is read under the MFMAs of the current one.  (6 contracted bits: units of 4, which is what lets
+  // the fused 6+4 instantiation fit the register file; 12 MFMAs still cover an LDS read)
+  static constexpr int U3 = KB == 6 ? 4 : 8;
+  static constexpr int NU3 = S / U3 > 0 ? S / U3 : 1;
   template <int BASE>
-  __device__ __forceinline__ void load_half(v2f_t (&buf)[8], unsigned li) const {
+  __device__ __forceinline__ void load_u3(v2f_t (&buf)[U3], unsigned li) const {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) buf[s] = lds_read8(li ^ ko(BASE + s));
+    for (int s = 0; s < U3; ++s) buf[s] = lds_read8(li ^ ko(BASE + s));
   }
   template <int BASE>
-  __device__ __forceinline__ void chain3(f32x16 &t1, f32x16 &t2, f32x16 &t3, const v2f_t (&buf)[8]) const {
+  __device__ __forceinline__ void chain3(f32x16 &t1, f32x16 &t2, f32x16 &t3, const v2f_t (&buf)[U3]) const {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < U3; ++s) {
       const float xs = buf[s].x + buf[s].y;
-#ifdef ARTN_ABLATE_MFMA
       // (re + im of the small operand is one v_add per MFMA triple: cheaper than 16-32 more fragment registers)
       const float ws = W0[BASE + s] + W1[BASE + s];
+#ifdef ARTN_ABLATE_MFMA
       asm volatile("" ::"v"(buf[s].x), "v"(buf[s].y), "v"(xs), "v"(W0[BASE + s]), "v"(W1[BASE + s]), "v"(ws));
 #else
-      const float ws = W0[BASE + s] + W1[BASE + s];
       t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[BASE + s], buf[s].x, t1, 0, 0, 0);
       t2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[BASE + s], buf[s].y, t2, 0, 0, 0);
       t3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs, t3, 0, 0, 0);
 #endif
     }
   }
+  template <int UI>
+  __device__ __forceinline__ void units3(f32x16 &t1, f32x16 &t2, f32x16 &t3, v2f_t (&b)[2][U3], unsigned li, bool more,
+                                         unsigned li_next) const {
+    if constexpr (UI < NU3) {
+      if constexpr (UI + 1 < NU3) load_u3<(UI + 1 < NU3 ? (UI + 1) * U3 : 0)>(b[(UI + 1) & 1], li);
+      else if (more) load_u3<0>(b[0], li_next); // (NU3 is even: the next sub-tile starts in b[0] again)
+      chain3<UI * U3>(t1, t2, t3, b[UI & 1]);
+      units3<UI + 1>(t1, t2, t3, b, li, more, li_next);
+    }
+  }
   __device__ __forceinline__ void run3() const {
-    constexpr int NU = S / 8; // half units per sub-tile: 2 (5 contracted bits) or 4 (6)
+    static_assert(NU3 % 2 == 0 || !CAN3M, "ping-pong parity");
     int msub = L.wm;
     if (msub >= L.msubs) return;
-    v2f_t bA[8], bB[8];
+    v2f_t b[2][U3];
     u2_t mo = lds_read_u2(L.msub_tab + msub * 8);
-    load_half<0>(bA, L.lane_in ^ mo.x);
+    load_u3<0>(b[0], L.lane_in ^ mo.x);
     for (;;) {
       const unsigned li = L.lane_in ^ mo.x, lo = L.lane_out ^ mo.y;
       const int nmsub = msub + L.wm_count;
@@ -898,19 +910,7 @@ struct StageRun {
       if (more) mo_n = lds_read_u2(L.msub_tab + nmsub * 8);
       f32x16 t1, t2, t3;
       zero(t1); zero(t2); zero(t3);
-      load_half<8>(bB, li);
-      chain3<0>(t1, t2, t3, bA);
-      if constexpr (NU == 2) {
-        if (more) load_half<0>(bA, L.lane_in ^ mo_n.x);
-        chain3<8>(t1, t2, t3, bB);
-      } else {
-        load_half<(NU == 4 ? 16 : 0)>(bA, li);
-        chain3<8>(t1, t2, t3, bB);
-        load_half<(NU == 4 ? 24 : 0)>(bB, li);
-        chain3<(NU == 4 ? 16 : 0)>(t1, t2, t3, bA);
-        if (more) load_half<0>(bA, L.lane_in ^ mo_n.x);
-        chain3<(NU == 4 ? 24 : 0)>(t1, t2, t3, bB);
-      }
+      units3<0>(t1, t2, t3, b, li, more, L.lane_in ^ mo_n.x);
       scatter3(t1, t2, t3, lo);
       if (!more) return;
       msub = nmsub;
