@@ -860,9 +860,10 @@ struct StageRun {
     }
   }
   // operands in units of U3 chain steps (2 VGPRs each), ping-pong: the next unit -- of this sub-tile or the first of
-  // the next one -- is read under the MFMAs of the current one.  (6 contracted bits: units of 4, which is what lets
-  // the fused 6+4 instantiation fit the register file; 12 MFMAs still cover an LDS read)
-  static constexpr int U3 = KB == 6 ? 4 : 8;
+  // the next one -- is read under the MFMAs of the current one.  (6 contracted bits: units of 2, which is what lets
+  // the fused 6+4 instantiation fit the register file without spilling a prefetched chunk -- the spill made the
+  // load-issue phase wait for HBM; 6 MFMAs = 384 cycles still cover an LDS read)
+  static constexpr int U3 = KB == 6 ? 2 : 8;
   static constexpr int NU3 = S / U3 > 0 ? S / U3 : 1;
   template <int BASE>
   __device__ __forceinline__ void load_u3(v2f_t (&buf)[U3], unsigned li) const {
@@ -1590,8 +1591,8 @@ static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, 
                               hipStream_t st) {
   const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2;
   float2 *c = (float2 *)C;
-#ifdef ARTN_DEV_FEW // development builds only: one family of artn_k_bits instantiations (compiles in seconds)
-  if (p.bits.st[0].k == 4) return launch_bits_k2<4>(p, a, b1, b2, c, st);
+#ifdef ARTN_DEV_FEW // development builds only: one family of artn_k_bits instantiations (compiles in under a minute)
+  if (p.bits.st[0].k == ARTN_DEV_FEW) return launch_bits_k2<ARTN_DEV_FEW>(p, a, b1, b2, c, st);
   return hipErrorInvalidValue;
 #else
   switch (std::min(p.bits.st[0].k, 6)) {
