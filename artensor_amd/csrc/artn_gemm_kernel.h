@@ -104,6 +104,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
     b_gi[b] = 9 + b < P.tb_bits ? P.b_stride[9 + b] * 8 : 0;
     b_li[b] = 9 + b < P.tb_bits ? (unsigned)P.b_lds[9 + b] : 0u;
   }
+
   const unsigned a_pair = (unsigned)P.a_lds[0], b_pair = (unsigned)P.b_lds[0]; // LDS bytes between the two elements of a lane load
 
   // ---- MFMA lanes
@@ -164,18 +165,33 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
 
   f32x4 va[NVA], vb[4];
   auto issue = [&](const char *__restrict__ Ab, const char *__restrict__ Bb) {
+    // (opaque per call: otherwise the tile-invariant part of every load address -- tile base + per-load offset +
+    //  lane offset -- is hoisted out of the chunk loop into 64-bit VGPR pairs, 16+ registers that the 3M
+    //  instantiations do not have: their spilled pairs were reloaded between the loads of one chunk, each reload
+    //  waiting for the load before it.  Scalar base + 32-bit lane offset is the addressing mode wanted here.)
+    unsigned agl = a_gl, bgl = b_gl;
+    OPAQUE_V(agl);
+    OPAQUE_V(bgl);
 #pragma unroll
     for (int u = 0; u < NVA; ++u) {
       if (u < a_iters && a_act) {
         const long o = ((u & 1) ? a_gi[0] : 0) + ((u & 2) ? a_gi[1] : 0) + ((u & 4) ? a_gi[2] : 0);
-        va[u] = *reinterpret_cast<const f32x4 *>(Ab + o + a_gl);
+#ifdef ARTN_ABLATE_MEM
+        asm volatile("" : "=v"(va[u]) : "s"(Ab), "s"(o), "v"(agl));
+#else
+        va[u] = *reinterpret_cast<const f32x4 *>(Ab + o + agl);
+#endif
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (u < b_iters && b_act) {
         const long o = ((u & 1) ? b_gi[0] : 0) + ((u & 2) ? b_gi[1] : 0);
-        vb[u] = *reinterpret_cast<const f32x4 *>(Bb + o + b_gl);
+#ifdef ARTN_ABLATE_MEM
+        asm volatile("" : "=v"(vb[u]) : "s"(Bb), "s"(o), "v"(bgl));
+#else
+        vb[u] = *reinterpret_cast<const f32x4 *>(Bb + o + bgl);
+#endif
       }
     }
   };
@@ -325,7 +341,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
 #pragma unroll
             for (int a = 0; a < MB; ++a) x[a] = lds_read8(xa + (unsigned)s * ROW2 + (unsigned)a * 256u);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) w[b] = lds_read8(wa + (unsigned)s * ROW2 + (unsigned)b * 128u);
+            for (int b = 0; b < NB; ++b) w[b] = lds_read8(wa + (unsigned)s * ROW2 + (unsigned)b * (NBW * 8u));
           };
           load_ops(0, X[0], Wr[0]);
 #pragma unroll
@@ -344,9 +360,13 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
               for (int a = 0; a < MB; ++a)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
+#ifdef ARTN_ABLATE_MFMA
+                  asm volatile("" ::"v"(Wr[s & 1][b]), "v"(X[s & 1][a]), "v"(wsum[b]), "v"(xs[a]));
+#else
                   acc[a][3 * b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].x, X[s & 1][a].x, acc[a][3 * b], 0, 0, 0);
                   acc[a][3 * b + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].y, X[s & 1][a].y, acc[a][3 * b + 1], 0, 0, 0);
                   acc[a][3 * b + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wsum[b], xs[a], acc[a][3 * b + 2], 0, 0, 0);
+#endif
                 }
               continue;
             }
@@ -361,8 +381,12 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
             for (int a = 0; a < MB; ++a)
 #pragma unroll
               for (int b = 0; b < NB; ++b) {
+#ifdef ARTN_ABLATE_MFMA
+                asm volatile("" ::"v"(W0[b]), "v"(W1[b]), "v"(X[s & 1][a]));
+#else
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[b], X[s & 1][a].x, acc[a][b], 0, 0, 0);
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[b], X[s & 1][a].y, acc[a][b], 0, 0, 0);
+#endif
               }
           }
           } // (WK == 1)
@@ -446,8 +470,12 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
                 if ((i >> b) & 1) o += o_gi[b];
               f32x4 *dst = reinterpret_cast<f32x4 *>(Cp + o + ogl);
               // (this thread wrote the same 16 bytes at the previous flush, long ago; read them past the L1)
+#ifdef ARTN_ABLATE_MEM
+              asm volatile("" ::"v"(x[u]), "v"(dst));
+#else
               if (accumulate) x[u] += __builtin_nontemporal_load(dst);
               *dst = x[u];
+#endif
             }
           }
         }

@@ -6,6 +6,30 @@ extern "C" int artn_dump_plan(const ArtnStepDesc *d1, const ArtnStepDesc *d2) {
   std::string err;
   int rc = d2 ? artn::make_plan_fused(d1, d2, p, err, 256, 1) : artn::make_plan(d1, p, err, 256, true, 1);
   if (rc) { printf("planner: rc %d %s\n", rc, err.c_str()); return rc; }
+  if (p.kernel == ARTN_KERNEL_GEMM_MFMA) {
+    const ArtnGemmPlan &g = p.gemm;
+    printf("gemm mt %d nt %d kc %d n_ko %d m3 %d MB %d NB %d tiles %ld\n a chunk bits -> (log2 stride : lds offset):", g.mt, g.nt, g.kc, g.n_ko, g.m3, 1 << g.mb_log2, 1 << g.nb_log2, (long)g.n_tiles);
+    for (int b = 0; b < g.ta_bits; ++b) printf(" (%d:%d)", 63 - __builtin_clzl((unsigned long)g.a_stride[b]), g.a_lds[b]);
+    printf("\n b chunk bits:");
+    for (int b = 0; b < g.tb_bits; ++b) printf(" (%d:%d)", 63 - __builtin_clzl((unsigned long)g.b_stride[b]), g.b_lds[b]);
+    // bank conflicts of the fill (stores: bank = (a/4) mod 32; ds_write_b128 groups of 8 lanes, ds_write_b64 of 16)
+    auto degree = [](const int32_t *lds, int nbits) {
+      const bool pair_kc = lds[0] >= 1024;
+      const int lanes = pair_kc ? 16 : 8, dwords = pair_kc ? 2 : 4;
+      int worst = 1;
+      int cnt[32] = {0};
+      for (int l = 0; l < lanes; ++l) {
+        unsigned a = 0;
+        for (int b = 0; b < 4; ++b) if (((l >> b) & 1) && b + 1 < nbits) a += (unsigned)lds[b + 1];
+        for (int w = 0; w < dwords; ++w) { int bank = ((a >> 2) + w) & 31; if (++cnt[bank] > worst) worst = cnt[bank]; }
+      }
+      return worst;
+    };
+    // (an XOR swizzle keyed on the chunk value removes these -- measured worth 1.5 % on the big GEMMs, while the two
+    //  extra address XORs per MFMA step on the read side cost 10 %: not kept)
+    printf("\n fill conflict degree: A %d  B %d\n", degree(g.a_lds, g.ta_bits), degree(g.b_lds, g.tb_bits));
+    return 0;
+  }
   if (p.kernel != ARTN_KERNEL_BITS_MFMA) { printf("kernel %d\n", p.kernel); return 0; }
   const ArtnBitsPlan &b = p.bits;
   printf("T_in %d T_mid %d T_out %d tiles %ld m3 %d\n", b.T_in, b.T_mid, b.T_out, (long)b.n_tiles, b.m3);
