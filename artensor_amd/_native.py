@@ -73,10 +73,12 @@ _EXPORTS = {
     "artn_contract2": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_program_record_bytes": (ctypes.c_int64, []),
+    "artn_program_image_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]),
     "artn_program_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                          ctypes.c_void_p, ctypes.c_void_p]),
-    "artn_program_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
-                                        ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_int64]),
+    "artn_program_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                        ctypes.c_void_p, ctypes.c_void_p]),
     "artn_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_axpy_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
@@ -113,7 +115,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.artn_abi_version() != 1:
+        if handle.artn_abi_version() != 2:
             raise RuntimeError("libartn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -542,7 +542,7 @@ class _Program:
     def device_copy(self, device):
         hit = self.dev.get(device)
         if hit is None:
-            hit = self.dev[device] = (self.host_image.to(device), self.host_groups.to(device))
+            hit = self.dev[device] = self.host_image.to(device)
         return hit
 
 
@@ -634,37 +634,45 @@ def _plan_small_program(scheme, shapes, dtype):
         flops += f
     if len(ext_ids) > N.ARTN_PROGRAM_MAX_EXT:
         return None, every
+    # results a remaining step reads, or the scheme's own result: those must be in the workspace after the
+    # launch (the last version of the id); everything else may live and die in the workgroup's LDS
+    needed = set()
+    for n in main:
+        needed.update(scheme[n][0])
+    needed.add(scheme[-1][0][0])
+    last_writer = {}
+    for k, n in enumerate(small_sorted):
+        last_writer[scheme[n][0][0]] = k
+    keep = [1 if last_writer[scheme[n][0][0]] == k and scheme[n][0][0] in needed else 0 for k, n in enumerate(small_sorted)]
     lib = N.lib()
-    rec_bytes = int(lib.artn_program_record_bytes())
-    image = torch.zeros(len(small_sorted) * rec_bytes, dtype=torch.uint8)
     arr = (ctypes.POINTER(N.ArtnStepDesc) * len(descs))(*[ctypes.pointer(d) for d in descs])
     i64 = lambda v: (ctypes.c_int64 * len(v))(*v)
-    rc = lib.artn_program_build(len(descs), arr, i64(la_), i64(lb_), i64(lc_), image.data_ptr())
+    n_groups = len(group_start) - 1
+    image_bytes = int(lib.artn_program_image_bytes(len(descs), arr, n_groups))
+    if image_bytes < 0:
+        return None, every
+    image = torch.zeros(image_bytes, dtype=torch.uint8)
+    rc = lib.artn_program_build(len(descs), arr, i64(la_), i64(lb_), i64(lc_), (ctypes.c_uint8 * len(keep))(*keep), n_groups,
+                                (ctypes.c_int32 * len(group_start))(*group_start), image.data_ptr(), image_bytes)
     if rc == -2:
         return None, every
     N.check(rc)
     prog = _Program()
     prog.host_image, prog.host_groups = image, torch.tensor(group_start, dtype=torch.int32)
-    prog.n_groups, prog.n_steps, prog.ext_ids, prog.ws_bytes = len(group_start) - 1, len(small_sorted), ext_ids, max(ws, 16)
-    # results a remaining step reads, or the scheme's own result
-    needed = set()
-    for n in main:
-        needed.update(scheme[n][0])
-    needed.add(scheme[-1][0][0])
+    prog.n_groups, prog.n_steps, prog.ext_ids, prog.ws_bytes = n_groups, len(small_sorted), ext_ids, max(ws, 16)
     prog.outputs = {t: v for t, v in where.items() if t in needed}
     prog.dev, prog.flops = {}, flops
     return prog, main
 
 
 def _run_program(prog, tensors, dtype, device, stream):
-    image, groups = prog.device_copy(device)
+    image = prog.device_copy(device)
     ws = torch.empty(prog.ws_bytes, dtype=torch.uint8, device=device)
     ext = (ctypes.c_void_p * len(prog.ext_ids))(*[tensors[t].data_ptr() for t in prog.ext_ids])
     if profiler is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    N.check(N.lib().artn_program_run(image.data_ptr(), groups.data_ptr(), prog.n_groups, ext, len(prog.ext_ids),
-                                     ws.data_ptr(), stream))
+    N.check(N.lib().artn_program_run(image.data_ptr(), prog.n_groups, ext, len(prog.ext_ids), ws.data_ptr(), stream))
     if profiler is not None:
         e1.record()
         profiler.record({"kernel": KERNEL_PROGRAM, "flops": prog.flops, "bytes": 0.0, "k_bits": 0, "k2_bits": 0, "m_tile_bits": 0,

@@ -22,6 +22,7 @@
 // 8*M*K*N real FLOP, exactly the 8 FLOP per complex multiply-add the metric counts.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <map>
 #include <stdio.h>
 #include <stdlib.h>
 #include <mutex>
@@ -109,8 +110,10 @@ __device__ unsigned long long artn_phase_buf[1024 * 20];
     }                                                                                                  \
     if (it_ >= 20 && it_ < 22) artn_phase_buf[blockIdx.x * 20 + 2 + 9 * (it_ - 20) + (k)] = __builtin_amdgcn_s_memrealtime(); \
   }
+#define PROG_MARK(k) if (threadIdx.x == 0 && blockIdx.x == 0 && (k) < 1024) artn_phase_buf[(k)] = __builtin_amdgcn_s_memrealtime()
 #else
 #define PHASE_MARK(k)
+#define PROG_MARK(k)
 #endif
 
 // Tile index -> element offsets of the tile in A, B1, B2, C.
@@ -1301,89 +1304,278 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_generic(const T2 *__re
 #define ARTN_PROG_MAX_OUT 24
 #define ARTN_PROG_MAX_RED 12
 #define ARTN_PROG_MAX_REDN 2048
+#define ARTN_PROG_RED_ENTRIES 2048              /* reduction-offset tables of one group: 16 KiB of LDS */
+#define ARTN_PROG_ARENA_BYTES (140 * 1024)      /* LDS arena of one group: operands and results of its steps */
+#define ARTN_PROG_LDS_BYTES (ARTN_PROG_RED_ENTRIES * 8 + ARTN_PROG_ARENA_BYTES)
+#define ARTN_PROG_PRELOAD_MAX 4096              /* external operands up to this many elements are copied into the arena */
+#define ARTN_PROG_MAGIC 0x41525032              /* "ARP2" */
+#define ARTN_PROG_TASK_ELEMS 128                /* output elements of a wave task (two per lane) */
 struct ArtnProgStep {
   int32_t n_out, n_red, out_numel, red_numel;
   int32_t a_numel, b_numel; // elements of the (dense) operands
   int64_t loc_a, loc_b, loc_c; // >= 0: workspace byte offset; < 0: external pointer -(loc + 1)
-  int32_t out_ext[ARTN_PROG_MAX_OUT], out_lg[ARTN_PROG_MAX_OUT], out_sA[ARTN_PROG_MAX_OUT], out_sB[ARTN_PROG_MAX_OUT];
+  int64_t tab_off;             // image byte offset of the step's reduction table: (ka, kb) element offsets per term
+  int32_t lds_a, lds_b, lds_c; // byte offset in the group's LDS arena, -1: not there
+  int32_t pre_a, pre_b;        // 1: this record copies its external operand into the arena before the first level
+  int32_t to_ws;               // 1: the result is (also) written to the workspace
+  int32_t red_base;            // first entry of the step's reduction-offset table in LDS (steps that are not `fast`)
+  int32_t level;
+  int32_t fast;                // 1: the 64 lanes of every wave task share their second-operand coordinates (see below)
+  int32_t pad_;
+  // output axes, fastest in the FIRST OPERAND first (axes it does not carry last): the 64 lanes of a wave task then
+  // read neighbouring elements of it for every reduction term (enumerated in C order, the lanes of one ds_read hit one
+  // LDS bank 32 deep on the transposing steps of a circuit: 8.5 us per level of n12); the result is scattered instead,
+  // one write per element against up to 2^11 reads
+  int32_t out_ext[ARTN_PROG_MAX_OUT], out_lg[ARTN_PROG_MAX_OUT], out_sA[ARTN_PROG_MAX_OUT], out_sB[ARTN_PROG_MAX_OUT], out_sC[ARTN_PROG_MAX_OUT];
   int32_t red_ext[ARTN_PROG_MAX_RED], red_lg[ARTN_PROG_MAX_RED], red_sA[ARTN_PROG_MAX_RED], red_sB[ARTN_PROG_MAX_RED];
 };
+// Image = header, groups, levels, wave tasks, records (byte offsets in the header; one device buffer).
+struct ArtnProgHeader {
+  int32_t magic, n_groups, n_steps, n_levels, n_wtasks, pad_[3];
+  int64_t off_groups, off_levels, off_wtasks, off_records, off_tables, pad2_;
+};
+struct ArtnProgGroup { int32_t step_begin, step_end, level_begin, level_end; };
+struct ArtnProgLevel { int32_t wt_begin, wt_count; };
+struct ArtnProgWTask { int32_t step, first; }; // 64 consecutive output elements of one step
 struct ArtnExtPtrs {
   const void *p[ARTN_PROGRAM_MAX_EXT];
 };
-// One workgroup per group of steps; 1024 threads.  Per step: both operands are copied into LDS when they
-// fit (the usual case: tensors of a few thousand elements), the reduction offsets are tabulated in LDS
-// once, then every thread takes output elements tid, tid + 1024, ... with the reduction loop unrolled
-// four times on independent accumulators (the loads of four terms are in flight together).  Extents
-// that are powers of two (every axis of a circuit) are decoded with shifts.  Global writes of one step
-// are read by the next after a workgroup barrier (same CU: its L1 sees its own stores).
-#define ARTN_PROG_LDS_ELEMS 6144
-template <typename PA, typename PB>
-__device__ __forceinline__ void prog_reduce(PA A, PB B, int oa, int ob, const int2 *red_tab, int red_numel, float &re, float &im) {
-  float r0 = 0.f, i0 = 0.f, r1 = 0.f, i1 = 0.f;
+// One workgroup (16 waves) per group of steps.  A group's steps are sorted into LEVELS of its dependency tree
+// (level 1 = both operands external, level n = an operand made at level n - 1): the steps of a level are
+// independent, their output elements are dealt to the waves in slices of 64 (a wave task: one step, so the record
+// is wave-uniform and read with scalar loads), one workgroup barrier per level -- n12: 19 barriers for 68 steps.
+// Intermediates live in an LDS arena laid out by the host (first fit, freed after the consumer's level), small
+// external operands are copied there first, the reduction offsets of every step are tabulated once up front;
+// only what a later launch reads (to_ws) or what the arena cannot hold goes through the workspace.
+// NE output elements per lane (a wave task is 64 * NE consecutive output elements): sum over the reduction table of
+// A[oa[e] + ka] * B[ob[e] + kb].  AL / BL: the operand sits in the LDS arena (byte address a_lds / b_lds, read with
+// ds_read_b64) or behind a global pointer.  Eight terms per trip: their table entries, then their 16 * NE operand
+// loads, are in flight together -- the loop is a chain of load latencies, not of arithmetic.
+template <bool AL, bool BL, int NE>
+__device__ __forceinline__ void prog_reduce(const float2 *__restrict__ Ag, unsigned a_lds, const float2 *__restrict__ Bg, unsigned b_lds,
+                                            const int (&oa)[NE], const int (&ob)[NE], unsigned red_addr, int red_numel, float (&re)[NE],
+                                            float (&im)[NE]) {
+  auto ldA = [&](int i) -> v2f_t {
+    if constexpr (AL) return lds_read8(a_lds + 8u * (unsigned)i);
+    else { const float2 v = Ag[i]; return v2f_t{v.x, v.y}; }
+  };
+  auto ldB = [&](int i) -> v2f_t {
+    if constexpr (BL) return lds_read8(b_lds + 8u * (unsigned)i);
+    else { const float2 v = Bg[i]; return v2f_t{v.x, v.y}; }
+  };
+#pragma unroll
+  for (int e = 0; e < NE; ++e) re[e] = im[e] = 0.f;
   int q = 0;
-  for (; q + 4 <= red_numel; q += 4) {
-    const int2 t0 = red_tab[q], t1 = red_tab[q + 1], t2 = red_tab[q + 2], t3 = red_tab[q + 3];
-    const float2 a0 = A[oa + t0.x], b0 = B[ob + t0.y], a1 = A[oa + t1.x], b1 = B[ob + t1.y];
-    const float2 a2 = A[oa + t2.x], b2 = B[ob + t2.y], a3 = A[oa + t3.x], b3 = B[ob + t3.y];
-    r0 += a0.x * b0.x - a0.y * b0.y; i0 += a0.x * b0.y + a0.y * b0.x;
-    r1 += a1.x * b1.x - a1.y * b1.y; i1 += a1.x * b1.y + a1.y * b1.x;
-    r0 += a2.x * b2.x - a2.y * b2.y; i0 += a2.x * b2.y + a2.y * b2.x;
-    r1 += a3.x * b3.x - a3.y * b3.y; i1 += a3.x * b3.y + a3.y * b3.x;
+  for (; q + 8 <= red_numel; q += 8) {
+    u2_t t[8];
+    v2f_t a[NE][8], b[NE][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = lds_read_u2(red_addr + 8u * (unsigned)(q + u));
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[e][u] = ldA(oa[e] + (int)t[u].x); b[e][u] = ldB(ob[e] + (int)t[u].y); }
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        re[e] += a[e][u].x * b[e][u].x - a[e][u].y * b[e][u].y;
+        im[e] += a[e][u].x * b[e][u].y + a[e][u].y * b[e][u].x;
+      }
   }
   for (; q < red_numel; ++q) {
-    const int2 t = red_tab[q];
-    const float2 a = A[oa + t.x], b = B[ob + t.y];
-    r0 += a.x * b.x - a.y * b.y; i0 += a.x * b.y + a.y * b.x;
-  }
-  re = r0 + r1;
-  im = i0 + i1;
-}
-__global__ __launch_bounds__(1024) void artn_k_program(const ArtnProgStep *__restrict__ image, const int32_t *__restrict__ group_start,
-                                                       const ArtnExtPtrs ext, char *__restrict__ ws) {
-  __shared__ int2 red_tab[ARTN_PROG_MAX_REDN];
-  __shared__ float2 opnd[ARTN_PROG_LDS_ELEMS];
-  const int g = blockIdx.x, tid = threadIdx.x;
-  for (int s = group_start[g]; s < group_start[g + 1]; ++s) {
-    const ArtnProgStep &R = image[s];
-    const float2 *A = reinterpret_cast<const float2 *>(R.loc_a >= 0 ? ws + R.loc_a : (const char *)ext.p[-(R.loc_a + 1)]);
-    const float2 *B = reinterpret_cast<const float2 *>(R.loc_b >= 0 ? ws + R.loc_b : (const char *)ext.p[-(R.loc_b + 1)]);
-    float2 *Cc = reinterpret_cast<float2 *>(ws + R.loc_c);
-    const int n_red = R.n_red, n_out = R.n_out, red_numel = R.red_numel, out_numel = R.out_numel;
-    const int a_numel = R.a_numel, b_numel = R.b_numel;
-    const bool in_lds = a_numel + b_numel <= ARTN_PROG_LDS_ELEMS;
-    if (in_lds) {
-      for (int e = tid; e < a_numel; e += 1024) opnd[e] = A[e];
-      for (int e = tid; e < b_numel; e += 1024) opnd[a_numel + e] = B[e];
+    const u2_t t = lds_read_u2(red_addr + 8u * (unsigned)q);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const v2f_t a = ldA(oa[e] + (int)t.x), b = ldB(ob[e] + (int)t.y);
+      re[e] += a.x * b.x - a.y * b.y;
+      im[e] += a.x * b.y + a.y * b.x;
     }
-    for (int q = tid; q < red_numel; q += 1024) {
+  }
+}
+// `fast` steps (the stem of a circuit scheme: a 2^12-element tensor absorbing one small tensor per step): the first
+// operand carries 128+ consecutive output elements, so the lanes of a wave task differ in first-operand coordinates
+// only and the second operand's value is the SAME for all of them in every term: the table entry comes through
+// scalar loads from the image, the second operand's value through one uniform-address global load (workspace or
+// leaf), per element one LDS read (the first operand) and the multiply-add.
+template <bool AL, int NE>
+__device__ __forceinline__ void prog_reduce_fast(const float2 *__restrict__ Ag, unsigned a_lds, const float2 *Bu, const int (&oa)[NE],
+                                                 const int2 *__restrict__ tab, int red_numel, float (&re)[NE], float (&im)[NE]) {
+  auto ldA = [&](int i) -> v2f_t {
+    if constexpr (AL) return lds_read8(a_lds + 8u * (unsigned)i);
+    else { const float2 v = Ag[i]; return v2f_t{v.x, v.y}; }
+  };
+#pragma unroll
+  for (int e = 0; e < NE; ++e) re[e] = im[e] = 0.f;
+  int q = 0;
+  for (; q + 8 <= red_numel; q += 8) {
+    int2 t[8];
+    float2 b[8];
+    v2f_t a[NE][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = tab[q + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      b[u] = Bu[t[u].y];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) a[e][u] = ldA(oa[e] + t[u].x);
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        re[e] += a[e][u].x * b[u].x - a[e][u].y * b[u].y;
+        im[e] += a[e][u].x * b[u].y + a[e][u].y * b[u].x;
+      }
+  }
+  for (; q < red_numel; ++q) {
+    const int2 t = tab[q];
+    const float2 b = Bu[t.y];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const v2f_t a = ldA(oa[e] + t.x);
+      re[e] += a.x * b.x - a.y * b.y;
+      im[e] += a.x * b.y + a.y * b.x;
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ image, const ArtnExtPtrs ext, char *__restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char prog_smem[];
+  int2 *red_all = reinterpret_cast<int2 *>(prog_smem);
+  unsigned char *arena = prog_smem + ARTN_PROG_RED_ENTRIES * 8;
+  const unsigned red_lds = (unsigned)(unsigned long)(lds_byte_t *)prog_smem, arena_lds = red_lds + ARTN_PROG_RED_ENTRIES * 8; // LDS byte addresses
+  const ArtnProgHeader *H = reinterpret_cast<const ArtnProgHeader *>(image);
+  const ArtnProgGroup G = reinterpret_cast<const ArtnProgGroup *>(image + H->off_groups)[blockIdx.x];
+  const ArtnProgLevel *levels = reinterpret_cast<const ArtnProgLevel *>(image + H->off_levels);
+  const ArtnProgWTask *wtasks = reinterpret_cast<const ArtnProgWTask *>(image + H->off_wtasks);
+  const ArtnProgStep *recs = reinterpret_cast<const ArtnProgStep *>(image + H->off_records);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  PROG_MARK(0);
+  // ---- reduction-offset tables and the external operands that live in the arena: one wave per record
+  for (int s = G.step_begin + wave; s < G.step_end; s += 16) {
+    const ArtnProgStep &R = recs[s];
+    const int n_red = R.n_red, red_numel = R.fast ? 0 : R.red_numel, red_base = R.red_base; // (fast steps read their table from the image)
+    int e4[4], l4[4], a4[4], b4[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { e4[d] = R.red_ext[d]; l4[d] = R.red_lg[d]; a4[d] = R.red_sA[d]; b4[d] = R.red_sB[d]; }
+    for (int q = lane; q < red_numel; q += 64) {
       int rr = q, ka = 0, kb = 0;
-      for (int d = 0; d < n_red; ++d) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        if (d < n_red) {
+          const int e = e4[d], lg = l4[d];
+          const int x = lg >= 0 ? rr & (e - 1) : rr % e;
+          rr = lg >= 0 ? rr >> lg : rr / e;
+          ka += x * a4[d];
+          kb += x * b4[d];
+        }
+      }
+      for (int d = 4; d < n_red; ++d) {
         const int e = R.red_ext[d], lg = R.red_lg[d];
         const int x = lg >= 0 ? rr & (e - 1) : rr % e;
         rr = lg >= 0 ? rr >> lg : rr / e;
         ka += x * R.red_sA[d];
         kb += x * R.red_sB[d];
       }
-      red_tab[q] = make_int2(ka, kb);
+      red_all[red_base + q] = make_int2(ka, kb);
     }
-    __syncthreads();
-    for (int idx = tid; idx < out_numel; idx += 1024) {
-      int r = idx, oa = 0, ob = 0;
-      for (int d = 0; d < n_out; ++d) {
-        const int e = R.out_ext[d], lg = R.out_lg[d];
-        const int x = lg >= 0 ? r & (e - 1) : r % e;
-        r = lg >= 0 ? r >> lg : r / e;
-        oa += x * R.out_sA[d];
-        ob += x * R.out_sB[d];
+    if (R.pre_a) {
+      const float2 *src = reinterpret_cast<const float2 *>(ext.p[-(R.loc_a + 1)]);
+      float2 *dst = reinterpret_cast<float2 *>(arena + R.lds_a);
+      for (int e = lane; e < R.a_numel; e += 64) dst[e] = src[e];
+    }
+    if (R.pre_b) {
+      const float2 *src = reinterpret_cast<const float2 *>(ext.p[-(R.loc_b + 1)]);
+      float2 *dst = reinterpret_cast<float2 *>(arena + R.lds_b);
+      for (int e = lane; e < R.b_numel; e += 64) dst[e] = src[e];
+    }
+  }
+  __syncthreads();
+  PROG_MARK(1);
+  // Record fields come through scalar loads from global memory, ~0.3 us each when they miss the scalar cache: a wave
+  // takes a CONTIGUOUS range of the level's tasks (mostly one step: its record is read once and kept), every field is
+  // requested up front -- the first 8 output axes as five 8-dword loads -- and the next task's table entry is fetched
+  // before the current task computes.  A task is 128 output elements, two per lane: half as many trips through the
+  // load-latency chain of the reduction.  (Dependent loads inside the decode loop, one element per lane, tasks dealt
+  // round-robin: the 19 levels of n12 took 290 us.)
+  constexpr int NE = ARTN_PROG_TASK_ELEMS / 64;
+  for (int L = G.level_begin; L < G.level_end; ++L) {
+    const ArtnProgLevel lv = levels[L];
+    const int per = (lv.wt_count + 15) >> 4, t_begin = wave * per, t_end = t_begin + per < lv.wt_count ? t_begin + per : lv.wt_count;
+    ArtnProgWTask W = {0, 0};
+    if (t_begin < t_end) W = wtasks[lv.wt_begin + t_begin];
+    int cur = -1;
+    int n_out = 0, out_numel = 0, red_numel = 0, red_base = 0, lds_a = -1, lds_b = -1, lds_c = -1, to_ws = 0, fast = 0;
+    long loc_a = 0, loc_b = 0, loc_c = 0, tab_off = 0;
+    int e8[8], l8[8], a8[8], b8[8], c8[8];
+    for (int t = t_begin; t < t_end; ++t) {
+      ArtnProgWTask Wn = W;
+      if (t + 1 < t_end) Wn = wtasks[lv.wt_begin + t + 1];
+      const ArtnProgStep &R = recs[W.step];
+      if (W.step != cur) {
+        cur = W.step;
+        n_out = R.n_out; out_numel = R.out_numel; red_numel = R.red_numel; red_base = R.red_base;
+        lds_a = R.lds_a; lds_b = R.lds_b; lds_c = R.lds_c; to_ws = R.to_ws; fast = R.fast;
+        loc_a = R.loc_a; loc_b = R.loc_b; loc_c = R.loc_c; tab_off = R.tab_off;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { e8[d] = R.out_ext[d]; l8[d] = R.out_lg[d]; a8[d] = R.out_sA[d]; b8[d] = R.out_sB[d]; c8[d] = R.out_sC[d]; }
       }
-      float re, im;
-      if (in_lds) prog_reduce(opnd, opnd + a_numel, oa, ob, red_tab, red_numel, re, im);
-      else prog_reduce(A, B, oa, ob, red_tab, red_numel, re, im);
-      Cc[idx] = make_float2(re, im);
+      // (an operand is in the arena, in the workspace or behind an external pointer)
+      const float2 *A = lds_a >= 0 ? nullptr : reinterpret_cast<const float2 *>(loc_a >= 0 ? ws + loc_a : (const char *)ext.p[-(loc_a + 1)]);
+      const float2 *B = lds_b >= 0 ? nullptr : reinterpret_cast<const float2 *>(loc_b >= 0 ? ws + loc_b : (const char *)ext.p[-(loc_b + 1)]);
+      const unsigned al = arena_lds + (unsigned)lds_a, bl = arena_lds + (unsigned)lds_b, rt = red_lds + 8u * (unsigned)red_base;
+      int oa[NE], ob[NE], oc[NE];
+      bool live[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int idx = W.first + 64 * e + lane;
+        live[e] = idx < out_numel;
+        int r = live[e] ? idx : 0; // (lanes past the end compute element 0 and store nothing)
+        oa[e] = ob[e] = oc[e] = 0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          if (d < n_out) {
+            const int ex = e8[d], lg = l8[d];
+            const int x = lg >= 0 ? r & (ex - 1) : r % ex;
+            r = lg >= 0 ? r >> lg : r / ex;
+            oa[e] += x * a8[d];
+            ob[e] += x * b8[d];
+            oc[e] += x * c8[d];
+          }
+        }
+        for (int d = 8; d < n_out; ++d) {
+          const int ex = R.out_ext[d], lg = R.out_lg[d];
+          const int x = lg >= 0 ? r & (ex - 1) : r % ex;
+          r = lg >= 0 ? r >> lg : r / ex;
+          oa[e] += x * R.out_sA[d];
+          ob[e] += x * R.out_sB[d];
+          oc[e] += x * R.out_sC[d];
+        }
+      }
+      float re[NE], im[NE];
+      if (fast) {
+        const float2 *Bu = B + __builtin_amdgcn_readfirstlane(ob[0]);
+        const int2 *tab = reinterpret_cast<const int2 *>(image + tab_off);
+        if (lds_a >= 0) prog_reduce_fast<true, NE>(A, al, Bu, oa, tab, red_numel, re, im);
+        else prog_reduce_fast<false, NE>(A, al, Bu, oa, tab, red_numel, re, im);
+      } else if (lds_a >= 0 && lds_b >= 0) prog_reduce<true, true, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
+      else if (lds_a >= 0) prog_reduce<true, false, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
+      else if (lds_b >= 0) prog_reduce<false, true, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
+      else prog_reduce<false, false, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        if (live[e]) {
+          if (lds_c >= 0) lds_write8(arena_lds + (unsigned)lds_c + 8u * (unsigned)oc[e], v2f_t{re[e], im[e]});
+          if (to_ws) reinterpret_cast<float2 *>(ws + loc_c)[oc[e]] = make_float2(re[e], im[e]);
+        }
+      }
+      W = Wn;
     }
+    PROG_MARK(2 + 2 * (L - G.level_begin));
     __threadfence_block();
     __syncthreads();
+    PROG_MARK(3 + 2 * (L - G.level_begin));
   }
 }
 
@@ -1847,10 +2039,38 @@ int artn_debug_read_stamps(unsigned long long *host, int n_waves) {
 
 int64_t artn_program_record_bytes(void) { return (int64_t)sizeof(ArtnProgStep); }
 
+static int64_t prog_image_layout(int32_t n_steps, int32_t n_groups, int64_t n_levels, int64_t n_wtasks, int64_t n_terms, ArtnProgHeader *h) {
+  int64_t off = sizeof(ArtnProgHeader);
+  auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 15) / 16 * 16; return o; };
+  const int64_t g = take((int64_t)n_groups * sizeof(ArtnProgGroup)), l = take(n_levels * sizeof(ArtnProgLevel));
+  const int64_t w = take(n_wtasks * sizeof(ArtnProgWTask)), r = take((int64_t)n_steps * sizeof(ArtnProgStep));
+  const int64_t t = take(n_terms * 8 + 64); // (+64: the 8-entry table loads of the last step may run past its end)
+  if (h) { h->off_groups = g; h->off_levels = l; h->off_wtasks = w; h->off_records = r; h->off_tables = t; }
+  return off;
+}
+
+int64_t artn_program_image_bytes(int32_t n_steps, const ArtnStepDesc *const *descs, int32_t n_groups) {
+  if (n_steps < 0 || n_groups < 0 || (n_steps && !descs)) return -1;
+  int64_t wt = 0, terms = 0;
+  for (int s = 0; s < n_steps; ++s) {
+    double f, na, nb, nc;
+    artn::step_cost(descs[s], f, na, nb, nc);
+    wt += (int64_t)((nc + 63.0) / 64.0) + 1;
+    ArtnPlan p;
+    std::string err;
+    if (artn::validate(descs[s], err) || !artn::make_generic(descs[s], p, err)) return -1;
+    terms += p.gen.red_numel;
+  }
+  return prog_image_layout(n_steps, n_groups, n_steps, wt, terms, nullptr); // (at most one level per step)
+}
+
 int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const int64_t *loc_a, const int64_t *loc_b,
-                       const int64_t *loc_c, void *host_image) {
-  if (n_steps < 0 || !descs || !loc_a || !loc_b || !loc_c || !host_image) return fail(ARTN_E_INVALID, "null argument");
-  ArtnProgStep *img = (ArtnProgStep *)host_image;
+                       const int64_t *loc_c, const uint8_t *keep, int32_t n_groups, const int32_t *group_start,
+                       void *host_image, int64_t image_bytes) {
+  if (n_steps < 0 || n_groups < 0 || !descs || !loc_a || !loc_b || !loc_c || !group_start || !host_image)
+    return fail(ARTN_E_INVALID, "null argument");
+  if (group_start[0] != 0 || group_start[n_groups] != n_steps) return fail(ARTN_E_INVALID, "group_start must cover the steps");
+  std::vector<ArtnProgStep> rec(n_steps);
   for (int s = 0; s < n_steps; ++s) {
     const ArtnStepDesc *d = descs[s];
     std::string err;
@@ -1863,16 +2083,17 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
     if (g.n_out > ARTN_PROG_MAX_OUT || g.n_red > ARTN_PROG_MAX_RED || g.red_numel > ARTN_PROG_MAX_REDN ||
         g.out_numel >= (1LL << 30) || loc_c[s] < 0)
       return fail(ARTN_E_UNSUPPORTED, "step does not fit a small-step record");
-    ArtnProgStep &r = img[s];
+    ArtnProgStep &r = rec[s];
     memset(&r, 0, sizeof(r));
     r.n_out = g.n_out; r.n_red = g.n_red; r.out_numel = (int32_t)g.out_numel; r.red_numel = (int32_t)g.red_numel;
     r.loc_a = loc_a[s]; r.loc_b = loc_b[s]; r.loc_c = loc_c[s];
+    r.lds_a = r.lds_b = r.lds_c = -1;
     {
       double f, na, nb, nc;
       artn::step_cost(d, f, na, nb, nc);
       if (na >= (double)(1 << 30) || nb >= (double)(1 << 30)) return fail(ARTN_E_UNSUPPORTED, "operand too large for a small-step record");
       r.a_numel = (int32_t)na; r.b_numel = (int32_t)nb;
-      // the LDS copy takes the operands as dense arrays of that many elements
+      // operands are addressed as dense arrays of that many elements
       for (int which = 0; which < 2; ++which) {
         std::vector<std::pair<int64_t, int64_t>> v;
         for (int l = 0; l < d->n_labels; ++l) {
@@ -1887,10 +2108,25 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
         }
       }
     }
-    for (int i = 0; i < g.n_out; ++i) {
-      if (g.out_sA[i] >= (1LL << 30) || g.out_sB[i] >= (1LL << 30)) return fail(ARTN_E_UNSUPPORTED, "stride too large for a small-step record");
-      r.out_ext[i] = (int32_t)g.out_ext[i]; r.out_sA[i] = (int32_t)g.out_sA[i]; r.out_sB[i] = (int32_t)g.out_sB[i];
-      r.out_lg[i] = artn::ilog2_exact(g.out_ext[i]);
+    {
+      // the generic plan lists the output axes fastest-in-C first: C strides are the running product; then the axes
+      // are put in first-operand order (see ArtnProgStep)
+      std::vector<int> ax(g.n_out);
+      std::vector<int64_t> sc(g.n_out);
+      int64_t run = 1;
+      for (int i = 0; i < g.n_out; ++i) {
+        if (g.out_sA[i] >= (1LL << 30) || g.out_sB[i] >= (1LL << 30)) return fail(ARTN_E_UNSUPPORTED, "stride too large for a small-step record");
+        ax[i] = i; sc[i] = run; run *= g.out_ext[i];
+      }
+      std::stable_sort(ax.begin(), ax.end(), [&](int x, int y) {
+        const bool nx = g.out_sA[x] == 0, ny = g.out_sA[y] == 0;
+        return nx != ny ? ny : (!nx && g.out_sA[x] < g.out_sA[y]);
+      });
+      for (int q = 0; q < g.n_out; ++q) {
+        const int i = ax[q];
+        r.out_ext[q] = (int32_t)g.out_ext[i]; r.out_sA[q] = (int32_t)g.out_sA[i]; r.out_sB[q] = (int32_t)g.out_sB[i]; r.out_sC[q] = (int32_t)sc[i];
+        r.out_lg[q] = artn::ilog2_exact(g.out_ext[i]);
+      }
     }
     for (int i = 0; i < g.n_red; ++i) {
       if (g.red_sA[i] >= (1LL << 30) || g.red_sB[i] >= (1LL << 30)) return fail(ARTN_E_UNSUPPORTED, "stride too large for a small-step record");
@@ -1898,20 +2134,198 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
       r.red_lg[i] = artn::ilog2_exact(g.red_ext[i]);
     }
   }
+  // ---- dependencies (a workspace offset names one result), levels, order by level inside each group
+  std::map<int64_t, int> producer; // workspace offset -> step
+  std::vector<int> level(n_steps, 1), last_use(n_steps, 0), group_of(n_steps, 0);
+  for (int g = 0; g < n_groups; ++g)
+    for (int s = group_start[g]; s < group_start[g + 1]; ++s) group_of[s] = g;
+  for (int s = 0; s < n_steps; ++s) {
+    for (int64_t loc : {loc_a[s], loc_b[s]}) {
+      if (loc < 0) continue;
+      auto it = producer.find(loc);
+      if (it == producer.end()) return fail(ARTN_E_INVALID, "a step reads a workspace offset no earlier step wrote");
+      if (group_of[it->second] != group_of[s]) return fail(ARTN_E_INVALID, "steps of different groups must be independent");
+      level[s] = std::max(level[s], level[it->second] + 1);
+    }
+    if (producer.count(loc_c[s])) return fail(ARTN_E_INVALID, "two steps write the same workspace offset");
+    producer[loc_c[s]] = s;
+  }
+  // fast steps (prog_reduce_fast): no output axis in both operands, and the leading first-operand axes cover whole
+  // wave tasks; their second operand is read from global memory (the producer writes it to the workspace) and needs
+  // no place in the arena.  last_use counts only the readers that go through the arena.
+  std::vector<char> need_ws(n_steps, 0);
+  for (int s = 0; s < n_steps; ++s) {
+    ArtnProgStep &r = rec[s];
+    int64_t lead = 1;
+    bool ok = r.red_numel > 0, in_b = false;
+    for (int d = 0; d < r.n_out && ok; ++d) {
+      if (r.out_sA[d] != 0 && r.out_sB[d] != 0) ok = false;
+      if (r.out_sB[d] != 0) in_b = true;
+      else if (!in_b) lead *= r.out_ext[d];
+      else ok = false; // (axes of neither operand: never produced by the scheme compilers)
+    }
+    r.fast = (ok && lead % ARTN_PROG_TASK_ELEMS == 0) ? 1 : 0;
+    if (r.fast && loc_b[s] >= 0) need_ws[producer[loc_b[s]]] = 1;
+  }
+  for (int s = 0; s < n_steps; ++s)
+    for (int which = 0; which < 2; ++which) {
+      const int64_t loc = which ? loc_b[s] : loc_a[s];
+      if (loc >= 0 && !(which == 1 && rec[s].fast)) last_use[producer[loc]] = std::max(last_use[producer[loc]], level[s]);
+    }
+  std::vector<int> order(n_steps), where(n_steps);
+  for (int s = 0; s < n_steps; ++s) order[s] = s;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+    return group_of[x] != group_of[y] ? group_of[x] < group_of[y] : level[x] < level[y];
+  });
+  for (int q = 0; q < n_steps; ++q) where[order[q]] = q;
+  // ---- per group: reduction tables, the LDS arena (first fit; a block is freed after its last consumer's level)
+  struct Block { int off, size; };
+  std::vector<ArtnProgGroup> groups(n_groups);
+  std::vector<ArtnProgLevel> levels;
+  std::vector<ArtnProgWTask> wtasks;
+  for (int g = 0; g < n_groups; ++g) {
+    const int b = group_start[g], e = group_start[g + 1];
+    std::vector<int> steps(order.begin() + b, order.begin() + e); // by level
+    int red = 0;
+    for (int s : steps) { rec[s].red_base = red; red += rec[s].fast ? 0 : rec[s].red_numel; rec[s].level = level[s]; }
+    if (red > ARTN_PROG_RED_ENTRIES) return fail(ARTN_E_UNSUPPORTED, "reduction tables of a group exceed their LDS share");
+    std::vector<Block> free_list = {{0, ARTN_PROG_ARENA_BYTES}};
+    // (two-ended: blocks of 16 KiB and more from the top of the arena, the many small ones from the bottom -- with
+    //  one first-fit list the long-lived leaves of n12 left no room for the second 32 KiB buffer of its stem)
+    auto alloc = [&](int bytes) {
+      bytes = (bytes + 15) / 16 * 16;
+      if (bytes >= 16384) {
+        for (size_t i = free_list.size(); i-- > 0;)
+          if (free_list[i].size >= bytes) {
+            free_list[i].size -= bytes;
+            const int off = free_list[i].off + free_list[i].size;
+            if (free_list[i].size == 0) free_list.erase(free_list.begin() + i);
+            return off;
+          }
+        return -1;
+      }
+      for (size_t i = 0; i < free_list.size(); ++i)
+        if (free_list[i].size >= bytes) {
+          const int off = free_list[i].off;
+          free_list[i].off += bytes; free_list[i].size -= bytes;
+          if (free_list[i].size == 0) free_list.erase(free_list.begin() + i);
+          return off;
+        }
+      return -1;
+    };
+    auto release = [&](int off, int bytes) {
+      bytes = (bytes + 15) / 16 * 16;
+      size_t i = 0;
+      while (i < free_list.size() && free_list[i].off < off) ++i;
+      free_list.insert(free_list.begin() + i, {off, bytes});
+      for (size_t k = 0; k + 1 < free_list.size();)
+        if (free_list[k].off + free_list[k].size == free_list[k + 1].off) { free_list[k].size += free_list[k + 1].size; free_list.erase(free_list.begin() + k + 1); }
+        else ++k;
+    };
+    const int max_level = steps.empty() ? 0 : level[steps.back()];
+    // external operands (live from the start to their last reader)
+    struct Ext { int lds, numel, last; };
+    std::map<int64_t, Ext> exts;
+    for (int s : steps)
+      for (int which = 0; which < 2; ++which) {
+        const int64_t loc = which ? loc_b[s] : loc_a[s];
+        if (loc >= 0 || (which == 1 && rec[s].fast)) continue;
+        const int numel = which ? rec[s].b_numel : rec[s].a_numel;
+        auto it = exts.find(loc);
+        if (it == exts.end()) {
+          Ext x = {-1, numel, level[s]};
+          if (numel <= ARTN_PROG_PRELOAD_MAX) x.lds = alloc(numel * 8);
+          if (x.lds >= 0) (which ? rec[s].pre_b : rec[s].pre_a) = 1;
+          it = exts.insert({loc, x}).first;
+        } else if (it->second.numel != numel) {
+          return fail(ARTN_E_INVALID, "an external operand is used with two sizes");
+        }
+        it->second.last = std::max(it->second.last, level[s]);
+        (which ? rec[s].lds_b : rec[s].lds_a) = it->second.lds;
+      }
+    groups[g].step_begin = b; groups[g].step_end = e;
+    groups[g].level_begin = (int)levels.size();
+    size_t q = 0;
+    for (int L = 1; L <= max_level; ++L) {
+      ArtnProgLevel lv = {(int)wtasks.size(), 0};
+      const size_t q0 = q;
+      for (; q < steps.size() && level[steps[q]] == L; ++q) {
+        const int s = steps[q];
+        ArtnProgStep &r = rec[s];
+        const bool read_inside = last_use[s] > 0; // (through the arena)
+        r.to_ws = (!keep || keep[s] || need_ws[s] || !read_inside) ? 1 : 0;
+        if (read_inside) r.lds_c = alloc(r.out_numel * 8);
+        if (r.lds_c < 0) r.to_ws = 1;
+        for (int first = 0; first < r.out_numel; first += ARTN_PROG_TASK_ELEMS) wtasks.push_back({where[s], first});
+      }
+      lv.wt_count = (int)wtasks.size() - lv.wt_begin;
+      levels.push_back(lv);
+      // operands whose last reader ran at this level
+      for (size_t k = q0; k < q; ++k) {
+        const int s = steps[k];
+        for (int which = 0; which < 2; ++which) {
+          const int64_t loc = which ? loc_b[s] : loc_a[s];
+          if (which == 1 && rec[s].fast) continue; // (read from global memory)
+          if (loc < 0) {
+            Ext &x = exts[loc];
+            if (x.lds >= 0 && x.last == L) { release(x.lds, x.numel * 8); x.last = -1; }
+          } else {
+            const int p = producer[loc];
+            (which ? rec[s].lds_b : rec[s].lds_a) = rec[p].lds_c;
+            if (rec[p].lds_c >= 0 && last_use[p] == L) { release(rec[p].lds_c, rec[p].out_numel * 8); last_use[p] = -1; }
+          }
+        }
+      }
+    }
+    groups[g].level_end = (int)levels.size();
+  }
+  ArtnProgHeader h;
+  memset(&h, 0, sizeof(h));
+  h.magic = ARTN_PROG_MAGIC; h.n_groups = n_groups; h.n_steps = n_steps; h.n_levels = (int32_t)levels.size(); h.n_wtasks = (int32_t)wtasks.size();
+  int64_t n_terms = 0;
+  for (int s = 0; s < n_steps; ++s) n_terms += rec[s].red_numel;
+  const int64_t need = prog_image_layout(n_steps, n_groups, (int64_t)levels.size(), (int64_t)wtasks.size(), n_terms, &h);
+  if (need > image_bytes) return fail(ARTN_E_INVALID, "image buffer too small (artn_program_image_bytes)");
+  char *img = (char *)host_image;
+  memset(img, 0, (size_t)need);
+  memcpy(img, &h, sizeof(h));
+  if (n_groups) memcpy(img + h.off_groups, groups.data(), groups.size() * sizeof(ArtnProgGroup));
+  if (!levels.empty()) memcpy(img + h.off_levels, levels.data(), levels.size() * sizeof(ArtnProgLevel));
+  if (!wtasks.empty()) memcpy(img + h.off_wtasks, wtasks.data(), wtasks.size() * sizeof(ArtnProgWTask));
+  {
+    int64_t toff = h.off_tables;
+    for (int s = 0; s < n_steps; ++s) {
+      ArtnProgStep &r = rec[s];
+      r.tab_off = toff;
+      int32_t *tab = (int32_t *)(img + toff);
+      for (int q = 0; q < r.red_numel; ++q) {
+        int rr = q, ka = 0, kb = 0;
+        for (int d = 0; d < r.n_red; ++d) {
+          const int x = rr % r.red_ext[d];
+          rr /= r.red_ext[d];
+          ka += x * r.red_sA[d];
+          kb += x * r.red_sB[d];
+        }
+        tab[2 * q] = ka; tab[2 * q + 1] = kb;
+      }
+      toff += (int64_t)r.red_numel * 8;
+    }
+  }
+  for (int q = 0; q < n_steps; ++q) memcpy(img + h.off_records + (int64_t)q * sizeof(ArtnProgStep), &rec[order[q]], sizeof(ArtnProgStep));
   return ARTN_OK;
 }
 
-int artn_program_run(const void *dev_image, const int32_t *dev_group_start, int32_t n_groups, const void *const *ext,
-                     int32_t n_ext, void *workspace, void *stream) {
+int artn_program_run(const void *dev_image, int32_t n_groups, const void *const *ext, int32_t n_ext, void *workspace, void *stream) {
   if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
   if (n_groups < 0 || n_ext < 0 || n_ext > ARTN_PROGRAM_MAX_EXT) return fail(ARTN_E_INVALID, "bad group or pointer count");
   if (n_groups == 0) return ARTN_OK;
-  if (!dev_image || !dev_group_start || !workspace || (n_ext && !ext)) return fail(ARTN_E_INVALID, "null pointer");
+  if (!dev_image || !workspace || (n_ext && !ext)) return fail(ARTN_E_INVALID, "null pointer");
   ArtnExtPtrs e;
   memset(&e, 0, sizeof(e));
   for (int i = 0; i < n_ext; ++i) e.p[i] = ext[i];
-  hipLaunchKernelGGL(artn_k_program, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, (const ArtnProgStep *)dev_image,
-                     dev_group_start, e, (char *)workspace);
+  HIP_TRY(ensure_lds<artn_k_program>(ARTN_PROG_LDS_BYTES));
+  hipLaunchKernelGGL(artn_k_program, dim3(n_groups), dim3(1024), ARTN_PROG_LDS_BYTES, (hipStream_t)stream, (const char *)dev_image, e,
+                     (char *)workspace);
   HIP_TRY(hipGetLastError());
   return ARTN_OK;
 }

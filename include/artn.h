@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ARTN_ABI_VERSION 1
+#define ARTN_ABI_VERSION 2
 #define ARTN_MAX_LABELS 96
 
 /* error codes */
@@ -144,25 +144,31 @@ int artn_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t nro
  * Small-step programs.  A circuit scheme is a few big steps plus hundreds of tiny ones (rank <= 16
  * operands) that are pure launch latency when issued one by one -- on the CPU the reference spends
  * 35-65 us per torch.einsum call on them (artensor/contraction.py:66-70; its whole n12 run is that).
- * Here the tiny steps of a scheme are compiled ONCE into a device-resident step list ("image") and
- * executed by ONE launch: workgroup g runs the steps of group g in order (steps of different groups
- * must be independent), every intermediate lives in a caller-provided workspace.
+ * Here the tiny steps of a scheme are compiled ONCE into a device-resident image and executed by ONE launch:
+ * workgroup g runs the steps of group g (steps of different groups must be independent).  Inside a group the
+ * steps are sorted into the levels of their dependency tree; the steps of a level run side by side on the 16 waves
+ * of the workgroup, one barrier per level; intermediates stay in an LDS arena laid out at build time, only the
+ * results flagged in `keep` (read after the program) and what the arena cannot hold go through the caller-provided
+ * workspace.  n12 (68 steps, 19 levels) is one launch of a few tens of microseconds.
  *
- *   artn_program_record_bytes()  size of one step record of the image
- *   artn_program_build(...)      host only: fills `host_image` (n_steps records) from the step
- *                                descriptors; operand k of step s is at workspace byte offset loc >= 0, or is
- *                                external pointer number -(loc + 1) when loc < 0.  Steps must be
- *                                complex64 with dense operands; returns ARTN_E_UNSUPPORTED when a step
- *                                does not fit a record (the caller then issues artn_contract per step).
- *   artn_program_run(...)        enqueue: `dev_image` / `dev_group_start` (n_groups + 1 int32) are the
- *                                device copies, `ext` a HOST array of n_ext (<= 256) device pointers.
+ *   artn_program_image_bytes(...)  host only: size of the image for these steps (upper bound)
+ *   artn_program_build(...)        host only: fills `host_image` from the step descriptors; operand k of step s is
+ *                                  the result written at workspace byte offset loc >= 0 by an earlier step, or
+ *                                  external pointer number -(loc + 1) when loc < 0; keep[s] != 0 (or keep == NULL):
+ *                                  the result of step s must be in the workspace after the launch.  Steps must be
+ *                                  complex64 with dense operands; returns ARTN_E_UNSUPPORTED when a step does
+ *                                  not fit a record (the caller then issues artn_contract per step).
+ *   artn_program_run(...)          enqueue: `dev_image` is the device copy of the image, `ext` a HOST array of
+ *                                  n_ext (<= 256) device pointers.
  */
 #define ARTN_PROGRAM_MAX_EXT 256
 int64_t artn_program_record_bytes(void);
+int64_t artn_program_image_bytes(int32_t n_steps, const ArtnStepDesc *const *descs, int32_t n_groups);
 int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const int64_t *loc_a, const int64_t *loc_b,
-                       const int64_t *loc_c, void *host_image);
-int artn_program_run(const void *dev_image, const int32_t *dev_group_start, int32_t n_groups, const void *const *ext,
-                     int32_t n_ext, void *workspace, void *stream);
+                       const int64_t *loc_c, const uint8_t *keep, int32_t n_groups, const int32_t *group_start,
+                       void *host_image, int64_t image_bytes);
+int artn_program_run(const void *dev_image, int32_t n_groups, const void *const *ext, int32_t n_ext, void *workspace,
+                     void *stream);
 
 /* acc[i] += x[i], i < n complex64 elements: the slice accumulation
  * `collect_tensor += ...` of artensor/simulation.py:114 and :210. */

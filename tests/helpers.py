@@ -178,3 +178,99 @@ def emulate2(eq1, a, b1, eq2, b2):
         return None, None
     assert rc == 0, rc
     return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+
+
+# ---- small-step program images (artn_program_build), executed on the CPU ------------------------------
+PROG_MAX_OUT, PROG_MAX_RED, PROG_TASK_ELEMS = 24, 12, 128
+PROG_RED_ENTRIES, PROG_ARENA_BYTES = 2048, 140 * 1024
+PROG_STEP_DTYPE = np.dtype([
+    ("n_out", "<i4"), ("n_red", "<i4"), ("out_numel", "<i4"), ("red_numel", "<i4"), ("a_numel", "<i4"), ("b_numel", "<i4"),
+    ("loc_a", "<i8"), ("loc_b", "<i8"), ("loc_c", "<i8"), ("tab_off", "<i8"),
+    ("lds_a", "<i4"), ("lds_b", "<i4"), ("lds_c", "<i4"), ("pre_a", "<i4"), ("pre_b", "<i4"), ("to_ws", "<i4"),
+    ("red_base", "<i4"), ("level", "<i4"), ("fast", "<i4"), ("pad_", "<i4"),
+    ("out_ext", "<i4", PROG_MAX_OUT), ("out_lg", "<i4", PROG_MAX_OUT), ("out_sA", "<i4", PROG_MAX_OUT), ("out_sB", "<i4", PROG_MAX_OUT), ("out_sC", "<i4", PROG_MAX_OUT),
+    ("red_ext", "<i4", PROG_MAX_RED), ("red_lg", "<i4", PROG_MAX_RED), ("red_sA", "<i4", PROG_MAX_RED), ("red_sB", "<i4", PROG_MAX_RED)])
+
+
+def parse_program_image(image):
+    """Header, groups, levels, wave tasks and records of an artn_program_build image (numpy uint8 array)."""
+    from artensor_amd import _native as N
+    buf = np.asarray(image, dtype=np.uint8)
+    hdr = np.frombuffer(buf[:32].tobytes(), dtype="<i4")
+    magic, n_groups, n_steps, n_levels, n_wtasks = (int(x) for x in hdr[:5])
+    assert magic == 0x41525032
+    offs = np.frombuffer(buf[32:64].tobytes(), dtype="<i8")
+    assert PROG_STEP_DTYPE.itemsize == N.lib().artn_program_record_bytes()
+    take = lambda off, dt, n: np.frombuffer(buf[off:off + np.dtype(dt).itemsize * n].tobytes(), dtype=dt)
+    groups = take(int(offs[0]), "<i4", 4 * n_groups).reshape(n_groups, 4)
+    levels = take(int(offs[1]), "<i4", 2 * n_levels).reshape(n_levels, 2)
+    wtasks = take(int(offs[2]), "<i4", 2 * n_wtasks).reshape(n_wtasks, 2)
+    recs = take(int(offs[3]), PROG_STEP_DTYPE, n_steps)
+    parse_program_image.raw = buf
+    return groups, levels, wtasks, recs
+
+
+def emulate_program(prog, leaves):
+    """Execute a compiled small-step program the way artn_k_program does -- per group: preloads, then level by
+    level, wave task by wave task, results written in place into the arena / workspace as soon as they are
+    computed -- and return the workspace (complex64 view).  An arena block handed out while its previous
+    tenant was still to be read shows up as a wrong result."""
+    groups, levels, wtasks, recs = parse_program_image(prog.host_image.numpy())
+    ws = np.zeros(prog.ws_bytes // 8 + 2, dtype=np.complex64)
+    ext = [np.ascontiguousarray(leaves[t]).reshape(-1).astype(np.complex64) for t in prog.ext_ids]
+    stats = {"levels": len(levels), "wtasks": len(wtasks), "in_lds": 0, "to_ws": 0, "fast": int((recs["fast"] != 0).sum())}
+    for (sb, se, lb, le) in groups:
+        arena = np.full(PROG_ARENA_BYTES // 8, np.nan + 0j, dtype=np.complex64)
+        red = {}
+        for s in range(sb, se):
+            R = recs[s]
+            assert R["fast"] or R["red_base"] + R["red_numel"] <= PROG_RED_ENTRIES
+            raw = parse_program_image.raw
+            from_image = np.frombuffer(raw[int(R["tab_off"]): int(R["tab_off"]) + 8 * int(R["red_numel"])].tobytes(), dtype="<i4").reshape(-1, 2)
+            tab = []
+            for q in range(int(R["red_numel"])):
+                rr, ka, kb = q, 0, 0
+                for d in range(int(R["n_red"])):
+                    e = int(R["red_ext"][d])
+                    ka += (rr % e) * int(R["red_sA"][d]); kb += (rr % e) * int(R["red_sB"][d]); rr //= e
+                tab.append((ka, kb))
+            assert [tuple(int(v) for v in row) for row in from_image] == tab   # the image's own table (fast steps read it)
+            red[s] = tab
+            for which in "ab":
+                if R["pre_" + which]:
+                    src = ext[-(int(R["loc_" + which]) + 1)]
+                    n, off = int(R[which + "_numel"]), int(R["lds_" + which])
+                    assert off % 16 == 0 and off + 8 * n <= PROG_ARENA_BYTES and src.size == n
+                    arena[off // 8: off // 8 + n] = src
+        for L in range(lb, le):
+            wb, wc = levels[L]
+            for (s, first) in wtasks[wb: wb + wc]:
+                R = recs[s]
+                assert sb <= s < se
+                def operand(which):
+                    if R["lds_" + which] >= 0:
+                        return arena[int(R["lds_" + which]) // 8:]
+                    loc = int(R["loc_" + which])
+                    return ws[loc // 8:] if loc >= 0 else ext[-(loc + 1)]
+                A, B = operand("a"), operand("b")
+                if R["fast"]:   # second operand from global memory, one value per term for the whole wave task
+                    assert R["lds_b"] < 0 and int(R["out_numel"]) % PROG_TASK_ELEMS == 0
+                idx = np.arange(int(first), min(int(first) + PROG_TASK_ELEMS, int(R["out_numel"])))
+                r, oa, ob, oc = idx.copy(), np.zeros_like(idx), np.zeros_like(idx), np.zeros_like(idx)
+                for d in range(int(R["n_out"])):
+                    e = int(R["out_ext"][d])
+                    oa += (r % e) * int(R["out_sA"][d]); ob += (r % e) * int(R["out_sB"][d]); oc += (r % e) * int(R["out_sC"][d]); r //= e
+                ka = np.array([t[0] for t in red[s]], dtype=np.int64); kb = np.array([t[1] for t in red[s]], dtype=np.int64)
+                if R["fast"]:
+                    assert (ob == ob[0]).all()
+                acc = (A[oa[:, None] + ka[None, :]].astype(np.complex128) * B[ob[:, None] + kb[None, :]].astype(np.complex128)).sum(axis=1)
+                assert R["lds_c"] >= 0 or R["to_ws"]
+                if R["lds_c"] >= 0:
+                    assert int(R["lds_c"]) + 8 * int(R["out_numel"]) <= PROG_ARENA_BYTES
+                    arena[int(R["lds_c"]) // 8 + oc] = acc
+                if R["to_ws"]:
+                    ws[int(R["loc_c"]) // 8 + oc] = acc
+        for s in range(sb, se):
+            stats["in_lds"] += int(recs[s]["lds_c"] >= 0)
+            stats["to_ws"] += int(recs[s]["to_ws"] != 0)
+    return ws, stats

@@ -140,3 +140,39 @@ def test_small_step_program_plan_keeps_sequential_semantics(name, limit, monkeyp
         assert tuple(cur[t].shape) == tuple(shape) and off % 16 == 0
     got = oracle.tensor_contraction(cur, [case.scheme[n] for n in main]) if main else cur[case.scheme[-1][0][0]]
     assert np.abs(np.asarray(got) - np.asarray(whole)).max() <= 1e-6 * max(np.abs(whole).max(), 1e-30)
+
+
+@pytest.mark.parametrize("name,limit", [("n12_dense", 1 << 14), ("n12_dense", 256), ("n30_dense", 1 << 14), ("rand_D2_closed", 1 << 14),
+                                        ("rand_D4_closed", 256), ("rand_D3_open", 1 << 12)])
+def test_small_step_program_image_emulated(name, limit, monkeypatch):
+    """The compiled image itself -- levels, wave tasks, LDS arena with reuse, preloaded leaves, which results
+    go to the workspace -- executed on the CPU the way artn_k_program executes it (tests/helpers.emulate_program)
+    must leave in the workspace exactly what the scheme's small steps leave for the remaining ones."""
+    from artensor_amd import contraction as C
+    from helpers import emulate_program
+    monkeypatch.setattr(C, "PROGRAM_MAX_NUMEL", limit)
+    case = load_case(os.path.join(GOLDEN, name + ".npz"))
+    if case.slicing_indices:
+        pytest.skip("unsliced cases only")
+    rng = np.random.default_rng(5)
+    leaves = {k: (rng.standard_normal(tuple(t.shape)) + 1j * rng.standard_normal(tuple(t.shape))).astype(np.complex64) for k, t in case.tensors.items()}
+    shapes = {k: v.shape for k, v in leaves.items()}
+    prog, main = C._plan_small_program(case.scheme, shapes, torch.complex64)
+    if prog is None:
+        pytest.skip("no program for this scheme")
+    ws, stats = emulate_program(prog, leaves)
+    small = [n for n in range(len(case.scheme)) if n not in set(main)]
+    cur = dict(leaves)
+    for n in small:
+        oracle.tensor_contraction(cur, [case.scheme[n]])
+    assert prog.outputs
+    for t, (off, shape) in prog.outputs.items():
+        want = np.asarray(cur[t]).reshape(-1)
+        got = ws[off // 8: off // 8 + want.size]
+        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-30), (name, t)
+    # the point of the image: far fewer barriers than steps, intermediates in LDS
+    assert stats["levels"] < prog.n_steps or prog.n_steps < 4
+    if name == "n12_dense" and limit == 1 << 14:
+        # 19 levels for 68 steps; the 15 steps of the stem (and two 2^10-element ones before it) (a 2^12-element tensor absorbing one small tensor each) are
+        # `fast`: their small operands come from the workspace, everything else lives in the arena
+        assert stats["levels"] == 19 and stats["fast"] >= 15 and stats["to_ws"] <= 1 + stats["fast"]
