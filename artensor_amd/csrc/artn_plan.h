@@ -169,7 +169,8 @@ struct Tuning {
   int tile_target = ARTN_TILE_BITS_TARGET;
   int run_max = 4;    // longest contiguous run (log2 elements) the tile is forced to keep
   int swizzle = 1;    // XOR-swizzle stage output regions against LDS bank conflicts
-  int stage_prio = 1; // asymmetric MFMA-stage priority between the two workgroups of a CU
+  int stage_prio = 3; // 1: asymmetric MFMA-stage priority between the two workgroups of a CU; 3: and every workgroup's copy
+                      // phases at raised priority (with 3M stages +1 % on n30, A/B in one session: 57.7 -> 57.1 ms; 2: copy only)
   int split = 0;      // complex64 chains: 0 fp32 MFMA, 3 fp32-grade split-bf16 MFMA
   int nt = 1;         // non-temporal loads of A tiles that are read once
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
