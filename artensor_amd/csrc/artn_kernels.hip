@@ -1255,6 +1255,11 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   STAMP_FLUSH
 }
 
+// Translation units.  The product library is linked from seven objects compiled from THIS file (make -j: the
+// ~100 artn_k_bits instantiations dominate the build): -DARTN_TU_BITS=K emits only artn_k_bits<K, *> behind
+// artn_launch_bits_kK(), -DARTN_TU_MAIN everything else and calls those; with neither macro (diagnostic and
+// development builds) the file is one translation unit as before.
+#ifndef ARTN_TU_BITS
 #include "artn_gemm_kernel.h"
 #include "artn_gemm128_kernel.h"
 
@@ -1645,6 +1650,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_divide(float2 *__restr
   }
 }
 
+#endif // !ARTN_TU_BITS
+
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
@@ -1779,6 +1786,22 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
   return hipGetLastError();
 }
 
+#define ARTN_CAT2(a, b) a##b
+#define ARTN_CAT(a, b) ARTN_CAT2(a, b)
+#ifdef ARTN_TU_BITS
+hipError_t ARTN_CAT(artn_launch_bits_k, ARTN_TU_BITS)(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, float2 *C,
+                                                     hipStream_t st) {
+  return launch_bits_k2<ARTN_TU_BITS>(p, A, B1, B2, C, st);
+}
+#else
+#ifdef ARTN_TU_MAIN
+hipError_t artn_launch_bits_k1(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits_k2(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits_k3(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits_k4(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits_k5(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits_k6(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+#endif
 static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C,
                               hipStream_t st) {
   const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2;
@@ -1788,12 +1811,21 @@ static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, 
   return hipErrorInvalidValue;
 #else
   switch (std::min(p.bits.st[0].k, 6)) {
+#ifdef ARTN_TU_MAIN
+    case 1: return artn_launch_bits_k1(p, a, b1, b2, c, st);
+    case 2: return artn_launch_bits_k2(p, a, b1, b2, c, st);
+    case 3: return artn_launch_bits_k3(p, a, b1, b2, c, st);
+    case 4: return artn_launch_bits_k4(p, a, b1, b2, c, st);
+    case 5: return artn_launch_bits_k5(p, a, b1, b2, c, st);
+    case 6: return artn_launch_bits_k6(p, a, b1, b2, c, st);
+#else
     case 1: return launch_bits_k2<1>(p, a, b1, b2, c, st);
     case 2: return launch_bits_k2<2>(p, a, b1, b2, c, st);
     case 3: return launch_bits_k2<3>(p, a, b1, b2, c, st);
     case 4: return launch_bits_k2<4>(p, a, b1, b2, c, st);
     case 5: return launch_bits_k2<5>(p, a, b1, b2, c, st);
     case 6: return launch_bits_k2<6>(p, a, b1, b2, c, st);
+#endif
   }
   return hipErrorInvalidValue;
 #endif
@@ -2401,3 +2433,4 @@ int artn_absmax_normalize_c64(void *x, int64_t n, float *out_absmax, void *strea
 }
 
 } // extern "C"
+#endif // !ARTN_TU_BITS
