@@ -652,6 +652,8 @@ def _plan_small_program(scheme, shapes, dtype):
     if image_bytes < 0:
         return None, every
     image = torch.zeros(image_bytes, dtype=torch.uint8)
+    if __import__("os").environ.get("ARTN_PROG_KEEP_ALL"):   # diagnostics: every result also goes to the workspace
+        keep = [1] * len(keep)
     rc = lib.artn_program_build(len(descs), arr, i64(la_), i64(lb_), i64(lc_), (ctypes.c_uint8 * len(keep))(*keep), n_groups,
                                 (ctypes.c_int32 * len(group_start))(*group_start), image.data_ptr(), image_bytes)
     if rc == -2:

@@ -110,10 +110,20 @@ __device__ unsigned long long artn_phase_buf[1024 * 20];
     }                                                                                                  \
     if (it_ >= 20 && it_ < 22) artn_phase_buf[blockIdx.x * 20 + 2 + 9 * (it_ - 20) + (k)] = __builtin_amdgcn_s_memrealtime(); \
   }
-#define PROG_MARK(k) if (threadIdx.x == 0 && blockIdx.x == 0 && (k) < 1024) artn_phase_buf[(k)] = __builtin_amdgcn_s_memrealtime()
+#define PROG_MARK(k)                                                                  \
+  if (threadIdx.x == 0 && blockIdx.x == 0 && (k) < 512) {                             \
+    artn_phase_buf[(k)] = __builtin_amdgcn_s_memrealtime();                           \
+    artn_phase_buf[512 + (k)] = __builtin_readcyclecounter(); /* shader clock */      \
+  }
+#define PROG_FINE(Lrel, k, val_)                                                       \
+  if (threadIdx.x == 0 && blockIdx.x == 0 && (Lrel) < 40) {                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"s"(val_) : "memory");            \
+    artn_phase_buf[100 + 8 * (Lrel) + (k)] = __builtin_amdgcn_s_memrealtime();       \
+  }
 #else
 #define PHASE_MARK(k)
 #define PROG_MARK(k)
+#define PROG_FINE(Lrel, k, val_)
 #endif
 
 // Tile index -> element offsets of the tile in A, B1, B2, C.
@@ -1310,8 +1320,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_generic(const T2 *__re
 #define ARTN_PROG_MAX_RED 12
 #define ARTN_PROG_MAX_REDN 2048
 #define ARTN_PROG_RED_ENTRIES 2048              /* reduction-offset tables of one group: 16 KiB of LDS */
-#define ARTN_PROG_ARENA_BYTES (140 * 1024)      /* LDS arena of one group: operands and results of its steps */
-#define ARTN_PROG_LDS_BYTES (ARTN_PROG_RED_ENTRIES * 8 + ARTN_PROG_ARENA_BYTES)
+#define ARTN_PROG_FAST_MAX 64                   /* matrix-core steps of one group: their bit-stride tables sit in LDS (12 KiB) */
+#define ARTN_PROG_BITS_BYTES (ARTN_PROG_FAST_MAX * 48 * 4)
+#define ARTN_PROG_ARENA_BYTES (128 * 1024)      /* LDS arena of one group: operands and results of its steps */
+#define ARTN_PROG_LDS_BYTES (ARTN_PROG_RED_ENTRIES * 8 + ARTN_PROG_BITS_BYTES + ARTN_PROG_ARENA_BYTES)
 #define ARTN_PROG_PRELOAD_MAX 4096              /* external operands up to this many elements are copied into the arena */
 #define ARTN_PROG_MAGIC 0x41525032              /* "ARP2" */
 #define ARTN_PROG_TASK_ELEMS 128                /* output elements of a wave task (two per lane) */
@@ -1325,8 +1337,11 @@ struct ArtnProgStep {
   int32_t to_ws;               // 1: the result is (also) written to the workspace
   int32_t red_base;            // first entry of the step's reduction-offset table in LDS (steps that are not `fast`)
   int32_t level;
-  int32_t fast;                // 1: the 64 lanes of every wave task share their second-operand coordinates (see below)
-  int32_t pad_;
+  int32_t fast;                // 1: matrix-core step (see prog_mfma_task): wave tasks are 32 x 16 blocks, not 128 elements
+  int32_t n_mbits, n_nbits;    // fast: output bits carried by the first / by the second operand
+  int32_t fast_index;          // fast: which 192-byte slot of the group's LDS bit-stride area
+  int32_t mbit_sA[14], mbit_sC[14]; // fast: first-operand bit b -> element stride in the first operand / in the result
+  int32_t nbit_sB[10], nbit_sC[10]; // fast: second-operand bit b -> element stride in the second operand / in the result
   // output axes, fastest in the FIRST OPERAND first (axes it does not carry last): the 64 lanes of a wave task then
   // read neighbouring elements of it for every reduction term (enumerated in C order, the lanes of one ds_read hit one
   // LDS bank 32 deep on the transposing steps of a circuit: 8.5 us per level of n12); the result is scattered instead,
@@ -1340,7 +1355,7 @@ struct ArtnProgHeader {
   int64_t off_groups, off_levels, off_wtasks, off_records, off_tables, pad2_;
 };
 struct ArtnProgGroup { int32_t step_begin, step_end, level_begin, level_end; };
-struct ArtnProgLevel { int32_t wt_begin, wt_count; };
+struct ArtnProgLevel { int32_t wt_begin, wt_count, first_step, pad_; }; // first_step: record of the level's first task (prefetch hint)
 struct ArtnProgWTask { int32_t step, first; }; // 64 consecutive output elements of one step
 struct ArtnExtPtrs {
   const void *p[ARTN_PROGRAM_MAX_EXT];
@@ -1398,57 +1413,124 @@ __device__ __forceinline__ void prog_reduce(const float2 *__restrict__ Ag, unsig
     }
   }
 }
-// `fast` steps (the stem of a circuit scheme: a 2^12-element tensor absorbing one small tensor per step): the first
-// operand carries 128+ consecutive output elements, so the lanes of a wave task differ in first-operand coordinates
-// only and the second operand's value is the SAME for all of them in every term: the table entry comes through
-// scalar loads from the image, the second operand's value through one uniform-address global load (workspace or
-// leaf), per element one LDS read (the first operand) and the multiply-add.
-template <bool AL, int NE>
-__device__ __forceinline__ void prog_reduce_fast(const float2 *__restrict__ Ag, unsigned a_lds, const float2 *Bu, const int (&oa)[NE],
-                                                 const int2 *__restrict__ tab, int red_numel, float (&re)[NE], float (&im)[NE]) {
+// `fast` steps -- the stem of a circuit scheme: a 2^12-element tensor absorbing one small tensor per step, 2^12 x 2^k
+// complex multiply-adds each, which one CU's vector ALU does in 7-17 us (8 wave-instructions per multiply-add: n12
+// spent 130 of its 176 us there) -- run on the matrix cores instead.  Every extent is a power of two, no output bit
+// belongs to both operands, 5+ output bits belong to the first operand: a wave task is a block of 32 first-operand
+// rows m x 16 second-operand columns n, computed like a sub-tile of artn_k_bits: interleaved complex64 times the
+// real block form of the small operand on v_mfma_f32_32x32x2_f32 (lane roles: see artn_k_bits).  Offsets are
+// bit-linear: the host tabulates a stride per output bit (mbit_* / nbit_*); the reduction table is the step's LDS
+// table, operands come from the arena or from global memory.
+template <bool AL, bool BL>
+__device__ __forceinline__ void prog_mfma_task(int n_mbits, int n_nbits, int task, int lane, const float2 *__restrict__ Ag, unsigned a_lds,
+                                               const float2 *__restrict__ Bg, unsigned b_lds, unsigned tab, int red_numel,
+                                               unsigned c_lds, bool c_in_lds, float2 *__restrict__ Cg, unsigned bits, int dbg = 1000) {
   auto ldA = [&](int i) -> v2f_t {
     if constexpr (AL) return lds_read8(a_lds + 8u * (unsigned)i);
     else { const float2 v = Ag[i]; return v2f_t{v.x, v.y}; }
   };
+  auto ldB = [&](int i) -> v2f_t {
+    if constexpr (BL) return lds_read8(b_lds + 8u * (unsigned)i);
+    else { const float2 v = Bg[i]; return v2f_t{v.x, v.y}; }
+  };
+  const int msub = task & ((1 << (n_mbits - 5)) - 1), ntile = task >> (n_mbits - 5);
+  const int j = lane & 31, h = lane >> 5, ro = j & 1;
+  // (48 scalar loads from the record, each waited for where the predicated adds below use it, were 3 of the 5 us of
+  //  a task: the tables are copied to LDS once per launch and read here with twelve 16-byte broadcast reads)
+  int bt[48];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) re[e] = im[e] = 0.f;
-  int q = 0;
-  for (; q + 8 <= red_numel; q += 8) {
-    int2 t[8];
-    float2 b[8];
-    v2f_t a[NE][8];
+  for (int v = 0; v < 12; ++v) {
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    const i32x4_t q4 = *(__attribute__((address_space(3))) i32x4_t *)(unsigned long)(bits + 16u * (unsigned)v); // (integers: read as integers)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = tab[q + u];
+    for (int c = 0; c < 4; ++c) bt[4 * v + c] = q4[c];
+  }
+  const int *sa = bt, *sc = bt + 14, *sb = bt + 28, *sn = bt + 38;
+  // X side: tile column j = first-operand row msub * 32 + j
+  const int midx = msub * 32 + j;
+  int oa = 0, ocm = 0;
+#pragma unroll
+  for (int b = 0; b < 14; ++b)
+    if (b < n_mbits && ((midx >> b) & 1)) { oa += sa[b]; ocm += sc[b]; }
+  // W side: MFMA row i = j = 2 * n_in_block + ro
+  const int nidx = ntile * 16 + (j >> 1);
+  const bool w_valid = nidx < (1 << n_nbits);
+  int ob = 0;
+#pragma unroll
+  for (int b = 0; b < 10; ++b)
+    if (b < n_nbits && ((nidx >> b) & 1)) ob += sb[b];
+  // result: accumulator register r of lane (j, h) is column n = ntile * 16 + ((r >> 1) & 1) + 2 h + 4 (r >> 2), part r & 1
+  const int nbase = ntile * 16 + 2 * h;
+  int ocn = 0;
+#pragma unroll
+  for (int b = 1; b < 10; ++b)
+    if (b < n_nbits && ((nbase >> b) & 1)) ocn += sn[b];
+  const int c0 = n_nbits > 0 ? sn[0] : 0, c2 = n_nbits > 2 ? sn[2] : 0, c3 = n_nbits > 3 ? sn[3] : 0;
+  PROG_FINE(dbg, 4, oa + ocm + ob + ocn + c0 + c2 + c3);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int n_steps = red_numel >> 1; // contracted values 2 s + h
+  int s0 = 0;
+  // (batches of 8, then 4, MFMA pairs: the table entries of a batch, then its 16 operand reads, are in flight together
+  //  -- per batch the chain pays two LDS round trips whatever its length)
+  for (; s0 + 8 <= n_steps; s0 += 8) {
+    u2_t t[8];
+    v2f_t x[8], w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = lds_read_u2(tab + 8u * (unsigned)(2 * (s0 + u) + h));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { x[u] = ldA(oa + (int)t[u].x); w[u] = ldB(ob + (int)t[u].y); }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      b[u] = Bu[t[u].y];
-#pragma unroll
-      for (int e = 0; e < NE; ++e) a[e][u] = ldA(oa[e] + t[u].x);
+      const float w0 = w_valid ? (ro ? w[u].y : w[u].x) : 0.f, w1 = w_valid ? (ro ? w[u].x : -w[u].y) : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x[u].y, acc, 0, 0, 0);
     }
+  }
+  for (; s0 + 4 <= n_steps; s0 += 4) {
+    u2_t t[4];
+    v2f_t x[4], w[4];
 #pragma unroll
-    for (int e = 0; e < NE; ++e)
+    for (int u = 0; u < 4; ++u) t[u] = lds_read_u2(tab + 8u * (unsigned)(2 * (s0 + u) + h));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        re[e] += a[e][u].x * b[u].x - a[e][u].y * b[u].y;
-        im[e] += a[e][u].x * b[u].y + a[e][u].y * b[u].x;
+    for (int u = 0; u < 4; ++u) { x[u] = ldA(oa + (int)t[u].x); w[u] = ldB(ob + (int)t[u].y); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float w0 = w_valid ? (ro ? w[u].y : w[u].x) : 0.f, w1 = w_valid ? (ro ? w[u].x : -w[u].y) : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x[u].y, acc, 0, 0, 0);
+    }
+  }
+  for (; s0 < n_steps; ++s0) {
+    const u2_t t = lds_read_u2(tab + 8u * (unsigned)(2 * s0 + h));
+    const v2f_t x = ldA(oa + (int)t.x), w = ldB(ob + (int)t.y);
+    const float w0 = w_valid ? (ro ? w.y : w.x) : 0.f, w1 = w_valid ? (ro ? w.x : -w.y) : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x.y, acc, 0, 0, 0);
+  }
+  PROG_FINE(dbg, 5, (int)acc[0]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b0 = 0; b0 < 2; ++b0) {
+      const int n = nbase + b0 + 4 * q;
+      if (n < (1 << n_nbits)) {
+        const int oc = ocm + ocn + (b0 ? c0 : 0) + ((q & 1) ? c2 : 0) + ((q >> 1) ? c3 : 0);
+        const v2f_t val = {acc[4 * q + 2 * b0], acc[4 * q + 2 * b0 + 1]};
+        if (c_in_lds) lds_write8(c_lds + 8u * (unsigned)oc, val);
+        if (Cg) Cg[oc] = make_float2(val.x, val.y);
       }
-  }
-  for (; q < red_numel; ++q) {
-    const int2 t = tab[q];
-    const float2 b = Bu[t.y];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const v2f_t a = ldA(oa[e] + t.x);
-      re[e] += a.x * b.x - a.y * b.y;
-      im[e] += a.x * b.y + a.y * b.x;
     }
-  }
 }
 __global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ image, const ArtnExtPtrs ext, char *__restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char prog_smem[];
   int2 *red_all = reinterpret_cast<int2 *>(prog_smem);
-  unsigned char *arena = prog_smem + ARTN_PROG_RED_ENTRIES * 8;
-  const unsigned red_lds = (unsigned)(unsigned long)(lds_byte_t *)prog_smem, arena_lds = red_lds + ARTN_PROG_RED_ENTRIES * 8; // LDS byte addresses
+  unsigned char *arena = prog_smem + ARTN_PROG_RED_ENTRIES * 8 + ARTN_PROG_BITS_BYTES;
+  int *bits_all = reinterpret_cast<int *>(prog_smem + ARTN_PROG_RED_ENTRIES * 8);
+  // LDS byte addresses: reduction tables, bit-stride tables of the matrix-core steps, arena
+  const unsigned red_lds = (unsigned)(unsigned long)(lds_byte_t *)prog_smem, bits_lds = red_lds + ARTN_PROG_RED_ENTRIES * 8,
+                 arena_lds = bits_lds + ARTN_PROG_BITS_BYTES;
   const ArtnProgHeader *H = reinterpret_cast<const ArtnProgHeader *>(image);
   const ArtnProgGroup G = reinterpret_cast<const ArtnProgGroup *>(image + H->off_groups)[blockIdx.x];
   const ArtnProgLevel *levels = reinterpret_cast<const ArtnProgLevel *>(image + H->off_levels);
@@ -1460,7 +1542,7 @@ __global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ 
   // ---- reduction-offset tables and the external operands that live in the arena: one wave per record
   for (int s = G.step_begin + wave; s < G.step_end; s += 16) {
     const ArtnProgStep &R = recs[s];
-    const int n_red = R.n_red, red_numel = R.fast ? 0 : R.red_numel, red_base = R.red_base; // (fast steps read their table from the image)
+    const int n_red = R.n_red, red_numel = R.red_numel, red_base = R.red_base;
     int e4[4], l4[4], a4[4], b4[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) { e4[d] = R.red_ext[d]; l4[d] = R.red_lg[d]; a4[d] = R.red_sA[d]; b4[d] = R.red_sB[d]; }
@@ -1485,6 +1567,8 @@ __global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ 
       }
       red_all[red_base + q] = make_int2(ka, kb);
     }
+    if (R.fast && lane < 48) // (mbit_sA, mbit_sC, nbit_sB, nbit_sC are contiguous: 48 ints)
+      bits_all[R.fast_index * 48 + lane] = (reinterpret_cast<const int *>(&R) + offsetof(ArtnProgStep, mbit_sA) / 4)[lane];
     if (R.pre_a) {
       const float2 *src = reinterpret_cast<const float2 *>(ext.p[-(R.loc_a + 1)]);
       float2 *dst = reinterpret_cast<float2 *>(arena + R.lds_a);
@@ -1504,32 +1588,57 @@ __global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ 
   // before the current task computes.  A task is 128 output elements, two per lane: half as many trips through the
   // load-latency chain of the reduction.  (Dependent loads inside the decode loop, one element per lane, tasks dealt
   // round-robin: the 19 levels of n12 took 290 us.)
+  // (the next level's table entry is requested a level ahead; pulling the lines it points to -- first task, that
+  //  task's record -- into the scalar cache before the barrier cost more than it saved: 152 -> 183 us on n12)
   constexpr int NE = ARTN_PROG_TASK_ELEMS / 64;
+  ArtnProgLevel lv_next = levels[G.level_begin];
   for (int L = G.level_begin; L < G.level_end; ++L) {
-    const ArtnProgLevel lv = levels[L];
+    const ArtnProgLevel lv = lv_next;
+    if (L + 1 < G.level_end) lv_next = levels[L + 1];
     const int per = (lv.wt_count + 15) >> 4, t_begin = wave * per, t_end = t_begin + per < lv.wt_count ? t_begin + per : lv.wt_count;
     ArtnProgWTask W = {0, 0};
     if (t_begin < t_end) W = wtasks[lv.wt_begin + t_begin];
-    int cur = -1;
-    int n_out = 0, out_numel = 0, red_numel = 0, red_base = 0, lds_a = -1, lds_b = -1, lds_c = -1, to_ws = 0, fast = 0;
-    long loc_a = 0, loc_b = 0, loc_c = 0, tab_off = 0;
+    int cur = -1, cur_dims = -1;
+    int n_out = 0, out_numel = 0, red_numel = 0, red_base = 0, lds_a = -1, lds_b = -1, lds_c = -1, to_ws = 0, fast = 0, fast_index = 0;
+    int n_mbits = 0, n_nbits = 0;
+    long loc_a = 0, loc_b = 0, loc_c = 0;
     int e8[8], l8[8], a8[8], b8[8], c8[8];
     for (int t = t_begin; t < t_end; ++t) {
+      if (t == t_begin) PROG_FINE(L - G.level_begin, 0, lv.wt_count);
+      if (t == t_begin) PROG_FINE(L - G.level_begin, 1, W.step);
       ArtnProgWTask Wn = W;
       if (t + 1 < t_end) Wn = wtasks[lv.wt_begin + t + 1];
       const ArtnProgStep &R = recs[W.step];
-      if (W.step != cur) {
+      if (W.step != cur) { // (one batch of scalar loads: the head of the record)
         cur = W.step;
         n_out = R.n_out; out_numel = R.out_numel; red_numel = R.red_numel; red_base = R.red_base;
-        lds_a = R.lds_a; lds_b = R.lds_b; lds_c = R.lds_c; to_ws = R.to_ws; fast = R.fast;
-        loc_a = R.loc_a; loc_b = R.loc_b; loc_c = R.loc_c; tab_off = R.tab_off;
+        lds_a = R.lds_a; lds_b = R.lds_b; lds_c = R.lds_c; to_ws = R.to_ws; fast = R.fast; fast_index = R.fast_index;
+        n_mbits = R.n_mbits; n_nbits = R.n_nbits;
+        loc_a = R.loc_a; loc_b = R.loc_b; loc_c = R.loc_c;
+      }
+      if (t == t_begin) PROG_FINE(L - G.level_begin, 2, n_out + (int)loc_c);
+      // (an operand is in the arena, in the workspace or behind an external pointer)
+      const float2 *A = nullptr, *B = nullptr;
+      if (lds_a < 0) A = reinterpret_cast<const float2 *>(loc_a >= 0 ? ws + loc_a : (const char *)ext.p[-(loc_a + 1)]);
+      if (lds_b < 0) B = reinterpret_cast<const float2 *>(loc_b >= 0 ? ws + loc_b : (const char *)ext.p[-(loc_b + 1)]);
+      const unsigned al = arena_lds + (unsigned)lds_a, bl = arena_lds + (unsigned)lds_b, rt = red_lds + 8u * (unsigned)red_base;
+      if (fast) {
+        float2 *Cg = to_ws ? reinterpret_cast<float2 *>(ws + loc_c) : nullptr;
+        const unsigned cl = arena_lds + (unsigned)lds_c, bits = bits_lds + 192u * (unsigned)fast_index;
+        const int dbg = t == t_begin ? L - G.level_begin : 1000;
+        if (lds_a >= 0 && lds_b >= 0) prog_mfma_task<true, true>(n_mbits, n_nbits, W.first, lane, A, al, B, bl, rt, red_numel, cl, lds_c >= 0, Cg, bits, dbg);
+        else if (lds_a >= 0) prog_mfma_task<true, false>(n_mbits, n_nbits, W.first, lane, A, al, B, bl, rt, red_numel, cl, lds_c >= 0, Cg, bits, dbg);
+        else if (lds_b >= 0) prog_mfma_task<false, true>(n_mbits, n_nbits, W.first, lane, A, al, B, bl, rt, red_numel, cl, lds_c >= 0, Cg, bits, dbg);
+        else prog_mfma_task<false, false>(n_mbits, n_nbits, W.first, lane, A, al, B, bl, rt, red_numel, cl, lds_c >= 0, Cg, bits, dbg);
+        if (t == t_begin) PROG_FINE(L - G.level_begin, 3, W.first);
+        W = Wn;
+        continue;
+      }
+      if (W.step != cur_dims) { // (the general path's axes: five 8-dword loads, kept while the wave stays on this step)
+        cur_dims = W.step;
 #pragma unroll
         for (int d = 0; d < 8; ++d) { e8[d] = R.out_ext[d]; l8[d] = R.out_lg[d]; a8[d] = R.out_sA[d]; b8[d] = R.out_sB[d]; c8[d] = R.out_sC[d]; }
       }
-      // (an operand is in the arena, in the workspace or behind an external pointer)
-      const float2 *A = lds_a >= 0 ? nullptr : reinterpret_cast<const float2 *>(loc_a >= 0 ? ws + loc_a : (const char *)ext.p[-(loc_a + 1)]);
-      const float2 *B = lds_b >= 0 ? nullptr : reinterpret_cast<const float2 *>(loc_b >= 0 ? ws + loc_b : (const char *)ext.p[-(loc_b + 1)]);
-      const unsigned al = arena_lds + (unsigned)lds_a, bl = arena_lds + (unsigned)lds_b, rt = red_lds + 8u * (unsigned)red_base;
       int oa[NE], ob[NE], oc[NE];
       bool live[NE];
 #pragma unroll
@@ -1559,12 +1668,7 @@ __global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ 
         }
       }
       float re[NE], im[NE];
-      if (fast) {
-        const float2 *Bu = B + __builtin_amdgcn_readfirstlane(ob[0]);
-        const int2 *tab = reinterpret_cast<const int2 *>(image + tab_off);
-        if (lds_a >= 0) prog_reduce_fast<true, NE>(A, al, Bu, oa, tab, red_numel, re, im);
-        else prog_reduce_fast<false, NE>(A, al, Bu, oa, tab, red_numel, re, im);
-      } else if (lds_a >= 0 && lds_b >= 0) prog_reduce<true, true, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
+      if (lds_a >= 0 && lds_b >= 0) prog_reduce<true, true, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
       else if (lds_a >= 0) prog_reduce<true, false, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
       else if (lds_b >= 0) prog_reduce<false, true, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
       else prog_reduce<false, false, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
@@ -2182,27 +2286,33 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
     if (producer.count(loc_c[s])) return fail(ARTN_E_INVALID, "two steps write the same workspace offset");
     producer[loc_c[s]] = s;
   }
-  // fast steps (prog_reduce_fast): no output axis in both operands, and the leading first-operand axes cover whole
-  // wave tasks; their second operand is read from global memory (the producer writes it to the workspace) and needs
-  // no place in the arena.  last_use counts only the readers that go through the arena.
-  std::vector<char> need_ws(n_steps, 0);
+  // fast steps (prog_mfma_task): every extent a power of two, no output axis in both operands, 5+ output bits in the
+  // first operand, 2+ contracted values; a stride per output bit
   for (int s = 0; s < n_steps; ++s) {
     ArtnProgStep &r = rec[s];
-    int64_t lead = 1;
-    bool ok = r.red_numel > 0, in_b = false;
+    bool ok = r.red_numel >= 2 && (r.red_numel & (r.red_numel - 1)) == 0;
+    for (int d = 0; d < r.n_red && ok; ++d) ok = r.red_lg[d] >= 0;
+    int mb = 0, nb = 0;
     for (int d = 0; d < r.n_out && ok; ++d) {
-      if (r.out_sA[d] != 0 && r.out_sB[d] != 0) ok = false;
-      if (r.out_sB[d] != 0) in_b = true;
-      else if (!in_b) lead *= r.out_ext[d];
-      else ok = false; // (axes of neither operand: never produced by the scheme compilers)
+      const int lg = r.out_lg[d];
+      if (lg < 0 || (r.out_sA[d] != 0 && r.out_sB[d] != 0) || (r.out_sA[d] == 0 && r.out_sB[d] == 0)) { ok = false; break; }
+      for (int b = 0; b < lg && ok; ++b) {
+        if (r.out_sB[d] == 0) {
+          if (mb >= 14) { ok = false; break; }
+          r.mbit_sA[mb] = r.out_sA[d] << b; r.mbit_sC[mb] = r.out_sC[d] << b; ++mb;
+        } else {
+          if (nb >= 10) { ok = false; break; }
+          r.nbit_sB[nb] = r.out_sB[d] << b; r.nbit_sC[nb] = r.out_sC[d] << b; ++nb;
+        }
+      }
     }
-    r.fast = (ok && lead % ARTN_PROG_TASK_ELEMS == 0) ? 1 : 0;
-    if (r.fast && loc_b[s] >= 0) need_ws[producer[loc_b[s]]] = 1;
+    r.fast = (ok && mb >= 5) ? 1 : 0;
+    r.n_mbits = r.fast ? mb : 0; r.n_nbits = r.fast ? nb : 0;
   }
   for (int s = 0; s < n_steps; ++s)
     for (int which = 0; which < 2; ++which) {
       const int64_t loc = which ? loc_b[s] : loc_a[s];
-      if (loc >= 0 && !(which == 1 && rec[s].fast)) last_use[producer[loc]] = std::max(last_use[producer[loc]], level[s]);
+      if (loc >= 0) last_use[producer[loc]] = std::max(last_use[producer[loc]], level[s]);
     }
   std::vector<int> order(n_steps), where(n_steps);
   for (int s = 0; s < n_steps; ++s) order[s] = s;
@@ -2219,7 +2329,14 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
     const int b = group_start[g], e = group_start[g + 1];
     std::vector<int> steps(order.begin() + b, order.begin() + e); // by level
     int red = 0;
-    for (int s : steps) { rec[s].red_base = red; red += rec[s].fast ? 0 : rec[s].red_numel; rec[s].level = level[s]; }
+    int n_fast = 0;
+    for (int s : steps) {
+      rec[s].red_base = red; red += rec[s].red_numel; rec[s].level = level[s];
+      if (rec[s].fast) {
+        if (n_fast < ARTN_PROG_FAST_MAX) rec[s].fast_index = n_fast++;
+        else rec[s].fast = 0; // (the general path takes what the bit-stride area cannot hold)
+      }
+    }
     if (red > ARTN_PROG_RED_ENTRIES) return fail(ARTN_E_UNSUPPORTED, "reduction tables of a group exceed their LDS share");
     std::vector<Block> free_list = {{0, ARTN_PROG_ARENA_BYTES}};
     // (two-ended: blocks of 16 KiB and more from the top of the arena, the many small ones from the bottom -- with
@@ -2261,7 +2378,7 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
     for (int s : steps)
       for (int which = 0; which < 2; ++which) {
         const int64_t loc = which ? loc_b[s] : loc_a[s];
-        if (loc >= 0 || (which == 1 && rec[s].fast)) continue;
+        if (loc >= 0) continue;
         const int numel = which ? rec[s].b_numel : rec[s].a_numel;
         auto it = exts.find(loc);
         if (it == exts.end()) {
@@ -2279,25 +2396,30 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
     groups[g].level_begin = (int)levels.size();
     size_t q = 0;
     for (int L = 1; L <= max_level; ++L) {
-      ArtnProgLevel lv = {(int)wtasks.size(), 0};
+      ArtnProgLevel lv = {(int)wtasks.size(), 0, 0, 0};
       const size_t q0 = q;
       for (; q < steps.size() && level[steps[q]] == L; ++q) {
         const int s = steps[q];
         ArtnProgStep &r = rec[s];
         const bool read_inside = last_use[s] > 0; // (through the arena)
-        r.to_ws = (!keep || keep[s] || need_ws[s] || !read_inside) ? 1 : 0;
+        r.to_ws = (!keep || keep[s] || !read_inside) ? 1 : 0;
         if (read_inside) r.lds_c = alloc(r.out_numel * 8);
         if (r.lds_c < 0) r.to_ws = 1;
-        for (int first = 0; first < r.out_numel; first += ARTN_PROG_TASK_ELEMS) wtasks.push_back({where[s], first});
+        if (r.fast) { // 32 x 16 blocks: first-operand sub-tile fastest
+          const int n_tasks = (1 << (r.n_mbits - 5)) * (r.n_nbits > 4 ? 1 << (r.n_nbits - 4) : 1);
+          for (int t = 0; t < n_tasks; ++t) wtasks.push_back({where[s], t});
+        } else {
+          for (int first = 0; first < r.out_numel; first += ARTN_PROG_TASK_ELEMS) wtasks.push_back({where[s], first});
+        }
       }
       lv.wt_count = (int)wtasks.size() - lv.wt_begin;
+      lv.first_step = lv.wt_count ? wtasks[lv.wt_begin].step : 0;
       levels.push_back(lv);
       // operands whose last reader ran at this level
       for (size_t k = q0; k < q; ++k) {
         const int s = steps[k];
         for (int which = 0; which < 2; ++which) {
           const int64_t loc = which ? loc_b[s] : loc_a[s];
-          if (which == 1 && rec[s].fast) continue; // (read from global memory)
           if (loc < 0) {
             Ext &x = exts[loc];
             if (x.lds >= 0 && x.last == L) { release(x.lds, x.numel * 8); x.last = -1; }

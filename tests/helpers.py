@@ -182,12 +182,13 @@ def emulate2(eq1, a, b1, eq2, b2):
 
 # ---- small-step program images (artn_program_build), executed on the CPU ------------------------------
 PROG_MAX_OUT, PROG_MAX_RED, PROG_TASK_ELEMS = 24, 12, 128
-PROG_RED_ENTRIES, PROG_ARENA_BYTES = 2048, 140 * 1024
+PROG_RED_ENTRIES, PROG_ARENA_BYTES = 2048, 128 * 1024
 PROG_STEP_DTYPE = np.dtype([
     ("n_out", "<i4"), ("n_red", "<i4"), ("out_numel", "<i4"), ("red_numel", "<i4"), ("a_numel", "<i4"), ("b_numel", "<i4"),
     ("loc_a", "<i8"), ("loc_b", "<i8"), ("loc_c", "<i8"), ("tab_off", "<i8"),
     ("lds_a", "<i4"), ("lds_b", "<i4"), ("lds_c", "<i4"), ("pre_a", "<i4"), ("pre_b", "<i4"), ("to_ws", "<i4"),
-    ("red_base", "<i4"), ("level", "<i4"), ("fast", "<i4"), ("pad_", "<i4"),
+    ("red_base", "<i4"), ("level", "<i4"), ("fast", "<i4"), ("n_mbits", "<i4"), ("n_nbits", "<i4"), ("fast_index", "<i4"),
+    ("mbit_sA", "<i4", 14), ("mbit_sC", "<i4", 14), ("nbit_sB", "<i4", 10), ("nbit_sC", "<i4", 10),
     ("out_ext", "<i4", PROG_MAX_OUT), ("out_lg", "<i4", PROG_MAX_OUT), ("out_sA", "<i4", PROG_MAX_OUT), ("out_sB", "<i4", PROG_MAX_OUT), ("out_sC", "<i4", PROG_MAX_OUT),
     ("red_ext", "<i4", PROG_MAX_RED), ("red_lg", "<i4", PROG_MAX_RED), ("red_sA", "<i4", PROG_MAX_RED), ("red_sB", "<i4", PROG_MAX_RED)])
 
@@ -203,7 +204,7 @@ def parse_program_image(image):
     assert PROG_STEP_DTYPE.itemsize == N.lib().artn_program_record_bytes()
     take = lambda off, dt, n: np.frombuffer(buf[off:off + np.dtype(dt).itemsize * n].tobytes(), dtype=dt)
     groups = take(int(offs[0]), "<i4", 4 * n_groups).reshape(n_groups, 4)
-    levels = take(int(offs[1]), "<i4", 2 * n_levels).reshape(n_levels, 2)
+    levels = take(int(offs[1]), "<i4", 4 * n_levels).reshape(n_levels, 4)[:, :2]
     wtasks = take(int(offs[2]), "<i4", 2 * n_wtasks).reshape(n_wtasks, 2)
     recs = take(int(offs[3]), PROG_STEP_DTYPE, n_steps)
     parse_program_image.raw = buf
@@ -253,17 +254,31 @@ def emulate_program(prog, leaves):
                     loc = int(R["loc_" + which])
                     return ws[loc // 8:] if loc >= 0 else ext[-(loc + 1)]
                 A, B = operand("a"), operand("b")
-                if R["fast"]:   # second operand from global memory, one value per term for the whole wave task
-                    assert R["lds_b"] < 0 and int(R["out_numel"]) % PROG_TASK_ELEMS == 0
-                idx = np.arange(int(first), min(int(first) + PROG_TASK_ELEMS, int(R["out_numel"])))
-                r, oa, ob, oc = idx.copy(), np.zeros_like(idx), np.zeros_like(idx), np.zeros_like(idx)
-                for d in range(int(R["n_out"])):
-                    e = int(R["out_ext"][d])
-                    oa += (r % e) * int(R["out_sA"][d]); ob += (r % e) * int(R["out_sB"][d]); oc += (r % e) * int(R["out_sC"][d]); r //= e
                 ka = np.array([t[0] for t in red[s]], dtype=np.int64); kb = np.array([t[1] for t in red[s]], dtype=np.int64)
                 if R["fast"]:
-                    assert (ob == ob[0]).all()
-                acc = (A[oa[:, None] + ka[None, :]].astype(np.complex128) * B[ob[:, None] + kb[None, :]].astype(np.complex128)).sum(axis=1)
+                    # matrix-core task: block of 32 first-operand rows x 16 second-operand columns, offsets from the
+                    # per-bit stride tables
+                    mb, nb = int(R["n_mbits"]), int(R["n_nbits"])
+                    assert mb >= 5 and len(ka) >= 2
+                    task = int(first)
+                    msub, ntile = task & ((1 << (mb - 5)) - 1), task >> (mb - 5)
+                    bits = lambda v, tab, n: sum(int(tab[b]) for b in range(n) if (v >> b) & 1)
+                    m = np.arange(msub * 32, msub * 32 + 32)
+                    n = np.array([x for x in range(ntile * 16, ntile * 16 + 16) if x < (1 << nb)])
+                    oa = np.array([bits(int(v), R["mbit_sA"], mb) for v in m]); ocm = np.array([bits(int(v), R["mbit_sC"], mb) for v in m])
+                    ob = np.array([bits(int(v), R["nbit_sB"], nb) for v in n]); ocn = np.array([bits(int(v), R["nbit_sC"], nb) for v in n])
+                    Am = A[oa[:, None] + ka[None, :]].astype(np.complex128)            # [m][k]
+                    Bm = B[ob[:, None] + kb[None, :]].astype(np.complex128)            # [n][k]
+                    acc = Am @ Bm.T                                                     # [m][n]
+                    oc = (ocm[:, None] + ocn[None, :]).reshape(-1)
+                    acc = acc.reshape(-1)
+                else:
+                    idx = np.arange(int(first), min(int(first) + PROG_TASK_ELEMS, int(R["out_numel"])))
+                    r, oa, ob, oc = idx.copy(), np.zeros_like(idx), np.zeros_like(idx), np.zeros_like(idx)
+                    for d in range(int(R["n_out"])):
+                        e = int(R["out_ext"][d])
+                        oa += (r % e) * int(R["out_sA"][d]); ob += (r % e) * int(R["out_sB"][d]); oc += (r % e) * int(R["out_sC"][d]); r //= e
+                    acc = (A[oa[:, None] + ka[None, :]].astype(np.complex128) * B[ob[:, None] + kb[None, :]].astype(np.complex128)).sum(axis=1)
                 assert R["lds_c"] >= 0 or R["to_ws"]
                 if R["lds_c"] >= 0:
                     assert int(R["lds_c"]) + 8 * int(R["out_numel"]) <= PROG_ARENA_BYTES
