@@ -537,7 +537,7 @@ class _Program:
     """Compiled small steps of a dense scheme: device image per device, workspace layout, which tensor
     ids it reads from the caller (`ext_ids`, in kernel-argument order) and which results it leaves
     (`outputs`: id -> (workspace byte offset, shape))."""
-    __slots__ = ("host_image", "host_groups", "n_groups", "n_steps", "ext_ids", "ws_bytes", "outputs", "dev", "flops")
+    __slots__ = ("host_image", "host_groups", "n_groups", "n_steps", "ext_ids", "ws_bytes", "outputs", "dev", "flops", "ext_array")
 
     def device_copy(self, device):
         hit = self.dev.get(device)
@@ -663,14 +663,18 @@ def _plan_small_program(scheme, shapes, dtype):
     prog.host_image, prog.host_groups = image, torch.tensor(group_start, dtype=torch.int32)
     prog.n_groups, prog.n_steps, prog.ext_ids, prog.ws_bytes = n_groups, len(small_sorted), ext_ids, max(ws, 16)
     prog.outputs = {t: v for t, v in where.items() if t in needed}
-    prog.dev, prog.flops = {}, flops
+    prog.dev, prog.flops, prog.ext_array = {}, flops, None
     return prog, main
 
 
 def _run_program(prog, tensors, dtype, device, stream):
     image = prog.device_copy(device)
     ws = torch.empty(prog.ws_bytes, dtype=torch.uint8, device=device)
-    ext = (ctypes.c_void_p * len(prog.ext_ids))(*[tensors[t].data_ptr() for t in prog.ext_ids])
+    ext = prog.ext_array
+    if ext is None:
+        ext = prog.ext_array = (ctypes.c_void_p * len(prog.ext_ids))()
+    for q, t in enumerate(prog.ext_ids):
+        ext[q] = tensors[t].data_ptr()
     if profiler is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -775,6 +779,18 @@ def _compile_dense(scheme, shapes, dtype):
     return prog, ops
 
 
+_scheme_ids = _Bounded(256)   # id(scheme) -> (scheme, ids it reads, first-use order)
+_os_environ = __import__("os").environ
+_NULL_CTX = __import__("contextlib").nullcontext()
+_pair_query = []
+
+
+def _HAS_PAIR_QUERY():
+    if not _pair_query:
+        _pair_query.append(N.lib().artn_contract2_query is not None)
+    return _pair_query[0]
+
+
 def tensor_contraction(tensors, scheme):
     """Run a dense scheme: for each ((i, j), eq): tensors[i] <- contract(eq, tensors[i],
     tensors[j]); returns the last tensors[i] (reference contraction.py:62-76; `tensors` is
@@ -786,30 +802,42 @@ def tensor_contraction(tensors, scheme):
     those of the step-by-step order."""
     if len(scheme) == 0:
         raise RuntimeError("empty contraction scheme")
-    ids = tensors.keys() if isinstance(tensors, dict) else range(len(tensors))
-    used = set()
-    for step in scheme:
-        used.update(step[0])
+    # (host time matters for the launch-latency workloads -- n12 is ONE 90 us launch: the ids a scheme reads are
+    #  resolved once per scheme object, the per-tensor checks are inlined, shapes are hashed as torch.Size)
+    su = _scheme_ids.get(id(scheme))
+    if su is None or su[0] is not scheme:
+        seen = {}
+        for step in scheme:
+            for k in step[0]:
+                seen.setdefault(k, None)
+        su = _scheme_ids[id(scheme)] = (scheme, tuple(seen))
+    is_dict = isinstance(tensors, dict)
+    n_list = 0 if is_dict else len(tensors)
     first = None
-    shapes = {}
-    for k in ids:
-        if k not in used:
+    dtype = device = None
+    shape_key = []
+    for k in su[1]:
+        if is_dict:
+            if k not in tensors:
+                continue   # (reported below, by the compiler, as the reference's KeyError would be)
+        elif not (isinstance(k, int) and 0 <= k < n_list):
             continue
         t = tensors[k]
-        N.require_gpu(t, "tensor_contraction")
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            N.require_gpu(t, "tensor_contraction")
         if first is None:
-            first = t
-        elif t.dtype != first.dtype or t.device != first.device:
+            first, dtype, device = t, t.dtype, t.device
+        elif t.dtype != dtype or t.device != device:
             raise RuntimeError("all tensors of a scheme must share dtype and device")
         if not t.is_contiguous():
             tensors[k] = t = t.contiguous()
-        shapes[k] = tuple(t.shape)
-    if first is None or first.dtype not in _DTYPES:
+        shape_key.append(t.shape)
+    if first is None or dtype not in _DTYPES:
         raise RuntimeError("tensor_contraction needs complex64 or complex128 GPU tensors")
-    key = (id(scheme), first.dtype, precision.current(), tuple(sorted(shapes.items())), N.lib().artn_contract2_query is not None,
-           bool(__import__("os").environ.get("ARTN_NO_FUSE")))
+    key = (id(scheme), dtype, precision.current(), tuple(shape_key), _HAS_PAIR_QUERY(), bool(_os_environ.get("ARTN_NO_FUSE")))
     hit = _plan_cache.get(key)
     if hit is None or hit[0] is not scheme:
+        shapes = {k: tuple(tensors[k].shape) for k in su[1] if (k in tensors if is_dict else isinstance(k, int) and 0 <= k < n_list)}
         try:
             prog, ops = _compile_dense(scheme, shapes, first.dtype)
         except KeyError as e:
@@ -817,9 +845,8 @@ def tensor_contraction(tensors, scheme):
         hit = _plan_cache[key] = (scheme, ops, prog)
     ops, prog = hit[1], hit[2]
     lib = N.lib()
-    dtype, device = first.dtype, first.device
     byref = ctypes.byref
-    with torch.cuda.device(device):
+    with (_NULL_CTX if torch.cuda.current_device() == device.index else torch.cuda.device(device)):
         stream = N.current_stream_ptr(device)
         if prog is not None:   # every step that only combines small leaf-derived tensors: one launch
             _run_program(prog, tensors, dtype, device, stream)
