@@ -305,7 +305,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    out = None
     for _ in range(args.warmup):
+        out = one_step()
+    if out is None:   # (--warmup 0: the check still needs a result; it is outside the timed region either way)
         out = one_step()
     # result check outside the timed region: amplitudes at Google's 10 000 bitstrings (this rank's share of them)
     if world == 1:
