@@ -1016,7 +1016,9 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1
 // GATHER: row indices on one outer axis (artn_contract_gather; single stage, fp32 chains).
 // NT: non-temporal loads of the A tiles (see issue_loads).
 // M3: every stage with 5 contracted bits runs the 3M arithmetic (StageRun::run3; fp32 chains only).
-template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false, bool NT = false, bool M3 = false>
+// FULL: input and output tiles are 2^12 elements (every big launch): the copy loops and their predicates are
+// compile-time constants -- a third of the scalar instructions and most of the branches of the tile loop go.
+template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false, bool NT = false, bool M3 = false, bool FULL = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(const float2 *__restrict__ A,
                                                                   const float2 *__restrict__ B1,
                                                                   const float2 *__restrict__ B2,
@@ -1056,10 +1058,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     out_hi[b] = 9 + b < P.T_out ? P.out_stride[9 + b] * 8 : 0;
   }
   const unsigned tid16 = tid * 16;
-  const int n_in_iters = 1 << (P.T_in - 9);
+  const int n_in_iters = FULL ? 8 : 1 << (P.T_in - 9);
   // output tiles smaller than one copy pass (2^9 elements): one pass, upper threads idle
-  const int n_out_iters = P.T_out >= 9 ? 1 << (P.T_out - 9) : 1;
-  const bool out_active = P.T_out >= 9 || tid < (1 << (P.T_out - 1));
+  const int n_out_iters = FULL ? 8 : (P.T_out >= 9 ? 1 << (P.T_out - 9) : 1);
+  const bool out_active = FULL || P.T_out >= 9 || tid < (1 << (P.T_out - 1));
 
   // ---- per-stage constants, sub-tile tables, outer-axis digits
   fill_msub_table(P.st[0], nullptr, tab1, tid);
@@ -1097,7 +1099,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   // (the 7-8 bit instantiation runs one wave per SIMD and prefetches 2^13-element tiles)
   constexpr int NV = BIGK ? 16 : 8;
   f32x4 v[NV];
-  const bool prefetch = n_in_iters == NV && n_out_iters <= 8;
+  const bool prefetch = FULL || (n_in_iters == NV && n_out_iters <= 8);
   TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
   // tiles of this workgroup: t0, t0 + G, ... < n_tiles (grid-stride), or one contiguous range
   long t0 = blockIdx.x, G = gridDim.x, n_tiles = P.n_tiles;
@@ -1804,6 +1806,7 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
   const size_t lds = (size_t)p.info.lds_bytes;
   const int k2 = p.bits.n_stages == 2 ? p.bits.st[1].k : 0;
   const int split = p.bits.split;
+  const bool full = p.bits.T_in == 12 && p.bits.T_out == 12; // (the FULL instantiations)
 #define ARTN_LAUNCH_NP(K2, NPV)                                                                           \
   {                                                                                                       \
     auto kern = artn_k_bits<KB1, K2, false, NPV>;                                                         \
@@ -1826,7 +1829,19 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
       if (split == 1) { ARTN_LAUNCH_NP(K2, 1) break; }                                                    \
     }                                                                                                     \
     if constexpr ((KB1 == 5 || KB1 == 6 || K2 == 5 || K2 == 6) && !((KB1 >= 5 && K2 >= 5) && KB1 + K2 > 10)) {      \
-      if (p.bits.m3 && p.bits.nt_loads) { /* three real products per complex product in the 5-bit stages */ \
+      if (p.bits.m3 && p.bits.nt_loads && full) { /* three real products per complex product in the 5-bit stages */ \
+        auto kern = artn_k_bits<KB1, K2, false, 0, false, true, true, true>;                              \
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, true, true, true>>(lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                             \
+        break;                                                                                            \
+      }                                                                                                   \
+      if (p.bits.m3 && full) {                                                                            \
+        auto kern = artn_k_bits<KB1, K2, false, 0, false, false, true, true>;                             \
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, false, true, true>>(lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                             \
+        break;                                                                                            \
+      }                                                                                                   \
+      if (p.bits.m3 && p.bits.nt_loads) {                                                                 \
         auto kern = artn_k_bits<KB1, K2, false, 0, false, true, true>;                                    \
         if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, true, true>>(lds); e != hipSuccess) return e; \
         hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                             \
@@ -1840,7 +1855,13 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
       }                                                                                                   \
     }                                                                                                     \
     if constexpr (KB1 >= 3 && (K2 == 0 || K2 >= 3)) {                                                     \
-      if (p.bits.nt_loads) { /* the big steps: non-temporal loads of A */                                 \
+      if (p.bits.nt_loads && full) { /* the big steps: non-temporal loads of A, 2^12-element tiles */     \
+        auto kern = artn_k_bits<KB1, K2, false, 0, false, true, false, true>;                             \
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, true, false, true>>(lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                             \
+        break;                                                                                            \
+      }                                                                                                   \
+      if (p.bits.nt_loads) { /* non-temporal loads of A */                                                \
         auto kern = artn_k_bits<KB1, K2, false, 0, false, true>;                                          \
         if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, true>>(lds); e != hipSuccess) return e; \
         hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                             \
