@@ -311,11 +311,11 @@ __device__ __forceinline__ f32x4 load_chunk(const char *__restrict__ Abase, long
 // NT: every A tile is read exactly once by the launch, in full 128-byte runs: non-temporal loads
 // keep the stream from displacing lines that will be used again.  (A compile-time choice: behind
 // a run-time branch the compiler merges the two loads and drops the hint.)
-template <int NV, bool NT = false>
+template <int NV, bool NT = false, int U0 = 0, int U1 = NV>
 __device__ __forceinline__ void issue_loads(f32x4 (&v)[NV], const char *__restrict__ Abase, const long (&hi)[4],
                                             unsigned lane_off) {
 #pragma unroll
-  for (int u = 0; u < NV; ++u) {
+  for (int u = U0; u < U1; ++u) {
 #ifndef ARTN_ABLATE_MEM
     if constexpr (NT) {
       v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Abase + chunk_off(hi, u) + lane_off));
@@ -1136,6 +1136,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   // instructions never queue behind the co-resident workgroup's MFMA stream (3: on top of the asymmetric stage priority)
   const bool copy_prio = P.stage_prio >= 2;
   STAMP_DECL
+  bool half_pending = false;
   for (long tile = t0; tile < n_tiles; tile += G) {
     if (off.b1 != prev_b1) {
       prev_b1 = off.b1;
@@ -1183,6 +1184,11 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     if (stage_prio && KB2 == 0) __builtin_amdgcn_s_setprio(0);
     PHASE_MARK(1);
     STAMP(5);
+    if (FULL && half_pending) { // the second half of the next tile's loads (see below)
+      unsigned li2 = in_lane;
+      OPAQUE_V(li2);
+      issue_loads<NV, NT, NV / 2, NV>(v, reinterpret_cast<const char *>(A + noff.a), in_hi, li2);
+    }
     __syncthreads();
     unsigned outr = R1;
     if (KB2 > 0) {
@@ -1234,7 +1240,13 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       }
       PHASE_MARK(5);
       STAMP(7);
-      if (next2 < n_tiles) issue_loads<NV, NT>(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
+      // (FULL: four of the eight chunks here, four after the next tile's first stage -- a workgroup's 32 KiB request
+      //  burst in two halves half a tile period apart: +0.5 % on n30, A/B in one session; all eight late, or a second
+      //  tile in flight, lose)
+      if (FULL) {
+        half_pending = next2 < n_tiles;
+        if (next2 < n_tiles) issue_loads<NV, NT, 0, NV / 2>(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
+      } else if (next2 < n_tiles) issue_loads<NV, NT>(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
       PHASE_MARK(6);
       STAMP(4);
     } else {
