@@ -325,10 +325,10 @@ __device__ __forceinline__ void issue_loads(f32x4 (&v)[NV], const char *__restri
     v[u] = load_chunk(Abase, chunk_off(hi, u), lane_off);
   }
 }
-template <int NV>
+template <int NV, int U1 = NV>
 __device__ __forceinline__ void store_lds(const f32x4 (&v)[NV], unsigned ldsb, unsigned tid16) {
 #pragma unroll
-  for (int u = 0; u < NV; ++u) lds_write16(ldsb + tid16 + u * (ARTN_WG_THREADS * 16), v[u]);
+  for (int u = 0; u < U1; ++u) lds_write16(ldsb + tid16 + u * (ARTN_WG_THREADS * 16), v[u]);
 }
 __device__ __forceinline__ void copy_in_sync(const char *__restrict__ Abase, const long (&hi)[4], unsigned lane_off,
                                              unsigned ldsb, unsigned tid16, int n_iters) {
@@ -1099,7 +1099,9 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   // (the 7-8 bit instantiation runs one wave per SIMD and prefetches 2^13-element tiles)
   constexpr int NV = BIGK ? 16 : 8;
   f32x4 v[NV];
-  const bool prefetch = FULL || (n_in_iters == NV && n_out_iters <= 8);
+  // (2^11-element input tiles -- steps that double their tensor -- prefetch too: half the chunks)
+  const bool pf_half = !FULL && !BIGK && n_in_iters == NV / 2 && n_out_iters <= 8;
+  const bool prefetch = FULL || ((n_in_iters == NV || pf_half) && n_out_iters <= 8);
   TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
   // tiles of this workgroup: t0, t0 + G, ... < n_tiles (grid-stride), or one contiguous range
   long t0 = blockIdx.x, G = gridDim.x, n_tiles = P.n_tiles;
@@ -1119,7 +1121,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     copy_in_sync(reinterpret_cast<const char *>(A + off.a), in_hi, in_lane, R0, tid16, n_in_iters);
     if (t0 + G < n_tiles) {
       noff = tile_offsets<GATHER>(P, OT, t0 + G);
-      if (prefetch) issue_loads<NV, NT>(v, reinterpret_cast<const char *>(A + noff.a), in_hi, in_lane);
+      if (pf_half) issue_loads<NV, NT, 0, NV / 2>(v, reinterpret_cast<const char *>(A + noff.a), in_hi, in_lane);
+      else if (prefetch) issue_loads<NV, NT>(v, reinterpret_cast<const char *>(A + noff.a), in_hi, in_lane);
     }
   }
   __syncthreads();
@@ -1219,7 +1222,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       PHASE_MARK(3);
       STAMP(1);
       // refill R0 with the next tile (its loads were issued one iteration ago)
-      if (next < n_tiles) store_lds(v, R0, t16);
+      if (next < n_tiles) {
+        if (pf_half) store_lds<NV, NV / 2>(v, R0, t16);
+        else store_lds(v, R0, t16);
+      }
       PHASE_MARK(4);
       STAMP(2);
       // stores of this tile, then the loads of the tile after next
@@ -1246,7 +1252,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       if (FULL) {
         half_pending = next2 < n_tiles;
         if (next2 < n_tiles) issue_loads<NV, NT, 0, NV / 2>(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
-      } else if (next2 < n_tiles) issue_loads<NV, NT>(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
+      } else if (next2 < n_tiles) {
+        if (pf_half) issue_loads<NV, NT, 0, NV / 2>(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
+        else issue_loads<NV, NT>(v, reinterpret_cast<const char *>(A + n2off.a), in_hi, lo_in);
+      }
       PHASE_MARK(6);
       STAMP(4);
     } else {
