@@ -54,7 +54,8 @@ __device__ __forceinline__ void lds_write4(unsigned a, unsigned v) {
 // accumulators, three MFMAs per pair of contracted values instead of four for the same 32 x 32 outputs:
 // 6 real FLOP per complex multiply-add on the matrix pipe, the other 2 become one add per operand element
 // and three per result.  NB counts 32-column blocks in this mode.
-template <int MB, int NB, bool BF = false, bool M3 = false>
+// TALL (single-block tiles, fp32): images of 2^6 contracted values x 2^5 rows (ArtnGemmPlan::pitch_log2 = 5, kc = 6)
+template <int MB, int NB, bool BF = false, bool M3 = false, bool TALL = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *__restrict__ A, const float2 *__restrict__ B,
                                                                  float2 *__restrict__ C, const ArtnGemmPlan P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,8 +67,11 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
   const int mt = P.mt, nt = P.nt;
   // both images are [16][2^7] whatever mt / nt (ARTN_GEMM_PITCH_LOG2): LDS offsets of the MFMA loop are immediates
   // (fp32: [16][128] x 8 B; bf16: [8][128][4] x 4 B -- 16 KiB either way)
-  constexpr unsigned a_bytes = 8u << (ARTN_GEMM_PITCH_LOG2 + ARTN_GEMM_KC), b_bytes = a_bytes, stage_bytes = a_bytes + b_bytes;
-  constexpr unsigned ROW2 = 16u << ARTN_GEMM_PITCH_LOG2; // fp32: bytes between k pairs (two image rows)
+  static_assert(!TALL || (MB == 1 && NB == 1 && !BF), "tall chunks: one 32 x 32 block, fp32");
+  constexpr int PITCH = TALL ? ARTN_GEMM_PITCH_TALL_LOG2 : ARTN_GEMM_PITCH_LOG2, KCB = TALL ? ARTN_GEMM_KC_TALL : ARTN_GEMM_KC;
+  constexpr int NS = 1 << (KCB - 1); // fp32 MFMA steps (pairs of contracted values) per chunk
+  constexpr unsigned a_bytes = 8u << (PITCH + KCB), b_bytes = a_bytes, stage_bytes = a_bytes + b_bytes;
+  constexpr unsigned ROW2 = 16u << PITCH; // fp32: bytes between k pairs (two image rows)
   constexpr int NVA = BF ? 8 : 4;                        // 16-byte global loads per thread and chunk, first operand
   const int epi_bits = P.tc_bits < ARTN_GEMM_EPI_BITS ? P.tc_bits : ARTN_GEMM_EPI_BITS;
   const unsigned epi_bytes = 8u << epi_bits;
@@ -119,8 +123,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
   const bool w_valid = M3 || nt >= 4 || n_in < (1 << nt);
   constexpr int NBW = M3 ? 32 : 16; // complex columns per MFMA block
   constexpr unsigned EB = BF ? 16u : 8u; // bytes per (row, k pair | k quad) slot
-  const unsigned lane_x = (((unsigned)h << ARTN_GEMM_PITCH_LOG2) + (unsigned)(wm * MB * 32 + j)) * EB;
-  const unsigned lane_w = a_bytes + (((unsigned)h << ARTN_GEMM_PITCH_LOG2) + (unsigned)(wn * NB * NBW) + (unsigned)(w_valid ? n_in : 0)) * EB;
+  const unsigned lane_x = (((unsigned)h << PITCH) + (unsigned)(wm * MB * 32 + j)) * EB;
+  const unsigned lane_w = a_bytes + (((unsigned)h << PITCH) + (unsigned)(wn * NB * NBW) + (unsigned)(w_valid ? n_in : 0)) * EB;
   const unsigned w_sel = ro ? 0x01000302u : 0x03020100u, w_sign = ro ? 0u : 0x80000000u; // bf16 W side: (im, re) / (re, -im)
 
   // ---- epilogue offsets (elements of the C-ordered result image, swizzled; fields are disjoint: XOR)
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
   const int n_chunks = 1 << P.n_ko;
   // chunks per partial sum - 1: 2^12 contracted values in fp32; bf16 operands carry 2^-9 of rounding each, the
   // length of the fp32 chain does not matter there
-  const int flush_mask = BF ? 0x7fffffff : (1 << (ARTN_GEMM_FLUSH_LOG2 - ARTN_GEMM_KC)) - 1;
+  const int flush_mask = BF ? 0x7fffffff : (1 << (ARTN_GEMM_FLUSH_LOG2 - KCB)) - 1;
   __syncthreads(); // tables are in LDS
   TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
   const char *Ac = reinterpret_cast<const char *>(A), *Bc = reinterpret_cast<const char *>(B);
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
           } // (WK == 1)
         } else {
           if (CAN_SPLIT && WK > 1) { // the waves of a block split the chunk (small tiles: no operand pipelining)
-            for (int s = wk; s < 8; s += WK) {
+            for (int s = wk; s < NS; s += WK) {
               v2f_t x[MB], w[NB];
 #pragma unroll
               for (int a = 0; a < MB; ++a) x[a] = lds_read8(xa + (unsigned)s * ROW2 + (unsigned)a * 256u);
@@ -345,8 +349,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
           };
           load_ops(0, X[0], Wr[0]);
 #pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            if (s + 1 < 8) load_ops(s + 1, X[(s + 1) & 1], Wr[(s + 1) & 1]);
+          for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) load_ops(s + 1, X[(s + 1) & 1], Wr[(s + 1) & 1]);
             // (left alone, the scheduler sinks these reads to just above their first use and waits for them there:
             //  every step then exposes an LDS round trip; pinned here they fly under this step's MFMAs)
             __builtin_amdgcn_sched_barrier(0);

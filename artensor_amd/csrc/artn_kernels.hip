@@ -2023,6 +2023,19 @@ static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, v
     return hipErrorInvalidValue;
   }
   const int key = g.mb_log2 * 4 + g.nb_log2;
+  if (g.kc == ARTN_GEMM_KC_TALL && !g.split) { // 32 x 32 tiles, chunks of 2^6 contracted values
+    if (key != 0) return hipErrorInvalidValue;
+    if (g.m3) {
+      auto kern = artn_k_gemm<1, 1, false, true, true>;
+      if (hipError_t e = ensure_lds<artn_k_gemm<1, 1, false, true, true>>(lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);
+    } else {
+      auto kern = artn_k_gemm<1, 1, false, false, true>;
+      if (hipError_t e = ensure_lds<artn_k_gemm<1, 1, false, false, true>>(lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);
+    }
+    return hipGetLastError();
+  }
   if (g.m3) {
     switch (key) {
       case 0: ARTN_GEMM_LAUNCH_M3(1, 1)

@@ -112,6 +112,8 @@ struct ArtnGenericPlan {
 // (7+ contracted bits; big x big steps of sliced circuits and random networks).
 #define ARTN_GEMM_MAX_KO 40
 #define ARTN_GEMM_KC 4           /* contracted bits per LDS chunk */
+#define ARTN_GEMM_KC_TALL 6      /* ... of a 32 x 32 tile (image rows 2^5 elements apart) */
+#define ARTN_GEMM_PITCH_TALL_LOG2 5
 #define ARTN_GEMM_FLUSH_LOG2 12   /* fp32: partial sums leave the registers every 2^12 contracted values */
 #define ARTN_GEMM_EPI_BITS 13    /* the result tile leaves in passes of 2^13 elements (64 KiB) */
 #define ARTN_GEMM_PITCH_LOG2 7   /* rows of both LDS images are 2^7 elements apart whatever mt / nt: every
@@ -140,7 +142,8 @@ struct ArtnGemmPlan {
   int32_t swz_n, swz_src[4], swz_dst[4]; // XOR swizzle of the LDS result image (as ArtnStage::swz_*)
   int32_t wk_log2;           // tiles with fewer than 4 MFMA blocks: 2^wk_log2 waves share a block and split each chunk's
                              // contracted values between them (partial blocks are added up in the LDS result image)
-  int32_t pad1_[2];
+  int32_t pitch_log2;        // rows of the fp32 operand images are 2^pitch_log2 elements apart: 7, or 5 with kc = 6 (32 x 32 tiles)
+  int32_t pad1_[1];
   ArtnOuterDim outer[ARTN_MAX_OUTER];
   // (unused by this kernel; present so tile_offsets<> compiles for both plan types)
   int32_t gather_dim;
@@ -175,6 +178,7 @@ struct Tuning {
   int nt = 1;         // non-temporal loads of A tiles that are read once
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
   int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
+  int gemm_tall = 1;  // GEMM kernel, fp32, 32 x 32 tiles: chunks of 2^6 contracted values
   int bits_3m = 2;    // state-streaming kernel, fp32 stages with 5/6 contracted bits and 32+ columns: the same
                       // (1: not in fused pairs that hold a 6-bit stage, 0: never)
 };
@@ -189,6 +193,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_NT")) x.nt = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
     return x;
@@ -731,7 +736,8 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   }
   const int k = (int)K.size();
   const bool bf16 = d->dtype == ARTN_C64_BF16;
-  const int kc = bf16 ? ARTN_GEMM_KC + 1 : ARTN_GEMM_KC; // bf16 MFMAs take 8 contracted values each: chunks of 32
+  int kc = bf16 ? ARTN_GEMM_KC + 1 : ARTN_GEMM_KC; // bf16 MFMAs take 8 contracted values each: chunks of 32
+  int pitch = ARTN_GEMM_PITCH_LOG2;
   if (k < kc) { p.why_generic = "fewer contracted bits than one LDS chunk of the GEMM kernel"; return false; }
   if (k - kc > ARTN_GEMM_MAX_KO) { p.why_generic = "too many contracted bits"; return false; }
   if (only_if_preferred) {
@@ -809,6 +815,13 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
     else if (mt > 5 && mt > (int)Mf.size()) --mt;
     else break;
   }
+  // tiles of one 32 x 32 block (closing steps: two big tensors down to a few amplitudes, 2^16 contracted values per
+  // tile): the same 16 KiB images hold 2^6 contracted values of 2^5 rows instead of 2^4 of 2^7 -- a quarter of the
+  // chunk iterations, each of them a latency chain (loads one chunk ahead), for the same bytes
+  if (!bf16 && mt <= 5 && nt <= 5 && k >= ARTN_GEMM_KC_TALL && (int)Kf.size() <= ARTN_GEMM_KC_TALL && tuning().gemm_tall) {
+    kc = ARTN_GEMM_KC_TALL;
+    pitch = ARTN_GEMM_PITCH_TALL_LOG2;
+  }
   std::vector<int> Kc(Kf), Mt(Mf), Nt(Nf);
   for (int i : K) { if ((int)Kc.size() >= kc) break; if (!in_set(Kc, i)) Kc.push_back(i); }
   for (int i : M) { if ((int)Mt.size() >= mt) break; if (!in_set(Mt, i)) Mt.push_back(i); }
@@ -819,6 +832,7 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   ArtnGemmPlan &g = p.gemm;
   memset(&g, 0, sizeof(g));
   g.mt = mt; g.nt = nt; g.kc = kc; g.n_ko = k - kc; g.swapped = swapped ? 1 : 0;
+  g.pitch_log2 = pitch;
   g.split = bf16 ? 1 : 0;
   g.gather_dim = -1;
   // ---- waves: blocks per wave from the allowed instantiations (1,1) (1,2) (2,2) (1,4) (2,4); 3M: (1,1) (1,2) (2,1)
@@ -866,7 +880,7 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   g.ta_bits = mt + kc; g.tb_bits = nt + kc; g.tc_bits = mt + nt;
   // byte offset of (row bit i | chunk bit q) in an image: fp32 [kc][128 rows] x 8 B; bf16 [kc >> 2][128 rows][kc & 3] x 4 B
   auto lds_row = [&](int i) { return bf16 ? 16 << i : 8 << i; };
-  auto lds_kc = [&](int q) { return bf16 ? (q < 2 ? 4 << q : (16 << ARTN_GEMM_PITCH_LOG2) << (q - 2)) : (8 << ARTN_GEMM_PITCH_LOG2) << q; };
+  auto lds_kc = [&](int q) { return bf16 ? (q < 2 ? 4 << q : (16 << ARTN_GEMM_PITCH_LOG2) << (q - 2)) : (8 << pitch) << q; };
   for (int b = 0; b < g.ta_bits; ++b) {
     g.a_stride[b] = ax[tA[b]].sA;
     g.a_lds[b] = in_set(Mt, tA[b]) ? lds_row(pos(Mt, tA[b])) : lds_kc(pos(Kc, tA[b]));

@@ -188,9 +188,10 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
   const cf *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
   const int mt = P.mt, nt = P.nt, MB = 1 << P.mb_log2, NB = 1 << P.nb_log2;
   const int epi_bits = std::min(P.tc_bits, ARTN_GEMM_EPI_BITS);
-  const int PL = ARTN_GEMM_PITCH_LOG2;
+  const int PL = P.split ? ARTN_GEMM_PITCH_LOG2 : P.pitch_log2; // (fp32: 7, or 5 for the tall chunks of 32 x 32 tiles)
+  const int NS = P.split ? 8 : 1 << (P.kc - 1);                 // fp32 MFMA steps per chunk
   const int EB = P.split ? 4 : 8; // bytes per image element (bf16 pairs / fp32 pairs)
-  std::vector<cf> imgA((size_t)(16 << PL) * 8 / EB), imgB((size_t)(16 << PL) * 8 / EB), res((size_t)1 << epi_bits);
+  std::vector<cf> imgA((size_t)(16 << ARTN_GEMM_PITCH_LOG2) * 8 / EB), imgB((size_t)(16 << ARTN_GEMM_PITCH_LOG2) * 8 / EB), res((size_t)1 << epi_bits);
   const int n_chunks = 1 << P.n_ko;
   for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
     int64_t r = tile, offA = 0, offB = 0, offC = 0;
@@ -258,7 +259,7 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
       }
     }
     };
-    const int flush_mask = P.split ? 0x7fffffff : (1 << (ARTN_GEMM_FLUSH_LOG2 - ARTN_GEMM_KC)) - 1;
+    const int flush_mask = P.split ? 0x7fffffff : (1 << (ARTN_GEMM_FLUSH_LOG2 - P.kc)) - 1;
     int64_t ka = 0, kb = 0;
     for (int c = 0; c < n_chunks; ++c) {
       if (c > 0) { // Gray code step from chunk c-1 to chunk c
@@ -292,7 +293,7 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
         const int wn = wave & ((1 << P.wn_log2) - 1), wm = (wave >> P.wn_log2) & ((1 << P.wm_log2) - 1);
         const int wk = wave >> (P.wn_log2 + P.wm_log2), WK = 1 << P.wk_log2; // waves sharing a block split the chunk
         if (P.m3) { // three real products: T1 = A_re B_re, T2 = A_im B_im, T3 = (A_re + A_im)(B_re + B_im); rows = 32 columns n
-          for (int s = wk; s < 8; s += WK)
+          for (int s = wk; s < NS; s += WK)
             for (int a = 0; a < MB; ++a)
               for (int b = 0; b < NB; ++b)
                 for (int lane = 0; lane < 64; ++lane)
@@ -329,7 +330,7 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
                   }
           continue;
         }
-        for (int s = wk; s < 8; s += WK)
+        for (int s = wk; s < NS; s += WK)
           for (int a = 0; a < MB; ++a)
             for (int b = 0; b < NB; ++b) {
               float W0[64], W1[64], ax[64], ay[64];

@@ -271,7 +271,8 @@ def _einsum128(eq, a, b):
 
 @pytest.mark.parametrize("m3", [0, 1])
 @pytest.mark.parametrize("m,n,k,batch", [(7, 7, 4, 0), (7, 7, 6, 0), (8, 7, 5, 0), (9, 3, 8, 0), (6, 6, 4, 3), (5, 4, 9, 0),
-                                         (10, 0, 5, 0), (3, 9, 6, 0), (7, 5, 7, 2), (6, 7, 5, 0), (8, 2, 10, 0), (5, 3, 13, 0)])
+                                         (10, 0, 5, 0), (3, 9, 6, 0), (7, 5, 7, 2), (6, 7, 5, 0), (8, 2, 10, 0), (5, 3, 13, 0),
+                                         (5, 5, 8, 0), (5, 5, 13, 2)])   # (one 32 x 32 block: chunks of 2^6 contracted values)
 def test_gemm_plan_emulated(monkeypatch, m, n, k, batch, m3):
     """The two-operand GEMM kernel replayed thread by thread from its plan (global -> LDS images, MFMA
     lane maps, Gray-code walk over the looped contracted bits, C-ordered swizzled result image in one
