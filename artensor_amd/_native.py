@@ -11,6 +11,7 @@ import threading
 
 import torch
 
+ABI_VERSION = 3
 ARTN_MAX_LABELS = 96
 ARTN_PROGRAM_MAX_EXT = 256
 ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
@@ -84,6 +85,9 @@ _EXPORTS = {
     "artn_axpy_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "artn_sum_axis_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_void_p]),
+    "artn_axpy_c128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "artn_sum_axis_c128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_int64, ctypes.c_void_p]),
     "artn_absmax_normalize_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                  ctypes.c_void_p]),
 }
@@ -115,7 +119,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.artn_abi_version() != 2:
+        if handle.artn_abi_version() != ABI_VERSION:
             raise RuntimeError("libartn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -210,7 +210,7 @@ def _one_scalar(dtype, device):
     return t
 
 
-def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None):
+def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None, dtype=torch.complex64):
     """Contracted labels to turn into a temporary batch label (split-K with the partial results in
     HBM, summed afterwards), or None.
 
@@ -240,7 +240,7 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None
     if b_shape is not None:
         d, out_shape = _descriptor(tuple(la), tuple(lb), tuple(lo), tuple(a_shape), tuple(a_stride), tuple(b_shape),
                                    tuple(b_stride if b_stride is not None else _dense_strides(tuple(b_shape))),
-                                   torch.complex64)
+                                   dtype)
         info = _step_info_cached(d)
         if info["kernel"] == N.KERNEL_GEMM_MFMA:
             want = 0   # bits to split off for parallelism
@@ -272,15 +272,15 @@ def sum_leading(part, n_rows, out=None):
     with torch.cuda.device(part.device):
         stream = N.current_stream_ptr(part.device)
         groups = 1
-        col_tiles = (n_cols // 2 + 63) // 64
+        col_tiles = (n_cols // per16 + 63) // 64
         while groups * col_tiles < 2048 and n_rows % (groups * 2) == 0 and n_rows // (groups * 2) >= 16:
             groups *= 2
         if groups > 1:
             tmp = torch.empty(groups * n_cols, dtype=part.dtype, device=part.device)
-            N.check(lib.artn_sum_axis_c64(part.data_ptr(), tmp.data_ptr(), groups, n_rows // groups, n_cols, stream))
-            N.check(lib.artn_sum_axis_c64(tmp.data_ptr(), out.data_ptr(), 1, groups, n_cols, stream))
+            N.check(sum_axis(part.data_ptr(), tmp.data_ptr(), groups, n_rows // groups, n_cols, stream))
+            N.check(sum_axis(tmp.data_ptr(), out.data_ptr(), 1, groups, n_cols, stream))
         else:
-            N.check(lib.artn_sum_axis_c64(part.data_ptr(), out.data_ptr(), 1, n_rows, n_cols, stream))
+            N.check(sum_axis(part.data_ptr(), out.data_ptr(), 1, n_rows, n_cols, stream))
     if dst is not None and dst is not out:
         dst.copy_(out.reshape(dst.shape))
         return dst
@@ -288,8 +288,9 @@ def sum_leading(part, n_rows, out=None):
 
 
 def _sum_leading_ok(t, n_rows):
-    return (t.dtype == torch.complex64 and t.is_contiguous() and n_rows > 1 and t.numel() % n_rows == 0
-            and (t.numel() // n_rows) % 2 == 0 and t.data_ptr() % 16 == 0)
+    if not (t.is_contiguous() and n_rows > 1 and t.numel() % n_rows == 0 and t.data_ptr() % 16 == 0):
+        return False
+    return t.dtype == torch.complex128 or (t.dtype == torch.complex64 and (t.numel() // n_rows) % 2 == 0)
 
 
 def _split_big_k(la, lb, lo, a, b):
@@ -297,9 +298,9 @@ def _split_big_k(la, lb, lo, a, b):
     15 bonds at once): keep the slowest-varying contracted labels as a temporary batch label,
     run the MFMA kernel per value, then sum that label out -- split-K with the partial results
     in HBM.  Returns None when the step does not need / allow it."""
-    if a.dtype != torch.complex64:
+    if a.dtype not in _DTYPES:
         return None
-    outer = _big_k_outer(la, lb, lo, tuple(a.shape), tuple(a.stride()), tuple(b.shape), tuple(b.stride()))
+    outer = _big_k_outer(la, lb, lo, tuple(a.shape), tuple(a.stride()), tuple(b.shape), tuple(b.stride()), a.dtype)
     if not outer:
         return None
     mid = tuple(outer) + tuple(lo)
@@ -656,9 +657,8 @@ def _plan_small_program(scheme, shapes, dtype):
         keep = [1] * len(keep)
     rc = lib.artn_program_build(len(descs), arr, i64(la_), i64(lb_), i64(lc_), (ctypes.c_uint8 * len(keep))(*keep), n_groups,
                                 (ctypes.c_int32 * len(group_start))(*group_start), image.data_ptr(), image_bytes)
-    if rc == -2:
+    if rc != 0:   # no program: every step runs as its own launch (what a scheme did before programs existed)
         return None, every
-    N.check(rc)
     prog = _Program()
     prog.host_image, prog.host_groups = image, torch.tensor(group_start, dtype=torch.int32)
     prog.n_groups, prog.n_steps, prog.ext_ids, prog.ws_bytes = n_groups, len(small_sorted), ext_ids, max(ws, 16)
@@ -720,7 +720,7 @@ def _compile_dense(scheme, shapes, dtype):
     def single(n):
         (i, j), eq = scheme[n][0], scheme[n][1]
         la, lb, lo = _labels(eq)
-        outer = _big_k_outer(la, lb, lo, shapes[i], None, shapes[j]) if dtype == torch.complex64 else None
+        outer = _big_k_outer(la, lb, lo, shapes[i], None, shapes[j], None, dtype)
         if outer:
             # more contracted bits than one LDS tile holds (big x big steps of random networks):
             # split-K through a temporary batch label, then sum it out (see _split_big_k)

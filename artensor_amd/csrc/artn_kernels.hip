@@ -2068,36 +2068,36 @@ static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, v
 // out[g][c] = sum_r in[g][r][c] over float4 columns (two complex64 each): the sum-out that closes a
 // split-K contraction.  256 threads = 64 columns x 4 row lanes; the lanes' partial sums are added in
 // a fixed order, so results do not depend on the launch shape.
-__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_sum_axis4(const float4 *__restrict__ in, float4 *__restrict__ out,
-                                                                   long n_rows, long n_cols4, long col_tiles) {
-  __shared__ float4 part[4][64];
+template <typename V>
+__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_sum_axis(const V *__restrict__ in, V *__restrict__ out,
+                                                                  long n_rows, long n_cols4, long col_tiles) {
+  __shared__ V part[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long g = blockIdx.x / col_tiles, ct = blockIdx.x % col_tiles;
   const long c = ct * 64 + tx;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  V acc = V(0);
   if (c < n_cols4) {
-    const float4 *p = in + (g * n_rows) * n_cols4 + c;
+    const V *p = in + (g * n_rows) * n_cols4 + c;
     long r = ty;
     for (; r + 12 < n_rows; r += 16) { // four independent loads in flight per thread
-      const float4 v0 = p[r * n_cols4], v1 = p[(r + 4) * n_cols4], v2 = p[(r + 8) * n_cols4], v3 = p[(r + 12) * n_cols4];
-      acc.x += (v0.x + v1.x) + (v2.x + v3.x);
-      acc.y += (v0.y + v1.y) + (v2.y + v3.y);
-      acc.z += (v0.z + v1.z) + (v2.z + v3.z);
-      acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+      const V v0 = p[r * n_cols4], v1 = p[(r + 4) * n_cols4], v2 = p[(r + 8) * n_cols4], v3 = p[(r + 12) * n_cols4];
+      acc += (v0 + v1) + (v2 + v3);
     }
-    for (; r < n_rows; r += 4) {
-      const float4 v = p[r * n_cols4];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
+    for (; r < n_rows; r += 4) acc += p[r * n_cols4];
   }
   part[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && c < n_cols4) {
-    float4 t = part[0][tx];
+    V t = part[0][tx];
 #pragma unroll
-    for (int q = 1; q < 4; ++q) { t.x += part[q][tx].x; t.y += part[q][tx].y; t.z += part[q][tx].z; t.w += part[q][tx].w; }
+    for (int q = 1; q < 4; ++q) t += part[q][tx];
     out[g * n_cols4 + c] = t;
   }
+}
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <typename V>
+__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_axpy_v(V *__restrict__ acc, const V *__restrict__ x, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc[i] += x[i];
 }
 
 extern "C" {
@@ -2246,7 +2246,9 @@ int64_t artn_program_image_bytes(int32_t n_steps, const ArtnStepDesc *const *des
   for (int s = 0; s < n_steps; ++s) {
     double f, na, nb, nc;
     artn::step_cost(descs[s], f, na, nb, nc);
-    wt += (int64_t)((nc + 63.0) / 64.0) + 1;
+    // wave tasks per step as artn_program_build cuts them: ceil(out / 128) for a general step, 2^(m bits - 5) *
+    // max(1, 2^(n bits - 4)) blocks for a matrix-core step -- out / 32 when the second operand is fully contracted
+    wt += (int64_t)((nc + 31.0) / 32.0) + 1;
     ArtnPlan p;
     std::string err;
     if (artn::validate(descs[s], err) || !artn::make_generic(descs[s], p, err)) return -1;
@@ -2589,8 +2591,34 @@ int artn_sum_axis_c64(const void *in, void *out, int64_t n_groups, int64_t n_row
     return fail(ARTN_E_UNSUPPORTED, "artn_sum_axis_c64 needs an even column count and 16-byte aligned buffers");
   const long n4 = n_cols / 2, col_tiles = (n4 + 63) / 64;
   if (n_groups * col_tiles > (1L << 30)) return fail(ARTN_E_UNSUPPORTED, "too many workgroups");
-  hipLaunchKernelGGL(artn_k_sum_axis4, dim3((unsigned)(n_groups * col_tiles)), dim3(ARTN_WG_THREADS), 0, (hipStream_t)stream,
-                     (const float4 *)in, (float4 *)out, (long)n_rows, n4, col_tiles);
+  hipLaunchKernelGGL(artn_k_sum_axis<f32x4>, dim3((unsigned)(n_groups * col_tiles)), dim3(ARTN_WG_THREADS), 0, (hipStream_t)stream,
+                     (const f32x4 *)in, (f32x4 *)out, (long)n_rows, n4, col_tiles);
+  HIP_TRY(hipGetLastError());
+  return ARTN_OK;
+}
+
+int artn_sum_axis_c128(const void *in, void *out, int64_t n_groups, int64_t n_rows, int64_t n_cols, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (n_groups < 0 || n_rows < 1 || n_cols < 0) return fail(ARTN_E_INVALID, "bad extent");
+  if (n_groups == 0 || n_cols == 0) return ARTN_OK;
+  if (!in || !out) return fail(ARTN_E_INVALID, "null pointer");
+  if ((((uintptr_t)in | (uintptr_t)out) & 15) != 0) return fail(ARTN_E_UNSUPPORTED, "artn_sum_axis_c128 needs 16-byte aligned buffers");
+  const long col_tiles = (n_cols + 63) / 64;
+  if (n_groups * col_tiles > (1L << 30)) return fail(ARTN_E_UNSUPPORTED, "too many workgroups");
+  hipLaunchKernelGGL(artn_k_sum_axis<f64x2>, dim3((unsigned)(n_groups * col_tiles)), dim3(ARTN_WG_THREADS), 0, (hipStream_t)stream,
+                     (const f64x2 *)in, (f64x2 *)out, (long)n_rows, (long)n_cols, col_tiles);
+  HIP_TRY(hipGetLastError());
+  return ARTN_OK;
+}
+
+int artn_axpy_c128(void *acc, const void *x, int64_t n, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (n < 0) return fail(ARTN_E_INVALID, "negative length");
+  if (n == 0) return ARTN_OK;
+  if (!acc || !x) return fail(ARTN_E_INVALID, "null pointer");
+  if ((((uintptr_t)acc | (uintptr_t)x) & 15) != 0) return fail(ARTN_E_UNSUPPORTED, "artn_axpy_c128 needs 16-byte aligned buffers");
+  const int grid = (int)std::min<long>((n + ARTN_WG_THREADS - 1) / ARTN_WG_THREADS, 256L * 8);
+  hipLaunchKernelGGL(artn_k_axpy_v<f64x2>, dim3(grid), dim3(ARTN_WG_THREADS), 0, (hipStream_t)stream, (f64x2 *)acc, (const f64x2 *)x, (long)n);
   HIP_TRY(hipGetLastError());
   return ARTN_OK;
 }

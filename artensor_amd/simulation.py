@@ -67,14 +67,14 @@ def accumulate(acc, x):
     """acc += x through artn_axpy_c64 (reference simulation.py:114 `collect_tensor += ...`)."""
     N.require_gpu(acc, "accumulate")
     N.require_gpu(x, "accumulate")
-    if acc.shape != x.shape or acc.dtype != torch.complex64 or x.dtype != torch.complex64:
-        raise RuntimeError(f"accumulate needs equal-shape complex64 tensors, got {acc.shape} {acc.dtype} / {x.shape} {x.dtype}")
+    if acc.shape != x.shape or acc.dtype != x.dtype or acc.dtype not in (torch.complex64, torch.complex128):
+        raise RuntimeError(f"accumulate needs equal-shape complex64 (or complex128) tensors, got {acc.shape} {acc.dtype} / {x.shape} {x.dtype}")
     if not acc.is_contiguous():
         raise RuntimeError("accumulator must be contiguous")
     x = x.contiguous()
+    axpy = N.lib().artn_axpy_c64 if acc.dtype == torch.complex64 else N.lib().artn_axpy_c128
     with torch.cuda.device(acc.device):
-        N.check(N.lib().artn_axpy_c64(acc.data_ptr(), x.data_ptr(), acc.numel(),
-                                      N.current_stream_ptr(acc.device)))
+        N.check(axpy(acc.data_ptr(), x.data_ptr(), acc.numel(), N.current_stream_ptr(acc.device)))
     return acc
 
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ARTN_ABI_VERSION 2
+#define ARTN_ABI_VERSION 3
 #define ARTN_MAX_LABELS 96
 
 /* error codes */
@@ -173,6 +173,8 @@ int artn_program_run(const void *dev_image, int32_t n_groups, const void *const 
 /* acc[i] += x[i], i < n complex64 elements: the slice accumulation
  * `collect_tensor += ...` of artensor/simulation.py:114 and :210. */
 int artn_axpy_c64(void *acc, const void *x, int64_t n, void *stream);
+/* the same for complex128 (the reference's slice loop takes any dtype, artensor/simulation.py:90, :101) */
+int artn_axpy_c128(void *acc, const void *x, int64_t n, void *stream);
 
 /* out[g][c] = sum_r in[g][r][c] for complex64 arrays in[n_groups][n_rows][n_cols] (n_cols even,
  * 16-byte aligned): sums out the leading label(s) of a dense tensor.  Closes a contraction whose
@@ -180,6 +182,8 @@ int artn_axpy_c64(void *acc, const void *x, int64_t n, void *stream);
  * number of labels in one call; here the slowest ones become a batch label of artn_contract and are
  * summed afterwards.  Applied twice (n_rows = R * n_rows') it is a two-pass tree sum. */
 int artn_sum_axis_c64(const void *in, void *out, int64_t n_groups, int64_t n_rows, int64_t n_cols, void *stream);
+/* the same for complex128 arrays (any n_cols; 16-byte aligned) */
+int artn_sum_axis_c128(const void *in, void *out, int64_t n_groups, int64_t n_rows, int64_t n_cols, void *stream);
 
 /* out[0] = max_i |x[i]| over n complex64 elements (float32, device pointer), then
  * x[i] /= out[0]: the running renormalisation of artensor/contraction.py:197-200

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert names == N.exported_symbols()
     for name in names:
         assert hasattr(lib, name), name
-    assert lib.artn_abi_version() == 2
+    assert lib.artn_abi_version() == N.ABI_VERSION
     assert lib.artn_device_count() >= 0
 
 

@@ -176,3 +176,36 @@ def test_small_step_program_image_emulated(name, limit, monkeypatch):
         # 19 levels for 68 steps; the 15 steps of the stem (a 2^12-element tensor absorbing one small tensor each,
         # and a few 2^10-element ones before it) are matrix-core steps; only the final result goes to the workspace
         assert stats["levels"] == 19 and stats["fast"] >= 15 and stats["to_ws"] == 1
+
+
+@pytest.mark.parametrize("mb,kb,extra", [(12, 2, 3), (9, 1, 3), (11, 3, 20), (12, 2, 60), (8, 3, 4)])
+def test_small_step_program_with_fully_contracted_second_operand(mb, kb, extra):
+    """A matrix-core step whose second operand is contracted away entirely ('abcdefghijkl,kl->abcdefghij') is cut
+    into out/32 wave tasks -- more than artn_program_image_bytes once allowed for (such schemes raised out of
+    tensor_contraction).  The image must build and, run by the CPU emulator, give the scheme's result."""
+    from artensor_amd import contraction as C
+    from helpers import emulate_program
+    rng = np.random.default_rng(mb * 100 + kb)
+    c = lambda shape: (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    la = list(range(mb))
+    leaves = {0: c((2,) * mb), 1: c((2,) * kb)}
+    out = la[:mb - kb]
+    scheme = [((0, 1), (tuple(la), tuple(la[mb - kb:]), tuple(out)))]
+    for q in range(extra):   # tiny steps (a 2 x 2 matrix on one label each) so that the scheme is worth a program
+        leaves[2 + q] = c((2, 2))
+        old, new = out[q % len(out)], 100 + q
+        nxt = [new if x == old else x for x in out]
+        scheme.append(((0, 2 + q), (tuple(out), (old, new), tuple(nxt))))
+        out = nxt
+    shapes = {k: v.shape for k, v in leaves.items()}
+    prog, main = C._plan_small_program(scheme, shapes, torch.complex64)
+    assert prog is not None and main == []
+    ws, stats = emulate_program(prog, leaves)
+    cur = {k: v.astype(np.complex128) for k, v in leaves.items()}
+    for (i, j), (a, b, o) in scheme:   # (label tuples: numpy's sublist einsum takes labels < 52)
+        m = {x: n for n, x in enumerate(dict.fromkeys(a + b))}
+        cur[i] = np.einsum(cur[i], [m[x] for x in a], cur[j], [m[x] for x in b], [m[x] for x in o])
+    want = cur[0].reshape(-1)
+    (off, shape), = [v for t, v in prog.outputs.items() if t == 0]
+    got = ws[off // 8: off // 8 + want.size]
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
