@@ -51,7 +51,8 @@ class ArtnStepInfo(ctypes.Structure):
         ("k2_bits", ctypes.c_int32),
         ("n2_tile_bits", ctypes.c_int32),
         ("tile_mid_bits", ctypes.c_int32),
-        ("reserved_", ctypes.c_int32),
+        ("arith", ctypes.c_int32),
+        ("mfma_flops", ctypes.c_double),
     ]
 
 

@@ -263,9 +263,12 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None
 def sum_leading(part, n_rows, out=None):
     """out[c] = sum_r part.reshape(n_rows, -1)[r, c] through artn_sum_axis_c64, as a two-pass tree
     when there are many rows (the first pass keeps every CU busy, the order of additions is
-    fixed).  `part` must be a contiguous complex64 GPU tensor with an even number of columns."""
+    fixed).  `part` must be a contiguous complex64 GPU tensor with an even number of columns, or a
+    complex128 one (artn_sum_axis_c128)."""
     n_cols = part.numel() // n_rows
     lib = N.lib()
+    sum_axis = lib.artn_sum_axis_c64 if part.dtype == torch.complex64 else lib.artn_sum_axis_c128
+    per16 = 2 if part.dtype == torch.complex64 else 1   # elements per 16-byte lane
     dst = out
     if out is None or not out.is_contiguous() or out.data_ptr() % 16 or out.numel() != n_cols:
         out = torch.empty(n_cols, dtype=part.dtype, device=part.device)

@@ -1197,6 +1197,18 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   double na, nb, nc;
   step_cost(d, p.info.flops, na, nb, nc);
   p.info.bytes = (d->dtype == ARTN_C128 ? 16.0 : 8.0) * (na + nb + nc);
+  // what the matrix pipe executes (3M: three real products per complex product) and in which arithmetic
+  if (p.kernel == ARTN_KERNEL_BITS_MFMA) {
+    const bool m3 = p.bits.st[0].m3 != 0;
+    p.info.arith = p.bits.split == 1 ? 2 : (m3 ? 1 : 0);
+    p.info.mfma_flops = p.info.flops * (m3 ? 0.75 : 1.0);
+  } else if (p.kernel == ARTN_KERNEL_GEMM_MFMA) {
+    p.info.arith = d->dtype == ARTN_C128 ? 3 : (p.gemm.split == 1 ? 2 : (p.gemm.m3 ? 1 : 0));
+    p.info.mfma_flops = p.info.flops * (p.gemm.m3 ? 0.75 : 1.0);
+  } else {
+    p.info.arith = -1;
+    p.info.mfma_flops = 0.0;
+  }
   return ARTN_OK;
 }
 
@@ -1215,6 +1227,8 @@ static inline int make_plan_fused(const ArtnStepDesc *d1, const ArtnStepDesc *d2
   step_cost(d2, f2, a2, b2, c2);
   p.info.flops = f1 + f2;
   p.info.bytes = 8.0 * (a1 + b1 + b2 + c2); // the intermediate C1 never touches HBM
+  p.info.arith = p.bits.split == 1 ? 2 : ((p.bits.st[0].m3 || p.bits.st[1].m3) ? 1 : 0);
+  p.info.mfma_flops = f1 * (p.bits.st[0].m3 ? 0.75 : 1.0) + f2 * (p.bits.st[1].m3 ? 0.75 : 1.0);
   return ARTN_OK;
 }
 

@@ -84,7 +84,9 @@ typedef struct ArtnStepInfo {
   int32_t k2_bits;      /* fused pair: contracted bits of the second step (else 0) */
   int32_t n2_tile_bits; /* fused pair: free B2 bits inside a tile                  */
   int32_t tile_mid_bits;/* log2 elements of the tile between the two stages        */
-  int32_t reserved_;
+  int32_t arith;        /* 0 fp32 MFMA 4M, 1 fp32 MFMA with 3M stages, 2 bf16 operands, 3 f64 MFMA, -1 no MFMA */
+  double mfma_flops;    /* real FLOP the matrix pipe executes: `flops` with 6 instead of 8 per complex
+                           multiply-add in every 3M stage (0 for the strided kernel)     */
 } ArtnStepInfo;
 
 int artn_abi_version(void);

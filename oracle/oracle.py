@@ -217,3 +217,67 @@ def tensor_contraction_torch_cpu(tensors, scheme, budget_s=None, threads=None):
     whole = done_n == len(scheme)
     return dict(result=ts[scheme[-1][0][0]] if whole else None, steps_done=done_n, flops_done=done_f,
                 flops_total=float(sum(per_step)), seconds=dt, threads=torch.get_num_threads())
+
+
+def tensor_contraction_sparse_torch_cpu(tensors, scheme, budget_s=None, threads=None):
+    """The reference's sparse-state executor as it runs on a CPU (/root/reference/artensor/contraction.py:132-205,
+    restated branch by branch on torch-CPU tensors: chunk loop with row gathers and torch.cat :140-175, gathered
+    batched einsum :176-179, einsum + reshape + optional row select :180-188, plain einsum :189-191).  CPU baseline
+    of bench.py's sparse and sliced workloads; nothing else calls it.  budget_s / return value as
+    tensor_contraction_torch_cpu (FLOP of a step = 8 * product of the extents of every label of its einsum, summed
+    over the chunks of a chunked step)."""
+    import time
+    import torch
+    if threads:
+        torch.set_num_threads(int(threads))
+    ts = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in
+          (tensors.items() if isinstance(tensors, dict) else enumerate(tensors))}
+
+    def flops_of(eq, a, b):
+        la, lb, _ = parse_eq(eq)
+        ext = dict(zip(la, a.shape))
+        ext.update(zip(lb, b.shape))
+        f = 8.0
+        for x in ext.values():
+            f *= x
+        return f
+
+    done_f, done_n = 0.0, 0
+    t0 = time.perf_counter()
+    for n, step in enumerate(scheme):
+        i, j = step[0]
+        eq = step[1]
+        batch_i, batch_j = step[2]
+        if len(batch_i) > 1:
+            parts = []
+            for k in range(len(batch_i)):
+                a, b = ts[i][batch_i[k]], ts[j][batch_j[k]]
+                done_f += flops_of(eq, a, b)
+                r = torch.einsum(eq, a, b)
+                if step[3]:
+                    r = r.reshape(step[3])
+                parts.append(r)
+            ts[j] = []
+            ts[i] = torch.cat(parts, dim=0)
+        elif len(step) > 3 and len(batch_i) == len(batch_j) == 1:
+            ts[i] = ts[i][batch_i[0]]
+            ts[j] = ts[j][batch_j[0]]
+            done_f += flops_of(eq, ts[i], ts[j])
+            ts[i] = torch.einsum(eq, ts[i], ts[j])
+        elif len(step) > 3:
+            done_f += flops_of(eq, ts[i], ts[j])
+            ts[i] = torch.einsum(eq, ts[i], ts[j]).reshape(step[3])
+            if len(batch_i) == 1:
+                ts[i] = ts[i][batch_i[0]]
+            ts[j] = []
+        else:
+            done_f += flops_of(eq, ts[i], ts[j])
+            ts[i] = torch.einsum(eq, ts[i], ts[j])
+            ts[j] = []
+        done_n += 1
+        if budget_s is not None and time.perf_counter() - t0 > budget_s and n + 1 < len(scheme):
+            break
+    dt = time.perf_counter() - t0
+    whole = done_n == len(scheme)
+    return dict(result=ts[scheme[-1][0][0]] if whole else None, steps_done=done_n, flops_done=done_f,
+                flops_total=None, seconds=dt, threads=torch.get_num_threads())

@@ -114,7 +114,13 @@ def run_all(dtype, path, only=None):
             continue
         torch.cuda.synchronize()
         t0 = time.time()
-        res.update(fn(dtype))
+        try:
+            res.update(fn(dtype))
+        except Exception:   # keep what the other cases give; the report lists what is there
+            import traceback
+            traceback.print_exc()
+            print(f"{name}: FAILED", flush=True)
+            continue
         torch.cuda.synchronize()
         secs[name] = time.time() - t0
         print(f"{name}: {secs[name]:.1f} s", flush=True)
