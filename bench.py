@@ -37,13 +37,25 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (spec)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (spec, ~2.5 PF)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak (spec)
+KERNEL_NAMES = {0: "artn_k_generic", 1: "artn_k_bits", 2: "artn_k_gemm", 3: "artn_k_program"}
 LOOSE_TOL = 1e-5              # |got - want| <= tol * max(|want|, rms(want)) for every amplitude
-STRICT_TOL = 5e-4             # relative error per amplitude over |want| >= 1e-3 rms.  The reference's own
-#                               complex64 executor is 2.9e-5 (n12) / 1.2e-5 (n30, 100 amplitudes) from its complex128 run
-#                               under this metric (tests/golden/c128_spread.npz); over 10 000 amplitudes of a 2^30 state the
-#                               smallest checked ones sit near 1e-2 rms, where 1e-5 * rms absolute is 1e-3 relative
+STRICT_FACTOR = 2.0           # relative error per amplitude over |truth| >= 1e-3 rms, against the complex128 truth
+#                               of the same leaves and scheme (tests/golden/c128_truth_gpu.npz): allowed up to this many times
+#                               the distance of the reference's OWN complex64 run from that truth (n30: 5.4e-5)
 BF16_MIN_FIDELITY = 0.99
+
+
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) of the kernel sources: profiles/rNN_traffic.json records the sources its
+    counters were collected on (tools/summarize_profile.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("artn_kernels.hip", "artn_gemm_kernel.h", "artn_gemm128_kernel.h", "artn_plan.h"):
+        with open(os.path.join(ROOT, "artensor_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 class KernelTimes:
@@ -58,12 +70,47 @@ class KernelTimes:
     def summarize(self):
         out = {}
         for info, e0, e1 in self.rows:
-            d = out.setdefault(info["kernel"], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d = out.setdefault(info["kernel"], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, mfma_flops=0.0, bf16_flops=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += info["flops"]
             d["bytes"] += info["bytes"]
+            d["mfma_flops"] += info.get("mfma_flops", 0.0)
+            if info.get("arith") == 2:
+                d["bf16_flops"] += info["flops"]
         return out
+
+
+def roofline_of(ks, gpu_ms, launches_div=1):
+    """roofline block of a workload leg from per-launch HIP-event timings (KernelTimes.summarize()): the kernel
+    family that takes most of the GPU time, its nominal FLOP / its time against the MFMA peak of its arithmetic,
+    the FLOP the matrix pipe really executes (3M stages: 6 of the 8 counted per complex multiply-add), and its
+    algorithmic bytes / its time against the HBM peak; `bound` is whichever of the two the family's arithmetic
+    intensity puts it under."""
+    if not ks:
+        return None
+    kid = max(ks, key=lambda k: ks[k]["ms"])
+    d = ks[kid]
+    sec = d["ms"] * 1e-3
+    bf16 = d["bf16_flops"] > 0.5 * d["flops"]
+    peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+    tf = d["flops"] / sec / 1e12 if sec else 0.0
+    gbs = d["bytes"] / sec / 1e9 if sec else 0.0
+    ai = d["flops"] / d["bytes"] if d["bytes"] else float("inf")
+    ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    mfma_bound = ai >= ridge
+    r = {"bound": "mfma" if mfma_bound else "hbm", "kernel": KERNEL_NAMES.get(kid, str(kid)),
+         "achieved": tf if mfma_bound else gbs, "peak": peak if mfma_bound else HBM_PEAK_GBS,
+         "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": (tf / peak) if mfma_bound else gbs / HBM_PEAK_GBS,
+         "traffic": None, "arithmetic": "bf16 operands, fp32 accumulate" if bf16 else "fp32 MFMA",
+         "nominal_TFLOPs": tf, "mfma_peak_TFLOPs": peak, "mfma_frac_nominal": tf / peak,
+         "executed_mfma_flop_frac": d["mfma_flops"] / d["flops"] if d["flops"] else 0.0,
+         "mfma_frac_executed": d["mfma_flops"] / sec / 1e12 / peak if sec else 0.0,
+         "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+         "launches": d["launches"] / launches_div, "avg_launch_ms": d["ms"] / max(d["launches"], 1),
+         "kernel_ms": d["ms"] / launches_div, "share_of_gpu_time": d["ms"] / gpu_ms if gpu_ms else None,
+         "other_kernels_ms": {KERNEL_NAMES.get(k, str(k)): v["ms"] / launches_div for k, v in ks.items() if k != kid}}
+    return r
 
 
 def error_figures(got, want):
@@ -80,6 +127,38 @@ def error_figures(got, want):
 def fidelity_of(got, want):
     w, a = np.asarray(want, dtype=np.complex128).reshape(-1), np.asarray(got, dtype=np.complex128).reshape(-1)
     return float(abs(np.vdot(w, a)) ** 2 / (np.vdot(w, w).real * np.vdot(a, a).real))
+
+
+_truth = []
+
+
+def truth_value(key):
+    """complex128 value of a checked quantity, computed on the GPU by this package's complex128 path and committed
+    (tests/golden/make_c128_truth_gpu.py); None when the file or the key is absent."""
+    if not _truth:
+        path = os.path.join(ROOT, "tests", "golden", "c128_truth_gpu.npz")
+        _truth.append(np.load(path) if os.path.exists(path) else None)
+    z = _truth[0]
+    return z[key].reshape(-1) if z is not None and key in z.files else None
+
+
+def cpu_leg(case, sparse, sliced, budget_s, what):
+    """cpu_baseline of one secondary workload: the reference's executor as it runs on a CPU (torch-CPU einsum loop,
+    oracle.tensor_contraction[_sparse]_torch_cpu) on this box's host cores, the scheme's steps in order (slice 0 of
+    a sliced workload) until `budget_s` seconds have gone."""
+    from oracle import oracle
+    import artensor_amd as A
+    leaves = {k: t.clone() for k, t in case.tensors.items()}
+    if sliced and case.slicing_indices:
+        leaves = A.apply_slice(leaves, case.slicing_indices, A.slice_assignments(len(case.slicing_indices), 0))
+    fn = oracle.tensor_contraction_sparse_torch_cpu if sparse else oracle.tensor_contraction_torch_cpu
+    r = fn(leaves, case.scheme, budget_s=budget_s)
+    return {"value": r["flops_done"] / r["seconds"] / 1e12, "unit": "TFLOP/s", "cores": int(r["threads"]), "kind": "port",
+            "sample": (f"torch-CPU einsum loop over {what}, steps 0..{r['steps_done'] - 1} of {len(case.scheme)} in order"
+                       f"{' (the whole scheme)' if r['steps_done'] == len(case.scheme) else ''}: {r['flops_done']:.3e} FLOP "
+                       f"(8 x product of the extents of every label, per einsum) in {r['seconds']:.1f} s, "
+                       f"torch.set_num_threads({r['threads']}); budget {budget_s:.0f} s"),
+            "steps_done": r["steps_done"], "seconds": r["seconds"]}
 
 
 def cpu_baseline(case_n30, case_n12, budget_s=25.0):
@@ -123,7 +202,7 @@ SLICED_WORKLOADS = {
 }
 
 
-def run_sliced(A, name, dev, world, rank, dist, steps, warmup, per_step, precision):
+def run_sliced(A, name, dev, world, rank, dist, steps, warmup, per_step, precision, profile=False):
     """Slice-sharded workloads: every step each rank contracts `per_step` slices of its round-robin
     shard, in Gray-code order, and accumulates; ONE all-reduce of the accumulator over RCCL closes the
     timed region.  Weak scaling (slices per rank fixed).  Returns the result dict (on every rank)."""
@@ -145,7 +224,7 @@ def run_sliced(A, name, dev, world, rank, dist, steps, warmup, per_step, precisi
     if precision == "bf16":
         ok = (fid is None and loose < 3e-2) or (fid is not None and fid >= BF16_MIN_FIDELITY)
     else:
-        ok = loose <= 2 * LOOSE_TOL
+        ok = loose <= 2 * LOOSE_TOL   # (against the reference's complex64 value; the contract is checked against the truth below)
 
     def run(first, count):
         if n_b == 0:
@@ -178,7 +257,29 @@ def run_sliced(A, name, dev, world, rank, dist, steps, warmup, per_step, precisi
     dt = float(t.item())
     n_slices = world * steps * per_step
     value = n_slices * flops_slice / dt / 1e12
+    kernel_times = None
+    if profile:   # one more step with per-launch HIP events on the launch stream (outside the timed region)
+        from artensor_amd import contraction as C
+        prof = KernelTimes()
+        C.profiler = prof
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(base + steps * per_step, per_step)
+        e1.record()
+        torch.cuda.synchronize()
+        C.profiler = None
+        kernel_times = (prof.summarize(), e0.elapsed_time(e1))
+    truth = truth_value(fixture[:-4] + "_slice0")
+    vs_truth = None
+    if truth is not None:
+        tl, ts, _ = error_figures(got, truth)
+        rl, rs, _ = error_figures(want, truth)
+        vs_truth = {"hip_loose": tl, "hip_strict": ts, "reference_c64_loose": rl, "reference_c64_strict": rs,
+                    "truth": "complex128 on the GPU (tests/golden/c128_truth_gpu.npz)"}
+        if precision != "bf16":   # the contract: 1e-5 of the truth, or no farther from it than 2 x the reference's own complex64 run
+            ok = ok and (tl <= LOOSE_TOL or tl <= 2 * rl)
     return {
+        "kernel_times_": kernel_times, "vs_c128_truth": vs_truth, "case_": case,
         "workload": f"{what}, tests/golden/{fixture}", "value": value, "unit": "TFLOP/s",
         "ms_per_step": dt / steps * 1e3, "ms_per_slice_per_rank": dt / (steps * per_step) * 1e3,
         "slices_per_rank_per_step": per_step, "slices_timed": n_slices, "flops_per_slice": flops_slice,
@@ -191,9 +292,117 @@ def run_sliced(A, name, dev, world, rank, dist, steps, warmup, per_step, precisi
     }
 
 
+def strip_private(d):
+    return {k: v for k, v in d.items() if not k.endswith("_")}
+
+
+def leg_sparse_whole(A, dev, steps, precision):
+    """BASELINE configs[2]: Sycamore n30 m14 sparse-state, Google's 10 000 bitstrings, one MI355X: one step = one
+    tensor_contraction_sparse of the whole 180-step scheme (151 plain, 28 outer-product and 1 chunked step)."""
+    from artensor_amd import contraction as C
+    from artensor_amd.fixtures import load_case
+    fixture = "n30_sparse10000.npz"
+    case = load_case(os.path.join(ROOT, "tests", "golden", fixture))
+    leaves = case.fresh_tensors(device=dev)
+    flops = 8.0 * 10 ** case.meta["log10_tc"]
+    run = lambda: A.tensor_contraction_sparse(dict(leaves), case.scheme)
+    got = run().reshape(-1).cpu().numpy()
+    want = case.arrays["final"].reshape(-1)
+    loose, strict, _ = error_figures(got, want)
+    ok = loose <= LOOSE_TOL if precision != "bf16" else fidelity_of(got, want) >= BF16_MIN_FIDELITY
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = KernelTimes()
+    C.profiler = prof
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run()
+    e1.record()
+    torch.cuda.synchronize()
+    C.profiler = None
+    truth = truth_value("n30_sparse10000_final")
+    vs_truth = None
+    if truth is not None:
+        tl, ts, _ = error_figures(got, truth)
+        rl, rs, _ = error_figures(want, truth)
+        vs_truth = {"hip_loose": tl, "hip_strict": ts, "reference_c64_loose": rl, "reference_c64_strict": rs,
+                    "truth": "complex128 on the GPU (tests/golden/c128_truth_gpu.npz)"}
+        if precision != "bf16":
+            ok = ok and (tl <= LOOSE_TOL or tl <= 2 * rl)
+    return {"workload": f"Sycamore n30 m14 sparse-state, Google's 10 000 bitstrings, tests/golden/{fixture}",
+            "value": steps * flops / dt / 1e12, "unit": "TFLOP/s", "ms_per_step": dt / steps * 1e3, "flops_per_step": flops,
+            "err_rel_to_max_abs_or_rms": loose, "rel_err_strict_over_1e-3rms": strict,
+            "fidelity_vs_reference": fidelity_of(got, want), "vs_c128_truth": vs_truth, "check": "ok" if ok else "FAILED",
+            "kernel_times_": (prof.summarize(), e0.elapsed_time(e1)), "case_": case}
+
+
+# secondary workloads of the default run: key -> (BASELINE config, runner, precision, slices per step, sparse, sliced)
+LEGS = [
+    ("n30_sparse10000", "configs[2]", "sparse", "fp32", 1),
+    ("n53", "configs[3] (one rank's share: slices are independent)", "n53", "fp32", 4),
+    ("n53m20b", "configs[4], complex64 arithmetic", "n53m20b", "fp32", 1),
+    ("n53m20b_bf16", "configs[4] as written: bf16-complex MFMA path", "n53m20b", "bf16", 1),
+    ("n53m20", "the bundled n53 m20 circuit, one bitstring", "n53m20", "fp32", 2),
+    ("rand2", "north_star: random tensor network, bond dimension 2", "rand2", "fp32", 4),
+    ("rand4", "north_star: random tensor network, bond dimension 4", "rand4", "fp32", 4),
+]
+
+
+def run_workloads(A, dev, cpu_budget, only=None):
+    """Short legs of every other BASELINE config on the same GPU, after (and outside) the headline's timed region:
+    each with its own value, roofline (per-launch HIP events of one extra step) and cpu_baseline."""
+    out = {}
+    for key, config, kind, precision, per_step in LEGS:
+        if only and key not in only:
+            continue
+        t_leg = time.perf_counter()
+        try:
+            with A.precision(precision):
+                if kind == "sparse":
+                    res = leg_sparse_whole(A, dev, 3, precision)
+                    sparse, sliced = True, False
+                else:
+                    res = run_sliced(A, kind, dev, 1, 0, None, 2, 1, per_step, precision, profile=True)
+                    sparse, sliced = SLICED_WORKLOADS[kind][1], True
+            ks, gpu_ms = res["kernel_times_"]
+            units = per_step if kind != "sparse" else 1
+            roof = roofline_of(ks, gpu_ms, 1)
+            peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+            entry = {"config": config, "value": res["value"], "unit": "TFLOP/s",
+                     "ms": res.get("ms_per_slice_per_rank", res["ms_per_step"]), "ms_is_per": "slice" if sliced else "contraction",
+                     "frac_of_peak": res["value"] / peak, "peak_TFLOPs": peak,
+                     "dtype": "c64 in memory, bf16 MFMA operands, fp32 accumulate" if precision == "bf16" else "c64 (fp32 MFMA)",
+                     "roofline": roof, "profiled_step_gpu_ms": gpu_ms / units,
+                     "check": {k: v for k, v in strip_private(res).items() if k not in ("value", "unit", "ms_per_step", "workload")},
+                     "workload": res["workload"]}
+            if cpu_budget > 0 and precision != "bf16":
+                entry["cpu_baseline"] = cpu_leg(res["case_"], sparse, sliced, cpu_budget,
+                                                ("slice 0 of " if sliced and res["case_"].slicing_indices else "") + key)
+            elif precision == "bf16":
+                entry["cpu_baseline"] = {"same_as": key.replace("_bf16", ""), "note": "the reference has no reduced-precision path: "
+                                         "its CPU executor runs this workload in complex64 (see that entry)"}
+            entry["leg_seconds"] = time.perf_counter() - t_leg
+            out[key] = entry
+        except Exception as e:   # a leg that cannot run must not take the headline with it; it is reported as failed
+            import traceback
+            out[key] = {"config": config, "check": {"check": "FAILED"}, "error": f"{type(e).__name__}: {e}",
+                        "traceback": traceback.format_exc()[-800:]}
+        torch.cuda.empty_cache()
+    return out
+
+
 def bench_sliced(args, A, dev, world, rank, dist):
-    res = run_sliced(A, args.workload, dev, world, rank, dist, args.steps, args.warmup, args.slices, args.precision)
+    res = run_sliced(A, args.workload, dev, world, rank, dist, args.steps, args.warmup, args.slices, args.precision,
+                     profile=world == 1)
     if rank == 0:
+        kt = res.pop("kernel_times_", None)
+        res = strip_private(res)
+        roof = roofline_of(*kt) if kt else None
         line = {
             "metric": f"contracted TFLOP/s, {args.workload} sliced contraction (8 real FLOP per complex MAC)"
                       + (", bf16 operands" if args.precision == "bf16" else ""),
@@ -201,7 +410,13 @@ def bench_sliced(args, A, dev, world, rank, dist):
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("c64 in memory, bf16 MFMA operands, fp32 accumulate" if args.precision == "bf16" else "c64 (fp32 MFMA)"),
             "data": "synthetic", "config": {k: v for k, v in res.items() if k not in ("value", "unit", "ms_per_step")},
+            "roofline": roof,
         }
+        if not args.no_cpu_baseline and world == 1 and args.precision != "bf16":
+            from artensor_amd.fixtures import load_case
+            fixture, sparse, _ = SLICED_WORKLOADS[args.workload]
+            line["cpu_baseline"] = cpu_leg(load_case(os.path.join(ROOT, "tests", "golden", fixture)), sparse, True,
+                                           args.cpu_budget_workloads, "slice 0 of " + args.workload)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -233,6 +448,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=420.0,
+                    help="seconds the torch-CPU einsum loop may spend on the n30 scheme (it stops after the first step that "
+                         "ends past the budget; the default lets the whole scheme finish on the GPU box's host: SURVEY 8d)")
+    ap.add_argument("--cpu-budget-workloads", type=float, default=10.0,
+                    help="the same, per secondary workload")
+    ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the legs of the other BASELINE configs")
+    ap.add_argument("--only-workloads", default=None, help="comma-separated subset of the legs (diagnostics)")
     ap.add_argument("--no-sliced", action="store_true", help="N > 1: skip the embedded slice-sharded n53 run")
     ap.add_argument("--detail", default=None, help="write a per-launch table of the MFMA kernels to this file")
     ap.add_argument("--workload", default="n30", choices=["n30"] + sorted(SLICED_WORKLOADS),
@@ -344,10 +566,31 @@ def main():
         fidelity = None
     else:
         fidelity = fidelity_of(at, want)
+    # the contract proper: against the complex128 truth of the same leaves and scheme, the reference's own
+    # complex64 distance from it measured beside it
+    truth_all = truth_value("n30_dense_at_google")
+    vs_truth = None
+    if truth_all is not None:
+        tw = truth_all[sel]
+        d_hip, d_ref = np.abs(at - tw), np.abs(want - tw)
+        den = np.maximum(np.abs(tw), rms_all)
+        bigt = np.abs(tw) >= 1e-3 * rms_all
+        e = [float((d_hip / den).max()) if len(tw) else 0.0, float((d_hip[bigt] / np.abs(tw)[bigt]).max()) if bigt.any() else 0.0,
+             float((d_ref / den).max()) if len(tw) else 0.0, float((d_ref[bigt] / np.abs(tw)[bigt]).max()) if bigt.any() else 0.0]
+        if world > 1:
+            et = torch.tensor(e, dtype=torch.float64, device=dev)
+            dist.all_reduce(et, op=dist.ReduceOp.MAX)
+            e = [float(x) for x in et.tolist()]
+        vs_truth = {"hip_loose": e[0], "hip_strict": e[1], "reference_c64_loose": e[2], "reference_c64_strict": e[3],
+                    "tol_loose": LOOSE_TOL, "tol_strict": f"{STRICT_FACTOR} x reference_c64_strict",
+                    "truth": "complex128 on the GPU, this package's f64-MFMA path (tests/golden/c128_truth_gpu.npz)"}
     if bf16:
         ok = fidelity is None or fidelity >= BF16_MIN_FIDELITY
+    elif vs_truth is not None:
+        ok = (loose <= LOOSE_TOL + vs_truth["reference_c64_loose"] and vs_truth["hip_loose"] <= LOOSE_TOL
+              and vs_truth["hip_strict"] <= STRICT_FACTOR * vs_truth["reference_c64_strict"])
     else:
-        ok = loose <= LOOSE_TOL and strict <= STRICT_TOL
+        ok = loose <= LOOSE_TOL
     del out
 
     prof = KernelTimes()
@@ -370,7 +613,8 @@ def main():
     if world > 1 and not args.no_sliced:
         del leaves
         torch.cuda.empty_cache()
-        sliced = run_sliced(A, "n53", dev, world, rank, dist, max(1, min(args.steps, 3)), 1, args.slices, args.precision)
+        sliced = strip_private(run_sliced(A, "n53", dev, world, rank, dist, max(1, min(args.steps, 3)), 1, args.slices, args.precision))
+        sliced["series"] = "n53 m14 slice-sharded, one all-reduce (the workload north_star's >= 6x at 8 GPUs refers to)"
         ok = ok and sliced["check"] == "ok"
 
     if rank == 0 and args.detail:
@@ -394,19 +638,26 @@ def main():
                         f"{ms:.3f} {info['bytes'] / ms / 1e6:.0f} {info['flops'] / ms / 1e9:.1f}\n")
     if rank == 0:
         ks = prof.summarize()
-        bits = ks.get(1, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        bits = ks.get(1, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, mfma_flops=0.0))
         ms_per_step = dt / args.steps * 1e3
         value = args.steps * flops_per_step / dt / 1e12   # one full n30 contraction per step, whatever N
         achieved = bits["flops"] / (bits["ms"] * 1e-3) / 1e12 if bits["ms"] else 0.0
         hbm_gbs = bits["bytes"] / (bits["ms"] * 1e-3) / 1e9 if bits["ms"] else 0.0
         # HBM bytes per launch of the dominant kernel come from separate rocprofv3 PMC passes
         # (tools/profile_round.sh -> profiles/rNN_traffic.json); bench.py cannot run them itself
-        traffic = None
+        traffic, traffic_note = None, "no profiles/r*_traffic.json"
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
         if tfiles and world == 1:
             with open(tfiles[-1]) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                tj = json.load(f)
+            # the counters belong to the kernel sources they were collected on: a traffic file recorded on other
+            # sources is stale and is not quoted
+            if tj.get("kernel_source_sha16") == kernel_source_sha16():
+                traffic, traffic_note = tj.get("hbm_bytes_per_launch"), f"{os.path.basename(tfiles[-1])} (same kernel sources)"
+            else:
+                traffic_note = (f"{os.path.basename(tfiles[-1])} was collected on other kernel sources "
+                                f"({tj.get('kernel_source_sha16')} != {kernel_source_sha16()}): not quoted")
         line = {
             "metric": "contracted TFLOP/s, Sycamore n30 m14 full-amplitude (8 real FLOP per complex MAC)"
                       + (", bf16 operands" if bf16 else ""),
@@ -421,16 +672,22 @@ def main():
                        "parallelism": (f"output-qubit partitioning: {n_fix} output label(s) fixed per rank at the leaves, "
                                        f"{world} disjoint slabs of 2^{30 - n_fix} amplitudes, no collective on the data path "
                                        f"(build-side extension; executed FLOP = {overhead:.2f} x nominal)") if world > 1 else "single",
+                       "series": ("n30 m14 full amplitude, output-partitioned over the ranks (strong scaling; executed FLOP grow with N)"
+                                  if world > 1 else "n30 m14 full amplitude, one GPU"),
+                       "ranks_in_collective": 0 if world > 1 else None,
                        "frac_mfma_peak": value / world / MFMA_F32_PEAK_TFLOPS,
                        "check": "ok" if ok else "FAILED",
                        "checked_amplitudes": "Google's 10 000 bitstrings (examples/amplitudes_n30_m14...txt positions) vs the "
                                              "reference's complex64 CPU run",
                        "err_rel_to_max_abs_or_rms": loose, "tol_rel_to_max_abs_or_rms": LOOSE_TOL,
-                       "rel_err_strict_over_1e-3rms": strict, "tol_strict": STRICT_TOL,
+                       "rel_err_strict_over_1e-3rms": strict, "vs_c128_truth": vs_truth,
                        "fidelity_vs_reference": fidelity},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+                "frac_is": "nominal FLOP (8 per complex multiply-add) / kernel time / fp32 MFMA spec peak",
+                "executed_mfma_flop_frac": bits["mfma_flops"] / bits["flops"] if bits["flops"] else 0.0,
+                "mfma_frac_executed": (bits["mfma_flops"] / (bits["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if bits["ms"] else 0.0,
                 "algorithmic_bytes_per_launch": bits["bytes"] / max(bits["launches"], 1),
                 "kernel": "artn_k_bits", "launches_per_step": bits["launches"] / max(args.steps, 1),
                 "avg_launch_ms": bits["ms"] / max(bits["launches"], 1),
@@ -447,8 +704,18 @@ def main():
         if world == 1:
             lat, case12 = n12_latency(A, dev)
             line["config"].update(lat)
+            if not args.no_workloads and not bf16:
+                del leaves
+                torch.cuda.empty_cache()
+                only = set(args.only_workloads.split(",")) if args.only_workloads else None
+                line["workloads"] = run_workloads(A, dev, 0.0 if args.no_cpu_baseline else args.cpu_budget_workloads, only)
+                bad = [k for k, v in line["workloads"].items() if v["check"].get("check") != "ok"]
+                if bad:
+                    ok = False
+                    line["config"]["check"] = "FAILED"
+                    line["config"]["failed_workloads"] = bad
             if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(case, case12)
+                line["cpu_baseline"] = cpu_baseline(case, case12, args.cpu_budget)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

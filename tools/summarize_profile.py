@@ -81,7 +81,9 @@ open(os.path.join(DST, f"{R}_summary.md"), "w").write("\n".join(md))
 fa, wa = list(fe.values()), list(wr.values())
 fetch_all = sum(d.get("FETCH_SIZE", 0) for d in fa) * 1024 * 2 / max(len(fa), 1)
 write_all = sum(d.get("WRITE_SIZE", 0) for d in wa) * 1024 / max(len(wa), 1)
-json.dump({"round": R, "kernel": "artn_k_bits",
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_sha16: the sources these counters belong to)
+json.dump({"round": R, "kernel": "artn_k_bits", "kernel_source_sha16": bench.kernel_source_sha16(),
            # averaged over EVERY artn_k_bits launch, like bench.py's roofline.achieved and
            # algorithmic_bytes_per_launch (20 launches per contraction: 13 fused 8-GiB passes, 7 growth steps)
            "hbm_bytes_per_launch": fetch_all + write_all, "launches": len(fa),
