@@ -673,9 +673,7 @@ def _plan_small_program(scheme, shapes, dtype):
 def _run_program(prog, tensors, dtype, device, stream):
     image = prog.device_copy(device)
     ws = torch.empty(prog.ws_bytes, dtype=torch.uint8, device=device)
-    ext = prog.ext_array
-    if ext is None:
-        ext = prog.ext_array = (ctypes.c_void_p * len(prog.ext_ids))()
+    ext = (ctypes.c_void_p * len(prog.ext_ids))()   # per call: the plan is shared by every thread and device that hits the cache
     for q, t in enumerate(prog.ext_ids):
         ext[q] = tensors[t].data_ptr()
     if profiler is not None:
@@ -886,8 +884,25 @@ def tensor_contraction(tensors, scheme):
 # sparse-state executor
 # ----------------------------------------------------------------------------------------
 _index_cache = _Bounded(4096)
-_flag_cache = {}      # device -> sticky int32 out-of-range flag written by the gather kernels
-_flags_used = set()   # devices whose flag some launch since the last check may have set
+# Out-of-range bookkeeping of the gather kernels is per THREAD (like `precision` and the deferred check of the slice
+# loop): a thread reads and clears only the flags its own launches may have set.
+_flag_state = threading.local()
+
+
+def _flag_cache():
+    """device -> sticky int32 out-of-range flag written by this thread's gather launches"""
+    c = getattr(_flag_state, "cache", None)
+    if c is None:
+        c = _flag_state.cache = {}
+    return c
+
+
+def _flags_used():
+    """devices whose flag some launch of this thread since its last check may have set"""
+    u = getattr(_flag_state, "used", None)
+    if u is None:
+        u = _flag_state.used = set()
+    return u
 
 
 def _device_index(idx, device, src_rows=None):
@@ -916,9 +931,10 @@ def _device_index(idx, device, src_rows=None):
 
 
 def _flag(device):
-    flag = _flag_cache.get(device)
+    cache = _flag_cache()
+    flag = cache.get(device)
     if flag is None:
-        flag = _flag_cache[device] = torch.zeros(1, dtype=torch.int32, device=device)
+        flag = cache[device] = torch.zeros(1, dtype=torch.int32, device=device)
     return flag
 
 
@@ -928,12 +944,13 @@ def check_gather_flag(what="gather"):
     _device_index catches bad schemes before launch; this is the device's own word, read once per
     scheme by the executors rather than after every launch."""
     bad = []
-    for device in list(_flags_used):
-        flag = _flag_cache[device]
+    used, cache = _flags_used(), _flag_cache()
+    for device in list(used):
+        flag = cache[device]
         if int(flag.item()) != 0:
             flag.zero_()
             bad.append(str(device))
-    _flags_used.clear()
+    used.clear()
     if bad:
         raise RuntimeError(f"{what}: a row gather read an index outside its operand on {', '.join(bad)} "
                            "(the reference raises IndexError, contraction.py:192-195)")
@@ -1015,7 +1032,7 @@ def contract_gathered(eq, a, rows_a, b, rows_b, out=None, label=None, _validate=
         if profiler is not None:
             e1.record()
             profiler.record(_step_info_cached(d), e0, e1)
-    _flags_used.add(a.device)
+    _flags_used().add(a.device)
     return out
 
 
@@ -1039,7 +1056,7 @@ def gather_rows(t, idx, _validate=True):
     with torch.cuda.device(t.device):
         N.check(N.lib().artn_gather_rows(t.data_ptr(), dev_idx.data_ptr(), out.data_ptr(), nrows, row_bytes,
                                          t.shape[0], flag.data_ptr(), N.current_stream_ptr(t.device)))
-    _flags_used.add(t.device)
+    _flags_used().add(t.device)
     return out
 
 
@@ -1164,7 +1181,7 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
         for n in range(len(scheme)):
             one(n)
             normalize(scheme[n][0][0])
-        if _flags_used and not getattr(_defer, "flag_check", False):
+        if _flags_used() and not getattr(_defer, "flag_check", False):
             check_gather_flag("tensor_contraction_sparse")
         return factor.reshape(()).to(tensors[last].dtype), tensors[last]
 
@@ -1201,7 +1218,7 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
             tensors[s2[0][1]] = []
     # abort-on-failure semantics of the reference (contraction.py:192-195) for the one failure the
     # kernels cannot raise themselves: one flag read per scheme (the slice loop defers it to its end)
-    if _flags_used and not getattr(_defer, "flag_check", False):
+    if _flags_used() and not getattr(_defer, "flag_check", False):
         check_gather_flag("tensor_contraction_sparse")
     return tensors[last]
 

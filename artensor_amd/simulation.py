@@ -270,7 +270,7 @@ class SliceRunner:
             self._run(slices)
         finally:
             _C._defer.flag_check = prev
-        if _C._flags_used and not prev:
+        if _C._flags_used() and not prev:
             _C.check_gather_flag("SliceRunner.run")
         return self.collect
 
@@ -328,6 +328,44 @@ def sliced_contraction(tensors, scheme, slicing_indices, out_shape, sparse=False
     return _shard_and_reduce(runner, permute_dims, group, slices, reduce)
 
 
+def plan_fingerprint(scheme, slicing_indices, permute_dims=None):
+    """sha256 over what every rank of a sliced contraction must agree on: the steps (edges, equations, index
+    tensors), the sliced bonds in order with their (tensor, dim) lists, and the output permutation.  The
+    reference's planner depends on PYTHONHASHSEED (bond labels pass through set(): three seeds give three
+    different trees), so ranks that each plan for themselves may hold DIFFERENT slicings of the same
+    network; summing their slices would be silently wrong."""
+    import hashlib
+    h = hashlib.sha256()
+    for step in scheme:
+        h.update(repr((tuple(step[0]), step[1] if isinstance(step[1], str) else tuple(map(tuple, step[1])))).encode())
+        if len(step) > 2:
+            for lst in step[2]:
+                for idx in lst:
+                    h.update(np.ascontiguousarray(torch.as_tensor(idx).cpu().numpy()).tobytes())
+            h.update(repr(tuple(step[3]) if len(step) > 3 and step[3] is not None else None).encode())
+    h.update(repr([(str(b), [tuple(x) for x in v]) for b, v in (slicing_indices or {}).items()]).encode())
+    h.update(repr(None if permute_dims is None else [int(x) for x in permute_dims]).encode())
+    return h.hexdigest()
+
+
+def _check_same_plan(runner, permute_dims, group):
+    """Every rank of the group must run the same scheme on the same slicing (one all_gather of a 64-byte digest,
+    once per runner and group)."""
+    import torch.distributed as dist
+    seen = getattr(runner, "_plan_checked", None)
+    if seen is not None and seen == id(group):
+        return
+    mine = plan_fingerprint(runner.scheme, runner.slicing_indices, permute_dims)
+    world = dist.get_world_size(group)
+    all_ = [None] * world
+    dist.all_gather_object(all_, mine, group=group)
+    if any(x != mine for x in all_):
+        raise RuntimeError("the ranks of this sliced contraction hold different plans (scheme / sliced bonds / output order): "
+                           "the reference's planner depends on PYTHONHASHSEED -- plan on one rank and broadcast the plan "
+                           "(tensor_network_contraction does), or pin PYTHONHASHSEED identically on every rank")
+    runner._plan_checked = id(group)
+
+
 def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce="all"):
     """Sharding + the single reduction of sliced_contraction around a ready SliceRunner (also the entry
     of the CPU tests, which hand in a runner built by SliceRunner._with_seams)."""
@@ -335,6 +373,8 @@ def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce
     distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
     rank = dist.get_rank(group) if distributed else 0
     world = dist.get_world_size(group) if distributed else 1
+    if distributed and reduce is not None:
+        _check_same_plan(runner, permute_dims, group)
     if slices is None:
         slices = rank_slices(2 ** runner.n_bonds, rank, world, gray=runner.reuse_small)
     collect = runner.run(slices)
@@ -424,18 +464,18 @@ def partition_output(scheme, leaf_shapes, n_fix):
     return new_scheme, selects, fixed_dims
 
 
-_partition_cache = {}
+_partition_cache = _C._Bounded(64)   # (id(scheme), n_fix, leaf shapes) -> (scheme, partitioned scheme, selects, fixed dims)
 
 
 def partitioned_contraction(tensors, scheme, n_fix, part, device="cuda", dtype=torch.complex64):
     """Slab `part` (0 <= part < 2^n_fix) of the result of a dense scheme: the output dims chosen by
     partition_output fixed to the bits of `part` (MSB = first fixed dim).  Returns
     (slab, fixed_dims, values); slab has the result's remaining dims in order."""
-    key = (id(scheme), n_fix)
-    hit = _partition_cache.get(key)
     items = list(tensors.items()) if isinstance(tensors, dict) else list(enumerate(tensors))
+    shapes = {k: tuple(t.shape) for k, t in items}
+    key = (id(scheme), n_fix, tuple(sorted(shapes.items(), key=lambda kv: repr(kv[0]))))
+    hit = _partition_cache.get(key)
     if hit is None or hit[0] is not scheme:
-        shapes = {k: tuple(t.shape) for k, t in items}
         hit = _partition_cache[key] = (scheme,) + partition_output(scheme, shapes, n_fix)
     _, new_scheme, selects, fixed_dims = hit
     values = slice_assignments(n_fix, part)
@@ -466,7 +506,7 @@ def _planner(planner=None):
 
 def _bond_owners(tensor_bonds):
     owners = {}
-    for tid, bonds in tensor_bonds.items():
+    for tid, bonds in (tensor_bonds.items() if isinstance(tensor_bonds, dict) else enumerate(tensor_bonds)):
         for b in bonds:
             owners.setdefault(b, []).append(tid)
     return owners
@@ -523,8 +563,15 @@ class TensorNetworkSimulation:
 
     @classmethod
     def from_planned(cls, sim):
-        """`sim`: a reference TensorNetworkSimulation after prepare_contraction()."""
-        return cls(sim.tensors, sim.scheme, sim.slicing_indices, sim.output_bonds, sim.pattern,
+        """`sim`: a reference TensorNetworkSimulation after prepare_contraction().  Slicing indices are re-taken
+        on the ACTUAL leaf tensors where the object carries `tensor_bonds` (a sparse final-qubit leaf has a leading
+        batch dim that the reference's indices, simulation.py:60-65, do not count: `_slicing_indices`) -- the same
+        correction prepare_contraction() and tensor_network_contraction() apply, so the three constructors agree."""
+        slicing = sim.slicing_indices
+        bonds = getattr(sim, "tensor_bonds", None)
+        if slicing and bonds is not None:
+            slicing = _slicing_indices(list(slicing.keys()), bonds, sim.tensors)
+        return cls(sim.tensors, sim.scheme, slicing, sim.output_bonds, sim.pattern,
                    getattr(sim, "bitstrings_sorted", None), getattr(sim, "permute_dims", None))
 
     # ---- the reference's own constructors and planning calls, forwarded to its front end -------------
@@ -601,31 +648,46 @@ def tensor_network_contraction(tensors, tensor_bonds, bond_dims, final_qubits, b
     (simulation.py:160-165: trials=trial_num, iters=50, betas 3..21 in 61 steps, start_seed 0); scheme
     compilation, the slice loop and every contraction run here.  `group`/`reduce`: slices are sharded
     over the ranks of a torch.distributed group with one reduction at the end (see sliced_contraction)."""
-    from copy import deepcopy
-    from .contraction import contraction_scheme, contraction_scheme_sparse
-    P = _planner(planner)
-    distinct = len(np.unique(bitstrings)) if len(bitstrings) else 0
-    sparse = distinct > 0
-    max_bitstrings = distinct if sparse else 1
-    net = P.NumericalTensorNetwork(tensors, tensor_bonds, bond_dims, final_qubits)
-    bonds_of, final_ids = net._simplify("sparse" if sparse else "normal")
-    order, slicing_bonds, ctree = P.find_order(
-        deepcopy(bonds_of), deepcopy(net.bond_dims), final_ids, 0, max_bitstrings, sc_target=sc_target,
-        trials=trial_num, iters=50, betas=np.linspace(3.0, 21.0, 61), start_seed=0, alpha=alpha)
-    leaves = {new: net.tensors[old] for new, old in enumerate(net.tensors.keys())}
-    slicing = _slicing_indices(slicing_bonds, bonds_of, leaves)
-    if sparse:
-        scheme, output_bonds, bitstrings = contraction_scheme_sparse(ctree, bitstrings, sc_target=sc_target)
-        if len(bitstrings) != max_bitstrings:
-            raise RuntimeError("the compiled scheme does not produce one row per distinct bitstring")
-        shape = [max_bitstrings] + [2] * len(output_bonds)
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
+
+    def plan():
+        from copy import deepcopy
+        from .contraction import contraction_scheme, contraction_scheme_sparse
+        P = _planner(planner)
+        distinct = len(np.unique(bitstrings)) if len(bitstrings) else 0
+        sparse = distinct > 0
+        max_bitstrings = distinct if sparse else 1
+        net = P.NumericalTensorNetwork(tensors, tensor_bonds, bond_dims, final_qubits)
+        bonds_of, final_ids = net._simplify("sparse" if sparse else "normal")
+        order, slicing_bonds, ctree = P.find_order(
+            deepcopy(bonds_of), deepcopy(net.bond_dims), final_ids, 0, max_bitstrings, sc_target=sc_target,
+            trials=trial_num, iters=50, betas=np.linspace(3.0, 21.0, 61), start_seed=0, alpha=alpha)
+        leaves = {new: net.tensors[old] for new, old in enumerate(net.tensors.keys())}
+        slicing = _slicing_indices(slicing_bonds, bonds_of, leaves)
+        if sparse:
+            scheme, output_bonds, sorted_bits = contraction_scheme_sparse(ctree, bitstrings, sc_target=sc_target)
+            if len(sorted_bits) != max_bitstrings:
+                raise RuntimeError("the compiled scheme does not produce one row per distinct bitstring")
+            shape = [max_bitstrings] + [2] * len(output_bonds)
+        else:
+            scheme, output_bonds, sorted_bits = contraction_scheme(ctree) + (bitstrings,)
+            shape = [2] * len(output_bonds)
+        perm = _output_permutation(list(output_bonds), bonds_of, final_ids, sparse)
+        return leaves, scheme, slicing, shape, sparse, perm, sorted_bits
+
+    # The planner's trees, sliced bonds and output order depend on PYTHONHASHSEED (SURVEY 8c), which torchrun
+    # children do not share: ONE rank plans (simplified leaves included: their numbering follows the plan) and
+    # the plan is broadcast, so every rank contracts slices of the same slicing.
+    if distributed:
+        box = [plan() if dist.get_rank(group) == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        leaves, scheme, slicing, shape, sparse, perm, sorted_bits = box[0]
     else:
-        scheme, output_bonds = contraction_scheme(ctree)
-        shape = [2] * len(output_bonds)
-    perm = _output_permutation(list(output_bonds), bonds_of, final_ids, sparse)
+        leaves, scheme, slicing, shape, sparse, perm, sorted_bits = plan()
     out = sliced_contraction(leaves, scheme, slicing, shape, sparse=sparse, permute_dims=perm, dtype=dtype,
                              device=device, group=group, reduce=reduce)
-    return out, bitstrings
+    return out, sorted_bits
 
 
 def quantum_circuit_simulation(circuit_filename, bitstrings=[], sc_target=31, trial_num=8, alpha=0.0,

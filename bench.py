@@ -548,7 +548,7 @@ def main():
             local |= ((rpos[sel] >> (29 - d)) & 1) << (len(keep) - 1 - q)
         from artensor_amd.contraction import _labels
         from artensor_amd import simulation as S
-        new_scheme = S._partition_cache[(id(case.scheme), n_fix)][1]
+        new_scheme = next(v for k, v in S._partition_cache.items() if k[0] == id(case.scheme) and k[1] == n_fix)[1]
         overhead = world * sum(2.0 ** len(set(_labels(e)[0]) | set(_labels(e)[1])) for _, e in new_scheme) / \
             sum(2.0 ** len(set(_labels(e)[0]) | set(_labels(e)[1])) for _, e in case.scheme)
     at = out.reshape(-1)[torch.from_numpy(local).to(dev)].cpu().numpy()
