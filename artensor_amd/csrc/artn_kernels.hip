@@ -120,7 +120,22 @@ __device__ unsigned long long artn_phase_buf[1024 * 20];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"s"(val_) : "memory");            \
     artn_phase_buf[100 + 8 * (Lrel) + (k)] = __builtin_amdgcn_s_memrealtime();       \
   }
+// artn_k_alt: lane 0 of wave 0 of each group, blocks < 128, halves 40..43: shader clock at up to 8 points of a half
+#define ALT_MARK(k)                                                                                                       \
+  if (lane == 0 && w4 == 0 && blockIdx.x < 64 && half >= 40 && half < 44) {                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    artn_phase_buf[(((blockIdx.x * 2 + grp) * 4) + (half - 40)) * 8 + (k)] = __builtin_amdgcn_s_memtime();               \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+#define SMARK(k)                                                                    \
+  if (L.mark_base >= 0 && lane == 0) {                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    artn_phase_buf[L.mark_base + (k)] = __builtin_amdgcn_s_memtime();                 \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+  }
 #else
+#define SMARK(k)
+#define ALT_MARK(k)
 #define PHASE_MARK(k)
 #define PROG_MARK(k)
 #define PROG_FINE(Lrel, k, val_)
@@ -146,7 +161,7 @@ struct OffTab {
   int g_log2;        // log2 of the grid size if it is a power of two inside the prefix, else -1
 };
 template <typename PlanT>
-__device__ __forceinline__ OffTab build_offset_table(const PlanT &P, long *tab, int tid) {
+__device__ __forceinline__ OffTab build_offset_table(const PlanT &P, long *tab, int tid, int stride = 0) {
   OffTab T;
   int bits = 0, d = 0;
   for (; d < P.n_outer && P.outer[d].log2ext >= 0; ++d) bits += P.outer[d].log2ext;
@@ -181,7 +196,7 @@ __device__ __forceinline__ OffTab build_offset_table(const PlanT &P, long *tab, 
   // sets the next bit, so the offset difference depends only on the number c of trailing ones.
   long *dl = tab + 8 * 16 * 4;
   T.delta = dl;
-  const int G = P.blocked ? 1 : gridDim.x; // distance between consecutive tiles of a workgroup
+  const int G = stride ? stride : (P.blocked ? 1 : gridDim.x); // distance between consecutive tiles of a workgroup
   T.g_log2 = -1;
   if ((G & (G - 1)) == 0 && T.first_generic == P.n_outer) {
     int g = 0;
@@ -364,8 +379,13 @@ struct StageConst {
   long kb_hi[2];
   int nt_eff, wm, wm_count, msubs;
   unsigned msub_tab;                  // LDS byte address of the table: sub-tile -> (input, output) byte offsets
+  unsigned mo0x, mo0y, mo1x, mo1y;    // the table entries of this wave's first two sub-tiles (wm, wm + wm_count): the first
+                                      // operand reads of a stage do not wait for a table read
   int ksplit_wave;                    // >= 0: the waves split the chain of a big-K tile; this wave's share
   unsigned ksplit_scratch;            // LDS byte address of the 3 x 4 KiB partial blocks
+#if defined(ARTN_PHASES)
+  int mark_base;                      // diagnostics: slot in artn_phase_buf for the marks inside the stage, or -1
+#endif
 };
 // zin: stage whose output region this stage reads (nullptr: the unswizzled copy-in region).
 // hb: the contracted bit carried by the lane half h (0 for the fp32 chain: kc = 2s + h; 2 for the
@@ -380,8 +400,29 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
   L.msubs = 1 << (st.m_bits - 5);
   L.nt_eff = st.nt < 4 ? st.nt : 4;
   L.msub_tab = tab;
+  {
+    unsigned e[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int m = L.wm + q * L.wm_count;
+      unsigned oi = 0, oo = 0;
+#pragma unroll
+      for (int b = 0; b < 9; ++b) {
+        if (b < st.m_bits - 5 && ((m >> b) & 1)) {
+          oi += 8u << st.msub_in_pos[b];
+          oo += 8u << st.msub_out_pos[b];
+        }
+      }
+      e[q][0] = swz(oi, zin);
+      e[q][1] = swz(oo, &st);
+    }
+    L.mo0x = e[0][0]; L.mo0y = e[0][1]; L.mo1x = e[1][0]; L.mo1y = e[1][1];
+  }
   L.ksplit_wave = -1;
   L.ksplit_scratch = 0;
+#if defined(ARTN_PHASES)
+  L.mark_base = -1;
+#endif
   L.lane_in = (unsigned)h << (st.k_in_pos[hb] + 3);
   L.lane_out = 0;
 #pragma unroll
@@ -914,18 +955,27 @@ struct StageRun {
     int msub = L.wm;
     if (msub >= L.msubs) return;
     v2f_t b[2][U3];
-    u2_t mo = lds_read_u2(L.msub_tab + msub * 8);
+    SMARK(0);
+    u2_t mo = u2_t{L.mo0x, L.mo0y};
     load_u3<0>(b[0], L.lane_in ^ mo.x);
+#if defined(ARTN_PHASES)
+    if (L.mark_base >= 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
+    SMARK(1);
+    bool first = true;
     for (;;) {
       const unsigned li = L.lane_in ^ mo.x, lo = L.lane_out ^ mo.y;
       const int nmsub = msub + L.wm_count;
       const bool more = nmsub < L.msubs;
       u2_t mo_n = mo;
-      if (more) mo_n = lds_read_u2(L.msub_tab + nmsub * 8);
+      if (more) mo_n = first ? u2_t{L.mo1x, L.mo1y} : lds_read_u2(L.msub_tab + nmsub * 8);
+      first = false;
       f32x16 t1, t2, t3;
       zero(t1); zero(t2); zero(t3);
       units3<0>(t1, t2, t3, b, li, more, L.lane_in ^ mo_n.x);
+      SMARK(2);
       scatter3(t1, t2, t3, lo);
+      SMARK(4);
       if (!more) return;
       msub = nmsub;
       mo = mo_n;
@@ -945,9 +995,14 @@ struct StageRun {
     if (msub >= L.msubs) return;
     v2f_t bA[CH], bB[CH];
     f32x16 acc0, acc1;
-    u2_t mo = lds_read_u2(L.msub_tab + msub * 8);
+    SMARK(0);
+    u2_t mo = u2_t{L.mo0x, L.mo0y};
     load_unit<0>(bA, L.lane_in ^ mo.x);
-    bool pending = false;
+#if defined(ARTN_PHASES)
+    if (L.mark_base >= 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
+    SMARK(1);
+    bool pending = false, first = true;
     unsigned plo = 0;
     // two sub-tiles per trip so buffers and accumulators have static names
     for (;;) {
@@ -957,7 +1012,8 @@ struct StageRun {
         const int nmsub = msub + L.wm_count;
         const bool more = nmsub < L.msubs;
         u2_t mo_n = mo;
-        if (more) mo_n = lds_read_u2(L.msub_tab + nmsub * 8);
+        if (more) mo_n = first ? u2_t{L.mo1x, L.mo1y} : lds_read_u2(L.msub_tab + nmsub * 8);
+        first = false;
         zero(acc0);
         if (UPS == 2) {
           load_unit<(UPS == 2 ? CH : 0)>(bB, li);
@@ -970,7 +1026,8 @@ struct StageRun {
         }
         pending = true;
         plo = lo;
-        if (!more) { scatter(acc0, plo); return; }
+        SMARK(2);
+        if (!more) { scatter(acc0, plo); SMARK(4); return; }
         msub = nmsub;
         mo = mo_n;
       }
@@ -992,7 +1049,8 @@ struct StageRun {
           chain_unit<0>(acc1, bB, pending, acc0, plo);
         }
         plo = lo;
-        if (!more) { scatter(acc1, plo); return; }
+        SMARK(3);
+        if (!more) { scatter(acc1, plo); SMARK(4); return; }
         msub = nmsub;
         mo = mo_n;
       }
@@ -1286,6 +1344,211 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     noff = n2off;
   }
   STAMP_FLUSH
+}
+
+// ----------------------------------------------------------------------------------------
+// artn_k_alt -- the same tiles, stages and plans as artn_k_bits, for the big launches (2^12-element tiles, fp32
+// chains, no row gather), with the overlap of MFMA stages and copy phases ENFORCED instead of hoped for.
+//
+// artn_k_bits puts two independent 4-wave workgroups on a CU and relies on one being in its copy phases while the
+// other runs its MFMA stages.  Measured (tools/diag_r03.sh, round 3) they do not: two workgroups per CU are only
+// 1.14-1.24 x as fast as one, and their phase offset is 0.2 of a period.  Sharing the matrix pipe is processor
+// sharing -- whichever workgroup is behind speeds up as soon as the other leaves its stage, so lockstep is an
+// attractor -- and in lockstep both fight for the pipe in their stages and both leave it idle while they copy.
+//
+// Here ONE workgroup of 8 waves per CU holds two groups of 4 waves (one wave of each group per SIMD), each group
+// with its own pair of LDS regions and its own grid-stride tile sequence, and the groups alternate roles every
+// half period, separated by workgroup barriers:
+//
+//     half h, group g with (h ^ g) even:  stage 1 | barrier | stage 2            | barrier     (matrix pipe)
+//              the other group:           result -> registers -> global stores | barrier | refill R0 with its
+//                                         next tile (loads issued a period ago), issue the loads of the tile after | barrier
+//
+// The four barriers of a period are all the synchronisation either group needs (stage 1 -> stage 2, result reads
+// before the refill, refill before stage 1), each SIMD's matrix pipe serves one chain at a time, and a group's copy
+// phases have the whole length of the other group's stages to hide in.
+template <int KB1, int KB2, bool NT, bool M3>
+__global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float2 *__restrict__ A, const float2 *__restrict__ B1,
+                                                                     const float2 *__restrict__ B2, float2 *__restrict__ C,
+                                                                     const ArtnBitsPlan P) {
+  constexpr int S1 = 1 << (KB1 - 1);
+  constexpr int KB2e = KB2 > 0 ? KB2 : 1;
+  constexpr int S2 = 1 << (KB2e - 1);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((unsigned)(unsigned long)(lds_byte_t *)smem != 0) __builtin_trap(); // see lds_read8
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3, tg = tid & (ARTN_WG_THREADS - 1);
+  const int j = lane & 31, h = lane >> 5, ro = j & 1;
+  // LDS: group g owns [g * 64 KiB, +64 KiB): R0 (input tile, result of a fused pair) and R1; tables behind both
+  const unsigned R0 = (unsigned)grp << 16, R1 = R0 + (8u << 12);
+  const unsigned regions_end = 2u << 16;
+  uint2 *tab1 = reinterpret_cast<uint2 *>(smem + regions_end);
+  uint2 *tab2 = tab1 + (1 << (P.st[0].m_bits - 5));
+  long *offtab = reinterpret_cast<long *>(tab2 + (KB2 > 0 ? 1 << (P.st[1].m_bits - 5) : 0));
+
+  unsigned in_lane = 0, out_lane = 0;
+#pragma unroll
+  for (int b = 1; b <= 8; ++b) {
+    if ((tg >> (b - 1)) & 1) {
+      in_lane += (unsigned)P.in_stride[b] * 8u;
+      out_lane += (unsigned)P.out_stride[b] * 8u;
+    }
+  }
+  long in_hi[4], out_hi[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    in_hi[b] = b < 3 ? P.in_stride[9 + b] * 8 : 0;
+    out_hi[b] = b < 3 ? P.out_stride[9 + b] * 8 : 0;
+  }
+  const unsigned tid16 = tg * 16;
+
+  fill_msub_table(P.st[0], nullptr, tab1, tid);
+  if (KB2 > 0) fill_msub_table(P.st[1], &P.st[0], tab2, tid);
+  const unsigned tab1_a = regions_end, tab2_a = tab1_a + (8u << (P.st[0].m_bits - 5));
+  const StageConst<KB1> L1 = stage_const<KB1, M3>(P.st[0], nullptr, j, h, w4, tab1_a, R0, R1, 0);
+  const StageConst<KB2e> L2 = stage_const<KB2e, M3>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, w4, tab2_a, R1, R0, 0);
+  const ArtnStage *zout = &P.st[KB2 > 0 ? 1 : 0];
+  const unsigned tid16_out = swz(tid16, zout);
+  unsigned out_i_swz[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out_i_swz[i] = swz(i * (ARTN_WG_THREADS * 16), zout);
+  // tiles: virtual workgroup vb = block + group * grid of a grid of VG = 2 * grid; XCD-aware start as in artn_k_bits
+  const long VG = 2L * gridDim.x, n_tiles = P.n_tiles;
+  const OffTab OT = build_offset_table(P, offtab, tid, (int)VG);
+  float W10[S1], W11[S1], W20[S2], W21[S2];
+  constexpr bool C31 = M3 && (KB1 == 5 || KB1 == 6), C32 = M3 && (KB2 == 5 || KB2 == 6);
+  float W12[1], W22[1];
+  u32x4_t WS1[1][KB1 >= 3 ? 1 << (KB1 - 3) : 1], WS2[1][KB2e >= 3 ? 1 << (KB2e - 3) : 1]; // (unused: fp32 chains only)
+  float WH0[1][S1], WH1[1][S1], WD0[1][S2], WD1[1][S2];
+  long prev_b1 = -1, prev_b2 = -1;
+  __syncthreads();
+
+  const long vb = (long)blockIdx.x + (long)grp * gridDim.x;
+  const long t0 = (VG & 7) == 0 ? (vb & 7) * (VG >> 3) + (vb >> 3) : vb;
+  const long t_max = (n_tiles + VG - 1) / VG; // tiles of the busiest virtual workgroup
+  f32x4 v[8];
+  // ct: the tile this group computes next (in R0 once refilled); rt: the tile whose loads are in flight in v[]
+  // (loff: its offsets).  Loads and refills are UNCONDITIONAL -- past its last tile a group simply loads its last tile
+  // again -- so that v[] has one definition per half: a conditional load leaves the compiler a merge of old and new
+  // v[], which it resolves with register copies guarded by vmcnt waits in the middle of the copy phase.
+  long ct = t0, rt = t0;
+  const long t_last = n_tiles - 1;
+  TileOff coff = tile_offsets(P, OT, t0 < n_tiles ? t0 : t_last), loff = coff;
+  long o_c = 0;          // C offset of the tile whose result waits for its copy-out
+  bool have_result = false;
+  if (grp == 0) { // group 0 computes first: its first tile goes straight to LDS
+    copy_in_sync(reinterpret_cast<const char *>(A + coff.a), in_hi, in_lane, R0, tid16, 8);
+    rt = t0 + VG;
+    if (rt < n_tiles) loff = tile_offsets(P, OT, rt);
+  }               // group 1 starts in the copy role: its first tile arrives through v[] like every later one
+  issue_loads<8, NT>(v, reinterpret_cast<const char *>(A + loff.a), in_hi, in_lane);
+  __syncthreads();
+
+  // Both groups run the SAME straight-line sequence compute half, copy half, ... (one definition of v[] per period:
+  // nothing for the compiler to merge or copy); group 1 is half a period behind because it enters through one extra
+  // copy half (which refills R0 with its first tile), and group 0 leaves through two extra barriers.
+  auto compute_half = [&](long half) {
+    const bool work = ct < n_tiles;
+    ALT_MARK(0);
+    if (work) {
+      if (coff.b1 != prev_b1) {
+        prev_b1 = coff.b1;
+        const char *Bb = reinterpret_cast<const char *>(B1 + coff.b1);
+        if constexpr (C31) load_w3<KB1>(W10, W11, W12, Bb, L1);
+        else load_w<KB1>(W10, W11, Bb, L1, ro);
+      }
+      if (KB2 > 0 && coff.b2 != prev_b2) {
+        prev_b2 = coff.b2;
+        if constexpr (C32) load_w3<KB2e>(W20, W21, W22, reinterpret_cast<const char *>(B2 + coff.b2), L2);
+        else load_w<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + coff.b2), L2, ro);
+      }
+#if defined(ARTN_PHASES)
+      StageConst<KB1> L1m = L1;
+      L1m.mark_base = (w4 == 0 && blockIdx.x < 64 && half >= 40 && half < 44) ? 4096 + ((((int)blockIdx.x * 2 + grp) * 4 + (int)(half - 40)) * 2 + 0) * 8 : -1;
+      run_stage<KB1, false, 0, M3>(L1m, W10, W11, W12, h, lane, WH0, WH1, WS1);
+#else
+      run_stage<KB1, false, 0, M3>(L1, W10, W11, W12, h, lane, WH0, WH1, WS1);
+#endif
+    }
+    ALT_MARK(1);
+    __syncthreads();
+    ALT_MARK(2);
+#if defined(ARTN_PHASES)
+    if (KB2 > 0 && work) {
+      StageConst<KB2e> L2m = L2;
+      L2m.mark_base = (w4 == 0 && blockIdx.x < 64 && half >= 40 && half < 44) ? 4096 + ((((int)blockIdx.x * 2 + grp) * 4 + (int)(half - 40)) * 2 + 1) * 8 : -1;
+      run_stage<KB2e, false, 0, M3>(L2m, W20, W21, W22, h, lane, WD0, WD1, WS2);
+    }
+#else
+    if (KB2 > 0 && work) run_stage<KB2e, false, 0, M3>(L2, W20, W21, W22, h, lane, WD0, WD1, WS2);
+#endif
+    ALT_MARK(3);
+    __syncthreads();
+    ALT_MARK(4);
+    if (work) {
+      have_result = true;
+      o_c = coff.c;
+      ct += VG;
+    }
+  };
+  auto copy_half = [&](long half) {
+    // result of the tile computed in the previous half -> registers -> global; next tile -> R0
+    unsigned lo_in = in_lane, lo_out = out_lane, t16 = tid16, t16o = tid16_out;
+    OPAQUE_V(lo_in);
+    OPAQUE_V(lo_out);
+    OPAQUE_V(t16);
+    OPAQUE_V(t16o);
+    // (order as in artn_k_bits: the refill waits on loads that nothing younger follows in the in-order VMEM queue;
+    //  stores first would put a vmcnt(0) -- a wait for the stores themselves -- in front of the refill)
+    f32x4 x[8];
+    const bool had = have_result;
+    ALT_MARK(0);
+    if (had) {
+      const unsigned outr = KB2 > 0 ? R0 : R1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = lds_read16(outr + (t16o ^ out_i_swz[i]));
+    }
+    ALT_MARK(1);
+    __syncthreads(); // every wave of the group has its part of the result in registers: R0 may be refilled
+    ALT_MARK(2);
+    store_lds(v, R0, t16);
+    ALT_MARK(5);
+    coff = loff; // (rt == ct: the tile now in R0 is the one this group computes next, if there is one)
+    if (had) {
+      char *Cbase = reinterpret_cast<char *>(C + o_c);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        long o = 0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          if ((i >> b) & 1) o += out_hi[b];
+#ifdef ARTN_ABLATE_MEM
+        asm volatile("" ::"v"(x[i]), "s"(Cbase), "v"(lo_out));
+#else
+        __builtin_nontemporal_store(x[i], reinterpret_cast<f32x4 *>(Cbase + o + lo_out));
+#endif
+      }
+      have_result = false;
+    }
+    ALT_MARK(6);
+    if (rt + VG < n_tiles) loff = next_offsets(P, OT, loff, rt, VG);
+    issue_loads<8, NT>(v, reinterpret_cast<const char *>(A + loff.a), in_hi, lo_in);
+    rt += VG;
+    ALT_MARK(3);
+    __syncthreads();
+    ALT_MARK(4);
+  };
+  if (grp == 1) copy_half(-1);
+  for (long it = 0; it < t_max; ++it) {
+    compute_half(2 * it + grp);
+    copy_half(2 * it + 1 + grp);
+  }
+  if (grp == 0) {
+    __syncthreads();
+    __syncthreads();
+  }
 }
 
 // Translation units.  The product library is linked from seven objects compiled from THIS file (make -j: the
@@ -1891,6 +2154,46 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
     }                                                                                                     \
     ARTN_LAUNCH_NP(K2, 0)                                                                                 \
     break;                                                                                                \
+  }
+  // the big launches (2^12-element tiles, fp32 chains, grid-stride tiles): one 8-wave workgroup per CU whose two
+  // groups alternate between the MFMA stages and the copy phases (artn_k_alt)
+  if constexpr (KB1 >= 3) {
+    if (full && p.bits.T_mid == 12 && split == 0 && p.bits.gather_dim < 0 && !p.bits.blocked && p.bits.st[0].k <= 6 &&
+        (artn::tuning().alt == 1 || (artn::tuning().alt == 2 && p.bits.run_out < 4)) &&
+        p.bits.n_tiles >= 64 && (k2 == 0 || k2 >= 3)) {
+      const long half_tiles = (long)((p.bits.n_tiles + 1) / 2);
+      dim3 agrid((unsigned)std::min<long>((long)p.n_cu, half_tiles)), ablock(2 * ARTN_WG_THREADS);
+      const size_t alds = lds + 65536;
+#define ARTN_ALT_GO(K2, NTV, M3V)                                                                           \
+  {                                                                                                       \
+    auto kern = artn_k_alt<KB1, K2, NTV, M3V>;                                                            \
+    if (hipError_t e = ensure_lds<artn_k_alt<KB1, K2, NTV, M3V>>(alds); e != hipSuccess) return e;        \
+    hipLaunchKernelGGL(kern, agrid, ablock, alds, st, A, B1, B2, C, p.bits);                              \
+    return hipGetLastError();                                                                             \
+  }
+#define ARTN_ALT_CASE(K2)                                                                                 \
+  case K2: {                                                                                              \
+    if constexpr ((KB1 == 5 || KB1 == 6 || K2 == 5 || K2 == 6) && !((KB1 >= 5 && K2 >= 5) && KB1 + K2 > 10)) { \
+      if (p.bits.m3) {                                                                                    \
+        if (p.bits.nt_loads) ARTN_ALT_GO(K2, true, true) else ARTN_ALT_GO(K2, false, true)                \
+      }                                                                                                   \
+    }                                                                                                     \
+    if (!p.bits.m3) {                                                                                     \
+      if (p.bits.nt_loads) ARTN_ALT_GO(K2, true, false) else ARTN_ALT_GO(K2, false, false)                \
+    }                                                                                                     \
+    break;                                                                                                \
+  }
+      switch (k2) {
+        ARTN_ALT_CASE(0)
+        ARTN_ALT_CASE(3)
+        ARTN_ALT_CASE(4)
+        ARTN_ALT_CASE(5)
+        ARTN_ALT_CASE(6)
+        default: break;
+      }
+#undef ARTN_ALT_CASE
+#undef ARTN_ALT_GO
+    }
   }
   if (p.bits.gather_dim >= 0) { // fused row gather: single stage, fp32 chains
     if (k2 != 0) return hipErrorInvalidValue;

@@ -156,6 +156,7 @@ struct ArtnGemmPlan {
 
 struct ArtnPlan {
   int kernel; // ARTN_KERNEL_*
+  int n_cu;   // compute units the plan was made for
   ArtnBitsPlan bits;
   ArtnGemmPlan gemm;
   ArtnGenericPlan gen;
@@ -179,6 +180,12 @@ struct Tuning {
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
   int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
   int gemm_tall = 1;  // GEMM kernel, fp32, 32 x 32 tiles: chunks of 2^6 contracted values
+  int alt = 2;        // big launches of the state-streaming kernel: 1: one 8-wave workgroup per CU, two groups alternating
+                      // between MFMA stages and copy phases (artn_k_alt); 0: two independent workgroups per CU (artn_k_bits);
+                      // 2: artn_k_alt where a tile's OUTPUT runs are shorter than a 128-byte line (its stores, slow
+                      // there, hide under the other group's stages: 5.15 -> 4.86 ms on the n30 pair that writes 64-byte
+                      // runs), artn_k_bits elsewhere (two waves per SIMD in the stages hide each other's LDS latencies:
+                      // measured equal or faster wherever the copies are cheap; A/B in one session)
   int bits_3m = 2;    // state-streaming kernel, fp32 stages with 5/6 contracted bits and 32+ columns: the same
                       // (1: not in fused pairs that hold a 6-bit stage, 0: never)
 };
@@ -194,6 +201,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_ALT")) x.alt = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
     return x;
@@ -1181,6 +1189,7 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   int rc = validate(d, err);
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
+  p.n_cu = n_cu;
   bool ok = false;
   if (d->dtype == ARTN_C128 && allow_bits && allow_gemm && gather_label < 0 && tuning().gemm)
     ok = make_gemm128(d, p, n_cu, min_tiles); // complex128: the f64 MFMA GEMM kernel or the strided kernel
@@ -1221,6 +1230,7 @@ static inline int make_plan_fused(const ArtnStepDesc *d1, const ArtnStepDesc *d2
   if (!rc) rc = validate(d2, err);
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
+  p.n_cu = n_cu;
   if (!make_bits(d1, d2, p, n_cu, min_tiles)) { err = "not fusable: " + p.why_generic; return ARTN_E_UNSUPPORTED; }
   double f1, f2, a1, b1, c1, a2, b2, c2;
   step_cost(d1, f1, a1, b1, c1);
