@@ -15,7 +15,7 @@ ABI_VERSION = 3
 ARTN_MAX_LABELS = 96
 ARTN_PROGRAM_MAX_EXT = 256
 ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
-KERNEL_GENERIC, KERNEL_BITS_MFMA, KERNEL_GEMM_MFMA = 0, 1, 2
+KERNEL_GENERIC, KERNEL_BITS_MFMA, KERNEL_GEMM_MFMA, KERNEL_PGEMM = 0, 1, 2, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARTN_LIB") or os.path.join(_HERE, "libartn_hip.so")  # ARTN_LIB: diagnostic builds
@@ -53,6 +53,7 @@ class ArtnStepInfo(ctypes.Structure):
         ("tile_mid_bits", ctypes.c_int32),
         ("arith", ctypes.c_int32),
         ("mfma_flops", ctypes.c_double),
+        ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -67,6 +68,8 @@ _EXPORTS = {
     "artn_last_plan_note": (ctypes.c_char_p, []),
     "artn_contract": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p]),
+    "artn_contract_ws": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "artn_contract_gather": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),

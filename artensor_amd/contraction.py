@@ -242,6 +242,8 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None
                                    tuple(b_stride if b_stride is not None else _dense_strides(tuple(b_shape))),
                                    dtype)
         info = _step_info_cached(d)
+        if info["kernel"] == N.KERNEL_PGEMM:
+            return None   # packed-operand GEMM: every contracted bit is looped over in the kernel, thousands of tiles
         if info["kernel"] == N.KERNEL_GEMM_MFMA:
             want = 0   # bits to split off for parallelism
             tiles = max(1, info["n_tiles"])
@@ -311,6 +313,19 @@ def _split_big_k(la, lb, lo, a, b):
     return (mid, (), tuple(lo)), part, _one_scalar(a.dtype, a.device), len(outer)
 
 
+def _launch_step(d, a, b, out, stream):
+    """artn_contract, or artn_contract_ws with a scratch buffer where the planner asks for one (reduced-precision
+    mode: the big contractions pack their operands to bfloat16 first).  The library never allocates: the scratch is
+    a torch buffer, returned to the caching allocator in stream order.  Returns the status code."""
+    lib = N.lib()
+    if d.dtype == N.ARTN_C64_BF16:
+        ws_bytes = _step_info_cached(d)["workspace_bytes"]
+        if ws_bytes > 0:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+            return lib.artn_contract_ws(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+    return lib.artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(), stream)
+
+
 def contract(eq, a, b, out=None):
     """C = einsum(eq, a, b) on the GPU through artn_contract (stands in for torch.einsum at
     reference contraction.py:70,147,156,163,169,179,181,190).  `eq` is an einsum string or
@@ -343,14 +358,12 @@ def contract(eq, a, b, out=None):
     _warn_if_generic(d, max(a.numel(), out.numel()), f"contract({eq!r})" if isinstance(eq, str) else "contract()")
     with torch.cuda.device(a.device):
         if profiler is None:
-            N.check(N.lib().artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                          N.current_stream_ptr(a.device)))
+            N.check(_launch_step(d, a, b, out, N.current_stream_ptr(a.device)))
         else:
             info = _step_info_cached(d)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            N.check(N.lib().artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                          N.current_stream_ptr(a.device)))
+            N.check(_launch_step(d, a, b, out, N.current_stream_ptr(a.device)))
             e1.record()
             profiler.record(info, e0, e1)
     return out
@@ -862,7 +875,7 @@ def tensor_contraction(tensors, scheme):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if op.d2 is None:
-                rc = lib.artn_contract(byref(op.d1), a.data_ptr(), b.data_ptr(), out.data_ptr(), stream) if out.numel() else 0
+                rc = _launch_step(op.d1, a, b, out, stream) if out.numel() else 0
             else:
                 b2 = tensors[op.j2]
                 rc = lib.artn_contract2(byref(op.d1), byref(op.d2), a.data_ptr(), b.data_ptr(), b2.data_ptr(),

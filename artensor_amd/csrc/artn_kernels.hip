@@ -1558,6 +1558,7 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 #ifndef ARTN_TU_BITS
 #include "artn_gemm_kernel.h"
 #include "artn_gemm128_kernel.h"
+#include "artn_pgemm_kernel.h"
 
 // ----------------------------------------------------------------------------------------
 // strided fallback: one thread per C element
@@ -2280,6 +2281,20 @@ static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, 
 #endif
 }
 
+static hipError_t launch_pgemm(const ArtnPlan &p, const void *A, const void *B, void *C, void *ws, hipStream_t st) {
+  const ArtnPackPlan &g = p.pack;
+  const float2 *a = (const float2 *)(g.swapped ? B : A), *b = (const float2 *)(g.swapped ? A : B);
+  const long a_units = 1L << (g.n_mo + g.n_ko + ARTN_PG_KC - 2 + ARTN_PG_MT), b_units = 1L << (g.n_no + g.n_ko + ARTN_PG_KC - 2 + ARTN_PG_NT);
+  unsigned char *Ap = (unsigned char *)ws, *Bp = Ap + a_units * 16;
+  auto blocks = [&](long units) { return dim3((unsigned)std::min<long>((units + ARTN_WG_THREADS - 1) / ARTN_WG_THREADS, (long)p.n_cu * 16)); };
+  hipLaunchKernelGGL(artn_k_pack_bf16, blocks(a_units), dim3(ARTN_WG_THREADS), 0, st, a, (u32x4_t *)Ap, g.a, g.n_ko, a_units);
+  hipLaunchKernelGGL(artn_k_pack_bf16, blocks(b_units), dim3(ARTN_WG_THREADS), 0, st, b, (u32x4_t *)Bp, g.b, g.n_ko, b_units);
+  const size_t lds = (size_t)p.info.lds_bytes;
+  if (hipError_t e = ensure_lds<artn_k_pgemm>(lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(artn_k_pgemm, dim3(p.info.grid), dim3(ARTN_PG_THREADS), lds, st, Ap, Bp, (float2 *)C, g);
+  return hipGetLastError();
+}
+
 static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, void *C, hipStream_t st) {
   const ArtnGemmPlan &g = p.gemm;
   const float2 *a = (const float2 *)(g.swapped ? B : A), *b = (const float2 *)(g.swapped ? A : B);
@@ -2419,7 +2434,7 @@ int artn_contract_query(const ArtnStepDesc *d, ArtnStepInfo *info) {
   std::string err;
   const bool no_bits = env_flag("ARTN_FORCE_GENERIC");
   const int64_t min_tiles = env_flag("ARTN_FORCE_BITS") ? 1 : 32;
-  int rc = artn::make_plan(d, p, err, g_ncu, !no_bits, min_tiles);
+  int rc = artn::make_plan(d, p, err, g_ncu, !no_bits, min_tiles, -1, true, true);
   if (rc) return fail(rc, err);
   *info = p.info;
   g_note = p.kernel == ARTN_KERNEL_GENERIC ? p.why_generic : std::string();
@@ -2461,6 +2476,22 @@ int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, 
                        (const double2 *)B, (double2 *)C, p.gen);
   HIP_TRY(hipGetLastError());
   return ARTN_OK;
+}
+
+int artn_contract_ws(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *ws, int64_t ws_bytes, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (!A || !B || !C) return fail(ARTN_E_INVALID, "null operand pointer");
+  if (ws && ws_bytes > 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) == 0 && !env_flag("ARTN_FORCE_GENERIC")) {
+    ArtnPlan p;
+    std::string err;
+    int rc = artn::make_plan(d, p, err, g_ncu, true, 32, -1, true, true);
+    if (rc) return fail(rc, err);
+    if (p.kernel == ARTN_KERNEL_PGEMM && p.info.workspace_bytes <= ws_bytes) {
+      HIP_TRY(launch_pgemm(p, A, B, C, ws, (hipStream_t)stream));
+      return ARTN_OK;
+    }
+  }
+  return artn_contract(d, A, B, C, stream);
 }
 
 int artn_contract_gather(const ArtnStepDesc *d, const void *A, const void *B, void *C, int label,

@@ -1,0 +1,238 @@
+// artn_pgemm_kernel.h -- packed-operand GEMM of the reduced-precision mode (included by artn_kernels.hip).
+//
+// BASELINE configs[4] (Sycamore n53 m20 big-batch sampling, bf16-complex MFMA path) is one contraction: 2^30 x 2^29
+// elements over 15 contracted bits, 98.9 % of a slice.  artn_k_gemm<.., BF> reads both operands as complex64 (8 bytes
+// per element) in 128 x 64 tiles, converts them to bfloat16 on the way into LDS and runs at 15 % of the bf16 MFMA
+// peak: every chunk of 32 contracted values moves 48 KiB from L2 for 16 MFMAs per wave (8-9 TB/s of L2 traffic at
+// 365 TFLOP/s).  Here
+//   * artn_k_pack_bf16 rounds each operand ONCE (round to nearest even, the same values the other kernel feeds its
+//     MFMAs) and writes it as 4-byte (re, im) bfloat16 pairs in the exact order of the GEMM's LDS images:
+//     [tile][chunk][plane g = kc >> 2 (8)][row][u = kc & 3]  -- 16 bytes per (plane, row);
+//   * artn_k_pgemm: one workgroup of 8 waves (4 along m x 2 along n) per CU owns a 256 x 128 tile; a chunk is 32 KiB
+//     + 16 KiB of CONTIGUOUS packed data that goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers,
+//     no ds_write, no conversion in the loop), three chunk buffers, loads two chunks ahead, one raw s_barrier per
+//     chunk with counted vmcnt waits; each wave multiplies 64 x 64 outputs (2 x 4 blocks of v_mfma_f32_32x32x16_bf16,
+//     32 MFMAs per chunk).  Half the bytes per element and a quarter of the re-reads: 1/8 of the L2 traffic per FLOP.
+// Lane roles of one MFMA (8 complex contracted values kc = 8t + 4h + u, h = lane >> 5):
+//   W side (MFMA A operand): row i = lane & 31 = 2 * n_in_block + ro; 16 bytes of the second operand's image
+//                            [2t + h][n], turned into (re, -im) / (im, re) per output parity ro
+//   X side (MFMA B operand): column j = lane & 31 = m_in_block; 16 bytes of the first operand's image [2t + h][m]
+//   accumulator register r of lane (j, h): n_in_block = ((r >> 1) & 1) + 2h + 4(r >> 2), ro = r & 1.
+
+// out[16-byte unit] = 4 consecutive chunk values of one row: units ordered [tile][chunk][plane][row]
+__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_pack_bf16(const float2 *__restrict__ X, u32x4_t *__restrict__ out,
+                                                                   const ArtnPackSide S, const int n_ko, const long n_units) {
+  const int rb = S.n_row;
+  for (long unit = (long)blockIdx.x * blockDim.x + threadIdx.x; unit < n_units; unit += (long)gridDim.x * blockDim.x) {
+    long r = unit, src = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < rb && ((r >> i) & 1)) src += S.row[i];
+    r >>= rb;
+#pragma unroll
+    for (int q = 2; q < ARTN_PG_KC; ++q)
+      if ((r >> (q - 2)) & 1) src += S.kc[q];
+    r >>= ARTN_PG_KC - 2;
+    for (int q = 0; q < n_ko; ++q)
+      if ((r >> q) & 1) src += S.ko[q];
+    r >>= n_ko;
+    for (int q = 0; q < S.n_to; ++q)
+      if ((r >> q) & 1) src += S.to[q];
+    u32x4_t v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float2 e = X[src + ((u & 1) ? S.kc[0] : 0) + ((u & 2) ? S.kc[1] : 0)];
+      v[u] = pack_bf16(e.x, e.y);
+    }
+    out[unit] = v;
+  }
+}
+
+// LDS-DMA: 64 lanes x 16 bytes land at lds_dst + lane * 16 (wave-uniform destination in M0, per-lane source)
+__device__ __forceinline__ void pg_glds16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+#define ARTN_PG_THREADS 512
+#define ARTN_PG_A_BYTES (4u << (ARTN_PG_MT + ARTN_PG_KC)) /* 32 KiB */
+#define ARTN_PG_B_BYTES (4u << (ARTN_PG_NT + ARTN_PG_KC)) /* 16 KiB */
+#define ARTN_PG_STAGE (ARTN_PG_A_BYTES + ARTN_PG_B_BYTES)
+
+__global__ __launch_bounds__(ARTN_PG_THREADS, 1) void artn_k_pgemm(const unsigned char *__restrict__ Ap, const unsigned char *__restrict__ Bp,
+                                                                   float2 *__restrict__ C, const ArtnPackPlan P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((unsigned)(unsigned long)(lds_byte_t *)smem != 0) __builtin_trap(); // LDS is addressed by raw byte offsets
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5, ro = j & 1;
+  const int wm = wave & 3, wn = wave >> 2;
+  constexpr int MB = 2, NB = 4;
+  constexpr unsigned RA = 1u << ARTN_PG_MT, RB = 1u << ARTN_PG_NT;
+  const unsigned lane_x = ((unsigned)h * RA + (unsigned)(wm * 64 + j)) * 16u;
+  const unsigned lane_w = ARTN_PG_A_BYTES + ((unsigned)h * RB + (unsigned)(wn * 64 + (j >> 1))) * 16u;
+  const unsigned w_sel = ro ? 0x01000302u : 0x03020100u, w_sign = ro ? 0u : 0x80000000u; // (im, re) / (re, -im)
+  const int n_chunks = 1 << P.n_ko;
+
+  // ---- epilogue offsets (elements of the C-ordered result image, swizzled; fields are disjoint: XOR)
+  auto m_off = [&](int m_local) {
+    unsigned o = 0;
+#pragma unroll
+    for (int i = 0; i < ARTN_PG_MT; ++i)
+      if ((m_local >> i) & 1) o |= 1u << P.m_pos[i];
+    return o;
+  };
+  auto n_off = [&](int n_local) {
+    unsigned o = 0;
+#pragma unroll
+    for (int i = 0; i < ARTN_PG_NT; ++i)
+      if ((n_local >> i) & 1) o |= 1u << P.n_pos[i];
+    return o;
+  };
+  const unsigned lane_c = swz_gemm(m_off(wm * 64 + j) | n_off(wn * 64 + 2 * h), P);
+  unsigned c_mb[MB], c_nb[NB];
+#pragma unroll
+  for (int q = 0; q < MB; ++q) c_mb[q] = swz_gemm(m_off(q * 32), P);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) c_nb[q] = swz_gemm(n_off(q * 16), P);
+  const unsigned c_b0 = swz_gemm(n_off(1), P), c_q0 = swz_gemm(n_off(4), P), c_q1 = swz_gemm(n_off(8), P);
+  constexpr int TC = ARTN_PG_MT + ARTN_PG_NT, EPI = ARTN_PG_EPI_BITS;
+  // copy-out: 16-byte unit c = tid + 512 * i of a pass (elements 2c, 2c + 1 of the image)
+  unsigned o_gl = 0;
+#pragma unroll
+  for (int b = 1; b <= 9; ++b)
+    if ((tid >> (b - 1)) & 1) o_gl += (unsigned)P.out_stride[b] * 8u;
+  long o_gi[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) o_gi[b] = P.out_stride[10 + b] * 8;
+  const unsigned o_ll = swz_gemm((unsigned)tid * 2u, P) * 8u;
+
+  // ---- tiles: index bits [no 0..2][mo 0..1][other no][other mo]: the 32 workgroups of an XCD (an XCD-contiguous range of
+  //      32 consecutive indices per grid-stride period) form a block of 4 x 8 tiles that share operand stripes in its L2
+  const long G = gridDim.x, n_tiles = P.n_tiles;
+  long t0 = blockIdx.x;
+  if ((G & 7) == 0) t0 = (long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int nl = P.n_no < 3 ? P.n_no : 3, ml = P.n_mo < 2 ? P.n_mo : 2;
+  const long a_tile_bytes = (long)n_chunks * ARTN_PG_A_BYTES, b_tile_bytes = (long)n_chunks * ARTN_PG_B_BYTES;
+
+  for (long tile = t0; tile < n_tiles; tile += G) {
+    // tile index -> (mo, no)
+    long r = tile;
+    long no = r & ((1L << nl) - 1);
+    r >>= nl;
+    long mo = r & ((1L << ml) - 1);
+    r >>= ml;
+    no |= (r & ((1L << (P.n_no - nl)) - 1)) << nl;
+    r >>= P.n_no - nl;
+    mo |= r << ml;
+    long c_off = 0;
+    for (int q = 0; q < P.n_mo; ++q)
+      if ((mo >> q) & 1) c_off += P.c_mo[q];
+    for (int q = 0; q < P.n_no; ++q)
+      if ((no >> q) & 1) c_off += P.c_no[q];
+    c_off = uniform64(c_off);
+    const unsigned char *At = Ap + uniform64(mo * a_tile_bytes), *Bt = Bp + uniform64(no * b_tile_bytes);
+
+    // chunk c -> buffer c % 3: 4 + 2 LDS-DMA instructions per thread (8 KiB per workgroup-wide instruction)
+    auto stage = [&](int c, unsigned buf) {
+      const unsigned char *ga = At + (long)c * ARTN_PG_A_BYTES + tid * 16, *gb = Bt + (long)c * ARTN_PG_B_BYTES + tid * 16;
+      const unsigned dst = buf * ARTN_PG_STAGE + (unsigned)wave * 1024u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pg_glds16(ga + q * 8192, dst + q * 8192u);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) pg_glds16(gb + q * 8192, dst + ARTN_PG_A_BYTES + q * 8192u);
+    };
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // (every wave is past the previous tile's last LDS read: the epilogue ends with a barrier)
+    stage(0, 0u);
+    if (n_chunks > 1) stage(1, 1u);
+    unsigned cur = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+      // this wave's part of chunk c has landed (6 younger DMA instructions -- chunk c + 1 -- may still be in flight) ...
+      if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // ... and after the barrier everybody's has; everybody is also done reading buffer (c + 2) % 3 (chunk c - 1)
+      __builtin_amdgcn_s_barrier();
+      if (c + 2 < n_chunks) stage(c + 2, cur >= 1 ? cur - 1 : 2u);
+      const unsigned xa = cur * ARTN_PG_STAGE + lane_x, wa = cur * ARTN_PG_STAGE + lane_w;
+      u32x4_t X[2][MB], Wr[2][NB];
+      auto load_ops = [&](int t, u32x4_t (&x)[MB], u32x4_t (&w)[NB]) {
+#pragma unroll
+        for (int a = 0; a < MB; ++a) x[a] = __builtin_bit_cast(u32x4_t, lds_read16(xa + (unsigned)t * (2u * RA * 16u) + (unsigned)a * 512u));
+#pragma unroll
+        for (int b = 0; b < NB; ++b) w[b] = __builtin_bit_cast(u32x4_t, lds_read16(wa + (unsigned)t * (2u * RB * 16u) + (unsigned)b * 256u));
+      };
+      load_ops(0, X[0], Wr[0]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t + 1 < 4) load_ops(t + 1, X[(t + 1) & 1], Wr[(t + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4_t W[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned d = Wr[t & 1][b][e];
+            W[b][e] = __builtin_amdgcn_perm(d, d, w_sel) ^ w_sign;
+          }
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, W[b]),
+                                                               __builtin_bit_cast(bf16x8_t, X[t & 1][a]), acc[a][b], 0, 0, 0);
+      }
+      cur = cur == 2 ? 0u : cur + 1;
+    }
+    // ---- epilogue: accumulators -> C-ordered LDS image (2^13 elements per pass) -> 16-byte coalesced stores
+    char *Cb = reinterpret_cast<char *>(C) + c_off * 8;
+    for (int pass = 0; pass < (1 << (TC - EPI)); ++pass) {
+      __syncthreads(); // chunk buffers / the previous pass are no longer in use
+      unsigned lc = lane_c;
+      OPAQUE_V(lc);
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b0 = 0; b0 < 2; ++b0) {
+              const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ (b0 ? c_b0 : 0u) ^ ((q & 1) ? c_q0 : 0u) ^ ((q >> 1) ? c_q1 : 0u);
+              if ((int)(pos >> EPI) == pass)
+                lds_write8((pos & ((1u << EPI) - 1u)) * 8u, v2f_t{acc[a][b][4 * q + 2 * b0], acc[a][b][4 * q + 2 * b0 + 1]});
+            }
+      __syncthreads();
+      unsigned oll = o_ll ^ ((swz_gemm((unsigned)pass << EPI, P) & ((1u << EPI) - 1u)) * 8u), ogl = o_gl;
+      OPAQUE_V(oll);
+      OPAQUE_V(ogl);
+      long po = 0;
+#pragma unroll
+      for (int b = 0; b < TC - EPI; ++b)
+        if ((pass >> b) & 1) po += P.out_stride[EPI + b] * 8;
+      f32x4 x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = lds_read16(oll ^ (swz_gemm((unsigned)i * 1024u, P) * 8u));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        long o = po;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          if ((i >> b) & 1) o += o_gi[b];
+        *reinterpret_cast<f32x4 *>(Cb + o + ogl) = x[i];
+      }
+    }
+    __syncthreads(); // the result image has been read: the chunk buffers are free for the next tile
+  }
+}
+

@@ -154,8 +154,39 @@ struct ArtnGemmPlan {
   int32_t *gather_err;
 };
 
+// Launch plan of the packed-operand GEMM (artn_k_pack_bf16 + artn_k_pgemm; ARTN_C64_BF16 only): big x big steps with
+// many contracted bits (BASELINE configs[4]: 2^30 x 2^29 elements over 15 contracted bits).  One pass per operand
+// rounds it to bfloat16 and writes it in the order the GEMM's LDS images have -- [tile][chunk][kc >> 2][row][kc & 3],
+// 4 bytes per complex element -- into a caller-supplied workspace; the GEMM then moves half the bytes per operand
+// element, as contiguous 16-byte lanes straight into LDS (LDS-DMA), and its 256 x 128 tiles re-read each operand
+// element a quarter as often as the 128 x 64 tiles of artn_k_gemm.
+#define ARTN_PG_MT 8 /* 256 rows of the first operand per tile  */
+#define ARTN_PG_NT 7 /* 128 rows of the second operand per tile */
+#define ARTN_PG_KC 5 /* 32 contracted values per chunk          */
+#define ARTN_PG_EPI_BITS 13
+struct ArtnPackSide { // one operand: element strides of its bits
+  int64_t row[8];     // tile-row bit i
+  int64_t kc[ARTN_PG_KC]; // chunk bit q (q = 0, 1: inside a 16-byte lane; q = 2..4: the plane index)
+  int64_t ko[ARTN_GEMM_MAX_KO]; // looped contracted bit
+  int64_t to[32];     // tile-outer bit
+  int32_t n_row, n_to;
+};
+struct ArtnPackPlan {
+  int32_t swapped;    // 1: the kernel's first operand is the caller's B
+  int32_t n_ko;       // 2^n_ko chunks per tile
+  int32_t n_mo, n_no; // tile-outer bits of the first / second operand
+  int64_t n_tiles;
+  ArtnPackSide a, b;
+  int64_t c_mo[32], c_no[32]; // C element strides of the tile-outer bits
+  int64_t out_stride[16];     // C-tile-local bit (tile bits ordered by C stride) -> C element stride
+  int32_t m_pos[8], n_pos[8]; // m_local / n_local bit -> C-tile-local position
+  int32_t swz_n, swz_src[4], swz_dst[4];
+  int32_t pad_;
+};
+
 struct ArtnPlan {
   int kernel; // ARTN_KERNEL_*
+  ArtnPackPlan pack;
   int n_cu;   // compute units the plan was made for
   ArtnBitsPlan bits;
   ArtnGemmPlan gemm;
@@ -180,6 +211,7 @@ struct Tuning {
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
   int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
   int gemm_tall = 1;  // GEMM kernel, fp32, 32 x 32 tiles: chunks of 2^6 contracted values
+  int packed = 1;     // reduced-precision mode, big steps with 2^9+ contracted values: packed-operand GEMM (ArtnPackPlan)
   int alt = 2;        // big launches of the state-streaming kernel: 1: one 8-wave workgroup per CU, two groups alternating
                       // between MFMA stages and copy phases (artn_k_alt); 0: two independent workgroups per CU (artn_k_bits);
                       // 2: artn_k_alt where a tile's OUTPUT runs are shorter than a 128-byte line (its stores, slow
@@ -201,6 +233,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_PACKED")) x.packed = atoi(e) != 0;
     if (const char *e = getenv("ARTN_ALT")) x.alt = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
@@ -1170,6 +1203,108 @@ static inline bool make_gemm128(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, in
   return true;
 }
 
+// ----------------------------------------------------------------------------------------
+// packed-operand GEMM (ARTN_C64_BF16): see ArtnPackPlan
+// ----------------------------------------------------------------------------------------
+static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
+  if (d->dtype != ARTN_C64_BF16) { p.why_generic = "packed GEMM: reduced-precision mode only"; return false; }
+  std::vector<Axis> ax;
+  expand_axes(d, ax);
+  std::vector<int> K, M, N;
+  for (int i = 0; i < (int)ax.size(); ++i) {
+    const Axis &a = ax[i];
+    if (!a.bit) { p.why_generic = "packed GEMM: non power-of-two extent"; return false; }
+    if (a.k1()) K.push_back(i);
+    else if (a.m1()) M.push_back(i);
+    else if (a.n1()) N.push_back(i);
+    else { p.why_generic = "packed GEMM: batch label or label summed out of one operand"; return false; }
+  }
+  const bool swapped = M.size() < N.size(); // the operand with more free bits supplies the 256-row side
+  if (swapped) {
+    for (auto &a : ax) std::swap(a.sA, a.sB1);
+    std::swap(M, N);
+  }
+  const int k = (int)K.size(), m = (int)M.size(), n = (int)N.size();
+  // worth two packing passes: 2^9+ contracted values, and enough tiles for every CU
+  if (k < 9 || m < ARTN_PG_MT || n < ARTN_PG_NT) { p.why_generic = "packed GEMM: too few contracted or free bits"; return false; }
+  if (k - ARTN_PG_KC > ARTN_GEMM_MAX_KO || m - ARTN_PG_MT > 32 || n - ARTN_PG_NT > 32) { p.why_generic = "packed GEMM: too many bits"; return false; }
+  if ((int64_t(1) << (m - ARTN_PG_MT + n - ARTN_PG_NT)) < n_cu) { p.why_generic = "packed GEMM: too few tiles to fill the chip"; return false; }
+  auto byA = [&](int x, int y) { return ax[x].sA < ax[y].sA; };
+  auto byB = [&](int x, int y) { return ax[x].sB1 < ax[y].sB1; };
+  auto byC = [&](int x, int y) { return ax[x].sC < ax[y].sC; };
+  auto in_set = [](const std::vector<int> &v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+  auto pos = [](const std::vector<int> &v, int axis) { return (int)(std::find(v.begin(), v.end(), axis) - v.begin()); };
+  // chunk bits: the contracted bits with the lowest strides in the first (bigger) operand, so that its packing pass
+  // reads neighbouring elements; tile rows: the free bits with the lowest C strides first (coalesced result stores),
+  // topped up by lowest operand stride
+  std::sort(K.begin(), K.end(), byA);
+  std::vector<int> Kc(K.begin(), K.begin() + ARTN_PG_KC);
+  auto pick_rows = [&](std::vector<int> &F, int want, auto byOp) {
+    std::vector<int> byc(F), out;
+    std::sort(byc.begin(), byc.end(), byC);
+    for (int i : byc) { if ((int)out.size() >= 4 || (int)out.size() >= want) break; if (ax[i].sC < 16) out.push_back(i); } // the bits inside a 128-byte run of C
+    std::vector<int> byo(F);
+    std::sort(byo.begin(), byo.end(), byOp);
+    for (int i : byo) { if ((int)out.size() >= want) break; if (!in_set(out, i)) out.push_back(i); }
+    std::sort(out.begin(), out.end(), byOp);
+    return out;
+  };
+  std::vector<int> Mt = pick_rows(M, ARTN_PG_MT, byA), Nt = pick_rows(N, ARTN_PG_NT, byB);
+  ArtnPackPlan &g = p.pack;
+  memset(&g, 0, sizeof(g));
+  g.swapped = swapped ? 1 : 0;
+  g.n_ko = k - ARTN_PG_KC;
+  g.n_mo = m - ARTN_PG_MT;
+  g.n_no = n - ARTN_PG_NT;
+  g.n_tiles = int64_t(1) << (g.n_mo + g.n_no);
+  g.a.n_row = ARTN_PG_MT; g.b.n_row = ARTN_PG_NT; g.a.n_to = g.n_mo; g.b.n_to = g.n_no;
+  for (int i = 0; i < ARTN_PG_MT; ++i) g.a.row[i] = ax[Mt[i]].sA;
+  for (int i = 0; i < ARTN_PG_NT; ++i) g.b.row[i] = ax[Nt[i]].sB1;
+  for (int q = 0; q < ARTN_PG_KC; ++q) { g.a.kc[q] = ax[Kc[q]].sA; g.b.kc[q] = ax[Kc[q]].sB1; }
+  { int q = 0; for (int i : K) if (!in_set(Kc, i)) { g.a.ko[q] = ax[i].sA; g.b.ko[q] = ax[i].sB1; ++q; } }
+  { int q = 0; for (int i : M) if (!in_set(Mt, i)) { g.a.to[q] = ax[i].sA; g.c_mo[q] = ax[i].sC; ++q; } }
+  { int q = 0; for (int i : N) if (!in_set(Nt, i)) { g.b.to[q] = ax[i].sB1; g.c_no[q] = ax[i].sC; ++q; } }
+  std::vector<int> tC(Mt);
+  tC.insert(tC.end(), Nt.begin(), Nt.end());
+  std::sort(tC.begin(), tC.end(), byC);
+  for (int b = 0; b < ARTN_PG_MT + ARTN_PG_NT; ++b) g.out_stride[b] = ax[tC[b]].sC;
+  if (g.out_stride[0] != 1) { p.why_generic = "packed GEMM: no 16-byte run at the bottom of the result"; return false; }
+  for (int b = 1; b < ARTN_PG_MT + ARTN_PG_NT; ++b) if (g.out_stride[b] & 1) { p.why_generic = "packed GEMM: odd C stride"; return false; }
+  for (int q = 0; q < g.n_mo; ++q) if (g.c_mo[q] & 1) { p.why_generic = "packed GEMM: odd C stride"; return false; }
+  for (int q = 0; q < g.n_no; ++q) if (g.c_no[q] & 1) { p.why_generic = "packed GEMM: odd C stride"; return false; }
+  {
+    int64_t sc = 0;
+    for (int b = 1; b <= 9; ++b) sc += g.out_stride[b];
+    if (sc > (int64_t(1) << 28) - 1) { p.why_generic = "packed GEMM: lane offsets exceed 32 bits"; return false; }
+  }
+  for (int i = 0; i < ARTN_PG_MT; ++i) g.m_pos[i] = pos(tC, Mt[i]);
+  for (int i = 0; i < ARTN_PG_NT; ++i) g.n_pos[i] = pos(tC, Nt[i]);
+  { // result-image swizzle, as in make_gemm: the 16 lanes of a ds_write_b64 group differ in m_local bits 0..3
+    bool taken[4] = {true, false, false, false};
+    for (int i = 0; i < 4; ++i) if (g.m_pos[i] < 4) taken[g.m_pos[i]] = true;
+    for (int i = 0; i < 4 && tuning().swizzle; ++i) {
+      if (g.m_pos[i] < 4) continue;
+      int f = -1;
+      for (int c = 1; c < 4; ++c) if (!taken[c]) { f = c; break; }
+      if (f < 0) break;
+      taken[f] = true;
+      g.swz_src[g.swz_n] = g.m_pos[i]; g.swz_dst[g.swz_n] = f; ++g.swz_n;
+    }
+  }
+  p.kernel = ARTN_KERNEL_PGEMM;
+  ArtnStepInfo &f = p.info;
+  f.kernel = ARTN_KERNEL_PGEMM;
+  f.k_bits = k; f.m_tile_bits = ARTN_PG_MT; f.n_tile_bits = ARTN_PG_NT;
+  f.tile_in_bits = ARTN_PG_MT + ARTN_PG_KC; f.tile_out_bits = ARTN_PG_MT + ARTN_PG_NT;
+  f.run_in_bits = 0; f.run_out_bits = 0;
+  f.lds_bytes = 3 * ((4 << (ARTN_PG_MT + ARTN_PG_KC)) + (4 << (ARTN_PG_NT + ARTN_PG_KC))); // three chunk buffers
+  f.n_tiles = g.n_tiles;
+  f.a_rereads = int64_t(1) << g.n_no;
+  f.grid = (int32_t)std::min<int64_t>(g.n_tiles, (int64_t)n_cu);
+  f.workspace_bytes = 4 * ((int64_t(1) << (m + k)) + (int64_t(1) << (n + k)));
+  return true;
+}
+
 static inline void step_cost(const ArtnStepDesc *d, double &flops, double &na, double &nb, double &nc) {
   double prod = 1;
   na = nb = nc = 1;
@@ -1185,12 +1320,17 @@ static inline void step_cost(const ArtnStepDesc *d, double &flops, double &na, d
 // min_tiles: below this many LDS tiles the strided kernel is used instead (a handful of
 // workgroups cannot fill 256 CUs; such steps are launch-latency bound either way).
 static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err, int n_cu = 256,
-                            bool allow_bits = true, int64_t min_tiles = 32, int gather_label = -1, bool allow_gemm = true) {
+                            bool allow_bits = true, int64_t min_tiles = 32, int gather_label = -1, bool allow_gemm = true,
+                            bool allow_packed = false) {
   int rc = validate(d, err);
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
   p.n_cu = n_cu;
   bool ok = false;
+  // (needs a workspace: only where the caller can supply one -- artn_contract_query reports its size, artn_contract_ws takes it)
+  if (allow_packed && allow_bits && allow_gemm && gather_label < 0 && tuning().gemm && tuning().packed && d->dtype == ARTN_C64_BF16)
+    ok = make_pgemm(d, p, n_cu);
+  allow_gemm = allow_gemm && !ok;
   if (d->dtype == ARTN_C128 && allow_bits && allow_gemm && gather_label < 0 && tuning().gemm)
     ok = make_gemm128(d, p, n_cu, min_tiles); // complex128: the f64 MFMA GEMM kernel or the strided kernel
   allow_gemm = allow_gemm && allow_bits && gather_label < 0 && tuning().gemm && d->dtype != ARTN_C128 && !ok;
@@ -1211,6 +1351,9 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
     const bool m3 = p.bits.st[0].m3 != 0;
     p.info.arith = p.bits.split == 1 ? 2 : (m3 ? 1 : 0);
     p.info.mfma_flops = p.info.flops * (m3 ? 0.75 : 1.0);
+  } else if (p.kernel == ARTN_KERNEL_PGEMM) {
+    p.info.arith = 2;
+    p.info.mfma_flops = p.info.flops;
   } else if (p.kernel == ARTN_KERNEL_GEMM_MFMA) {
     p.info.arith = d->dtype == ARTN_C128 ? 3 : (p.gemm.split == 1 ? 2 : (p.gemm.m3 ? 1 : 0));
     p.info.mfma_flops = p.info.flops * (p.gemm.m3 ? 0.75 : 1.0);

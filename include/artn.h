@@ -66,6 +66,7 @@ typedef struct ArtnStepDesc {
 #define ARTN_KERNEL_GENERIC 0 /* one thread per output element, strided loops       */
 #define ARTN_KERNEL_BITS_MFMA 1 /* LDS-tiled bit-permuted complex GEMM on fp32 MFMA */
 #define ARTN_KERNEL_GEMM_MFMA 2 /* two-operand LDS GEMM on fp32 MFMA, contracted bits looped in-kernel */
+#define ARTN_KERNEL_PGEMM 4     /* ARTN_C64_BF16, big steps: operands packed to bfloat16 in a workspace, LDS-DMA GEMM */
 typedef struct ArtnStepInfo {
   int32_t kernel;       /* ARTN_KERNEL_*                                        */
   int32_t k_bits;       /* contracted bits handled inside a tile                */
@@ -87,6 +88,7 @@ typedef struct ArtnStepInfo {
   int32_t arith;        /* 0 fp32 MFMA 4M, 1 fp32 MFMA with 3M stages, 2 bf16 operands, 3 f64 MFMA, -1 no MFMA */
   double mfma_flops;    /* real FLOP the matrix pipe executes: `flops` with 6 instead of 8 per complex
                            multiply-add in every 3M stage (0 for the strided kernel)     */
+  int64_t workspace_bytes; /* scratch the step wants from artn_contract_ws (0: none; artn_contract never needs any) */
 } ArtnStepInfo;
 
 int artn_abi_version(void);
@@ -103,6 +105,13 @@ const char *artn_last_plan_note(void);
 
 /* Enqueue one pairwise contraction (replaces torch.einsum at contraction.py:70 etc.). */
 int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *stream);
+
+/* The same with `ws_bytes` bytes of device scratch (16-byte aligned; ArtnStepInfo::workspace_bytes of
+ * artn_contract_query says how much the step can use): steps that pack their operands first -- the big
+ * contractions of the reduced-precision mode -- run that way when the scratch is big enough, and exactly like
+ * artn_contract otherwise.  The library never allocates. */
+int artn_contract_ws(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *ws, int64_t ws_bytes,
+                     void *stream);
 
 /*
  * artn_contract with a fused row gather: along `label` (an output label; the batch label of the

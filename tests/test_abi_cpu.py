@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # sizes the C side was compiled with (ArtnStepDesc: 2 int32 + 4 arrays of 96 int64)
     assert ctypes.sizeof(N.ArtnStepDesc) == 8 + 4 * 96 * 8
-    assert ctypes.sizeof(N.ArtnStepInfo) == 10 * 4 + 2 * 8 + 2 * 8 + 4 * 4 + 8
+    assert ctypes.sizeof(N.ArtnStepInfo) == 10 * 4 + 2 * 8 + 2 * 8 + 4 * 4 + 8 + 8
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the CPU-only refusal")

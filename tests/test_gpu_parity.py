@@ -1006,3 +1006,33 @@ def test_tn_contract_bookkeeping_and_values():
     assert tn.tensor_bonds == {2: ["e"]} and set(tn.bond_tensors) == {"e"}
     want = np.einsum("abv,v,bc,cde,da->e", arrs[0], arrs[4], arrs[1], arrs[2], arrs[3])
     assert rel(out.cpu().numpy(), want) < 1e-5
+
+
+@pytest.mark.parametrize("m,n,k,seed", [(12, 11, 9, 0), (11, 12, 10, 1), (13, 10, 9, 2)])
+def test_packed_gemm_bf16(m, n, k, seed):
+    """precision("bf16"), big x big steps with 2^9+ contracted values (BASELINE configs[4]'s step in small): both operands
+    are packed to bfloat16 once (artn_k_pack_bf16) into a scratch buffer the HOST allocates (artn_contract_ws), the GEMM
+    (artn_k_pgemm: 256 x 128 tiles, LDS-DMA, 32x32x16 bf16 MFMA) reads the packed copies.  Labels are shuffled so that
+    every operand bit lands somewhere else in memory.  Against the numpy restatement of that arithmetic: operands
+    rounded to bfloat16 (nearest even), products and sums exact (complex128): only the fp32 accumulation differs."""
+    rng = np.random.default_rng(100 + seed)
+    kl = [chr(65 + x) for x in range(k)]
+    ml = [chr(97 + x) for x in range(m)]
+    nl = [chr(65 + k + x) for x in range(n)]
+    assert k + n <= 25 and m <= 25
+    la, lb, lo = kl + ml, kl + nl, ml + nl
+    for l in (la, lb, lo):
+        rng.shuffle(l)
+    eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
+    info = A.step_info(eq, (2,) * len(la), (2,) * len(lb))
+    assert info["workspace_bytes"] == 0   # complex64 arithmetic never asks for scratch
+    with A.precision("bf16"):
+        info = A.step_info(eq, (2,) * len(la), (2,) * len(lb))
+        assert info["kernel"] == N.KERNEL_PGEMM and info["workspace_bytes"] == 4 * (2 ** (m + k) + 2 ** (n + k)), info
+        a, b = crandn(rng, (2,) * len(la)), crandn(rng, (2,) * len(lb))
+        got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
+    # (numpy in chunks of the m labels would be faster; 2^(m+n+k) = 2^32 complex MACs as one matmul is fine)
+    want = oracle.einsum_pair(eq, _bf16_round(a).astype(np.complex128), _bf16_round(b).astype(np.complex128))
+    assert rel(got, want) < 2e-6, (eq, rel(got, want))
+    exact = oracle.einsum_pair(eq, a, b)
+    assert 1e-4 < rel(got, exact) < 3e-2
