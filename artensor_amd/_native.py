@@ -92,6 +92,7 @@ _EXPORTS = {
     "artn_axpy_c128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "artn_sum_axis_c128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_int64, ctypes.c_void_p]),
+    "artn_probe_mfma_rate": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "artn_absmax_normalize_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                  ctypes.c_void_p]),
 }

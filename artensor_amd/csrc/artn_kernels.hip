@@ -2418,6 +2418,55 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_axpy_v(V *__restrict__
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc[i] += x[i];
 }
 
+// ----------------------------------------------------------------------------------------
+// Matrix-pipe rate probe (measurement aid of bench.py: the peak a complex128 roofline is priced against is the
+// f64 MFMA rate measured on the device it runs on -- the guide tabulates no f64 figure).  Every wave issues
+// independent accumulator chains back to back; nothing touches memory inside the loop.
+// ----------------------------------------------------------------------------------------
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+template <int KIND>
+__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_mfma_probe(float *sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  if constexpr (KIND == 2) { // v_mfma_f64_16x16x4_f64: 2048 FLOP
+    f64x4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const double a = 1.0 + lane * 1e-3, b = 1.0 - lane * 1e-3;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+    double t = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t += acc[q][0] + acc[q][3];
+    if (t == 12345.678) sink[0] = (float)t;
+  } else if constexpr (KIND == 0) { // v_mfma_f32_32x32x2_f32: 4096 FLOP
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    const float a = 1.f + lane * 1e-3f, b = 1.f - lane * 1e-3f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+    float t = acc[0][0] + acc[1][5];
+    if (t == 12345.678f) sink[0] = t;
+  } else { // v_mfma_f32_32x32x16_bf16: 32768 FLOP
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    u32x4_t a = {0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = {0x3f803f80u, 0x3f803f80u - lane, 0x3f803f80u, 0x3f803f80u};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[q], 0, 0, 0);
+    float t = acc[0][0] + acc[1][5];
+    if (t == 12345.678f) sink[0] = t;
+  }
+}
+
 extern "C" {
 
 int artn_abi_version(void) { return ARTN_ABI_VERSION; }
@@ -2954,6 +3003,32 @@ int artn_axpy_c128(void *acc, const void *x, int64_t n, void *stream) {
   const int grid = (int)std::min<long>((n + ARTN_WG_THREADS - 1) / ARTN_WG_THREADS, 256L * 8);
   hipLaunchKernelGGL(artn_k_axpy_v<f64x2>, dim3(grid), dim3(ARTN_WG_THREADS), 0, (hipStream_t)stream, (f64x2 *)acc, (const f64x2 *)x, (long)n);
   HIP_TRY(hipGetLastError());
+  return ARTN_OK;
+}
+
+int artn_probe_mfma_rate(int kind, void *scratch4, double *tflops) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (kind < 0 || kind > 2 || !scratch4 || !tflops) return fail(ARTN_E_INVALID, "bad argument");
+  const int iters = 20000, waves_per_cu = 8;
+  const double flop_per_mfma[3] = {4096.0, 32768.0, 2048.0}, per_iter[3] = {2.0, 2.0, 4.0};
+  dim3 grid((unsigned)(g_ncu * waves_per_cu / 4)), block(ARTN_WG_THREADS);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float ms = 0.f;
+  for (int rep = 0; rep < 2; ++rep) { // (the first launch warms the clocks up)
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    if (kind == 0) hipLaunchKernelGGL(artn_k_mfma_probe<0>, grid, block, 0, nullptr, (float *)scratch4, iters);
+    else if (kind == 1) hipLaunchKernelGGL(artn_k_mfma_probe<1>, grid, block, 0, nullptr, (float *)scratch4, iters);
+    else hipLaunchKernelGGL(artn_k_mfma_probe<2>, grid, block, 0, nullptr, (float *)scratch4, iters);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const double mfmas = (double)g_ncu * waves_per_cu * iters * per_iter[kind];
+  *tflops = mfmas * flop_per_mfma[kind] / (ms * 1e-3) / 1e12;
   return ARTN_OK;
 }
 

@@ -78,10 +78,29 @@ class KernelTimes:
             d["mfma_flops"] += info.get("mfma_flops", 0.0)
             if info.get("arith") == 2:
                 d["bf16_flops"] += info["flops"]
+            if info.get("arith") == 3:
+                d["f64_flops"] = d.get("f64_flops", 0.0) + info["flops"]
         return out
 
 
-def roofline_of(ks, gpu_ms, launches_div=1):
+_probe = {}
+
+
+def mfma_rate_probe(kind, dev):
+    """TFLOP/s of back-to-back MFMAs with operands in registers, measured on this device (artn_probe_mfma_rate):
+    kind 0 fp32 32x32x2, 1 bf16 32x32x16, 2 f64 16x16x4."""
+    if kind not in _probe:
+        import ctypes
+        from artensor_amd import _native as N
+        scratch = torch.zeros(4, dtype=torch.uint8, device=dev)
+        out = ctypes.c_double(0.0)
+        torch.cuda.synchronize()
+        N.check(N.lib().artn_probe_mfma_rate(kind, scratch.data_ptr(), ctypes.byref(out)))
+        _probe[kind] = float(out.value)
+    return _probe[kind]
+
+
+def roofline_of(ks, gpu_ms, launches_div=1, f64_peak=None):
     """roofline block of a workload leg from per-launch HIP-event timings (KernelTimes.summarize()): the kernel
     family that takes most of the GPU time, its nominal FLOP / its time against the MFMA peak of its arithmetic,
     the FLOP the matrix pipe really executes (3M stages: 6 of the 8 counted per complex multiply-add), and its
@@ -93,7 +112,8 @@ def roofline_of(ks, gpu_ms, launches_div=1):
     d = ks[kid]
     sec = d["ms"] * 1e-3
     bf16 = d["bf16_flops"] > 0.5 * d["flops"]
-    peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+    f64 = d.get("f64_flops", 0.0) > 0.5 * d["flops"]
+    peak = MFMA_BF16_PEAK_TFLOPS if bf16 else (f64_peak if f64 and f64_peak else MFMA_F32_PEAK_TFLOPS)
     tf = d["flops"] / sec / 1e12 if sec else 0.0
     gbs = d["bytes"] / sec / 1e9 if sec else 0.0
     ai = d["flops"] / d["bytes"] if d["bytes"] else float("inf")
@@ -102,7 +122,7 @@ def roofline_of(ks, gpu_ms, launches_div=1):
     r = {"bound": "mfma" if mfma_bound else "hbm", "kernel": KERNEL_NAMES.get(kid, str(kid)),
          "achieved": tf if mfma_bound else gbs, "peak": peak if mfma_bound else HBM_PEAK_GBS,
          "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": (tf / peak) if mfma_bound else gbs / HBM_PEAK_GBS,
-         "traffic": None, "arithmetic": "bf16 operands, fp32 accumulate" if bf16 else "fp32 MFMA",
+         "traffic": None, "arithmetic": "bf16 operands, fp32 accumulate" if bf16 else ("f64 MFMA (peak = measured back-to-back v_mfma_f64_16x16x4_f64 rate)" if f64 else "fp32 MFMA"),
          "nominal_TFLOPs": tf, "mfma_peak_TFLOPs": peak, "mfma_frac_nominal": tf / peak,
          "executed_mfma_flop_frac": d["mfma_flops"] / d["flops"] if d["flops"] else 0.0,
          "mfma_frac_executed": d["mfma_flops"] / sec / 1e12 / peak if sec else 0.0,
@@ -341,6 +361,91 @@ def leg_sparse_whole(A, dev, steps, precision):
             "kernel_times_": (prof.summarize(), e0.elapsed_time(e1)), "case_": case}
 
 
+def leg_n30_c128(A, dev):
+    """The headline scheme in complex128 (the reference takes any dtype, simulation.py:90): every big step is one pass of
+    artn_k_gemm128 on v_mfma_f64_16x16x4_f64 (no fused pairs, no state-streaming variant), the small ones run on the
+    strided kernel.  Priced against the f64 MFMA rate measured on this device."""
+    from artensor_amd import contraction as C
+    from artensor_amd.fixtures import load_case
+    case = load_case(os.path.join(ROOT, "tests", "golden", "n30_dense.npz"))
+    leaves = case.fresh_tensors(dtype=torch.complex128, device=dev)
+    flops = 8.0 * 10 ** case.meta["log10_tc"]
+    run = lambda: A.tensor_contraction(dict(leaves), case.scheme)
+    out = run()
+    perm = case.meta["permute_dims"]
+    fpos = np.array([int(b, 2) for b in case.meta["google_bitstrings"]], dtype=np.int64)
+    rpos = np.zeros_like(fpos)
+    for d in range(30):
+        rpos |= ((fpos >> (29 - d)) & 1) << (29 - perm[d])
+    at = out.reshape(-1)[torch.from_numpy(rpos).to(dev)].cpu().numpy()
+    del out
+    truth = truth_value("n30_dense_at_google")
+    want = truth if truth is not None else case.arrays["amps_at_google"]
+    rms = 2.0 ** -15
+    err = float((np.abs(at - want) / np.maximum(np.abs(want), rms)).max())
+    ok = err <= (1e-10 if truth is not None else LOOSE_TOL)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 2
+    for _ in range(steps):
+        o = run()
+        del o
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = KernelTimes()
+    C.profiler = prof
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    o = run()
+    e1.record()
+    torch.cuda.synchronize()
+    C.profiler = None
+    del o
+    return {"workload": "Sycamore n30 m14 full-amplitude in complex128, tests/golden/n30_dense.npz", "value": steps * flops / dt / 1e12,
+            "unit": "TFLOP/s", "ms_per_step": dt / steps * 1e3, "flops_per_step": flops,
+            "err_rel_to_max_abs_or_rms_vs_c128_truth": err, "check": "ok" if ok else "FAILED",
+            "kernel_times_": (prof.summarize(), e0.elapsed_time(e1)), "case_": case}
+
+
+def leg_n30_sliced3(A, dev):
+    """The alternative N > 1 split of the unsliced n30 contraction, timed on ONE GPU: the reference's own mechanism --
+    inner-bond slicing (simulation.py:107-114) -- with k = 3 sliced bonds (8 slices, one per rank of an 8-GPU node;
+    plan by the reference's order finder, tests/golden/n30_dense_sliced3.npz).  Every slice is a full 2^30-amplitude
+    tensor; an 8-rank run would close with a reduce-scatter of 8.6 GB per rank (DESIGN section 6 prices it).  All 8
+    slices are run and summed here and the sum is checked against the complex128 truth."""
+    from artensor_amd.fixtures import load_case
+    case = load_case(os.path.join(ROOT, "tests", "golden", "n30_dense_sliced3.npz"))
+    dense = load_case(os.path.join(ROOT, "tests", "golden", "n30_dense.npz"))
+    leaves = case.fresh_tensors(device=dev)
+    n_b = len(case.slicing_indices)
+    flops_slice = 8.0 * 10 ** case.meta["log10_tc_per_slice"]
+    runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (2,) * 30, device=dev)
+    total = runner.run(range(2 ** n_b))
+    perm = case.meta["permute_dims"]
+    fpos = np.array([int(b, 2) for b in dense.meta["google_bitstrings"]], dtype=np.int64)
+    rpos = np.zeros_like(fpos)
+    for d in range(30):
+        rpos |= ((fpos >> (29 - d)) & 1) << (29 - perm[d])
+    at = total.reshape(-1)[torch.from_numpy(rpos).to(dev)].cpu().numpy()
+    truth = truth_value("n30_dense_at_google")
+    want = truth if truth is not None else dense.arrays["amps_at_google"]
+    rms = 2.0 ** -15
+    err = float((np.abs(at - want) / np.maximum(np.abs(want), rms)).max())
+    ok = err <= LOOSE_TOL
+    runner.collect.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    runner.run(range(2 ** n_b))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = 2 ** n_b
+    return {"workload": "Sycamore n30 m14 full-amplitude, 3 inner bonds sliced (8 slices of 2^30 amplitudes), tests/golden/n30_dense_sliced3.npz",
+            "value": n * flops_slice / dt / 1e12, "unit": "TFLOP/s", "ms_per_step": dt * 1e3, "ms_per_slice_per_rank": dt / n * 1e3,
+            "flops_per_slice": flops_slice, "slices": n, "executed_flop_over_unsliced": n * flops_slice / (8.0 * 10 ** dense.meta["log10_tc"]),
+            "sum_of_slices_err_rel_to_max_abs_or_rms_vs_truth": err, "check": "ok" if ok else "FAILED",
+            "kernel_times_": None, "case_": case}
+
+
 # secondary workloads of the default run: key -> (BASELINE config, runner, precision, slices per step, sparse, sliced)
 LEGS = [
     ("n30_sparse10000", "configs[2]", "sparse", "fp32", 1),
@@ -350,6 +455,8 @@ LEGS = [
     ("n53m20", "the bundled n53 m20 circuit, one bitstring", "n53m20", "fp32", 2),
     ("rand2", "north_star: random tensor network, bond dimension 2", "rand2", "fp32", 4),
     ("rand4", "north_star: random tensor network, bond dimension 4", "rand4", "fp32", 4),
+    ("n30_c128", "configs[1] in complex128 (reference simulation.py:90: any dtype)", "c128", "fp32", 1),
+    ("n30_sliced3", "configs[1] split over 3 inner bonds: the N > 1 alternative to output partitioning, on one GPU", "n30s3", "fp32", 1),
 ]
 
 
@@ -366,21 +473,38 @@ def run_workloads(A, dev, cpu_budget, only=None):
                 if kind == "sparse":
                     res = leg_sparse_whole(A, dev, 3, precision)
                     sparse, sliced = True, False
+                elif kind == "c128":
+                    res = leg_n30_c128(A, dev)
+                    sparse, sliced = False, False
+                elif kind == "n30s3":
+                    res = leg_n30_sliced3(A, dev)
+                    sparse, sliced = False, True
                 else:
                     res = run_sliced(A, kind, dev, 1, 0, None, 2, 1, per_step, precision, profile=True)
                     sparse, sliced = SLICED_WORKLOADS[kind][1], True
-            ks, gpu_ms = res["kernel_times_"]
-            units = per_step if kind != "sparse" else 1
-            roof = roofline_of(ks, gpu_ms, 1)
-            peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+            units = per_step if kind not in ("sparse", "c128", "n30s3") else 1
+            f64_peak = mfma_rate_probe(2, dev) if kind == "c128" else None
+            if res["kernel_times_"] is not None:
+                ks, gpu_ms = res["kernel_times_"]
+                roof = roofline_of(ks, gpu_ms, 1, f64_peak)
+            else:
+                ks, gpu_ms, roof = None, 0.0, None
+            peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else (f64_peak if kind == "c128" else MFMA_F32_PEAK_TFLOPS)
             entry = {"config": config, "value": res["value"], "unit": "TFLOP/s",
                      "ms": res.get("ms_per_slice_per_rank", res["ms_per_step"]), "ms_is_per": "slice" if sliced else "contraction",
                      "frac_of_peak": res["value"] / peak, "peak_TFLOPs": peak,
-                     "dtype": "c64 in memory, bf16 MFMA operands, fp32 accumulate" if precision == "bf16" else "c64 (fp32 MFMA)",
+                     "dtype": ("c64 in memory, bf16 MFMA operands, fp32 accumulate" if precision == "bf16"
+                               else ("c128 (f64 MFMA)" if kind == "c128" else "c64 (fp32 MFMA)")),
                      "roofline": roof, "profiled_step_gpu_ms": gpu_ms / units,
                      "check": {k: v for k, v in strip_private(res).items() if k not in ("value", "unit", "ms_per_step", "workload")},
                      "workload": res["workload"]}
-            if cpu_budget > 0 and precision != "bf16":
+            if kind == "c128":
+                entry["peak_is"] = "v_mfma_f64_16x16x4_f64 back to back, measured on this device (artn_probe_mfma_rate)"
+                entry["cpu_baseline"] = {"same_as": "the headline cpu_baseline", "note": "the same scheme on the same host cores "
+                                         "(complex64 there; a complex128 torch-CPU run needs 2 x 16 GiB per step)"}
+            elif kind == "n30s3":
+                entry["cpu_baseline"] = {"same_as": "the headline cpu_baseline", "note": "one slice is the same kind of work at 0.27 x the FLOP"}
+            elif cpu_budget > 0 and precision != "bf16":
                 entry["cpu_baseline"] = cpu_leg(res["case_"], sparse, sliced, cpu_budget,
                                                 ("slice 0 of " if sliced and res["case_"].slicing_indices else "") + key)
             elif precision == "bf16":

@@ -201,6 +201,12 @@ int artn_sum_axis_c128(const void *in, void *out, int64_t n_groups, int64_t n_ro
  * (`norm_factor = tensors[i].abs().max(); tensors[i] /= norm_factor`). */
 int artn_absmax_normalize_c64(void *x, int64_t n, float *out_absmax, void *stream);
 
+/* Measurement aid (bench.py): the rate the matrix pipes of this device sustain on back-to-back MFMAs with operands
+ * in registers, in TFLOP/s -- kind 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_bf16, 2: v_mfma_f64_16x16x4_f64
+ * (the arithmetic of complex128 steps; the roofline of a complex128 run is priced against this measured figure).
+ * `scratch4`: 4 bytes of device memory.  Synchronous (runs on the null stream and waits). */
+int artn_probe_mfma_rate(int kind, void *scratch4, double *tflops);
+
 #ifdef __cplusplus
 }
 #endif
