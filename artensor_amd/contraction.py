@@ -554,7 +554,7 @@ class _Program:
     """Compiled small steps of a dense scheme: device image per device, workspace layout, which tensor
     ids it reads from the caller (`ext_ids`, in kernel-argument order) and which results it leaves
     (`outputs`: id -> (workspace byte offset, shape))."""
-    __slots__ = ("host_image", "host_groups", "n_groups", "n_steps", "ext_ids", "ws_bytes", "outputs", "dev", "flops", "ext_array")
+    __slots__ = ("host_image", "host_groups", "n_groups", "n_steps", "ext_ids", "ws_bytes", "outputs", "step_out", "dev", "flops", "ext_array")
 
     def device_copy(self, device):
         hit = self.dev.get(device)
@@ -584,8 +584,8 @@ def _plan_small_program(scheme, shapes, dtype):
     for n, step in enumerate(scheme):
         (i, j), eq = step[0], step[1]
         la, lb, lo = _labels(eq)
-        ok = (i not in tainted and j not in tainted and i not in main_reads and i in cur and j in cur and i != j
-              and len(la) == len(cur[i]) and len(lb) == len(cur[j]))
+        ok = (_is_plain_step(step) and i not in tainted and j not in tainted and i not in main_reads and i in cur and j in cur
+              and i != j and len(la) == len(cur[i]) and len(lb) == len(cur[j]))
         out_shape = None
         if ok:
             ext = dict(zip(la, cur[i]))
@@ -603,6 +603,28 @@ def _plan_small_program(scheme, shapes, dtype):
             cur.pop(i, None)
     if len(small) < PROGRAM_MIN_STEPS:
         return None, every
+    needed = set()
+    for n in main:
+        needed.update(scheme[n][0])
+    needed.add(scheme[-1][0][0])
+    prog = _build_program(scheme, small, recs, needed)
+    if prog is None:
+        return None, every
+    return prog, main
+
+
+def _build_program(scheme, small, recs, needed=None):
+    """Compile the steps `small` (indices into `scheme`, in execution order; recs[n] = (la, lb, lo, shape_i, shape_j,
+    out_shape)) into a one-launch program image.  needed: tensor ids whose LAST version must be in the workspace after
+    the launch (everything else may live and die in LDS); None: the result of EVERY step is kept (prog.step_out[n] =
+    (workspace byte offset, shape)) -- what the slice loop needs, which keeps each step's result for later slices.
+    Returns a _Program or None (the caller then runs the steps one by one)."""
+    def numel(sh):
+        n = 1
+        for e in sh:
+            n *= e
+        return n
+
     # groups = connected components of the small steps (steps of different groups share no tensor)
     parent = {}
 
@@ -615,7 +637,7 @@ def _plan_small_program(scheme, shapes, dtype):
     for n in small:
         i, j = scheme[n][0]
         parent[find(i)] = find(j)
-    order, seen = [], {}
+    seen = {}
     for n in small:
         r = find(scheme[n][0][0])
         if r not in seen:
@@ -626,10 +648,10 @@ def _plan_small_program(scheme, shapes, dtype):
         if find(scheme[small_sorted[k]][0][0]) != find(scheme[small_sorted[k - 1]][0][0]):
             group_start.append(k)
     group_start.append(len(small_sorted))
-    # locations: leaves are external pointers, results live in the workspace
+    # locations: tensors the steps read but do not produce are external pointers, results live in the workspace
     loc, ext_ids, ws = {}, [], 0
     la_, lb_, lc_, descs, flops = [], [], [], [], 0.0
-    where = {}
+    where, step_out = {}, {}
     for n in small_sorted:
         i, j = scheme[n][0]
         la, lb, lo, sa, sb, so = recs[n]
@@ -644,43 +666,44 @@ def _plan_small_program(scheme, shapes, dtype):
         lc_.append(ws)
         loc[i] = ws
         where[i] = (ws, so)
+        step_out[n] = (ws, so)
         ws += (numel(so) * 8 + 15) // 16 * 16
         f = 8.0
         for x in dict.fromkeys(la + lb):
             f *= dict(zip(la, sa)).get(x) or dict(zip(lb, sb))[x]
         flops += f
     if len(ext_ids) > N.ARTN_PROGRAM_MAX_EXT:
-        return None, every
-    # results a remaining step reads, or the scheme's own result: those must be in the workspace after the
-    # launch (the last version of the id); everything else may live and die in the workgroup's LDS
-    needed = set()
-    for n in main:
-        needed.update(scheme[n][0])
-    needed.add(scheme[-1][0][0])
-    last_writer = {}
-    for k, n in enumerate(small_sorted):
-        last_writer[scheme[n][0][0]] = k
-    keep = [1 if last_writer[scheme[n][0][0]] == k and scheme[n][0][0] in needed else 0 for k, n in enumerate(small_sorted)]
+        return None
+    if needed is None:
+        keep = [1] * len(small_sorted)
+    else:
+        # results a remaining step reads, or the scheme's own result: those must be in the workspace after the
+        # launch (the last version of the id); everything else may live and die in the workgroup's LDS
+        last_writer = {}
+        for k, n in enumerate(small_sorted):
+            last_writer[scheme[n][0][0]] = k
+        keep = [1 if last_writer[scheme[n][0][0]] == k and scheme[n][0][0] in needed else 0 for k, n in enumerate(small_sorted)]
     lib = N.lib()
     arr = (ctypes.POINTER(N.ArtnStepDesc) * len(descs))(*[ctypes.pointer(d) for d in descs])
     i64 = lambda v: (ctypes.c_int64 * len(v))(*v)
     n_groups = len(group_start) - 1
     image_bytes = int(lib.artn_program_image_bytes(len(descs), arr, n_groups))
     if image_bytes < 0:
-        return None, every
+        return None
     image = torch.zeros(image_bytes, dtype=torch.uint8)
     if __import__("os").environ.get("ARTN_PROG_KEEP_ALL"):   # diagnostics: every result also goes to the workspace
         keep = [1] * len(keep)
     rc = lib.artn_program_build(len(descs), arr, i64(la_), i64(lb_), i64(lc_), (ctypes.c_uint8 * len(keep))(*keep), n_groups,
                                 (ctypes.c_int32 * len(group_start))(*group_start), image.data_ptr(), image_bytes)
     if rc != 0:   # no program: every step runs as its own launch (what a scheme did before programs existed)
-        return None, every
+        return None
     prog = _Program()
     prog.host_image, prog.host_groups = image, torch.tensor(group_start, dtype=torch.int32)
     prog.n_groups, prog.n_steps, prog.ext_ids, prog.ws_bytes = n_groups, len(small_sorted), ext_ids, max(ws, 16)
-    prog.outputs = {t: v for t, v in where.items() if t in needed}
+    prog.outputs = {t: v for t, v in where.items() if needed is None or t in needed}
+    prog.step_out = step_out
     prog.dev, prog.flops, prog.ext_array = {}, flops, None
-    return prog, main
+    return prog
 
 
 def _run_program(prog, tensors, dtype, device, stream):
@@ -698,10 +721,21 @@ def _run_program(prog, tensors, dtype, device, stream):
         profiler.record({"kernel": KERNEL_PROGRAM, "flops": prog.flops, "bytes": 0.0, "k_bits": 0, "k2_bits": 0, "m_tile_bits": 0,
                          "n_tile_bits": 0, "tile_in_bits": 0, "tile_out_bits": 0, "n_tiles": prog.n_steps, "a_rereads": 1}, e0, e1)
     for t, (off, shape) in prog.outputs.items():
-        n = 8
-        for e in shape:
-            n *= e
-        tensors[t] = ws[off:off + n].view(torch.complex64).reshape(shape)
+        tensors[t] = _ws_view(ws, off, shape)
+    return ws
+
+
+def _ws_view(ws, off, shape):
+    n = 8
+    for e in shape:
+        n *= e
+    return ws[off:off + n].view(torch.complex64).reshape(shape)
+
+
+def _is_plain_step(step):
+    """A dense 2-tuple, or a sparse 3-tuple that is not chunked (branch D of the sparse executor, reference
+    contraction.py:189-191: its index lists are not looked at): one einsum."""
+    return len(step) == 2 or (len(step) == 3 and len(step[2][0]) <= 1)
 
 
 def _compile_dense(scheme, shapes, dtype):
@@ -1153,6 +1187,32 @@ def _sparse_step(tensors, step):
         tensors[j] = []
 
 
+_sparse_prog_cache = _Bounded(64)   # id(scheme) -> (scheme, shape signature, program or None, hoisted step indices)
+_NO_HOIST = frozenset()
+
+
+def _sparse_program(scheme, tensors):
+    """Small-step program of a sparse-state scheme (compiled once per scheme object and leaf shapes): the plain
+    steps (branch D) whose operands are small leaf-derived tensors, hoisted in front of everything else with the
+    sequential semantics kept (_plan_small_program)."""
+    items = tensors.items() if isinstance(tensors, dict) else enumerate(tensors)
+    shapes, dtype, on_gpu = {}, None, True
+    for k, t in items:
+        if isinstance(t, torch.Tensor):
+            shapes[k] = tuple(t.shape)
+            dtype = dtype or t.dtype
+            on_gpu = on_gpu and t.is_cuda and t.is_contiguous()
+    if dtype != torch.complex64 or not on_gpu:
+        return None, _NO_HOIST
+    sig = tuple(shapes.items())
+    hit = _sparse_prog_cache.get(id(scheme))
+    if hit is None or hit[0] is not scheme or hit[1] != sig:
+        prog, main = _plan_small_program(scheme, shapes, dtype)
+        hoisted = frozenset(range(len(scheme))) - frozenset(main) if prog is not None else _NO_HOIST
+        hit = _sparse_prog_cache[id(scheme)] = (scheme, sig, prog, hoisted)
+    return hit[2], hit[3]
+
+
 _defer = threading.local()   # .flag_check: the slice loop reads the gather flag once, after its last slice
 
 
@@ -1198,11 +1258,28 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
             check_gather_flag("tensor_contraction_sparse")
         return factor.reshape(()).to(tensors[last].dtype), tensors[last]
 
+    # the plain steps that only combine small leaf-derived tensors: one launch of the small-step program, as in the dense
+    # executor (151 of the 180 steps of the n30 sparse-state schemes are of this kind)
+    prog, hoisted = _sparse_program(scheme, tensors)
+    if prog is not None:
+        first = next(t for t in (tensors.values() if isinstance(tensors, dict) else tensors) if isinstance(t, torch.Tensor))
+        with torch.cuda.device(first.device):
+            _run_program(prog, tensors, first.dtype, first.device, N.current_stream_ptr(first.device))
+        for n in hoisted:   # consumed operands are released, as the step-by-step loop does
+            j = scheme[n][0][1]
+            if j not in prog.outputs:
+                tensors[j] = []
     for entry in hit[1]:
         if entry[0] == "one":
-            one(entry[1])
+            if entry[1] not in hoisted:
+                one(entry[1])
             continue
         n, m = entry[1], entry[2]
+        if n in hoisted or m in hoisted:
+            for q in (n, m):
+                if q not in hoisted:
+                    one(q)
+            continue
         s1, s2 = scheme[n], scheme[m]
         fused = None
         a = tensors[s1[0][0]]

@@ -186,7 +186,7 @@ class SliceRunner:
         self.scheme = scheme
         self.device = torch.device(device)
         items = tensors.items() if isinstance(tensors, dict) else enumerate(tensors)
-        self.leaves = {k: (t.to(dtype).to(device) if isinstance(t, torch.Tensor) else t) for k, t in items}
+        self.leaves = {k: (t.to(dtype).to(device).contiguous() if isinstance(t, torch.Tensor) else t) for k, t in items}
         self.slicing_indices = slicing_indices or {}
         self.n_bonds = len(self.slicing_indices)
         self.collect = torch.zeros(tuple(out_shape), dtype=dtype, device=device)
@@ -220,6 +220,21 @@ class SliceRunner:
             self._leaf_rel = {tid: tuple(sorted(sel.values())) for tid, sel in self._selects.items()}
             self._memo = {}
             self._last_id = scheme[-1][0][0]
+            # small steps that are one plain einsum on small tensors can be recomputed in batches, each batch ONE
+            # launch of the small-step program (artn_program_*): recs[n] = labels and shapes, the same for every slice
+            self._recs, self._progs = {}, {}
+            self.program_launches = 0
+            if dtype == torch.complex64 and __import__("os").environ.get("ARTN_NO_PROGRAM", "0") in ("", "0"):
+                cur_shapes = dict(shapes)
+                numel = lambda sh: int(np.prod(sh, dtype=np.int64)) if len(sh) else 1
+                for n in small:
+                    step = scheme[n]
+                    i, j = step[0]
+                    out_shape = _small_step_shape(step, cur_shapes[i], cur_shapes[j])
+                    if _C._is_plain_step(step) and 0 < max(numel(cur_shapes[i]), numel(cur_shapes[j]), numel(out_shape)) <= _C.PROGRAM_MAX_NUMEL:
+                        la, lb, lo = _labels(step[1])
+                        self._recs[n] = (la, lb, lo, tuple(cur_shapes[i]), tuple(cur_shapes[j]), tuple(out_shape))
+                    cur_shapes[i] = out_shape
 
     def _index(self, tid, cfg):
         sel, t = self._selects[tid], self.leaves[tid]
@@ -242,21 +257,71 @@ class SliceRunner:
             if hit is None or hit[0] != key:
                 hit = memo[("leaf", tid)] = (key, self.leaves[tid][self._index(tid, cfg)].contiguous())
             cur[tid] = hit[1]
+        # stale small steps are recomputed; runs of plain ones go into one program launch each (a stale step only feeds
+        # stale steps -- its bonds are a subset of theirs -- and every tensor version is read once, so a batch can be
+        # deferred while the walk goes on: what it reads from outside is captured when the step joins the batch)
+        batch, batch_ext, produced = [], {}, set()
+
+        def run_one(n, src):
+            step = self.scheme[n]
+            i, j = step[0]
+            if len(step) == 2:
+                return contract(step[1], src[i], src[j])
+            scratch = {i: src[i], j: src[j]}   # sparse step: the executor's own branch logic on a scratch pair
+            _sparse_step(scratch, step)
+            return scratch[i]
+
+        def flush():
+            if not batch:
+                return
+            prog = None
+            if len(batch) >= _C.PROGRAM_MIN_STEPS:
+                pk = tuple(batch)
+                if pk not in self._progs:
+                    if len(self._progs) > 256:
+                        self._progs.clear()
+                    self._progs[pk] = _C._build_program(self.scheme, list(batch), self._recs, None)
+                prog = self._progs[pk]
+            if prog is not None:
+                with torch.cuda.device(self.device):
+                    ws = _C._run_program(prog, batch_ext, torch.complex64, self.device, N.current_stream_ptr(self.device))
+                self.program_launches += 1
+                for n in batch:
+                    off, shape = prog.step_out[n]
+                    memo[n] = (tuple(cfg[x] for x in self._step_rel[n]), _C._ws_view(ws, off, shape))
+            else:
+                src = dict(batch_ext)
+                for n in batch:
+                    val = run_one(n, src)
+                    src[self.scheme[n][0][0]] = val
+                    memo[n] = (tuple(cfg[x] for x in self._step_rel[n]), val)
+            for n in batch:
+                cur[self.scheme[n][0][0]] = memo[n][1]
+            self.small_steps_run += len(batch)
+            batch.clear()
+            batch_ext.clear()
+            produced.clear()
+
         for n in self._small:
             i, j = self.scheme[n][0]
             key = tuple(cfg[x] for x in self._step_rel[n])
             hit = memo.get(n)
-            if hit is None or hit[0] != key:
-                step = self.scheme[n]
-                if len(step) == 2:
-                    val = contract(step[1], cur[i], cur[j])
-                else:  # sparse step: the executor's own branch logic on a scratch pair
-                    scratch = {i: cur[i], j: cur[j]}
-                    _sparse_step(scratch, step)
-                    val = scratch[i]
-                hit = memo[n] = (key, val)
-                self.small_steps_run += 1
-            cur[i] = hit[1]
+            if hit is not None and hit[0] == key:
+                cur[i] = hit[1]
+                continue
+            if n in self._recs:
+                for t in (i, j):
+                    if t not in produced and t not in batch_ext:
+                        batch_ext[t] = cur[t]
+                produced.add(i)
+                batch.append(n)
+                continue
+            flush()
+            val = run_one(n, cur)
+            memo[n] = (key, val)
+            self.small_steps_run += 1
+            cur[i] = val
+        flush()
         res = self.execute(cur, self._main) if self._main else cur[self._last_id]
         self.add(self.collect, res.reshape(self.collect.shape))
 

@@ -143,7 +143,9 @@ def test_small_step_program_plan_keeps_sequential_semantics(name, limit, monkeyp
 
 
 @pytest.mark.parametrize("name,limit", [("n12_dense", 1 << 14), ("n12_dense", 256), ("n30_dense", 1 << 14), ("rand_D2_closed", 1 << 14),
-                                        ("rand_D4_closed", 256), ("rand_D3_open", 1 << 12)])
+                                        ("rand_D4_closed", 256), ("rand_D3_open", 1 << 12),
+                                        # sparse-state schemes: the plain (branch D) small steps are hoisted the same way
+                                        ("n12_sparse5", 1 << 14), ("n30_sparse100", 1 << 14)])
 def test_small_step_program_image_emulated(name, limit, monkeypatch):
     """The compiled image itself -- levels, wave tasks, LDS arena with reuse, preloaded leaves, which results
     go to the workspace -- executed on the CPU the way artn_k_program executes it (tests/helpers.emulate_program)
