@@ -92,3 +92,95 @@ def test_slice_bookkeeping():
     # descending order is where the reference is well defined: same answer as its selects
     out = A.apply_slice({0: t}, {"y": [(0, 2)], "x": [(0, 0)]}, [3, 1])
     assert torch.equal(out[0], t.select(2, 3).select(0, 1))
+
+
+def _worker_mismatch(rank, world, port, out_dir):
+    """Rank 1 holds a different slicing of the same network (what PYTHONHASHSEED does to the reference's planner):
+    the fingerprint check of _shard_and_reduce must refuse to sum the slices."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = load_case(os.path.join(GOLDEN, "n12_sparse_sliced.npz"))
+        slicing = dict(case.slicing_indices)
+        if rank == 1:   # the same bonds in the other order: slice number s means another assignment
+            slicing = dict(reversed(list(slicing.items())))
+        from artensor_amd import simulation as S
+        runner = S.SliceRunner._with_seams(case.tensors, case.scheme, slicing, case.arrays["final"].shape, True,
+                                           torch.complex64, "cpu", _oracle_execute(True), _cpu_add)
+        try:
+            S._shard_and_reduce(runner, reduce="all")
+            msg = "no error"
+        except RuntimeError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, f"mismatch_{rank}.txt"), "w") as f:
+            f.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_with_different_plans_are_refused(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_mismatch, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert "different plans" in open(tmp_path / f"mismatch_{r}.txt").read()
+
+
+class _FakePlanner:
+    """A planner module whose products depend on the rank (the reference's do, through PYTHONHASHSEED): only what
+    rank 0 plans may be executed."""
+    def __init__(self, case, rank):
+        self.case, self.rank = case, rank
+
+    def NumericalTensorNetwork(self, tensors, tensor_bonds, bond_dims, final_qubits):
+        case, rank = self.case, self.rank
+
+        class Net:
+            pass
+        net = Net()
+        net.tensors = dict(tensors)
+        net.bond_dims = bond_dims
+        net._simplify = lambda pattern: (tensor_bonds, final_qubits)
+        return net
+
+    def find_order(self, *a, **k):
+        return None, list(self.case.slicing_indices.keys()), ("tree of rank", self.rank)
+
+
+def _worker_plan_once(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from artensor_amd import simulation as S
+        from artensor_amd import contraction as C
+        case = load_case(os.path.join(GOLDEN, "rand_D2_closed_sliced.npz"))
+        planned = []
+        # the scheme compiler stands in for the tree walk: it records which rank's tree it was given
+        orig = C.contraction_scheme
+        C.contraction_scheme = lambda ctree, labels="einsum": (planned.append(ctree) or (case.scheme, []))
+        seen = {}
+        orig_sc = S.sliced_contraction
+        S.sliced_contraction = lambda leaves, scheme, slicing, shape, **kw: seen.update(n=len(scheme), bonds=list(slicing)) or torch.zeros(())
+        try:
+            bonds = {k: [f"b{k}_{d}" for d in range(t.dim())] for k, t in case.tensors.items()}
+            for bond, lst in case.slicing_indices.items():   # name the sliced bonds as the fixture does
+                for tid, dim in lst:
+                    bonds[tid][dim] = bond
+            S.tensor_network_contraction(case.tensors, bonds, {}, [], planner=_FakePlanner(case, rank), device="cpu")
+        finally:
+            C.contraction_scheme, S.sliced_contraction = orig, orig_sc
+        with open(os.path.join(out_dir, f"plan_{rank}.txt"), "w") as f:
+            f.write(f"{len(planned)} {seen['n']} {seen['bonds']}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_plans_and_the_plan_is_broadcast(tmp_path):
+    """tensor_network_contraction under torch.distributed: rank 0 runs the planner and the scheme compiler, every
+    other rank receives the plan (leaves, scheme, slicing, output order) and plans nothing itself."""
+    port = _free_port()
+    mp.spawn(_worker_plan_once, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (open(tmp_path / f"plan_{r}.txt").read().split(" ", 2) for r in range(2))
+    assert r0[0] == "1" and r1[0] == "0"          # only rank 0 compiled a scheme
+    assert r0[1:] == r1[1:]                        # both execute the same scheme on the same slicing

@@ -29,7 +29,7 @@ def counters(sub):
     f = one(f"{sub}/**/*_counter_collection.csv")
     per = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
-        if "artn_k_bits" not in r["Kernel_Name"]:
+        if "artn_k_bits" not in r["Kernel_Name"] and "artn_k_alt" not in r["Kernel_Name"]:
             continue
         d = per.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"].split("(")[0].replace("void ", ""),
                                               "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
@@ -40,14 +40,14 @@ def counters(sub):
 sq, fe, wr = counters("pmc_sq"), counters("pmc_fetch"), counters("pmc_write")
 big = lambda per: [d for d in per.values() if d["t1"] - d["t0"] > 1e6]  # launches longer than 1 ms
 md = [f"# rocprofv3 summary, round {R}", "",
-      "Command: `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (Sycamore n30 m14 full amplitude, 1 x MI355X).",
+      "Command: `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-workloads` (Sycamore n30 m14 full amplitude, 1 x MI355X).",
       "Kernel trace and each PMC group were collected in separate rocprofv3 runs.", "",
       "## Kernel time (rocprofv3 --kernel-trace --stats)", "",
       "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
 for r in rows[:12]:
     name = r["Name"].split("(")[0].replace("void ", "")[:60]
     md.append(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
-bits = [r for r in rows if "artn_k_bits" in r["Name"]]
+bits = [r for r in rows if "artn_k_bits" in r["Name"] or "artn_k_alt" in r["Name"]]
 tot_ns = sum(float(r["TotalDurationNs"]) for r in bits)
 tot_calls = sum(int(r["Calls"]) for r in bits)
 md += ["", f"All `artn_k_bits<KB1,KB2>` instantiations together: {tot_calls} launches, {tot_ns / 1e6:.2f} ms, "
@@ -74,6 +74,22 @@ if sb:
            f"* SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: {conf:.3f}",
            f"* SQ_WAIT_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}",
            f"* SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_INST_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}", ""]
+# per instantiation: launches, average duration, matrix-pipe busy fraction, LDS bank-conflict ratio
+if sb:
+    clk_eff = clk or 2.1e9
+    per_name = collections.OrderedDict()
+    for d in sb:
+        e = per_name.setdefault(d["name"], {"n": 0, "t": 0.0, "mf": 0.0, "conf": 0.0, "act": 0.0})
+        e["n"] += 1
+        e["t"] += (d["t1"] - d["t0"]) * 1e-9
+        e["mf"] += d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+        e["conf"] += d.get("SQ_LDS_BANK_CONFLICT", 0)
+        e["act"] += d.get("SQ_LDS_IDX_ACTIVE", 0)
+    md += ["## Per instantiation (launches > 1 ms; template arguments KB1, KB2, BIGK, NP, GATHER, NT, M3, FULL -- artn_k_alt: KB1, KB2, NT, M3)", "",
+           "| kernel | launches | avg ms | SQ_VALU_MFMA_BUSY | LDS conflict / active |", "|---|---|---|---|---|"]
+    for name, e in per_name.items():
+        md.append(f"| `{name[:70]}` | {e['n']} | {e['t'] / e['n'] * 1e3:.2f} | {e['mf'] / (e['t'] * 1024 * clk_eff):.3f} | {e['conf'] / max(e['act'], 1):.3f} |")
+    md.append("")
 bj = os.path.join(SRC, "bench_under_rocprof.json")
 if os.path.exists(bj) and os.path.getsize(bj):
     md += ["## bench.py line of the kernel-trace run", "", "```", open(bj).read().strip(), "```", ""]

@@ -54,6 +54,33 @@ if pm:
                f"* SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: {sum(d.get('SQ_LDS_BANK_CONFLICT', 0) for d in sb) / max(sum(d.get('SQ_LDS_IDX_ACTIVE', 0) for d in sb), 1):.3f}",
                f"* SQ_WAIT_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}",
                f"* SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_INST_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}", ""]
+# the same for the packed-operand GEMM of the reduced-precision mode
+pm = glob.glob(f"{root}/n53m20b_bf16_pmc/**/*_counter_collection.csv", recursive=True)
+ck = glob.glob(f"{root}/n53m20b_bf16_clk/**/*_counter_collection.csv", recursive=True)
+if pm:
+    def load2(f):
+        per = collections.OrderedDict()
+        for r in csv.DictReader(open(f)):
+            if "artn_k_pgemm" not in r["Kernel_Name"]:
+                continue
+            d = per.setdefault(r["Dispatch_Id"], {"t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        return [d for d in per.values() if d["t1"] - d["t0"] > 2e7]
+    sb = load2(pm[0])
+    clk = 0.0
+    if ck:
+        cb = load2(ck[0])
+        if cb:
+            clk = sum(d.get("GRBM_GUI_ACTIVE", 0) for d in cb) / 8 / (sum(d["t1"] - d["t0"] for d in cb) * 1e-9)
+    if sb:
+        dur = sum(d["t1"] - d["t0"] for d in sb) * 1e-9
+        mf = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for d in sb)
+        md += ["## artn_k_pgemm on the n53 m20 big-batch slice (15 contracted bits, bf16 operands packed once, LDS-DMA): PMC counters", "",
+               f"* launches counted: {len(sb)}, {dur / len(sb) * 1e3:.1f} ms each (1.407e14 real FLOP: {1.407e14 / (dur / len(sb)) / 1e12:.0f} TFLOP/s)",
+               f"* SQ_VALU_MFMA_BUSY_CYCLES / (duration x 1024 SIMDs x clock): {mf / (dur * 1024 * (clk or 2.1e9)):.3f} (clock {clk / 1e9:.2f} GHz from GRBM_GUI_ACTIVE)",
+               f"* SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: {sum(d.get('SQ_LDS_BANK_CONFLICT', 0) for d in sb) / max(sum(d.get('SQ_LDS_IDX_ACTIVE', 0) for d in sb), 1):.3f}",
+               f"* SQ_WAIT_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}",
+               f"* SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_INST_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}", ""]
 st = f"{root}/sparse_times.txt"
 if os.path.exists(st):
     md += ["## n30 sparse wall times (tools/time_sparse.py)", "", "```", open(st).read().strip(), "```", ""]
