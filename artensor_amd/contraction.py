@@ -314,11 +314,11 @@ def _split_big_k(la, lb, lo, a, b):
 
 
 def _launch_step(d, a, b, out, stream):
-    """artn_contract, or artn_contract_ws with a scratch buffer where the planner asks for one (reduced-precision
-    mode: the big contractions pack their operands to bfloat16 first).  The library never allocates: the scratch is
+    """artn_contract, or artn_contract_ws with a scratch buffer where the planner asks for one (big contractions over
+    2^9+ / 2^10+ values pack their operands first: to bfloat16 in the reduced-precision mode, in tile order otherwise).  The library never allocates: the scratch is
     a torch buffer, returned to the caching allocator in stream order.  Returns the status code."""
     lib = N.lib()
-    if d.dtype == N.ARTN_C64_BF16:
+    if d.dtype != N.ARTN_C128 and a.numel() >= (1 << 20):   # (only big contractions ever pack their operands)
         ws_bytes = _step_info_cached(d)["workspace_bytes"]
         if ws_bytes > 0:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)

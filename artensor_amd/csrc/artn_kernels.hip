@@ -2284,14 +2284,23 @@ static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, 
 static hipError_t launch_pgemm(const ArtnPlan &p, const void *A, const void *B, void *C, void *ws, hipStream_t st) {
   const ArtnPackPlan &g = p.pack;
   const float2 *a = (const float2 *)(g.swapped ? B : A), *b = (const float2 *)(g.swapped ? A : B);
-  const long a_units = 1L << (g.n_mo + g.n_ko + ARTN_PG_KC - 2 + ARTN_PG_MT), b_units = 1L << (g.n_no + g.n_ko + ARTN_PG_KC - 2 + ARTN_PG_NT);
+  // 16-byte units of the packed copies: bf16 -- 4 chunk values of one row; fp32 -- one chunk value of a row pair
+  const int unit_bits = g.arith == 0 ? g.kc_bits - 2 : g.kc_bits - 1;
+  const long a_units = 1L << (g.n_mo + g.n_ko + unit_bits + ARTN_PG_MT), b_units = 1L << (g.n_no + g.n_ko + unit_bits + ARTN_PG_NT);
   unsigned char *Ap = (unsigned char *)ws, *Bp = Ap + a_units * 16;
   auto blocks = [&](long units) { return dim3((unsigned)std::min<long>((units + ARTN_WG_THREADS - 1) / ARTN_WG_THREADS, (long)p.n_cu * 16)); };
-  hipLaunchKernelGGL(artn_k_pack_bf16, blocks(a_units), dim3(ARTN_WG_THREADS), 0, st, a, (u32x4_t *)Ap, g.a, g.n_ko, a_units);
-  hipLaunchKernelGGL(artn_k_pack_bf16, blocks(b_units), dim3(ARTN_WG_THREADS), 0, st, b, (u32x4_t *)Bp, g.b, g.n_ko, b_units);
   const size_t lds = (size_t)p.info.lds_bytes;
-  if (hipError_t e = ensure_lds<artn_k_pgemm>(lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL(artn_k_pgemm, dim3(p.info.grid), dim3(ARTN_PG_THREADS), lds, st, Ap, Bp, (float2 *)C, g);
+  if (g.arith == 0) {
+    hipLaunchKernelGGL(artn_k_pack_bf16, blocks(a_units), dim3(ARTN_WG_THREADS), 0, st, a, (u32x4_t *)Ap, g.a, g.n_ko, a_units);
+    hipLaunchKernelGGL(artn_k_pack_bf16, blocks(b_units), dim3(ARTN_WG_THREADS), 0, st, b, (u32x4_t *)Bp, g.b, g.n_ko, b_units);
+    if (hipError_t e = ensure_lds<artn_k_pgemm>(lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(artn_k_pgemm, dim3(p.info.grid), dim3(ARTN_PG_THREADS), lds, st, Ap, Bp, (float2 *)C, g);
+  } else {
+    hipLaunchKernelGGL(artn_k_pack_f32, blocks(a_units), dim3(ARTN_WG_THREADS), 0, st, a, (f32x4 *)Ap, g.a, g.n_ko, a_units);
+    hipLaunchKernelGGL(artn_k_pack_f32, blocks(b_units), dim3(ARTN_WG_THREADS), 0, st, b, (f32x4 *)Bp, g.b, g.n_ko, b_units);
+    if (hipError_t e = ensure_lds<artn_k_pgemm3m>(lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(artn_k_pgemm3m, dim3(p.info.grid), dim3(ARTN_PG_THREADS), lds, st, Ap, Bp, (float2 *)C, g);
+  }
   return hipGetLastError();
 }
 

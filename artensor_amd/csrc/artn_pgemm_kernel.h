@@ -236,3 +236,203 @@ __global__ __launch_bounds__(ARTN_PG_THREADS, 1) void artn_k_pgemm(const unsigne
   }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// The same scheme for complex64 ARITHMETIC (ArtnPackPlan::arith = 1): elements stay 8 bytes, so packing saves no bytes --
+// what it buys is the contiguous [tile][chunk][k][row] order (LDS-DMA fills, no address arithmetic and no ds_write in the
+// loop, conflict-free operand reads) and the 256 x 128 tile.  Chunks of 2^4 contracted values (the same 48 KiB stage),
+// 3M arithmetic on v_mfma_f32_32x32x2_f32: each wave 2 x 2 blocks of 32 rows x 32 complex columns with three
+// accumulators each, 96 MFMAs per chunk; partial sums leave the registers every 2^12 contracted values (read-add-write
+// of C through the epilogue), as in artn_k_gemm.
+// ----------------------------------------------------------------------------------------
+// out[16-byte unit] = rows 2r, 2r + 1 of one contracted value: units ordered [tile][chunk][k][row pair]
+__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_pack_f32(const float2 *__restrict__ X, f32x4 *__restrict__ out,
+                                                                  const ArtnPackSide S, const int n_ko, const long n_units) {
+  const int rb = S.n_row;
+  for (long unit = (long)blockIdx.x * blockDim.x + threadIdx.x; unit < n_units; unit += (long)gridDim.x * blockDim.x) {
+    long r = unit, src = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+      if (i < rb && ((r >> (i - 1)) & 1)) src += S.row[i];
+    r >>= rb - 1;
+#pragma unroll
+    for (int q = 0; q < ARTN_PG_KC - 1; ++q)
+      if ((r >> q) & 1) src += S.kc[q];
+    r >>= ARTN_PG_KC - 1;
+    for (int q = 0; q < n_ko; ++q)
+      if ((r >> q) & 1) src += S.ko[q];
+    r >>= n_ko;
+    for (int q = 0; q < S.n_to; ++q)
+      if ((r >> q) & 1) src += S.to[q];
+    const float2 e0 = X[src], e1 = X[src + S.row[0]];
+    out[unit] = f32x4{e0.x, e0.y, e1.x, e1.y};
+  }
+}
+
+__global__ __launch_bounds__(ARTN_PG_THREADS, 1) void artn_k_pgemm3m(const unsigned char *__restrict__ Ap, const unsigned char *__restrict__ Bp,
+                                                                     float2 *__restrict__ C, const ArtnPackPlan P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((unsigned)(unsigned long)(lds_byte_t *)smem != 0) __builtin_trap();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  constexpr int MB = 2, NB = 2; // blocks of 32 rows x 32 complex columns
+  constexpr unsigned RA = 1u << ARTN_PG_MT, RB = 1u << ARTN_PG_NT;
+  const unsigned lane_x = ((unsigned)h * RA + (unsigned)(wm * 64 + j)) * 8u;
+  const unsigned lane_w = ARTN_PG_A_BYTES + ((unsigned)h * RB + (unsigned)(wn * 64 + j)) * 8u;
+  const int n_chunks = 1 << P.n_ko;
+  const int seg_len = P.flush_chunks > 0 && P.flush_chunks < n_chunks ? P.flush_chunks : n_chunks;
+
+  auto m_off = [&](int m_local) {
+    unsigned o = 0;
+#pragma unroll
+    for (int i = 0; i < ARTN_PG_MT; ++i)
+      if ((m_local >> i) & 1) o |= 1u << P.m_pos[i];
+    return o;
+  };
+  auto n_off = [&](int n_local) {
+    unsigned o = 0;
+#pragma unroll
+    for (int i = 0; i < ARTN_PG_NT; ++i)
+      if ((n_local >> i) & 1) o |= 1u << P.n_pos[i];
+    return o;
+  };
+  // accumulator register r of lane (j, h): n_in_block = (r & 3) + 4h + 8(r >> 2)
+  const unsigned lane_c = swz_gemm(m_off(wm * 64 + j) | n_off(wn * 64 + 4 * h), P);
+  unsigned c_mb[MB], c_nb[NB];
+#pragma unroll
+  for (int q = 0; q < MB; ++q) c_mb[q] = swz_gemm(m_off(q * 32), P);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) c_nb[q] = swz_gemm(n_off(q * 32), P);
+  const unsigned c_b0 = swz_gemm(n_off(1), P), c_b1 = swz_gemm(n_off(2), P), c_q0 = swz_gemm(n_off(8), P), c_q1 = swz_gemm(n_off(16), P);
+  constexpr int TC = ARTN_PG_MT + ARTN_PG_NT, EPI = ARTN_PG_EPI_BITS;
+  unsigned o_gl = 0;
+#pragma unroll
+  for (int b = 1; b <= 9; ++b)
+    if ((tid >> (b - 1)) & 1) o_gl += (unsigned)P.out_stride[b] * 8u;
+  long o_gi[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) o_gi[b] = P.out_stride[10 + b] * 8;
+  const unsigned o_ll = swz_gemm((unsigned)tid * 2u, P) * 8u;
+
+  const long G = gridDim.x, n_tiles = P.n_tiles;
+  long t0 = blockIdx.x;
+  if ((G & 7) == 0) t0 = (long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int nl = P.n_no < 3 ? P.n_no : 3, ml = P.n_mo < 2 ? P.n_mo : 2;
+  const long a_tile_bytes = (long)n_chunks * ARTN_PG_A_BYTES, b_tile_bytes = (long)n_chunks * ARTN_PG_B_BYTES;
+
+  for (long tile = t0; tile < n_tiles; tile += G) {
+    long r = tile;
+    long no = r & ((1L << nl) - 1);
+    r >>= nl;
+    long mo = r & ((1L << ml) - 1);
+    r >>= ml;
+    no |= (r & ((1L << (P.n_no - nl)) - 1)) << nl;
+    r >>= P.n_no - nl;
+    mo |= r << ml;
+    long c_off = 0;
+    for (int q = 0; q < P.n_mo; ++q)
+      if ((mo >> q) & 1) c_off += P.c_mo[q];
+    for (int q = 0; q < P.n_no; ++q)
+      if ((no >> q) & 1) c_off += P.c_no[q];
+    c_off = uniform64(c_off);
+    const unsigned char *At = Ap + uniform64(mo * a_tile_bytes), *Bt = Bp + uniform64(no * b_tile_bytes);
+    auto stage = [&](int c, unsigned buf) {
+      const unsigned char *ga = At + (long)c * ARTN_PG_A_BYTES + tid * 16, *gb = Bt + (long)c * ARTN_PG_B_BYTES + tid * 16;
+      const unsigned dst = buf * ARTN_PG_STAGE + (unsigned)wave * 1024u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pg_glds16(ga + q * 8192, dst + q * 8192u);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) pg_glds16(gb + q * 8192, dst + ARTN_PG_A_BYTES + q * 8192u);
+    };
+    char *Cb = reinterpret_cast<char *>(C) + c_off * 8;
+    for (int seg = 0; seg < n_chunks; seg += seg_len) {
+      f32x16 acc[MB][NB * 3];
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB * 3; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+      const int seg_end = seg + seg_len;
+      stage(seg, 0u);
+      if (seg + 1 < seg_end) stage(seg + 1, 1u);
+      unsigned cur = 0;
+      for (int c = seg; c < seg_end; ++c) {
+        if (c + 1 < seg_end) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + 2 < seg_end) stage(c + 2, cur >= 1 ? cur - 1 : 2u);
+        const unsigned xa = cur * ARTN_PG_STAGE + lane_x, wa = cur * ARTN_PG_STAGE + lane_w;
+        v2f_t X[2][MB], W[2][NB];
+        auto load_ops = [&](int sidx, v2f_t (&x)[MB], v2f_t (&w)[NB]) {
+#pragma unroll
+          for (int a = 0; a < MB; ++a) x[a] = lds_read8(xa + (unsigned)sidx * (2u * RA * 8u) + (unsigned)a * 256u);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) w[b] = lds_read8(wa + (unsigned)sidx * (2u * RB * 8u) + (unsigned)b * 256u);
+        };
+        load_ops(0, X[0], W[0]);
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) {
+          if (sidx + 1 < 8) load_ops(sidx + 1, X[(sidx + 1) & 1], W[(sidx + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          float xs[MB], wsum[NB];
+#pragma unroll
+          for (int a = 0; a < MB; ++a) xs[a] = X[sidx & 1][a].x + X[sidx & 1][a].y;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) wsum[b] = W[sidx & 1][b].x + W[sidx & 1][b].y;
+#pragma unroll
+          for (int a = 0; a < MB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              acc[a][3 * b] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[sidx & 1][b].x, X[sidx & 1][a].x, acc[a][3 * b], 0, 0, 0);
+              acc[a][3 * b + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[sidx & 1][b].y, X[sidx & 1][a].y, acc[a][3 * b + 1], 0, 0, 0);
+              acc[a][3 * b + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wsum[b], xs[a], acc[a][3 * b + 2], 0, 0, 0);
+            }
+        }
+        cur = cur == 2 ? 0u : cur + 1;
+      }
+      // ---- epilogue of this partial sum: T1, T2, T3 -> (T1 - T2, T3 - T1 - T2) -> C-ordered LDS image -> global
+      const bool accumulate = seg > 0;
+      for (int pass = 0; pass < (1 << (TC - EPI)); ++pass) {
+        __syncthreads();
+        unsigned lc = lane_c;
+        OPAQUE_V(lc);
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ ((rr & 1) ? c_b0 : 0u) ^ ((rr & 2) ? c_b1 : 0u) ^ ((rr & 4) ? c_q0 : 0u) ^ ((rr & 8) ? c_q1 : 0u);
+              const float t1 = acc[a][3 * b][rr], t2 = acc[a][3 * b + 1][rr], t3 = acc[a][3 * b + 2][rr];
+              if ((int)(pos >> EPI) == pass) lds_write8((pos & ((1u << EPI) - 1u)) * 8u, v2f_t{t1 - t2, t3 - t1 - t2});
+            }
+        __syncthreads();
+        unsigned oll = o_ll ^ ((swz_gemm((unsigned)pass << EPI, P) & ((1u << EPI) - 1u)) * 8u), ogl = o_gl;
+        OPAQUE_V(oll);
+        OPAQUE_V(ogl);
+        long po = 0;
+#pragma unroll
+        for (int b = 0; b < TC - EPI; ++b)
+          if ((pass >> b) & 1) po += P.out_stride[EPI + b] * 8;
+        f32x4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = lds_read16(oll ^ (swz_gemm((unsigned)i * 1024u, P) * 8u));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          long o = po;
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+            if ((i >> b) & 1) o += o_gi[b];
+          f32x4 *dst = reinterpret_cast<f32x4 *>(Cb + o + ogl);
+          if (accumulate) x[i] += __builtin_nontemporal_load(dst); // (this thread wrote the same 16 bytes at the previous flush)
+          *dst = x[i];
+        }
+      }
+      __syncthreads(); // the result image has been read: the chunk buffers are free again
+    }
+  }
+}

@@ -172,6 +172,8 @@ struct ArtnPackSide { // one operand: element strides of its bits
   int32_t n_row, n_to;
 };
 struct ArtnPackPlan {
+  int32_t arith;      // 0: bfloat16 operands (4-byte packed elements, chunks of 2^5); 1: fp32, 3M arithmetic (8-byte elements, chunks of 2^4)
+  int32_t kc_bits;    // contracted bits per chunk
   int32_t swapped;    // 1: the kernel's first operand is the caller's B
   int32_t n_ko;       // 2^n_ko chunks per tile
   int32_t n_mo, n_no; // tile-outer bits of the first / second operand
@@ -181,7 +183,7 @@ struct ArtnPackPlan {
   int64_t out_stride[16];     // C-tile-local bit (tile bits ordered by C stride) -> C element stride
   int32_t m_pos[8], n_pos[8]; // m_local / n_local bit -> C-tile-local position
   int32_t swz_n, swz_src[4], swz_dst[4];
-  int32_t pad_;
+  int32_t flush_chunks; // fp32: partial sums leave the registers every this many chunks (2^12 contracted values); 0: never
 };
 
 struct ArtnPlan {
@@ -211,7 +213,8 @@ struct Tuning {
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
   int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
   int gemm_tall = 1;  // GEMM kernel, fp32, 32 x 32 tiles: chunks of 2^6 contracted values
-  int packed = 1;     // reduced-precision mode, big steps with 2^9+ contracted values: packed-operand GEMM (ArtnPackPlan)
+  int packed = 2;     // packed-operand GEMM (ArtnPackPlan): 1 reduced-precision mode only (2^9+ contracted values),
+                      // 2 also complex64 arithmetic (3M on fp32 MFMA, 2^10+ contracted values), 0 never
   int alt = 2;        // big launches of the state-streaming kernel: 1: one 8-wave workgroup per CU, two groups alternating
                       // between MFMA stages and copy phases (artn_k_alt); 0: two independent workgroups per CU (artn_k_bits);
                       // 2: artn_k_alt where a tile's OUTPUT runs are shorter than a 128-byte line (its stores, slow
@@ -233,7 +236,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
-    if (const char *e = getenv("ARTN_PACKED")) x.packed = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_PACKED")) x.packed = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_ALT")) x.alt = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
@@ -1207,7 +1210,9 @@ static inline bool make_gemm128(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, in
 // packed-operand GEMM (ARTN_C64_BF16): see ArtnPackPlan
 // ----------------------------------------------------------------------------------------
 static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
-  if (d->dtype != ARTN_C64_BF16) { p.why_generic = "packed GEMM: reduced-precision mode only"; return false; }
+  if (d->dtype != ARTN_C64_BF16 && d->dtype != ARTN_C64) { p.why_generic = "packed GEMM: complex64 only"; return false; }
+  const bool bf = d->dtype == ARTN_C64_BF16;
+  const int KC = bf ? ARTN_PG_KC : ARTN_PG_KC - 1; // the stage holds the same bytes either way
   std::vector<Axis> ax;
   expand_axes(d, ax);
   std::vector<int> K, M, N;
@@ -1225,9 +1230,10 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
     std::swap(M, N);
   }
   const int k = (int)K.size(), m = (int)M.size(), n = (int)N.size();
-  // worth two packing passes: 2^9+ contracted values, and enough tiles for every CU
-  if (k < 9 || m < ARTN_PG_MT || n < ARTN_PG_NT) { p.why_generic = "packed GEMM: too few contracted or free bits"; return false; }
-  if (k - ARTN_PG_KC > ARTN_GEMM_MAX_KO || m - ARTN_PG_MT > 32 || n - ARTN_PG_NT > 32) { p.why_generic = "packed GEMM: too many bits"; return false; }
+  // worth two packing passes: 2^9+ contracted values (fp32, whose MFMAs are 16 times slower per FLOP and whose packed copy
+  // saves no bytes: 2^10+), and enough tiles for every CU
+  if (k < (bf ? 9 : 10) || m < ARTN_PG_MT || n < ARTN_PG_NT) { p.why_generic = "packed GEMM: too few contracted or free bits"; return false; }
+  if (k - KC > ARTN_GEMM_MAX_KO || m - ARTN_PG_MT > 32 || n - ARTN_PG_NT > 32) { p.why_generic = "packed GEMM: too many bits"; return false; }
   if ((int64_t(1) << (m - ARTN_PG_MT + n - ARTN_PG_NT)) < n_cu) { p.why_generic = "packed GEMM: too few tiles to fill the chip"; return false; }
   auto byA = [&](int x, int y) { return ax[x].sA < ax[y].sA; };
   auto byB = [&](int x, int y) { return ax[x].sB1 < ax[y].sB1; };
@@ -1238,7 +1244,7 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
   // reads neighbouring elements; tile rows: the free bits with the lowest C strides first (coalesced result stores),
   // topped up by lowest operand stride
   std::sort(K.begin(), K.end(), byA);
-  std::vector<int> Kc(K.begin(), K.begin() + ARTN_PG_KC);
+  std::vector<int> Kc(K.begin(), K.begin() + KC);
   auto pick_rows = [&](std::vector<int> &F, int want, auto byOp) {
     std::vector<int> byc(F), out;
     std::sort(byc.begin(), byc.end(), byC);
@@ -1252,15 +1258,18 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
   std::vector<int> Mt = pick_rows(M, ARTN_PG_MT, byA), Nt = pick_rows(N, ARTN_PG_NT, byB);
   ArtnPackPlan &g = p.pack;
   memset(&g, 0, sizeof(g));
+  g.arith = bf ? 0 : 1;
+  g.kc_bits = KC;
+  g.flush_chunks = bf ? 0 : 1 << (ARTN_GEMM_FLUSH_LOG2 - KC);
   g.swapped = swapped ? 1 : 0;
-  g.n_ko = k - ARTN_PG_KC;
+  g.n_ko = k - KC;
   g.n_mo = m - ARTN_PG_MT;
   g.n_no = n - ARTN_PG_NT;
   g.n_tiles = int64_t(1) << (g.n_mo + g.n_no);
   g.a.n_row = ARTN_PG_MT; g.b.n_row = ARTN_PG_NT; g.a.n_to = g.n_mo; g.b.n_to = g.n_no;
   for (int i = 0; i < ARTN_PG_MT; ++i) g.a.row[i] = ax[Mt[i]].sA;
   for (int i = 0; i < ARTN_PG_NT; ++i) g.b.row[i] = ax[Nt[i]].sB1;
-  for (int q = 0; q < ARTN_PG_KC; ++q) { g.a.kc[q] = ax[Kc[q]].sA; g.b.kc[q] = ax[Kc[q]].sB1; }
+  for (int q = 0; q < KC; ++q) { g.a.kc[q] = ax[Kc[q]].sA; g.b.kc[q] = ax[Kc[q]].sB1; }
   { int q = 0; for (int i : K) if (!in_set(Kc, i)) { g.a.ko[q] = ax[i].sA; g.b.ko[q] = ax[i].sB1; ++q; } }
   { int q = 0; for (int i : M) if (!in_set(Mt, i)) { g.a.to[q] = ax[i].sA; g.c_mo[q] = ax[i].sC; ++q; } }
   { int q = 0; for (int i : N) if (!in_set(Nt, i)) { g.b.to[q] = ax[i].sB1; g.c_no[q] = ax[i].sC; ++q; } }
@@ -1295,13 +1304,13 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
   ArtnStepInfo &f = p.info;
   f.kernel = ARTN_KERNEL_PGEMM;
   f.k_bits = k; f.m_tile_bits = ARTN_PG_MT; f.n_tile_bits = ARTN_PG_NT;
-  f.tile_in_bits = ARTN_PG_MT + ARTN_PG_KC; f.tile_out_bits = ARTN_PG_MT + ARTN_PG_NT;
+  f.tile_in_bits = ARTN_PG_MT + KC; f.tile_out_bits = ARTN_PG_MT + ARTN_PG_NT;
   f.run_in_bits = 0; f.run_out_bits = 0;
   f.lds_bytes = 3 * ((4 << (ARTN_PG_MT + ARTN_PG_KC)) + (4 << (ARTN_PG_NT + ARTN_PG_KC))); // three chunk buffers
   f.n_tiles = g.n_tiles;
   f.a_rereads = int64_t(1) << g.n_no;
   f.grid = (int32_t)std::min<int64_t>(g.n_tiles, (int64_t)n_cu);
-  f.workspace_bytes = 4 * ((int64_t(1) << (m + k)) + (int64_t(1) << (n + k)));
+  f.workspace_bytes = (bf ? 4 : 8) * ((int64_t(1) << (m + k)) + (int64_t(1) << (n + k)));
   return true;
 }
 
@@ -1328,7 +1337,8 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   p.n_cu = n_cu;
   bool ok = false;
   // (needs a workspace: only where the caller can supply one -- artn_contract_query reports its size, artn_contract_ws takes it)
-  if (allow_packed && allow_bits && allow_gemm && gather_label < 0 && tuning().gemm && tuning().packed && d->dtype == ARTN_C64_BF16)
+  if (allow_packed && allow_bits && allow_gemm && gather_label < 0 && tuning().gemm && tuning().packed &&
+      (d->dtype == ARTN_C64_BF16 || (d->dtype == ARTN_C64 && tuning().packed >= 2)))
     ok = make_pgemm(d, p, n_cu);
   allow_gemm = allow_gemm && !ok;
   if (d->dtype == ARTN_C128 && allow_bits && allow_gemm && gather_label < 0 && tuning().gemm)
@@ -1352,8 +1362,8 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
     p.info.arith = p.bits.split == 1 ? 2 : (m3 ? 1 : 0);
     p.info.mfma_flops = p.info.flops * (m3 ? 0.75 : 1.0);
   } else if (p.kernel == ARTN_KERNEL_PGEMM) {
-    p.info.arith = 2;
-    p.info.mfma_flops = p.info.flops;
+    p.info.arith = p.pack.arith == 0 ? 2 : 1;
+    p.info.mfma_flops = p.info.flops * (p.pack.arith == 0 ? 1.0 : 0.75);
   } else if (p.kernel == ARTN_KERNEL_GEMM_MFMA) {
     p.info.arith = d->dtype == ARTN_C128 ? 3 : (p.gemm.split == 1 ? 2 : (p.gemm.m3 ? 1 : 0));
     p.info.mfma_flops = p.info.flops * (p.gemm.m3 ? 0.75 : 1.0);

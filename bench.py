@@ -39,7 +39,7 @@ import torch  # noqa: E402
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (spec, ~2.5 PF)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak (spec)
-KERNEL_NAMES = {0: "artn_k_generic", 1: "artn_k_bits", 2: "artn_k_gemm", 3: "artn_k_program", 4: "artn_k_pgemm (+ artn_k_pack_bf16)"}
+KERNEL_NAMES = {0: "artn_k_generic", 1: "artn_k_bits", 2: "artn_k_gemm", 3: "artn_k_program", 4: "artn_k_pgemm / artn_k_pgemm3m (+ packing passes)"}
 LOOSE_TOL = 1e-5              # |got - want| <= tol * max(|want|, rms(want)) for every amplitude
 STRICT_FACTOR = 4.0           # relative error per amplitude over |truth| >= 1e-3 rms, against the complex128 truth
 #                               of the same leaves and scheme (tests/golden/c128_truth_gpu.npz): allowed up to this many times

@@ -1036,7 +1036,8 @@ def test_packed_gemm_bf16(m, n, k, seed):
         rng.shuffle(l)
     eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
     info = A.step_info(eq, (2,) * len(la), (2,) * len(lb))
-    assert info["workspace_bytes"] == 0   # complex64 arithmetic never asks for scratch
+    # (complex64 arithmetic packs only from 2^10 contracted values on, and its elements stay 8 bytes)
+    assert info["workspace_bytes"] == (0 if k < 10 else 8 * (2 ** (m + k) + 2 ** (n + k)))
     with A.precision("bf16"):
         info = A.step_info(eq, (2,) * len(la), (2,) * len(lb))
         assert info["kernel"] == N.KERNEL_PGEMM and info["workspace_bytes"] == 4 * (2 ** (m + k) + 2 ** (n + k)), info
@@ -1047,3 +1048,34 @@ def test_packed_gemm_bf16(m, n, k, seed):
     assert rel(got, want) < 2e-6, (eq, rel(got, want))
     exact = oracle.einsum_pair(eq, a, b)
     assert 1e-4 < rel(got, exact) < 3e-2
+
+
+@pytest.mark.parametrize("m,n,k,seed", [(12, 11, 10, 0), (11, 12, 13, 1)])
+def test_packed_gemm_complex64(m, n, k, seed):
+    """The packed-operand GEMM in complex64 arithmetic (3M on fp32 MFMA, 2^10+ contracted values): operands copied once
+    into [tile][chunk][k][row] order, LDS-DMA fills, 256 x 128 tiles; k = 13 crosses a partial-sum flush (2^12 contracted
+    values per fp32 chain).  Against artn_contract WITHOUT scratch (the two-operand LDS GEMM artn_k_gemm) on the same
+    operands, and -- where numpy finishes in seconds -- against a complex128 einsum."""
+    import ctypes
+    from artensor_amd import contraction as C
+    rng = np.random.default_rng(200 + seed)
+    kl = [chr(65 + x) for x in range(k)]
+    ml = [chr(97 + x) for x in range(m)]
+    nl = [chr(65 + k + x) for x in range(n)]
+    la, lb, lo = kl + ml, kl + nl, ml + nl
+    for l in (la, lb, lo):
+        rng.shuffle(l)
+    eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
+    info = A.step_info(eq, (2,) * len(la), (2,) * len(lb))
+    assert info["kernel"] == N.KERNEL_PGEMM and info["workspace_bytes"] == 8 * (2 ** (m + k) + 2 ** (n + k)), info
+    assert abs(info["mfma_flops"] / info["flops"] - 0.75) < 1e-9
+    a, b = gpu(crandn(rng, (2,) * len(la))), gpu(crandn(rng, (2,) * len(lb)))
+    got = A.contract(eq, a, b)
+    d, out_shape = C._descriptor(tuple(la), tuple(lb), tuple(lo), tuple(a.shape), tuple(a.stride()), tuple(b.shape), tuple(b.stride()), a.dtype)
+    plain = torch.empty(out_shape, dtype=a.dtype, device=a.device)
+    N.check(N.lib().artn_contract(ctypes.byref(d), a.data_ptr(), b.data_ptr(), plain.data_ptr(), N.current_stream_ptr(a.device)))
+    assert (got - plain).abs().max().item() <= 1e-5 * plain.abs().max().item()
+    assert not torch.equal(got, plain)   # (another kernel, another order of additions)
+    if k <= 10:
+        want = oracle.einsum_pair(eq, a.cpu().numpy().astype(np.complex128), b.cpu().numpy().astype(np.complex128))
+        assert rel(got.cpu().numpy(), want) < 1e-5
