@@ -215,6 +215,9 @@ struct Tuning {
   int gemm_tall = 1;  // GEMM kernel, fp32, 32 x 32 tiles: chunks of 2^6 contracted values
   int packed = 2;     // packed-operand GEMM (ArtnPackPlan): 1 reduced-precision mode only (2^9+ contracted values),
                       // 2 also complex64 arithmetic (3M on fp32 MFMA, 2^10+ contracted values), 0 never
+  int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
+                           // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
+  int packed_min_ai = 64;  // ... and the FLOP per byte of the step it needs
   int alt = 2;        // big launches of the state-streaming kernel: 1: one 8-wave workgroup per CU, two groups alternating
                       // between MFMA stages and copy phases (artn_k_alt); 0: two independent workgroups per CU (artn_k_bits);
                       // 2: artn_k_alt where a tile's OUTPUT runs are shorter than a 128-byte line (its stores, slow
@@ -236,6 +239,8 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_PACKED_MIN_K")) x.packed_min_k = std::max(6, atoi(e));
+    if (const char *e = getenv("ARTN_PACKED_MIN_AI")) x.packed_min_ai = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_PACKED")) x.packed = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_ALT")) x.alt = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
@@ -1232,7 +1237,12 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
   const int k = (int)K.size(), m = (int)M.size(), n = (int)N.size();
   // worth two packing passes: 2^9+ contracted values (fp32, whose MFMAs are 16 times slower per FLOP and whose packed copy
   // saves no bytes: 2^10+), and enough tiles for every CU
-  if (k < (bf ? 9 : 10) || m < ARTN_PG_MT || n < ARTN_PG_NT) { p.why_generic = "packed GEMM: too few contracted or free bits"; return false; }
+  if (k < (bf ? 9 : tuning().packed_min_k) || m < ARTN_PG_MT || n < ARTN_PG_NT) { p.why_generic = "packed GEMM: too few contracted or free bits"; return false; }
+  if (!bf) { // the packing passes move every operand element twice more: only where the GEMM itself is far from memory-bound
+    const double flops = 8.0 * (double)(int64_t(1) << (m + n)) * (double)(int64_t(1) << k);
+    const double bytes = 8.0 * ((double)(int64_t(1) << (m + k)) + (double)(int64_t(1) << (n + k)) + (double)(int64_t(1) << (m + n)));
+    if (flops / bytes < tuning().packed_min_ai) { p.why_generic = "packed GEMM: too few FLOP per byte to pay for the packing passes"; return false; }
+  }
   if (k - KC > ARTN_GEMM_MAX_KO || m - ARTN_PG_MT > 32 || n - ARTN_PG_NT > 32) { p.why_generic = "packed GEMM: too many bits"; return false; }
   if ((int64_t(1) << (m - ARTN_PG_MT + n - ARTN_PG_NT)) < n_cu) { p.why_generic = "packed GEMM: too few tiles to fill the chip"; return false; }
   auto byA = [&](int x, int y) { return ax[x].sA < ax[y].sA; };

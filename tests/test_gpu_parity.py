@@ -1036,8 +1036,8 @@ def test_packed_gemm_bf16(m, n, k, seed):
         rng.shuffle(l)
     eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
     info = A.step_info(eq, (2,) * len(la), (2,) * len(lb))
-    # (complex64 arithmetic packs only from 2^10 contracted values on, and its elements stay 8 bytes)
-    assert info["workspace_bytes"] == (0 if k < 10 else 8 * (2 ** (m + k) + 2 ** (n + k)))
+    # (complex64 arithmetic packs too -- from 2^8 contracted values on -- and its elements stay 8 bytes)
+    assert info["workspace_bytes"] == 8 * (2 ** (m + k) + 2 ** (n + k))
     with A.precision("bf16"):
         info = A.step_info(eq, (2,) * len(la), (2,) * len(lb))
         assert info["kernel"] == N.KERNEL_PGEMM and info["workspace_bytes"] == 4 * (2 ** (m + k) + 2 ** (n + k)), info
