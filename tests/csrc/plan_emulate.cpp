@@ -4,6 +4,8 @@
 // the optional fused second stage and the copy-out -- from the same ArtnBitsPlan the GPU
 // receives, so the planner's index algebra can be checked against the oracle on a box
 // without a GPU.  Never linked into the product.
+#include <algorithm>
+#include <cmath>
 #include <complex>
 #include <vector>
 #include "artn_plan.h"
@@ -477,6 +479,155 @@ static void run_generic(const ArtnGenericPlan &G, const cf *A, const cf *B, cf *
     }
     C[idx] = sum;
   }
+}
+
+// ---- packed-operand GEMM (artn_pgemm_kernel.h), replayed from the same ArtnPackPlan ---------------------------------
+// The packing passes unit by unit (same index arithmetic as artn_k_pack_bf16 / artn_k_pack_f32), then artn_k_pgemm /
+// artn_k_pgemm3m tile by tile: tile index -> (m-outer, n-outer), the chunk images addressed as the kernels address them
+// (planes 2t + h of 4 values / contracted value 2s + h), the T1 / T2 / T3 arithmetic of the complex64 form with its
+// partial-sum flush, the C-ordered swizzled result image pass by pass and the copy-out through out_stride.  (The MFMA
+// lane and accumulator maps are those of artn_k_gemm, replayed lane by lane in run_gemm above; here an output element
+// is computed directly from the image elements its lanes read.)
+static unsigned swzp(unsigned off, const ArtnPackPlan &P) {
+  for (int i = 0; i < P.swz_n; ++i)
+    if ((off >> P.swz_src[i]) & 1) off ^= 1u << P.swz_dst[i];
+  return off;
+}
+static void pack_side(const ArtnPackSide &S, int n_ko, int kc_bits, bool bf, const cf *X, std::vector<cf> &out, int n_to) {
+  const int rb = S.n_row;
+  const size_t n_elems = (size_t)1 << (n_to + n_ko + kc_bits + rb);
+  out.assign(n_elems, cf(0, 0));
+  if (bf) { // unit = [row][plane g][chunk][tile], 4 values kc = 4g + u per unit
+    const size_t n_units = n_elems / 4;
+    for (size_t unit = 0; unit < n_units; ++unit) {
+      size_t r = unit;
+      int64_t src = 0;
+      for (int i = 0; i < rb; ++i) if ((r >> i) & 1) src += S.row[i];
+      r >>= rb;
+      for (int q = 2; q < kc_bits; ++q) if ((r >> (q - 2)) & 1) src += S.kc[q];
+      r >>= kc_bits - 2;
+      for (int q = 0; q < n_ko; ++q) if ((r >> q) & 1) src += S.ko[q];
+      r >>= n_ko;
+      for (int q = 0; q < S.n_to; ++q) if ((r >> q) & 1) src += S.to[q];
+      for (int u = 0; u < 4; ++u) {
+        const cf e = X[src + ((u & 1) ? S.kc[0] : 0) + ((u & 2) ? S.kc[1] : 0)];
+        out[unit * 4 + u] = cf(bf16r(e.real()), bf16r(e.imag()));
+      }
+    }
+  } else { // unit = [row pair][k][chunk][tile]
+    const size_t n_units = n_elems / 2;
+    for (size_t unit = 0; unit < n_units; ++unit) {
+      size_t r = unit;
+      int64_t src = 0;
+      for (int i = 1; i < rb; ++i) if ((r >> (i - 1)) & 1) src += S.row[i];
+      r >>= rb - 1;
+      for (int q = 0; q < kc_bits; ++q) if ((r >> q) & 1) src += S.kc[q];
+      r >>= kc_bits;
+      for (int q = 0; q < n_ko; ++q) if ((r >> q) & 1) src += S.ko[q];
+      r >>= n_ko;
+      for (int q = 0; q < S.n_to; ++q) if ((r >> q) & 1) src += S.to[q];
+      out[unit * 2] = X[src];
+      out[unit * 2 + 1] = X[src + S.row[0]];
+    }
+  }
+}
+static void run_pgemm(const ArtnPackPlan &P, const cf *A0, const cf *B0, cf *C) {
+  const cf *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
+  const bool bf = P.arith == 0;
+  const int KC = P.kc_bits, RA = 1 << ARTN_PG_MT, RB = 1 << ARTN_PG_NT, TC = ARTN_PG_MT + ARTN_PG_NT, EPI = ARTN_PG_EPI_BITS;
+  std::vector<cf> Ap, Bp;
+  pack_side(P.a, P.n_ko, KC, bf, A, Ap, P.n_mo);
+  pack_side(P.b, P.n_ko, KC, bf, B, Bp, P.n_no);
+  const int n_chunks = 1 << P.n_ko;
+  const size_t a_chunk = (size_t)RA << KC, b_chunk = (size_t)RB << KC; // elements per (tile, chunk)
+  const int seg_len = (!bf && P.flush_chunks > 0 && P.flush_chunks < n_chunks) ? P.flush_chunks : n_chunks;
+  const int nl = std::min(P.n_no, 3), ml = std::min(P.n_mo, 2);
+  auto m_off = [&](int m) { unsigned o = 0; for (int i = 0; i < ARTN_PG_MT; ++i) if ((m >> i) & 1) o |= 1u << P.m_pos[i]; return o; };
+  auto n_off = [&](int n) { unsigned o = 0; for (int i = 0; i < ARTN_PG_NT; ++i) if ((n >> i) & 1) o |= 1u << P.n_pos[i]; return o; };
+  std::vector<cf> img((size_t)1 << EPI);
+  for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
+    int64_t r = tile;
+    int64_t no = r & ((1LL << nl) - 1); r >>= nl;
+    int64_t mo = r & ((1LL << ml) - 1); r >>= ml;
+    no |= (r & ((1LL << (P.n_no - nl)) - 1)) << nl; r >>= P.n_no - nl;
+    mo |= r << ml;
+    int64_t c_off = 0;
+    for (int q = 0; q < P.n_mo; ++q) if ((mo >> q) & 1) c_off += P.c_mo[q];
+    for (int q = 0; q < P.n_no; ++q) if ((no >> q) & 1) c_off += P.c_no[q];
+    const cf *At = Ap.data() + (size_t)mo * n_chunks * a_chunk, *Bt = Bp.data() + (size_t)no * n_chunks * b_chunk;
+    for (int seg = 0; seg < n_chunks; seg += seg_len) {
+      // acc[wave][lane][block a][block b][register]: complex value per (m_local, n_local), kept as T1/T2/T3 in the 3M form
+      std::vector<float> t1((size_t)RA * RB * 2, 0.f), t2, t3;
+      if (!bf) { t2.assign((size_t)RA * RB, 0.f); t3.assign((size_t)RA * RB, 0.f); t1.assign((size_t)RA * RB, 0.f); }
+      for (int c = seg; c < seg + seg_len; ++c) {
+        const cf *ia = At + (size_t)c * a_chunk, *ib = Bt + (size_t)c * b_chunk; // the chunk's LDS images, in element units
+        // per output element (m_local, n_local) of the tile: the image elements its MFMAs read -- planes 2t + h, unit slot u
+        // (bf16) / contracted value 2s + h (fp32) -- in the order the chains accumulate them
+        for (int m = 0; m < RA; ++m)
+          for (int n = 0; n < RB; ++n) {
+            if (bf) {
+              float re = t1[((size_t)m * RB + n) * 2], im = t1[((size_t)m * RB + n) * 2 + 1];
+              for (int t = 0; t < 4; ++t)
+                for (int h = 0; h < 2; ++h)
+                  for (int u = 0; u < 4; ++u) {
+                    const cf x = ia[((size_t)(2 * t + h) * RA + m) * 4 + u], w = ib[((size_t)(2 * t + h) * RB + n) * 4 + u];
+                    re = fmaf(w.real(), x.real(), re); re = fmaf(-w.imag(), x.imag(), re);
+                    im = fmaf(w.imag(), x.real(), im); im = fmaf(w.real(), x.imag(), im);
+                  }
+              t1[((size_t)m * RB + n) * 2] = re; t1[((size_t)m * RB + n) * 2 + 1] = im;
+            } else {
+              float a1 = t1[(size_t)m * RB + n], a2 = t2[(size_t)m * RB + n], a3 = t3[(size_t)m * RB + n];
+              for (int sidx = 0; sidx < (1 << (KC - 1)); ++sidx)
+                for (int h = 0; h < 2; ++h) {
+                  const cf x = ia[(size_t)(2 * sidx + h) * RA + m], w = ib[(size_t)(2 * sidx + h) * RB + n];
+                  a1 = fmaf(w.real(), x.real(), a1);
+                  a2 = fmaf(w.imag(), x.imag(), a2);
+                  a3 = fmaf(w.real() + w.imag(), x.real() + x.imag(), a3);
+                }
+              t1[(size_t)m * RB + n] = a1; t2[(size_t)m * RB + n] = a2; t3[(size_t)m * RB + n] = a3;
+            }
+          }
+      }
+      // epilogue: register (m_local, n_local) -> swizzled image position -> pass -> copy-out
+      for (int pass = 0; pass < (1 << (TC - EPI)); ++pass) {
+        std::fill(img.begin(), img.end(), cf(0, 0));
+        for (int m = 0; m < RA; ++m)
+          for (int n = 0; n < RB; ++n) {
+            const unsigned pos = swzp(m_off(m) | n_off(n), P);
+            if ((int)(pos >> EPI) != pass) continue;
+            const cf v = bf ? cf(t1[((size_t)m * RB + n) * 2], t1[((size_t)m * RB + n) * 2 + 1])
+                            : cf(t1[(size_t)m * RB + n] - t2[(size_t)m * RB + n], t3[(size_t)m * RB + n] - t1[(size_t)m * RB + n] - t2[(size_t)m * RB + n]);
+            img[pos & ((1u << EPI) - 1u)] = v;
+          }
+        for (int tid = 0; tid < 512; ++tid)
+          for (int i = 0; i < 8; ++i) {
+            const unsigned e0 = (unsigned)tid * 2u + (unsigned)i * 1024u; // elements e0, e0 + 1 of the pass
+            int64_t o = c_off;
+            const unsigned full = e0 | ((unsigned)pass << EPI);
+            for (int b = 1; b < TC; ++b) if ((full >> b) & 1) o += P.out_stride[b];
+            const unsigned src = swzp(e0, P) ^ (swzp((unsigned)pass << EPI, P) & ((1u << EPI) - 1u));
+            for (int q = 0; q < 2; ++q) {
+              cf v = img[src + q];
+              if (seg > 0) v += C[o + q * P.out_stride[0]];
+              C[o + q * P.out_stride[0]] = v;
+            }
+          }
+      }
+    }
+  }
+}
+
+extern "C" int artn_emulate_pgemm(const ArtnStepDesc *d, const void *A, const void *B, void *C, ArtnStepInfo *info) {
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::validate(d, err);
+  if (rc) return rc;
+  memset(&p.info, 0, sizeof(p.info));
+  const char *e = getenv("ARTN_EMU_NCU");
+  if (!artn::make_pgemm(d, p, e ? atoi(e) : 256)) return ARTN_E_UNSUPPORTED;
+  if (info) *info = p.info;
+  run_pgemm(p.pack, (const cf *)A, (const cf *)B, (cf *)C);
+  return 0;
 }
 
 extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B, void *C, int force_generic,

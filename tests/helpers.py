@@ -64,7 +64,8 @@ def emulator():
     src = os.path.join(ROOT, "tests", "csrc", "plan_emulate.cpp")
     deps = [src, os.path.join(ROOT, "artensor_amd", "csrc", "artn_plan.h"), os.path.join(ROOT, "include", "artn.h"),
             os.path.join(ROOT, "artensor_amd", "csrc", "artn_gemm_kernel.h"),
-            os.path.join(ROOT, "artensor_amd", "csrc", "artn_gemm128_kernel.h")]
+            os.path.join(ROOT, "artensor_amd", "csrc", "artn_gemm128_kernel.h"),
+            os.path.join(ROOT, "artensor_amd", "csrc", "artn_pgemm_kernel.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "artensor_amd", "csrc"), src, "-o", so])
@@ -125,6 +126,29 @@ def emulate_gemm(eq, a, b, bf16=False, m3=-1):
     emu.artn_emulate_gemm.restype = ctypes.c_int
     rc = emu.artn_emulate_gemm(ctypes.byref(d), a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
                                out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info), ctypes.c_int(m3))
+    if rc == -2:
+        return None, None
+    assert rc == 0, rc
+    return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+
+
+def emulate_pgemm(eq, a, b, bf16=False):
+    """One step through the CPU replay of the packed-operand GEMM (packing passes + artn_k_pgemm / artn_k_pgemm3m from the
+    same ArtnPackPlan); (result, planner info) or (None, None) when the planner declines."""
+    import torch
+    from artensor_amd import contraction as C
+    from artensor_amd import _native as N
+    la, lb, lo = C._labels(eq)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    with C.precision("bf16" if bf16 else None):
+        d, out_shape = C._descriptor(la, lb, lo, tuple(ta.shape), tuple(ta.stride()), tuple(tb.shape),
+                                     tuple(tb.stride()), torch.complex64)
+    out = np.zeros(out_shape, dtype=np.complex64)
+    info = N.ArtnStepInfo()
+    emu = emulator()
+    emu.artn_emulate_pgemm.restype = ctypes.c_int
+    rc = emu.artn_emulate_pgemm(ctypes.byref(d), a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                                out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info))
     if rc == -2:
         return None, None
     assert rc == 0, rc

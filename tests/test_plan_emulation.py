@@ -8,7 +8,7 @@ import pytest
 from artensor_amd import step_info
 from artensor_amd.fixtures import load_case
 from oracle import oracle
-from helpers import GOLDEN, crandn, dense_scheme_shapes, emulate, emulate128, emulate_gemm, shrink_step
+from helpers import emulate_pgemm, GOLDEN, crandn, dense_scheme_shapes, emulate, emulate128, emulate_gemm, shrink_step
 
 KERNEL_BITS = 1
 KERNEL_GEMM = 2
@@ -361,3 +361,35 @@ def test_complex128_big_steps_of_n30_plan_onto_the_matrix_cores():
     for eq, sa, sb in big:
         info = step_info(eq, sa, sb, dtype=torch.complex128)
         assert info["kernel"] == KERNEL_GEMM, (eq, info)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("m,n,k", [(9, 8, 9), (8, 9, 10), (10, 7, 8), (8, 7, 13)])
+def test_packed_gemm_plan_emulated(monkeypatch, m, n, k, bf16):
+    """The packed-operand GEMM replayed on the CPU from its plan: both packing passes (which source element lands in which
+    16-byte unit of which tile / chunk / plane), the tile index -> (m-outer, n-outer) map, the chunk images as the MFMA
+    lanes address them, 3M arithmetic with the partial-sum flush past 2^12 contracted values (k = 13), the swizzled
+    C-ordered result image in four passes and the copy-out strides -- on random bit permutations, operands exchanged
+    (n > m), against a complex128 einsum (of the bfloat16-rounded operands in the reduced-precision form)."""
+    monkeypatch.setenv("ARTN_EMU_NCU", "1")   # (a handful of tiles: the planner's fill-the-chip test is not the subject)
+    if bf16 and k < 9:
+        pytest.skip("the reduced-precision form packs from 2^9 contracted values on")
+    rng = np.random.default_rng(1000 * m + 10 * n + k)
+    eq, sa, sb = _random_gemm_step(rng, m, n, k, 0)
+    a, b = crandn(rng, sa), crandn(rng, sb)
+    got, info = emulate_pgemm(eq, a, b, bf16=bf16)
+    assert got is not None, "planner declined"
+    assert info["kernel"] == 4 and info["workspace_bytes"] == (4 if bf16 else 8) * (2 ** (max(m, n) + k) + 2 ** (min(m, n) + k))
+    if bf16:
+        import torch
+
+        def bf(x):
+            r = torch.view_as_real(torch.from_numpy(np.ascontiguousarray(x))).to(torch.bfloat16).to(torch.float32)
+            return torch.view_as_complex(r.contiguous()).numpy()
+        want = _einsum128(eq, bf(a), bf(b))
+        tol = 2e-6 if k <= 10 else 1e-5   # (one unflushed fp32 chain over 2^13 values: 4e-6)
+    else:
+        want = _einsum128(eq, a, b)
+        tol = 1e-5
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() / np.abs(want).max() < tol, (eq, info)
