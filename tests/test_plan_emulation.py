@@ -319,8 +319,11 @@ def test_planner_routes_big_contractions_to_the_gemm_kernel():
     la = tuple(f"m{x}" for x in range(15)) + tuple(f"k{x}" for x in range(15))
     lb = tuple(f"k{x}" for x in range(15)) + tuple(f"n{x}" for x in range(14))
     lo = tuple(f"m{x}" for x in range(15)) + tuple(f"n{x}" for x in range(14))
+    # -- the packed-operand GEMM (256 x 128 tiles) where the caller can supply scratch (the query says how much: two
+    # packed copies of 8-byte elements), the two-operand LDS GEMM otherwise; either way every contracted bit in the kernel
     info = step_info((la, lb, lo), (2,) * 30, (2,) * 29)
-    assert info["kernel"] == KERNEL_GEMM and info["k_bits"] == 15 and info["m_tile_bits"] == 7 and info["n_tile_bits"] in (6, 7)
+    assert info["kernel"] == 4 and info["k_bits"] == 15 and info["m_tile_bits"] == 8 and info["n_tile_bits"] == 7
+    assert info["workspace_bytes"] == 8 * (2 ** 30 + 2 ** 29)
     from artensor_amd.contraction import _big_k_outer
     assert _big_k_outer(la, lb, lo, (2,) * 30, None, (2,) * 29) is None
     # a closing step (two 2^26 tensors down to 2^10 amplitudes): contracted labels are split off only
