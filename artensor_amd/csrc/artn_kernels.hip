@@ -2113,7 +2113,7 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
       }                                                                                                   \
       if (split == 1) { ARTN_LAUNCH_NP(K2, 1) break; }                                                    \
     }                                                                                                     \
-    if constexpr ((KB1 == 5 || KB1 == 6 || K2 == 5 || K2 == 6) && !((KB1 >= 5 && K2 >= 5) && KB1 + K2 > 10)) {      \
+    if constexpr ((KB1 == 5 || KB1 == 6 || K2 == 5 || K2 == 6) && !((KB1 >= 5 && K2 >= 5) && KB1 + K2 > 11)) {      \
       if (p.bits.m3 && p.bits.nt_loads && full) { /* three real products per complex product in the 5-bit stages */ \
         auto kern = artn_k_bits<KB1, K2, false, 0, false, true, true, true>;                              \
         if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, true, true, true>>(lds); e != hipSuccess) return e; \
@@ -2174,7 +2174,7 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
   }
 #define ARTN_ALT_CASE(K2)                                                                                 \
   case K2: {                                                                                              \
-    if constexpr ((KB1 == 5 || KB1 == 6 || K2 == 5 || K2 == 6) && !((KB1 >= 5 && K2 >= 5) && KB1 + K2 > 10)) { \
+    if constexpr ((KB1 == 5 || KB1 == 6 || K2 == 5 || K2 == 6) && !((KB1 >= 5 && K2 >= 5) && KB1 + K2 > 11)) { \
       if (p.bits.m3) {                                                                                    \
         if (p.bits.nt_loads) ARTN_ALT_GO(K2, true, true) else ARTN_ALT_GO(K2, false, true)                \
       }                                                                                                   \

@@ -215,6 +215,7 @@ struct Tuning {
   int gemm_tall = 1;  // GEMM kernel, fp32, 32 x 32 tiles: chunks of 2^6 contracted values
   int packed = 2;     // packed-operand GEMM (ArtnPackPlan): 1 reduced-precision mode only (2^9+ contracted values),
                       // 2 also complex64 arithmetic (3M on fp32 MFMA, 2^10+ contracted values), 0 never
+  int m3_frag = 96;        // 3M in fused pairs up to this many fragment registers (80: not in 5+6 / 6+5 pairs)
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
   int packed_min_ai = 64;  // ... and the FLOP per byte of the step it needs
@@ -239,6 +240,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_M3_FRAG")) x.m3_frag = atoi(e);
     if (const char *e = getenv("ARTN_PACKED_MIN_K")) x.packed_min_k = std::max(6, atoi(e));
     if (const char *e = getenv("ARTN_PACKED_MIN_AI")) x.packed_min_ai = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_PACKED")) x.packed = std::min(2, std::max(0, atoi(e)));
@@ -632,7 +634,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
       if (wide) { any = any || b.st[q].m3; all = all && b.st[q].m3; }
       frag += 2 << (std::min(b.st[q].k, 6) - 1);
     }
-    if (frag > 80) all = false; // fragments of both stages next to three accumulators: 6+4 (80) fits, 6+5 (96) spills
+    if (frag > tuning().m3_frag) all = false; // fragments of both stages next to three accumulators: 6+4 (80) fits, 6+5 (96) spills 24-36 registers
     // (a fused pair with a 6-bit 3M stage compiles with 8 spilled registers and still wins: 6+4 pairs of n30
     //  6.98 -> 5.98 ms; ARTN_BITS_3M=1 excludes them)
     if (b.n_stages == 2 && (b.st[0].k == 6 || b.st[1].k == 6) && tuning().bits_3m < 2) all = false;
