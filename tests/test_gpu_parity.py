@@ -811,7 +811,8 @@ def test_gemm_kernel_steps(m, n, k, batch):
     eq, sa, sb = _random_gemm_step(rng, m, n, k, batch)
     a, b = crandn(rng, sa), crandn(rng, sb)
     info = A.step_info(eq, sa, sb)
-    assert info["kernel"] == N.KERNEL_GEMM_MFMA, info
+    # (the two-operand LDS GEMM, or -- 2^8+ contracted values, 8+ / 7+ free bits, no batch label -- its packed-operand form)
+    assert info["kernel"] in (N.KERNEL_GEMM_MFMA, N.KERNEL_PGEMM), info
     got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
     assert rel(got, _einsum128(eq, a, b)) < STEP_TOL, (eq, info)
     with A.precision("bf16"):
