@@ -492,6 +492,9 @@ def step_info(eq, a_shape, b_shape, dtype=torch.complex64, a_stride=None, b_stri
 # dense executor
 # ----------------------------------------------------------------------------------------
 FUSE_MIN_NUMEL = 1 << 22  # pairs are fused only when the shared operand is at least this big
+FUSE_MIN_MID = 4          # ... and the intermediate at least 1/4 of it: a first step that shrinks its tensor 8x or more leaves
+                          # little traffic to save, while the fused kernel's two stages per tile cost more than they hide
+                          # (n53 m14: the 5+4 pair 2^30 -> 2^27 -> 2^26 took 4.26 ms fused at 2.1 TB/s, 2.4 ms as two launches)
 
 
 def fusion_schedule(scheme):
@@ -806,7 +809,10 @@ def _compile_dense(scheme, shapes, dtype):
             la2, lb2, lo2 = _labels(eq2)
             d1, mid = _descriptor(la1, lb1, lo1, shapes[i], _dense_strides(shapes[i]), shapes[j],
                                   _dense_strides(shapes[j]), dtype)
-            if len(la2) == len(mid):
+            mid_numel = 1
+            for e in mid:
+                mid_numel *= e
+            if len(la2) == len(mid) and mid_numel * FUSE_MIN_MID >= numel:
                 d2, out_shape = _descriptor(la2, lb2, lo2, mid, _dense_strides(mid), shapes[j2],
                                             _dense_strides(shapes[j2]), dtype)
                 q = N.ArtnStepInfo()
@@ -1284,7 +1290,8 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
         fused = None
         a = tensors[s1[0][0]]
         if (_fusable_kind(s1) and _fusable_kind(s2)
-                and isinstance(a, torch.Tensor) and a.is_cuda and a.numel() >= FUSE_MIN_NUMEL):
+                and isinstance(a, torch.Tensor) and a.is_cuda and a.numel() >= FUSE_MIN_NUMEL
+                and _out_numel(s1[1], a, tensors[s1[0][1]]) * FUSE_MIN_MID >= a.numel()):
             # between the two contractions the first step may only reshape (free) or select every
             # row in order (the identity): anything else needs the intermediate in memory
             mid_view = s1[3] if len(s1) > 3 else None
