@@ -6,16 +6,20 @@ LIB := artensor_amd/libartn_hip.so
 
 all: $(LIB)
 
-# seven objects from ONE source (see "Translation units" in artn_kernels.hip): `make -j8` builds in about a
+# eight objects from ONE source (see "Translation units" in artn_kernels.hip): `make -j8` builds in about a
 # minute and a half instead of four
-SRCS := $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_plan.h include/artn.h
+SRCS := $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_pgemm_kernel.h \
+        $(CSRC)/artn_bits128_kernel.h $(CSRC)/artn_plan.h include/artn.h
 OBJDIR := build/obj
-OBJS := $(OBJDIR)/main.o $(foreach k,1 2 3 4 5 6,$(OBJDIR)/bits_k$(k).o)
+OBJS := $(OBJDIR)/main.o $(OBJDIR)/b128.o $(foreach k,1 2 3 4 5 6,$(OBJDIR)/bits_k$(k).o)
 FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -I$(CSRC)
 
 $(OBJDIR)/main.o: $(SRCS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -DARTN_TU_MAIN -c $< -o $@
+$(OBJDIR)/b128.o: $(SRCS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FLAGS) -DARTN_TU_B128 -c $< -o $@
 $(OBJDIR)/bits_k%.o: $(SRCS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -DARTN_TU_BITS=$* -c $< -o $@
@@ -27,14 +31,14 @@ single: $(SRCS)
 	$(HIPCC) $(FLAGS) -shared $< -o $(LIB)
 
 # diagnostic build with in-kernel phase stamps (never loaded by the product; tools/stamps.py)
-stamps: $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_plan.h include/artn.h
+stamps: $(SRCS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_STAMPS -Iinclude -I$(CSRC) $< -o tools/libartn_hip_stamps.so
 
-phases: $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_plan.h include/artn.h
+phases: $(SRCS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_PHASES -Iinclude -I$(CSRC) $< -o tools/libartn_hip_phases.so
 
 # timing-only ablations (wrong results by construction; never loaded by the product)
-ablate: $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_plan.h include/artn.h
+ablate: $(SRCS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MFMA -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomfma.so
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MEM -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomem.so
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MEM -DARTN_ABLATE_MFMA -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomem_nomfma.so

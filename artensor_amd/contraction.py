@@ -436,7 +436,7 @@ def contract2(eq1, a, b1, eq2, b2, mid_view=None):
     eq2 addresses the first result (see _pair_descriptors)."""
     for t in (a, b1, b2):
         N.require_gpu(t, "contract2")
-    if not (a.dtype == b1.dtype == b2.dtype == torch.complex64) or not a.is_contiguous():
+    if not (a.dtype == b1.dtype == b2.dtype and a.dtype in _DTYPES) or not a.is_contiguous():
         return None
     b1, b2 = _as_operand(b1), _as_operand(b2)
     d1, d2, out_shape = _pair_descriptors(eq1, a, b1, eq2, b2, mid_view)
@@ -746,7 +746,7 @@ def _compile_dense(scheme, shapes, dtype):
     (host-only planner queries), descriptors and result shapes.  Everything the per-call loop needs
     except pointers.  Returns (program or None, launch list)."""
     shapes = dict(shapes)
-    fuse_ok = dtype == torch.complex64
+    fuse_ok = dtype in _DTYPES   # (complex128 pairs: artn_k_bits128)
     ops = []
     prog, main_idx = _plan_small_program(scheme, shapes, dtype)
     in_prog = set(range(len(scheme))) - set(main_idx)

@@ -18,10 +18,7 @@
 //   W side (A operand): row i = lane & 15 = 2 * n_in + ro     value (ro, p): (0,0) re(b)  (0,1) -im(b)  (1,0) im(b)  (1,1) re(b)
 //   X side (B operand): column j = lane & 15 = m_in           value p ? im(a) : re(a)
 //   accumulator register r of lane (j, g): row i = g + 4r  ->  ro = g & 1, n_in = (g >> 1) + 2r   (guide: f64 C/D map)
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef double __attribute__((address_space(3))) lds_f64_t;
-__device__ __forceinline__ double lds_read_f64(unsigned a) { return *(lds_f64_t *)(unsigned long)a; }
-__device__ __forceinline__ void lds_write_f64(unsigned a, double v) { *(lds_f64_t *)(unsigned long)a = v; }
+// (f64x4, lds_read_f64, lds_write_f64: artn_kernels.hip, next to the other LDS accessors)
 
 template <int NB>
 __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm128(const double2 *__restrict__ A, const double2 *__restrict__ B,

@@ -299,6 +299,10 @@ __device__ __forceinline__ void lds_write8(unsigned a, v2f_t v) { *(lds_v2f_t *)
 __device__ __forceinline__ f32x4 lds_read16(unsigned a) { return *(lds_v4f_t *)(unsigned long)a; }
 __device__ __forceinline__ void lds_write16(unsigned a, f32x4 v) { *(lds_v4f_t *)(unsigned long)a = v; }
 __device__ __forceinline__ u2_t lds_read_u2(unsigned a) { return *(lds_u2_t *)(unsigned long)a; }
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double __attribute__((address_space(3))) lds_f64_t;
+__device__ __forceinline__ double lds_read_f64(unsigned a) { return *(lds_f64_t *)(unsigned long)a; }
+__device__ __forceinline__ void lds_write_f64(unsigned a, double v) { *(lds_f64_t *)(unsigned long)a = v; }
 
 // Copy-in.  Full-size tiles (2^12 elements: exactly 8 x 16 B per thread) are software
 // pipelined: issue_loads puts the 8 chunks of tile t+1 in flight (uniform 64-bit base in SGPRs
@@ -1551,11 +1555,18 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
   }
 }
 
-// Translation units.  The product library is linked from seven objects compiled from THIS file (make -j: the
+// Translation units.  The product library is linked from eight objects compiled from THIS file (make -j: the
 // ~100 artn_k_bits instantiations dominate the build): -DARTN_TU_BITS=K emits only artn_k_bits<K, *> behind
-// artn_launch_bits_kK(), -DARTN_TU_MAIN everything else and calls those; with neither macro (diagnostic and
-// development builds) the file is one translation unit as before.
-#ifndef ARTN_TU_BITS
+// artn_launch_bits_kK(), -DARTN_TU_B128 only artn_k_bits128<*, *> behind artn_launch_bits128(), -DARTN_TU_MAIN
+// everything else and calls those; with none of the macros (diagnostic and development builds) the file is one
+// translation unit as before.
+#if defined(ARTN_TU_BITS) || defined(ARTN_TU_B128)
+#define ARTN_TU_PART 1
+#endif
+#if defined(ARTN_TU_B128) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
+#include "artn_bits128_kernel.h"
+#endif
+#ifndef ARTN_TU_PART
 #include "artn_gemm_kernel.h"
 #include "artn_gemm128_kernel.h"
 #include "artn_pgemm_kernel.h"
@@ -2041,7 +2052,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_divide(float2 *__restr
   }
 }
 
-#endif // !ARTN_TU_BITS
+#endif // !ARTN_TU_PART
 
 // ----------------------------------------------------------------------------------------
 // host side
@@ -2236,9 +2247,54 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
   return hipGetLastError();
 }
 
+// complex128 plans of make_bits: artn_k_bits128<KB1, KB2>
+#if defined(ARTN_TU_B128) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
+hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st) {
+  dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
+  const size_t lds = (size_t)p.info.lds_bytes;
+  const int k1 = p.bits.st[0].k, k2 = p.bits.n_stages == 2 ? p.bits.st[1].k : 0;
+  const double2 *a = (const double2 *)A, *b1 = (const double2 *)B1, *b2 = (const double2 *)B2;
+  double2 *c = (double2 *)C;
+#define ARTN_B128_GO(K1, K2)                                                                        \
+  {                                                                                                 \
+    auto kern = artn_k_bits128<K1, K2>;                                                             \
+    if (hipError_t e = ensure_lds<artn_k_bits128<K1, K2>>(lds); e != hipSuccess) return e;          \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b1, b2, c, p.bits);                           \
+    return hipGetLastError();                                                                       \
+  }
+#define ARTN_B128_K2(K1)                                                                            \
+  case K1:                                                                                          \
+    switch (k2) {                                                                                   \
+      case 0: ARTN_B128_GO(K1, 0)                                                                   \
+      case 1: ARTN_B128_GO(K1, 1)                                                                   \
+      case 2: ARTN_B128_GO(K1, 2)                                                                   \
+      case 3: ARTN_B128_GO(K1, 3)                                                                   \
+      case 4: ARTN_B128_GO(K1, 4)                                                                   \
+      case 5: ARTN_B128_GO(K1, 5)                                                                   \
+      case 6: ARTN_B128_GO(K1, 6)                                                                   \
+      default: return hipErrorInvalidValue;                                                         \
+    }
+  switch (k1) {
+    ARTN_B128_K2(1)
+    ARTN_B128_K2(2)
+    ARTN_B128_K2(3)
+    ARTN_B128_K2(4)
+    ARTN_B128_K2(5)
+    ARTN_B128_K2(6)
+    default: return hipErrorInvalidValue;
+  }
+#undef ARTN_B128_K2
+#undef ARTN_B128_GO
+}
+#elif defined(ARTN_TU_MAIN)
+hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st);
+#endif
+
 #define ARTN_CAT2(a, b) a##b
 #define ARTN_CAT(a, b) ARTN_CAT2(a, b)
-#ifdef ARTN_TU_BITS
+#if defined(ARTN_TU_B128)
+// (nothing else in this translation unit)
+#elif defined(ARTN_TU_BITS)
 hipError_t ARTN_CAT(artn_launch_bits_k, ARTN_TU_BITS)(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, float2 *C,
                                                      hipStream_t st) {
   return launch_bits_k2<ARTN_TU_BITS>(p, A, B1, B2, C, st);
@@ -2254,6 +2310,7 @@ hipError_t artn_launch_bits_k6(const ArtnPlan &, const float2 *, const float2 *,
 #endif
 static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C,
                               hipStream_t st) {
+  if (p.bits.c128) return artn_launch_bits128(p, A, B1, B2, C, st);
   const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2;
   float2 *c = (float2 *)C;
 #ifdef ARTN_DEV_FEW // development builds only: one family of artn_k_bits instantiations (compiles in under a minute)
@@ -3056,4 +3113,4 @@ int artn_absmax_normalize_c64(void *x, int64_t n, float *out_absmax, void *strea
 }
 
 } // extern "C"
-#endif // !ARTN_TU_BITS
+#endif // !ARTN_TU_PART

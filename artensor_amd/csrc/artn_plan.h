@@ -58,7 +58,7 @@ struct ArtnStage {
   // The 16 lanes of one ds_write_b64 group differ in MFMA column bits 0..3; where those sit
   // above the 128-byte bank window (tile-local position >= 4) they are folded into a free
   // position 1..3 so the group spreads over the banks (at most 2-way conflicts remain).
-  int32_t swz_n, swz_src[3], swz_dst[3];
+  int32_t swz_n, swz_src[4], swz_dst[4]; // (complex128: units of 16 bytes, targets 0..3, up to four entries)
   int32_t m3; // 1: three real products per complex product (5 contracted bits, 32+ columns: a wave owns 32-column
               // sub-tiles; wn_log2 = nt - 5; lane half h carries column bit 2)
 };
@@ -74,7 +74,7 @@ struct ArtnBitsPlan {
   int32_t blocked;            // 1: a workgroup takes a contiguous range of tiles instead of a grid-stride sequence
   int64_t n_tiles;
   int32_t m3;                 // 1: every stage with 5 contracted bits runs the 3M arithmetic (ArtnStage::m3): the M3 instantiation
-  int32_t pad_m3_;
+  int32_t c128;               // 1: complex128 elements -- artn_k_bits128 (16-column sub-tiles: 4 lane bits, f64 MFMA)
   int32_t ksplit;             // 1: 7-8 contracted bits, one 32 x 16 block per tile: the four waves split the chain
   int32_t split;              // MFMA arithmetic: 0 fp32; 3 fp32-grade from three bf16 pieces; 1 plain bf16 operands
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
@@ -215,6 +215,7 @@ struct Tuning {
   int gemm_tall = 1;  // GEMM kernel, fp32, 32 x 32 tiles: chunks of 2^6 contracted values
   int packed = 2;     // packed-operand GEMM (ArtnPackPlan): 1 reduced-precision mode only (2^9+ contracted values),
                       // 2 also complex64 arithmetic (3M on fp32 MFMA, 2^10+ contracted values), 0 never
+  int bits128 = 1;         // complex128 on the state-streaming kernel: 0 never, 1 fused pairs (+ singles the GEMM declines), 2 singles first
   int m3_frag = 96;        // 3M in fused pairs up to this many fragment registers (80: not in 5+6 / 6+5 pairs)
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
@@ -241,6 +242,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
     if (const char *e = getenv("ARTN_M3_FRAG")) x.m3_frag = atoi(e);
+    if (const char *e = getenv("ARTN_BITS128")) x.bits128 = atoi(e);
     if (const char *e = getenv("ARTN_PACKED_MIN_K")) x.packed_min_k = std::max(6, atoi(e));
     if (const char *e = getenv("ARTN_PACKED_MIN_AI")) x.packed_min_ai = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_PACKED")) x.packed = std::min(2, std::max(0, atoi(e)));
@@ -403,7 +405,12 @@ static inline bool chain_axes(const ArtnStepDesc *d2, std::vector<Axis> &ax, std
 static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, ArtnPlan &p, int n_cu,
                              int64_t min_tiles, int gather_label = -1) {
   auto c64 = [](int dt) { return dt == ARTN_C64 || dt == ARTN_C64_BF16; };
-  if (!c64(d1->dtype) || (d2 && d2->dtype != d1->dtype)) { p.why_generic = "dtype is not complex64"; return false; }
+  // complex128 (artn_k_bits128): 16-byte elements -- half the elements per LDS region, one element per copy lane,
+  // sub-tiles of 16 columns (4 lane bits), blocks of 8 result columns (at most 4 blocks: nt <= 5)
+  const bool c128 = d1->dtype == ARTN_C128;
+  if ((!c64(d1->dtype) && !c128) || (d2 && d2->dtype != d1->dtype)) { p.why_generic = "dtype is not complex64 / complex128"; return false; }
+  if (c128 && (gather_label >= 0 || !tuning().bits128)) { p.why_generic = "complex128: no row gather on the state-streaming kernel"; return false; }
+  const int esz = c128 ? 16 : 8, lb = c128 ? 4 : 5, pass_bits = c128 ? 8 : 9, shrink = c128 ? 1 : 0;
   const bool fused = d2 != nullptr;
   std::vector<Axis> ax;
   expand_axes(d1, ax, gather_label);
@@ -452,7 +459,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   const int k1 = (int)K1.size(), k2 = (int)K2.size();
   // up to 6 contracted bits run as one MFMA chain with the small operand in registers; a 7th
   // and 8th are looped over inside the stage (fragments reloaded per value, single steps only)
-  if (k1 < 1 || k1 > (fused ? 6 : 8)) { p.why_generic = "contracted bit count outside 1..8 (1..6 when fused)"; return false; }
+  if (k1 < 1 || k1 > (fused || c128 ? 6 : 8)) { p.why_generic = "contracted bit count outside 1..8 (1..6 when fused)"; return false; }
   if (fused && (k2 < 1 || k2 > 6)) { p.why_generic = "contracted bit count outside 1..6 (second step)"; return false; }
   auto byA = [&](int x, int y) { return ax[x].sA < ax[y].sA; };
   auto byC1 = [&](int x, int y) { return ax[x].sC1 < ax[y].sC1; };
@@ -467,7 +474,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   // contiguous run at the bottom of A (over K1 u M1 bits) and of the final C (bits that reach it)
   auto run_len = [&](bool in_side) {
     int r = 0;
-    for (; r < tuning().run_max; ++r) {
+    for (; r < tuning().run_max - shrink; ++r) {
       bool found = false;
       for (int i = 0; i < (int)ax.size() && !found; ++i) {
         const Axis &a = ax[i];
@@ -480,7 +487,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     return r;
   };
   int run_in = run_len(true), run_out = run_len(false);
-  if (run_in < 1 || run_out < 1) { p.why_generic = "no contiguous 16-byte run at the bottom of A or C"; return false; }
+  if (!c128 && (run_in < 1 || run_out < 1)) { p.why_generic = "no contiguous 16-byte run at the bottom of A or C"; return false; }
 
   // ---- choose the tile
   // Forced members: every M bit inside the input/output runs (16-byte lanes in >= 2^run x 8 B
@@ -501,11 +508,12 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     for (int i : N2)
       if (ax[i].sC < rout) N2t.push_back(i);
     // grow N tiles towards full 16-column MFMA tiles (lowest result positions first)
-    int n1_target = std::min(n1, std::min(6, std::max(std::min(k1, 6), 4)));
+    const int n_cap = c128 ? 5 : 6, n_lo = c128 ? 3 : 4;
+    int n1_target = std::min(n1, std::min(n_cap, std::max(std::min(k1, n_cap), n_lo)));
     for (int i : N1) { if ((int)N1t.size() >= n1_target) break; if (!in_set(N1t, i)) N1t.push_back(i); }
-    int n2_target = std::min(n2, std::min(6, std::max(k2, 4)));
+    int n2_target = std::min(n2, std::min(n_cap, std::max(k2, n_lo)));
     for (int i : N2) { if ((int)N2t.size() >= n2_target) break; if (!in_set(N2t, i)) N2t.push_back(i); }
-    if ((int)N1t.size() > 6 || (int)N2t.size() > 6) return false;
+    if ((int)N1t.size() > n_cap || (int)N2t.size() > n_cap) return false;
     auto sizes = [&](int mt) {
       T_in = k1 + mt;
       T_mid = mt + (int)N1t.size();
@@ -515,21 +523,21 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
       sizes(mt);
       // a fused pair only pays with two workgroups per CU (2^12-element regions): with 2^13 it
       // measured slower than the two steps one after the other
-      const int tmax = fused ? ARTN_TILE_BITS_MAX - 1 : ARTN_TILE_BITS_MAX;
+      const int tmax = (fused ? ARTN_TILE_BITS_MAX - 1 : ARTN_TILE_BITS_MAX) - shrink;
       if (T_in > tmax || T_mid > tmax || T_out > tmax) return false;
       int r0 = fused ? std::max(T_in, T_out) : T_in;
-      return (8LL << r0) + (8LL << T_mid) <= ARTN_LDS_BUDGET;
+      return ((long long)esz << r0) + ((long long)esz << T_mid) <= ARTN_LDS_BUDGET;
     };
     if (!fits((int)Mt.size())) return false;
     // 7-8 contracted bits: the kernel instantiation for them prefetches 2^13-element tiles
-    const int target = k1 > 6 ? ARTN_TILE_BITS_MAX : tuning().tile_target;
+    const int target = (k1 > 6 ? ARTN_TILE_BITS_MAX : tuning().tile_target) - shrink;
     if (need_target && std::max(T_in, std::max(T_mid, T_out)) > target && (int)Mt.size() >= 5) return false;
     // grow M_t towards the target tile size (lowest A positions first), within the LDS budget
     for (int i : M1) {
       if (in_set(Mt, i)) continue;
       sizes((int)Mt.size());
       int biggest = std::max(T_in, std::max(T_mid, T_out));
-      const bool enough = (int)Mt.size() >= 5 && T_in >= 9 && T_out >= 9; // prefer one full copy pass per tile
+      const bool enough = (int)Mt.size() >= 5 && T_in >= pass_bits && T_out >= pass_bits; // prefer one full copy pass per tile
       if ((enough && biggest >= target) || !fits((int)Mt.size() + 1)) break;
       Mt.push_back(i);
     }
@@ -544,7 +552,8 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
         for (int co = (cut + 1) / 2; co >= 0 && !done; --co) {
           const int ci = cut - co;                       // shave the output run first
           const int ri = r_in0 - ci, ro = r_out0 - co;
-          if (ri < std::min(r_in0, 2) || ro < std::min(r_out0, 2) || ri < 1 || ro < 1) continue;
+          const int r_floor = c128 ? 1 : 2, r_min = c128 ? 0 : 1; // (runs of 32 bytes at least, where the labels allow)
+          if (ri < std::min(r_in0, r_floor) || ro < std::min(r_out0, r_floor) || ri < r_min || ro < r_min) continue;
           if (try_runs(ri, ro, pass == 0)) { run_in = ri; run_out = ro; done = true; }
         }
       }
@@ -555,7 +564,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   if (mt < 5) { p.why_generic = "too few free A bits for a tile"; return false; }
   const int m2 = T_mid - k2; // free bits of stage 2's input tile
   if (fused && m2 < 5) { p.why_generic = "too few free bits for the second stage"; return false; }
-  if (mt - 5 > 9 || (fused && m2 - 5 > 9)) { p.why_generic = "too many sub-tile bits"; return false; }
+  if (mt - lb > 9 || (fused && m2 - lb > 9)) { p.why_generic = "too many sub-tile bits"; return false; }
 
   ArtnBitsPlan &b = p.bits;
   memset(&b, 0, sizeof(b));
@@ -564,6 +573,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   b.r0_bits = fused ? std::max(T_in, T_out) : T_in;
   b.run_in = run_in; b.run_out = run_out;
   b.stage_prio = tuning().stage_prio;
+  b.c128 = c128 ? 1 : 0;
 
   // ---- tile-local orders: input (by A stride), mid (by C1 stride), output (by final C stride)
   std::vector<int> tin(K1), tmid(Mt), tout;
@@ -593,24 +603,24 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
                         const std::vector<int> &tile_out, bool second) {
     s.k = (int)Kx.size();
     s.nt = (int)Nx.size();
-    s.wn_log2 = std::max(0, s.nt - 4);
+    s.wn_log2 = std::max(0, s.nt - (c128 ? 3 : 4));
     s.m3 = (use_3m && (s.k == 5 || s.k == 6) && s.nt >= 5 && gather_label < 0 && (int)K1.size() <= 6) ? 1 : 0;
     if (s.m3) s.wn_log2 = s.nt - 5;
     s.m_bits = (int)Mx.size();
     std::vector<int> Ms(Mx);
     std::sort(Ms.begin(), Ms.end(), [&](int x, int y) { return pos(tile_in, x) < pos(tile_in, y); });
-    for (int i = 0; i < 5; ++i) { s.lane_in_pos[i] = pos(tile_in, Ms[i]); s.lane_out_pos[i] = pos(tile_out, Ms[i]); }
-    for (int i = 5; i < s.m_bits; ++i) { s.msub_in_pos[i - 5] = pos(tile_in, Ms[i]); s.msub_out_pos[i - 5] = pos(tile_out, Ms[i]); }
+    for (int i = 0; i < lb; ++i) { s.lane_in_pos[i] = pos(tile_in, Ms[i]); s.lane_out_pos[i] = pos(tile_out, Ms[i]); }
+    for (int i = lb; i < s.m_bits; ++i) { s.msub_in_pos[i - lb] = pos(tile_in, Ms[i]); s.msub_out_pos[i - lb] = pos(tile_out, Ms[i]); }
     for (int i = 0; i < s.k; ++i) { s.k_in_pos[i] = pos(tile_in, Kx[i]); s.k_b_stride[i] = second ? ax[Kx[i]].sB2 : ax[Kx[i]].sB1; }
     for (int i = 0; i < s.nt; ++i) { s.n_out_pos[i] = pos(tile_out, Nx[i]); s.n_b_stride[i] = second ? ax[Nx[i]].sB2 : ax[Nx[i]].sB1; }
     // output-region swizzle
     s.swz_n = 0;
-    bool taken[4] = {true, false, false, false}; // position 0 (the 8-byte half) is never a target
+    bool taken[4] = {!c128, false, false, false}; // complex64: position 0 (the 8-byte half) is never a target
     for (int i = 0; i < 4; ++i) if (s.lane_out_pos[i] < 4) taken[s.lane_out_pos[i]] = true;
     for (int i = 0; i < 4 && tuning().swizzle; ++i) {
       if (s.lane_out_pos[i] < 4) continue;
       int f = -1;
-      for (int c = 1; c < 4; ++c) if (!taken[c]) { f = c; break; }
+      for (int c = 0; c < 4; ++c) if (!taken[c]) { f = c; break; }
       if (f < 0) break;
       taken[f] = true;
       s.swz_src[s.swz_n] = s.lane_out_pos[i];
@@ -641,7 +651,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     b.m3 = (any && all) ? 1 : 0;
     if (!b.m3)
       for (int q = 0; q < b.n_stages; ++q)
-        if (b.st[q].m3) { b.st[q].m3 = 0; b.st[q].wn_log2 = std::max(0, b.st[q].nt - 4); }
+        if (b.st[q].m3) { b.st[q].m3 = 0; b.st[q].wn_log2 = std::max(0, b.st[q].nt - 4); } // (never complex128: no 3M there)
   }
 
   // ---- outer axes: N-outer fastest (tiles sharing an A tile run together), then M-outer by A
@@ -694,7 +704,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   // workgroup (a reload of up to 256 fragment registers per lane from global memory); in
   // contiguous ranges the batch axes, which are the slowest tile digits, change once per row.
   if (gather_label >= 0 && b.gather_dim < 0) { p.why_generic = "gathered label is not an outer axis"; return false; }
-  b.nt_loads = (a_rereads == 1 && run_in >= 4 && b.n_tiles >= (1 << 14) && tuning().nt) ? 1 : 0;
+  b.nt_loads = (!c128 && a_rereads == 1 && run_in >= 4 && b.n_tiles >= (1 << 14) && tuning().nt) ? 1 : 0;
   // (not when the small operand also has outer free bits: those are the fastest tile digits, in
   //  grid-stride order a workgroup keeps its value of them -- and its fragments -- while a
   //  contiguous range would step through them tile by tile)
@@ -706,17 +716,17 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
 
   // ---- envelope checks
   // the copy phases move 16 bytes (two elements) per lane and need every thread busy
-  if (b.T_in < 9 || b.T_out < 5) { p.why_generic = "tile smaller than one copy pass"; return false; }
-  for (int i = 1; i < b.T_in; ++i) if (b.in_stride[i] & 1) { p.why_generic = "odd A stride"; return false; }
-  for (int i = 1; i < b.T_out; ++i) if (b.out_stride[i] & 1) { p.why_generic = "odd C stride"; return false; }
-  for (int i = 0; i < b.n_outer; ++i)
+  if (b.T_in < pass_bits || b.T_out < 5 - shrink) { p.why_generic = "tile smaller than one copy pass"; return false; }
+  for (int i = 1; i < b.T_in && !c128; ++i) if (b.in_stride[i] & 1) { p.why_generic = "odd A stride"; return false; }
+  for (int i = 1; i < b.T_out && !c128; ++i) if (b.out_stride[i] & 1) { p.why_generic = "odd C stride"; return false; }
+  for (int i = 0; i < b.n_outer && !c128; ++i)
     if ((b.outer[i].sA & 1) || (b.outer[i].sC & 1)) { p.why_generic = "odd outer stride"; return false; }
   {
     // per-lane byte offsets inside the kernel are 32-bit: copy chunks span tile bits 1..8,
     // the small operands are addressed by their N_t / K bits
     int64_t si = 0, so = 0;
-    for (int i = 1; i <= 8; ++i) { si += b.in_stride[i]; if (i < b.T_out) so += b.out_stride[i]; }
-    const int64_t lim = (int64_t(1) << 28) - 1; // elements: * 8 B < 2^31
+    for (int i = 1 - shrink; i <= 8 - shrink; ++i) { if (i < b.T_in) si += b.in_stride[i]; if (i < b.T_out) so += b.out_stride[i]; }
+    const int64_t lim = (int64_t(1) << (28 - shrink)) - 1; // elements: * 8 B (16 B) < 2^31
     // (the small operands are addressed with 64-bit offsets: a "small" operand of a split-K
     // step can itself be gigabytes)
     if (si > lim || so > lim) { p.why_generic = "lane offsets exceed 32 bits"; return false; }
@@ -741,8 +751,8 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     b.ksplit = (k1 > 6 && !fused && mt == 5 && b.st[0].wn_log2 == 0) ? 1 : 0;
     // arithmetic of the chains: ARTN_C64_BF16 asks for plain bf16 operands; complex64 uses the
     // split (three bf16 pieces) when tuning().split says so; 7-8 contracted bits stay fp32
-    b.split = d1->dtype == ARTN_C64_BF16 ? 1 : (k1 > 6 ? 0 : tuning().split);
-    f.lds_bytes = (int32_t)((8LL << b.r0_bits) + (8LL << b.T_mid) + (8LL << (mt - 5)) + (fused ? (8LL << (m2 - 5)) : 0) + off_tab +
+    b.split = d1->dtype == ARTN_C64_BF16 ? 1 : ((k1 > 6 || c128) ? 0 : tuning().split);
+    f.lds_bytes = (int32_t)(((long long)esz << b.r0_bits) + ((long long)esz << b.T_mid) + (8LL << (mt - lb)) + (fused ? (8LL << (m2 - lb)) : 0) + off_tab +
                             (b.ksplit ? 3 * 4096 + 16 : 0));
   }
   f.n_tiles = b.n_tiles;
@@ -1353,11 +1363,13 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
       (d->dtype == ARTN_C64_BF16 || (d->dtype == ARTN_C64 && tuning().packed >= 2)))
     ok = make_pgemm(d, p, n_cu);
   allow_gemm = allow_gemm && !ok;
-  if (d->dtype == ARTN_C128 && allow_bits && allow_gemm && gather_label < 0 && tuning().gemm)
-    ok = make_gemm128(d, p, n_cu, min_tiles); // complex128: the f64 MFMA GEMM kernel or the strided kernel
+  if (d->dtype == ARTN_C128 && allow_bits && gather_label < 0 && tuning().bits128 >= 2)
+    ok = make_bits(d, nullptr, p, n_cu, min_tiles); // (development: the state-streaming kernel for single steps too)
+  if (!ok && d->dtype == ARTN_C128 && allow_bits && allow_gemm && gather_label < 0 && tuning().gemm)
+    ok = make_gemm128(d, p, n_cu, min_tiles); // complex128: the f64 MFMA GEMM kernel, else the state-streaming one, else strided
   allow_gemm = allow_gemm && allow_bits && gather_label < 0 && tuning().gemm && d->dtype != ARTN_C128 && !ok;
   if (allow_gemm) ok = make_gemm(d, p, n_cu, min_tiles, tuning().gemm < 2);
-  if (!ok && d->dtype != ARTN_C128) ok = allow_bits && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
+  if (!ok) ok = allow_bits && (d->dtype != ARTN_C128 || gather_label < 0) && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
   if (!ok && allow_gemm) { // what the state-streaming kernel declines
     const std::string why = p.why_generic;
     ok = make_gemm(d, p, n_cu, min_tiles, false);
@@ -1371,7 +1383,7 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   // what the matrix pipe executes (3M: three real products per complex product) and in which arithmetic
   if (p.kernel == ARTN_KERNEL_BITS_MFMA) {
     const bool m3 = p.bits.st[0].m3 != 0;
-    p.info.arith = p.bits.split == 1 ? 2 : (m3 ? 1 : 0);
+    p.info.arith = p.bits.c128 ? 3 : (p.bits.split == 1 ? 2 : (m3 ? 1 : 0));
     p.info.mfma_flops = p.info.flops * (m3 ? 0.75 : 1.0);
   } else if (p.kernel == ARTN_KERNEL_PGEMM) {
     p.info.arith = p.pack.arith == 0 ? 2 : 1;
@@ -1401,8 +1413,8 @@ static inline int make_plan_fused(const ArtnStepDesc *d1, const ArtnStepDesc *d2
   step_cost(d1, f1, a1, b1, c1);
   step_cost(d2, f2, a2, b2, c2);
   p.info.flops = f1 + f2;
-  p.info.bytes = 8.0 * (a1 + b1 + b2 + c2); // the intermediate C1 never touches HBM
-  p.info.arith = p.bits.split == 1 ? 2 : ((p.bits.st[0].m3 || p.bits.st[1].m3) ? 1 : 0);
+  p.info.bytes = (d1->dtype == ARTN_C128 ? 16.0 : 8.0) * (a1 + b1 + b2 + c2); // the intermediate C1 never touches HBM
+  p.info.arith = p.bits.c128 ? 3 : (p.bits.split == 1 ? 2 : ((p.bits.st[0].m3 || p.bits.st[1].m3) ? 1 : 0));
   p.info.mfma_flops = f1 * (p.bits.st[0].m3 ? 0.75 : 1.0) + f2 * (p.bits.st[1].m3 ? 0.75 : 1.0);
   return ARTN_OK;
 }

@@ -169,6 +169,105 @@ static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf 
 }
 
 
+// ---- artn_k_bits128 (artn_bits128_kernel.h), replayed lane by lane from the same ArtnBitsPlan: 16-byte elements, sub-tiles
+//      of 16 columns, v_mfma_f64_16x16x4_f64 (D[i][j] += sum_kk Aop[i][kk] Bop[kk][j]; lane = (j or i) + 16 kk; accumulator
+//      register r of lane (j, g) = row g + 4 r)
+typedef std::complex<double> cd;
+static void run_stage128(const ArtnStage &st, const ArtnStage *zin, const cd *in, cd *out, const cd *B, int64_t offB) {
+  const int KB = st.k, S = 1 << (KB - 1);
+  const int nt3 = st.nt < 3 ? st.nt : 3, n_lim = 1 << nt3;
+  const int wm_count = 4 >> st.wn_log2, msubs = 1 << (st.m_bits - 4);
+  for (int wave = 0; wave < 4; ++wave) {
+    const int wn = wave & ((1 << st.wn_log2) - 1), wm = wave >> st.wn_log2;
+    for (int msub = wm; msub < msubs; msub += wm_count) {
+      int oi = 0, oo = 0;
+      for (int b = 0; b < st.m_bits - 4; ++b)
+        if ((msub >> b) & 1) { oi += 1 << st.msub_in_pos[b]; oo += 1 << st.msub_out_pos[b]; }
+      double acc[64][4];
+      for (auto &r : acc) for (double &x : r) x = 0.0;
+      int lane_out[64];
+      for (int s = 0; s < S; ++s) {
+        int ko = 0; int64_t kbo = 0;
+        for (int b = 1; b < KB; ++b) if ((s >> (b - 1)) & 1) { ko += 1 << st.k_in_pos[b]; kbo += st.k_b_stride[b]; }
+        double W[64], X[64];
+        for (int lane = 0; lane < 64; ++lane) {
+          const int j = lane & 15, g = lane >> 4, ro = j & 1, n_in = j >> 1, pp = g & 1, kcl = g >> 1;
+          int li = kcl << st.k_in_pos[0], lo = 0;
+          for (int b = 0; b < 4; ++b) if ((j >> b) & 1) { li += 1 << st.lane_in_pos[b]; lo += 1 << st.lane_out_pos[b]; }
+          if (st.nt > 0) lo += kcl << st.n_out_pos[0];
+          int64_t lb = (int64_t)kcl * st.k_b_stride[0];
+          for (int b = 0; b < nt3; ++b) if ((n_in >> b) & 1) lb += st.n_b_stride[b];
+          for (int b = 0; b < st.wn_log2; ++b) if ((wn >> b) & 1) { lo += 1 << st.n_out_pos[3 + b]; lb += st.n_b_stride[3 + b]; }
+          lane_out[lane] = lo;
+          cd bv(0.0, 0.0);
+          if ((n_in >> nt3) == 0) bv = B[offB + lb + kbo];
+          // (ro, p): (0,0) re  (0,1) -im  (1,0) im  (1,1) re
+          W[lane] = (ro ^ pp) ? (ro == 0 ? -bv.imag() : bv.imag()) : bv.real();
+          const cd a = in[swz(li + oi + ko, zin)];
+          X[lane] = pp ? a.imag() : a.real();
+        }
+        for (int lane = 0; lane < 64; ++lane)
+          for (int r = 0; r < 4; ++r) {
+            const int i = (lane >> 4) + 4 * r, jj = lane & 15;
+            for (int kk = 0; kk < 4; ++kk) acc[lane][r] += W[i + 16 * kk] * X[jj + 16 * kk];
+          }
+      }
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4;
+        for (int r = 0; r < 4; ++r) {
+          if ((g >> 1) + 2 * r >= n_lim) continue;
+          const int o = lane_out[lane] + oo + ((r & 1) && st.nt > 1 ? 1 << st.n_out_pos[1] : 0) + ((r & 2) && st.nt > 2 ? 1 << st.n_out_pos[2] : 0);
+          double *dst = reinterpret_cast<double *>(&out[swz(o, &st)]);
+          dst[g & 1] = acc[lane][r];
+        }
+      }
+    }
+  }
+}
+
+static void run_bits128(const ArtnBitsPlan &P, const cd *A, const cd *B1, const cd *B2, cd *C) {
+  std::vector<cd> R0((size_t)1 << P.r0_bits), R1((size_t)1 << P.T_mid);
+  const int n_in_iters = 1 << (P.T_in - 8), n_out_iters = P.T_out >= 8 ? 1 << (P.T_out - 8) : 1;
+  for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
+    int64_t r = tile, offA = 0, offB1 = 0, offB2 = 0, offC = 0;
+    for (int d = 0; d < P.n_outer; ++d) {
+      int64_t ext = P.outer[d].ext, x;
+      if (P.outer[d].log2ext >= 0) { x = r & (ext - 1); r >>= P.outer[d].log2ext; }
+      else { x = r % ext; r /= ext; }
+      offA += x * P.outer[d].sA; offB1 += x * P.outer[d].sB1; offB2 += x * P.outer[d].sB2; offC += x * P.outer[d].sC;
+    }
+    for (auto &x : R0) x = cd(-777.0, -777.0);
+    for (auto &x : R1) x = cd(-777.0, -777.0);
+    for (int tid = 0; tid < 256; ++tid) {
+      int64_t in_lane = 0;
+      for (int b = 0; b < 8 && b < P.T_in; ++b) if ((tid >> b) & 1) in_lane += P.in_stride[b];
+      for (int i = 0; i < n_in_iters; ++i) {
+        int64_t off = 0;
+        for (int b = 8; b < P.T_in; ++b) if ((i >> (b - 8)) & 1) off += P.in_stride[b];
+        R0[tid + 256 * i] = A[offA + in_lane + off];
+      }
+    }
+    run_stage128(P.st[0], nullptr, R0.data(), R1.data(), B1, offB1);
+    const cd *outr = R1.data();
+    const ArtnStage *zout = &P.st[0];
+    if (P.n_stages == 2) {
+      run_stage128(P.st[1], &P.st[0], R1.data(), R0.data(), B2, offB2);
+      outr = R0.data();
+      zout = &P.st[1];
+    }
+    for (int tid = 0; tid < 256; ++tid) {
+      if (P.T_out < 8 && tid >= (1 << P.T_out)) continue;
+      int64_t out_lane = 0;
+      for (int b = 0; b < 8 && b < P.T_out; ++b) if ((tid >> b) & 1) out_lane += P.out_stride[b];
+      for (int i = 0; i < n_out_iters; ++i) {
+        int64_t off = 0;
+        for (int b = 8; b < P.T_out; ++b) if ((i >> (b - 8)) & 1) off += P.out_stride[b];
+        C[offC + out_lane + off] = outr[swz(tid + 256 * i, zout)];
+      }
+    }
+  }
+}
+
 // ---- artn_k_gemm (artn_gemm_kernel.h), replayed thread by thread from the same ArtnGemmPlan ---------
 static unsigned swzg(unsigned off, const ArtnGemmPlan &P) {
   for (int i = 0; i < P.swz_n; ++i)
@@ -366,7 +465,7 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
 
 
 // ---- artn_k_gemm128 (complex128 on v_mfma_f64_16x16x4_f64), replayed from the same plan --------------------
-typedef std::complex<double> cd;
+
 static void run_gemm128(const ArtnGemmPlan &P, const cd *A0, const cd *B0, cd *C) {
   const cd *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
   const int mt = P.mt, nt = P.nt, MB = 2, NB = 1 << P.nb_log2, PL = ARTN_GEMM_PITCH_LOG2;
@@ -638,6 +737,7 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
   if (rc) return rc;
   if (kernel_used) *kernel_used = p.kernel;
   if (d->dtype == ARTN_C128) {
+    if (p.kernel == ARTN_KERNEL_BITS_MFMA) { run_bits128(p.bits, (const cd *)A, (const cd *)B, nullptr, (cd *)C); return 0; }
     if (p.kernel != ARTN_KERNEL_GEMM_MFMA) return ARTN_E_UNSUPPORTED;
     run_gemm128(p.gemm, (const cd *)A, (const cd *)B, (cd *)C);
     return 0;
@@ -678,6 +778,20 @@ extern "C" int artn_emulate_gather(const ArtnStepDesc *d, const void *A, const v
   return 0;
 }
 
+// Force the state-streaming plan of one step (complex64 or complex128); ARTN_E_UNSUPPORTED if make_bits declines.
+extern "C" int artn_emulate_bits(const ArtnStepDesc *d, const void *A, const void *B, void *C, ArtnStepInfo *info) {
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::validate(d, err);
+  if (rc) return rc;
+  memset(&p.info, 0, sizeof(p.info));
+  if (!artn::make_bits(d, nullptr, p, 256, 1)) return ARTN_E_UNSUPPORTED;
+  if (info) *info = p.info;
+  if (p.bits.c128) run_bits128(p.bits, (const cd *)A, (const cd *)B, nullptr, (cd *)C);
+  else run_bits(p.bits, (const cf *)A, (const cf *)B, nullptr, (cf *)C);
+  return 0;
+}
+
 // Fused pair.  Returns ARTN_E_UNSUPPORTED when the planner declines to fuse.
 extern "C" int artn_emulate2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A, const void *B1,
                              const void *B2, void *C, ArtnStepInfo *info) {
@@ -686,7 +800,8 @@ extern "C" int artn_emulate2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, con
   int rc = artn::make_plan_fused(d1, d2, p, err, 256, 1);
   if (rc) return rc;
   if (info) *info = p.info;
-  run_bits(p.bits, (const cf *)A, (const cf *)B1, (const cf *)B2, (cf *)C);
+  if (p.bits.c128) run_bits128(p.bits, (const cd *)A, (const cd *)B1, (const cd *)B2, (cd *)C);
+  else run_bits(p.bits, (const cf *)A, (const cf *)B1, (const cf *)B2, (cf *)C);
   return 0;
 }
 

@@ -193,11 +193,32 @@ def emulate2(eq1, a, b1, eq2, b2):
     emu.artn_emulate2.restype = ctypes.c_int
     ta, tb1, tb2 = torch.from_numpy(a), torch.from_numpy(b1), torch.from_numpy(b2)
     d1, d2, out_shape = C._pair_descriptors(eq1, ta, tb1, eq2, tb2)
-    out = np.zeros(out_shape, dtype=np.complex64)
+    out = np.zeros(out_shape, dtype=a.dtype)   # (complex128 pairs: the replay of artn_k_bits128)
     info = N.ArtnStepInfo()
     rc = emu.artn_emulate2(ctypes.byref(d1), ctypes.byref(d2), a.ctypes.data_as(ctypes.c_void_p),
                            b1.ctypes.data_as(ctypes.c_void_p), b2.ctypes.data_as(ctypes.c_void_p),
                            out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info))
+    if rc == -2:
+        return None, None
+    assert rc == 0, rc
+    return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+
+
+def emulate_bits(eq, a, b):
+    """One step forced onto the state-streaming plan (make_bits; complex64 -> artn_k_bits, complex128 -> artn_k_bits128);
+    (result, info) or (None, None) when make_bits declines."""
+    import torch
+    from artensor_amd import contraction as C
+    from artensor_amd import _native as N
+    la, lb, lo = C._labels(eq)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    d, out_shape = C._descriptor(la, lb, lo, tuple(ta.shape), tuple(ta.stride()), tuple(tb.shape), tuple(tb.stride()), ta.dtype)
+    out = np.zeros(out_shape, dtype=a.dtype)
+    info = N.ArtnStepInfo()
+    emu = emulator()
+    emu.artn_emulate_bits.restype = ctypes.c_int
+    rc = emu.artn_emulate_bits(ctypes.byref(d), a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                               out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info))
     if rc == -2:
         return None, None
     assert rc == 0, rc

@@ -855,6 +855,83 @@ def test_complex128_on_the_matrix_cores():
     assert raw.dtype == np.complex128 and amp_rel(raw.reshape(-1), arrays["n12_dense_c128"]) < 1e-12
 
 
+def test_complex128_fused_pairs():
+    """complex128 pairs in ONE pass (artn_k_bits128: 16-byte elements, f64 MFMA stages, the intermediate in LDS): the 13
+    fusable pairs of the n30 scheme truncated to 2^21 elements and random pairs, 1e-12 against complex128 einsums; single
+    steps forced onto the same kernel (ARTN_FORCE_BITS) as well."""
+    from artensor_amd.contraction import fusion_schedule, contract2
+    from helpers import shrink_pair
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    pairs = [e for e in fusion_schedule(case.scheme) if e[0] == "pair" and np.prod(steps[e[1]][1]) >= 2 ** 22]
+    c128 = lambda rng, shape: rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    e128 = lambda eq, x, y: torch.einsum(eq, torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(np.ascontiguousarray(y))).numpy()
+    fused = 0
+    for _, n, m in pairs:
+        eq1, sa, sb1 = steps[n]
+        eq2, _, sb2 = steps[m]
+        e1, a_s, b1_s, e2, b2_s = shrink_pair(eq1, sa, sb1, eq2, sb2, max_log2=21)
+        rng = np.random.default_rng(n)
+        a, b1, b2 = c128(rng, a_s), c128(rng, b1_s), c128(rng, b2_s)
+        got = contract2(e1, gpu(a), gpu(b1), e2, gpu(b2))
+        if got is None:
+            continue
+        fused += 1
+        want = e128(e2, e128(e1, a, b1), b2)
+        assert got.dtype == torch.complex128 and rel(got.cpu().numpy(), want) < 1e-12, (n, m)
+    assert fused >= 10
+    rng = np.random.default_rng(9)
+    done = 0
+    for trial in range(30):
+        ra = int(rng.integers(13, 19))
+        k1, n1, k2, n2 = (int(x) for x in rng.integers(1, 6, size=4))
+        la = [chr(65 + x) for x in range(ra)]
+        kl1 = list(rng.choice(la, size=k1, replace=False))
+        nl1 = [chr(97 + x) for x in range(n1)]
+        lb1 = kl1 + nl1
+        rng.shuffle(lb1)
+        lo1 = [x for x in la if x not in kl1] + nl1
+        rng.shuffle(lo1)
+        if k2 > len(lo1) - 6:
+            continue
+        kl2 = list(rng.choice(lo1, size=k2, replace=False))
+        nl2 = [chr(110 + x) for x in range(n2)]
+        lb2 = kl2 + nl2
+        rng.shuffle(lb2)
+        lo2 = [x for x in lo1 if x not in kl2] + nl2
+        rng.shuffle(lo2)
+        eq1 = "".join(la) + "," + "".join(lb1) + "->" + "".join(lo1)
+        eq2 = "".join(lo1) + "," + "".join(lb2) + "->" + "".join(lo2)
+        a, b1, b2 = c128(rng, (2,) * ra), c128(rng, (2,) * len(lb1)), c128(rng, (2,) * len(lb2))
+        got = contract2(eq1, gpu(a), gpu(b1), eq2, gpu(b2))
+        if got is None:
+            continue
+        want = e128(eq2, e128(eq1, a, b1), b2)
+        assert rel(got.cpu().numpy(), want) < 1e-12, (eq1, eq2)
+        done += 1
+    assert done >= 12
+
+
+def test_complex128_n30_dense_full_size_against_committed_truth():
+    """The whole n30 contraction in complex128 (32 GiB of state buffers; fused pairs on artn_k_bits128, the rest on
+    artn_k_gemm128) reproduces the committed complex128 truth (tests/golden/c128_truth_gpu.npz, computed in round 3 with
+    un-fused GEMM passes only) to 1e-11: two different kernel families, the same amplitudes."""
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    raw = A.tensor_contraction(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme)
+    assert raw.dtype == torch.complex128 and raw.numel() == 2 ** 30
+    perm = case.meta["permute_dims"]
+    flat = raw.reshape(-1)
+    fpos = np.array([int(b, 2) for b in case.meta["google_bitstrings"]], dtype=np.int64)
+    at = flat[torch.from_numpy(raw_index(fpos, perm)).to(DEV)].cpu().numpy()
+    want = gpu_truth("n30_dense_at_google")
+    assert np.abs(at - want).max() <= 1e-11 * np.abs(want).max()
+    blocks = block_sums(raw, perm[:10])
+    tb = gpu_truth("n30_dense_block_sums")
+    assert np.abs(blocks - tb).max() <= 1e-11 * np.abs(tb).max()
+    del raw, flat
+    torch.cuda.empty_cache()
+
+
 def test_gemm_kernel_strided_operands_and_split_k():
     """Operands that are views (the slice loop hands in selected leaves), and a closing step whose result
     is too small to fill the chip: contracted labels become a batch label (split-K) and are summed."""

@@ -396,3 +396,101 @@ def test_packed_gemm_plan_emulated(monkeypatch, m, n, k, bf16):
         tol = 1e-5
     assert got.shape == want.shape
     assert np.abs(got - want).max() / np.abs(want).max() < tol, (eq, info)
+
+
+# ---- complex128 on the state-streaming kernel (artn_k_bits128): the lane-by-lane replay of the f64 MFMA stages ----------
+def _c128(rng, shape):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex128)
+
+
+@pytest.mark.parametrize("k,n,ra", [(1, 1, 12), (2, 0, 13), (3, 3, 14), (4, 4, 14), (5, 5, 14), (6, 5, 15), (4, 6, 13), (6, 2, 15),
+                                    (1, 5, 12), (5, 1, 14), (2, 4, 11)])
+def test_complex128_random_bit_steps(k, n, ra):
+    """Single steps forced onto the complex128 state-streaming plan: K and N bits scattered, output order scrambled."""
+    from helpers import emulate_bits
+    rng = np.random.default_rng(1000 + 100 * k + n)
+    done = 0
+    for trial in range(3):
+        la = [chr(65 + x) for x in range(ra)]
+        kl = list(rng.choice(la, size=k, replace=False))
+        nl = [chr(97 + x) for x in range(n)]
+        lb = kl + nl
+        rng.shuffle(lb)
+        lo = [x for x in la if x not in kl] + nl
+        rng.shuffle(lo)
+        eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
+        a, b = _c128(rng, (2,) * ra), _c128(rng, (2,) * len(lb))
+        got, info = emulate_bits(eq, a, b)
+        if got is None:
+            continue
+        want = np.einsum(eq, a, b)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-13, eq
+        assert info["lds_bytes"] <= 80 * 1024
+        done += 1
+    assert done >= 2
+
+
+def test_complex128_random_fused_pairs():
+    from helpers import emulate2
+    rng = np.random.default_rng(5)
+    done = 0
+    for trial in range(40):
+        ra = int(rng.integers(12, 16))
+        k1, n1, k2, n2 = (int(x) for x in rng.integers(1, 5, size=4))
+        la = [chr(65 + x) for x in range(ra)]
+        kl1 = list(rng.choice(la, size=k1, replace=False))
+        nl1 = [chr(97 + x) for x in range(n1)]
+        lb1 = kl1 + nl1
+        rng.shuffle(lb1)
+        lo1 = [x for x in la if x not in kl1] + nl1
+        rng.shuffle(lo1)
+        if k2 > len(lo1) - 6:
+            continue
+        kl2 = list(rng.choice(lo1, size=k2, replace=False))
+        nl2 = [chr(110 + x) for x in range(n2)]
+        lb2 = kl2 + nl2
+        rng.shuffle(lb2)
+        lo2 = [x for x in lo1 if x not in kl2] + nl2
+        rng.shuffle(lo2)
+        eq1 = "".join(la) + "," + "".join(lb1) + "->" + "".join(lo1)
+        eq2 = "".join(lo1) + "," + "".join(lb2) + "->" + "".join(lo2)
+        a, b1, b2 = _c128(rng, (2,) * ra), _c128(rng, (2,) * len(lb1)), _c128(rng, (2,) * len(lb2))
+        got, info = emulate2(eq1, a, b1, eq2, b2)
+        if got is None:
+            continue
+        want = np.einsum(eq2, np.einsum(eq1, a, b1), b2)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-13, (eq1, eq2)
+        assert info["arith"] == 3
+        done += 1
+    assert done >= 15
+
+
+def test_complex128_n30_fused_pairs_surrogates():
+    """The 13 fusable pairs of big n30 steps in complex128: planned as fused pairs at full size (2^11-element tiles: two
+    32 KiB regions, two workgroups per CU) and replayed at 2^15."""
+    import torch
+    from artensor_amd.contraction import fusion_schedule, pair_info
+    from helpers import emulate2, shrink_pair
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    pairs = [e for e in fusion_schedule(case.scheme) if e[0] == "pair" and np.prod(steps[e[1]][1]) >= 2 ** 22]
+    assert len(pairs) == 13
+    planned = fused = 0
+    for _, n, m in pairs:
+        eq1, sa, sb1 = steps[n]
+        eq2, _, sb2 = steps[m]
+        info = pair_info(eq1, sa, sb1, eq2, sb2, dtype=torch.complex128)
+        if info is None:
+            continue
+        planned += 1
+        assert info["arith"] == 3 and info["lds_bytes"] <= 80 * 1024, info
+        e1, a_s, b1_s, e2, b2_s = shrink_pair(eq1, sa, sb1, eq2, sb2, max_log2=15)
+        rng = np.random.default_rng(n)
+        a, b1, b2 = _c128(rng, a_s), _c128(rng, b1_s), _c128(rng, b2_s)
+        got, _ = emulate2(e1, a, b1, e2, b2)
+        if got is None:
+            continue
+        fused += 1
+        want = np.einsum(e2, np.einsum(e1, a, b1), b2)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-13, (n, m)
+    assert planned >= 10 and fused >= 8, (planned, fused)
