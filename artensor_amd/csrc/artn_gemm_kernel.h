@@ -502,3 +502,254 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
     off = noff;
   }
 }
+
+// ----------------------------------------------------------------------------------------
+// artn_k_gemm_deep<MB, NB> -- artn_k_gemm<MB, NB, false, true> (fp32, 3M) with the operand loads TWO chunks ahead.
+// The memory-bound steps of the sliced circuits (7-8 contracted bits, a 2^30-element first operand, a few thousand
+// elements in the second) are latency-bound with one chunk (20 KiB per workgroup) in flight: a workgroup's chunk period
+// is the load latency (2.7 us measured against 0.7 us of MFMA work), 3.1 TB/s chip-wide.  Two register sets alternate
+// statically (the chunk loop is unrolled by two): while chunk p is multiplied, chunk p + 1 waits in one set and the
+// loads of chunk p + 2 -- of this tile or of the next one -- fly into the other.  Every step issues its loads
+// UNCONDITIONALLY (past the end of the last tile a valid chunk is simply loaded again): with conditional loads the
+// compiler cannot count what is in flight and falls back to s_waitcnt vmcnt(0) before the LDS fill, which waits for the
+// loads just issued as well -- one chunk in flight again.  Same plan, same images, same epilogue as artn_k_gemm; used for
+// 2..256 chunks per tile (no partial-sum flush inside a tile), one block column per wave, and images every thread moves
+// the same number of 16-byte pieces of (NA of the first operand's, NBI of the second's: compile-time constants).
+// ----------------------------------------------------------------------------------------
+template <int MB, int NB, int NA, int NBI>
+__global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                                                      float2 *__restrict__ C, const ArtnGemmPlan P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((unsigned)(unsigned long)(lds_byte_t *)smem != 0) __builtin_trap();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int mt = P.mt, nt = P.nt;
+  constexpr int PITCH = ARTN_GEMM_PITCH_LOG2, KCB = ARTN_GEMM_KC;
+  constexpr int NS = 1 << (KCB - 1);
+  constexpr unsigned a_bytes = 8u << (PITCH + KCB), stage_bytes = 2 * a_bytes;
+  constexpr unsigned ROW2 = 16u << PITCH;
+  constexpr int NVA = NA, NVB = NBI;
+  const int epi_bits = P.tc_bits < ARTN_GEMM_EPI_BITS ? P.tc_bits : ARTN_GEMM_EPI_BITS;
+  const unsigned epi_bytes = 8u << epi_bits;
+  const unsigned tab_base = 2 * stage_bytes > epi_bytes ? 2 * stage_bytes : epi_bytes;
+  long *offtab = reinterpret_cast<long *>(smem + tab_base);
+  long *kotab = offtab + 512 + 128;
+  if (tid < P.n_ko) {
+    kotab[2 * tid] = P.ko_sA[tid] * 8;
+    kotab[2 * tid + 1] = P.ko_sB[tid] * 8;
+  }
+  const OffTab OT = build_offset_table(P, offtab, tid);
+  // (the launcher checked: 2^(ta_bits - 1) = 256 NA and 2^(tb_bits - 1) = 256 NBI 16-byte pieces per image)
+  unsigned a_gl = 0, a_ll = 0, b_gl = 0, b_ll = 0;
+#pragma unroll
+  for (int b = 1; b <= 8; ++b) {
+    if ((tid >> (b - 1)) & 1) {
+      if (b < P.ta_bits) { a_gl += (unsigned)P.a_stride[b] * 8u; a_ll += (unsigned)P.a_lds[b]; }
+      if (b < P.tb_bits) { b_gl += (unsigned)P.b_stride[b] * 8u; b_ll += (unsigned)P.b_lds[b]; }
+    }
+  }
+  long a_gi[2], b_gi[2];
+  unsigned a_li[2], b_li[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    a_gi[b] = 9 + b < P.ta_bits ? P.a_stride[9 + b] * 8 : 0;
+    a_li[b] = 9 + b < P.ta_bits ? (unsigned)P.a_lds[9 + b] : 0u;
+    b_gi[b] = 9 + b < P.tb_bits ? P.b_stride[9 + b] * 8 : 0;
+    b_li[b] = 9 + b < P.tb_bits ? (unsigned)P.b_lds[9 + b] : 0u;
+  }
+  const unsigned a_pair = (unsigned)P.a_lds[0], b_pair = (unsigned)P.b_lds[0];
+  const int wn = wave & ((1 << P.wn_log2) - 1), wm = (wave >> P.wn_log2) & ((1 << P.wm_log2) - 1);
+  constexpr int NBW = 32;
+  const unsigned lane_x = (((unsigned)h << PITCH) + (unsigned)(wm * MB * 32 + j)) * 8u;
+  const unsigned lane_w = a_bytes + (((unsigned)h << PITCH) + (unsigned)(wn * NB * NBW) + (unsigned)j) * 8u;
+  auto m_off = [&](int m_local) {
+    unsigned o = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i < mt && ((m_local >> i) & 1)) o |= 1u << P.m_pos[i];
+    return o;
+  };
+  auto n_off = [&](int n_local) {
+    unsigned o = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i < nt && ((n_local >> i) & 1)) o |= 1u << P.n_pos[i];
+    return o;
+  };
+  const unsigned lane_c = swz_gemm(m_off(wm * MB * 32 + j) | n_off(wn * NB * NBW + 4 * h), P);
+  unsigned c_mb[MB], c_nb[NB];
+#pragma unroll
+  for (int q = 0; q < MB; ++q) c_mb[q] = swz_gemm(m_off(q * 32), P);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) c_nb[q] = swz_gemm(n_off(q * NBW), P);
+  const unsigned c_b0 = swz_gemm(n_off(1), P), c_b1 = swz_gemm(n_off(2), P), c_q0 = swz_gemm(n_off(8), P), c_q1 = swz_gemm(n_off(16), P);
+  const int o_cb = epi_bits - 1;
+  const int o_iters = o_cb > 8 ? 1 << (o_cb - 8) : 1;
+  const bool o_act = o_cb >= 8 || tid < (1 << o_cb);
+  unsigned o_gl = 0;
+#pragma unroll
+  for (int b = 1; b <= 8; ++b)
+    if (((tid >> (b - 1)) & 1) && b < P.tc_bits) o_gl += (unsigned)P.out_stride[b] * 8u;
+  long o_gi[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) o_gi[b] = 9 + b < epi_bits ? P.out_stride[9 + b] * 8 : 0;
+  const int n_pass = 1 << (P.tc_bits - epi_bits);
+  const long pass_stride = P.tc_bits > epi_bits ? P.out_stride[epi_bits] * 8 : 0;
+  const unsigned o_ll = swz_gemm((unsigned)tid * 2u, P) * 8u;
+
+  f32x4 va0[NVA], vb0[NVB], va1[NVA], vb1[NVB]; // two register sets: chunk parity 0 / 1
+  auto issue = [&](f32x4 (&va)[NVA], f32x4 (&vb)[NVB], const char *__restrict__ Ab, const char *__restrict__ Bb) {
+    unsigned agl = a_gl, bgl = b_gl;
+    OPAQUE_V(agl);
+    OPAQUE_V(bgl);
+#pragma unroll
+    for (int u = 0; u < NVA; ++u) va[u] = *reinterpret_cast<const f32x4 *>(Ab + ((u & 1) ? a_gi[0] : 0) + ((u & 2) ? a_gi[1] : 0) + agl);
+#pragma unroll
+    for (int u = 0; u < NVB; ++u) vb[u] = *reinterpret_cast<const f32x4 *>(Bb + ((u & 1) ? b_gi[0] : 0) + ((u & 2) ? b_gi[1] : 0) + bgl);
+  };
+  auto put = [&](unsigned d, unsigned pair, const f32x4 &v) {
+    if (pair == 8u) lds_write16(d, v);
+    else { lds_write8(d, v2f_t{v[0], v[1]}); lds_write8(d + pair, v2f_t{v[2], v[3]}); }
+  };
+  auto fill = [&](const f32x4 (&va)[NVA], const f32x4 (&vb)[NVB], unsigned buf) {
+#pragma unroll
+    for (int u = 0; u < NVA; ++u) put(buf + a_ll + ((u & 1) ? a_li[0] : 0u) + ((u & 2) ? a_li[1] : 0u), a_pair, va[u]);
+#pragma unroll
+    for (int u = 0; u < NVB; ++u) put(buf + a_bytes + b_ll + ((u & 1) ? b_li[0] : 0u) + ((u & 2) ? b_li[1] : 0u), b_pair, vb[u]);
+  };
+
+  long t0 = blockIdx.x;
+  const long G = gridDim.x, n_tiles = P.n_tiles;
+  if ((G & 7) == 0) t0 = (long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int n_chunks = 1 << P.n_ko; // even, 2..256 (checked by the launcher)
+  __syncthreads();
+  if (t0 >= n_tiles) return; // (never: the grid is at most n_tiles)
+  TileOff off = tile_offsets<false>(P, OT, t0), noff = off;
+  const char *Ac = reinterpret_cast<const char *>(A), *Bc = reinterpret_cast<const char *>(B);
+  // (ka, kb): byte offsets of the most recently issued chunk inside its tile (Gray-code walk over the looped bits)
+  long ka = 0, kb = 0;
+  auto advance = [&](int idx_next) { // offsets of chunk idx_next from those of chunk idx_next - 1
+    const int bit = __builtin_ctz((unsigned)idx_next);
+    const unsigned gn = (unsigned)idx_next ^ ((unsigned)idx_next >> 1);
+    const long sa = kotab[2 * bit], sb = kotab[2 * bit + 1];
+    if ((gn >> bit) & 1) { ka += sa; kb += sb; } else { ka -= sa; kb -= sb; }
+    ka = uniform64(ka);
+    kb = uniform64(kb);
+  };
+  issue(va0, vb0, Ac + off.a * 8, Bc + off.b1 * 8);
+  fill(va0, vb0, 0u);
+  advance(1);
+  issue(va1, vb1, Ac + off.a * 8 + ka, Bc + off.b1 * 8 + kb);
+  __syncthreads();
+  unsigned cur = 0;
+  for (long tile = t0; tile < n_tiles; tile += G) {
+    const bool more_tiles = tile + G < n_tiles;
+    if (more_tiles) noff = next_offsets<false>(P, OT, off, tile, G);
+    f32x16 acc[MB][NB * 3];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int b = 0; b < NB * 3; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // one chunk: issue chunk c + 2 into the set that chunk c came from, multiply chunk c, then chunk c + 1 (the other set) -> LDS
+    auto step = [&](int c, f32x4 (&va_free)[NVA], f32x4 (&vb_free)[NVB], const f32x4 (&va_next)[NVA], const f32x4 (&vb_next)[NVB]) {
+      const int c2 = c + 2;
+      long base_a = off.a, base_b = off.b1;
+      if (c2 < n_chunks) {
+        advance(c2);
+      } else {
+        if (c2 == n_chunks) { ka = 0; kb = 0; } else advance(1);
+        if (more_tiles) { base_a = noff.a; base_b = noff.b1; } // (else: a chunk of this tile again, never used)
+      }
+      issue(va_free, vb_free, Ac + base_a * 8 + ka, Bc + base_b * 8 + kb);
+      const unsigned base = cur * stage_bytes;
+      const unsigned xa = base + lane_x, wa = base + lane_w;
+      v2f_t X[2][MB], Wr[2][NB];
+      auto load_ops = [&](int s, v2f_t (&x)[MB], v2f_t (&w)[NB]) {
+#pragma unroll
+        for (int a = 0; a < MB; ++a) x[a] = lds_read8(xa + (unsigned)s * ROW2 + (unsigned)a * 256u);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) w[b] = lds_read8(wa + (unsigned)s * ROW2 + (unsigned)b * (NBW * 8u));
+      };
+      load_ops(0, X[0], Wr[0]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) load_ops(s + 1, X[(s + 1) & 1], Wr[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        float xs[MB], wsum[NB];
+#pragma unroll
+        for (int a = 0; a < MB; ++a) xs[a] = X[s & 1][a].x + X[s & 1][a].y;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) wsum[b] = Wr[s & 1][b].x + Wr[s & 1][b].y;
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            acc[a][3 * b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].x, X[s & 1][a].x, acc[a][3 * b], 0, 0, 0);
+            acc[a][3 * b + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].y, X[s & 1][a].y, acc[a][3 * b + 1], 0, 0, 0);
+            acc[a][3 * b + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wsum[b], xs[a], acc[a][3 * b + 2], 0, 0, 0);
+          }
+      }
+      if (c + 1 < n_chunks) {
+        fill(va_next, vb_next, (cur ^ 1u) * stage_bytes);
+        __syncthreads();
+        cur ^= 1u;
+        return;
+      }
+      // ---- last chunk of the tile: epilogue, then the next tile's first chunk (already in va_next / vb_next) -> buffer 0
+      char *Cb = reinterpret_cast<char *>(C) + off.c * 8;
+      for (int pass = 0; pass < n_pass; ++pass) {
+        __syncthreads();
+        unsigned lc = lane_c;
+        OPAQUE_V(lc);
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ ((r & 1) ? c_b0 : 0u) ^ ((r & 2) ? c_b1 : 0u) ^ ((r & 4) ? c_q0 : 0u) ^ ((r & 8) ? c_q1 : 0u);
+              const float t1 = acc[a][3 * b][r], t2 = acc[a][3 * b + 1][r], t3 = acc[a][3 * b + 2][r];
+              if ((int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
+                lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{t1 - t2, t3 - t1 - t2});
+            }
+        __syncthreads();
+        char *Cp = Cb + pass * pass_stride;
+        unsigned oll = o_ll ^ ((swz_gemm((unsigned)pass << ARTN_GEMM_EPI_BITS, P) & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u), ogl = o_gl;
+        OPAQUE_V(oll);
+        OPAQUE_V(ogl);
+        for (int i0 = 0; i0 < o_iters; i0 += 4) {
+          f32x4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i < o_iters && o_act) x[u] = lds_read16(oll ^ (swz_gemm((unsigned)i * 512u, P) * 8u));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i < o_iters && o_act) {
+              long o = 0;
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+                if ((i >> b) & 1) o += o_gi[b];
+              *reinterpret_cast<f32x4 *>(Cp + o + ogl) = x[u];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      fill(va_next, vb_next, 0u); // (after the last tile: the re-loaded chunk, never read)
+      __syncthreads();
+      cur = 0;
+    };
+    for (int c = 0; c < n_chunks; c += 2) {
+      step(c, va0, vb0, va1, vb1);     // chunk c came from set 0; chunk c + 1 waits in set 1
+      step(c + 1, va1, vb1, va0, vb0);
+    }
+    off = noff;
+  }
+}

@@ -234,8 +234,15 @@ __device__ __forceinline__ long uniform64(long x) {
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x >> 32));
   return (long)(((unsigned long)hi << 32) | lo);
 }
+// (gc: the contribution of the non power-of-two axes of the last tile looked up.  A workgroup that walks a contiguous
+//  range of tiles -- every launch with batch rows -- stays on one batch row for 2^pow2_bits tiles: without the cache
+//  each tile paid two 64-bit divisions and, with a row gather, two dependent loads of row indices before its first
+//  LDS read could be waited for: 1.2 us of a 5.8 us tile period in the chunked steps of the n30 x 10 000 scheme)
+struct GenCache {
+  long r, a, b1, b2, c;
+};
 template <bool GATHER = false, typename PlanT = ArtnBitsPlan>
-__device__ __forceinline__ TileOff tile_offsets(const PlanT &P, const OffTab &T, long tile) {
+__device__ __forceinline__ TileOff tile_offsets(const PlanT &P, const OffTab &T, long tile, GenCache *gc = nullptr) {
   long a = 0, b1 = 0, b2 = 0, c = 0;
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
@@ -247,6 +254,12 @@ __device__ __forceinline__ TileOff tile_offsets(const PlanT &P, const OffTab &T,
   TileOff t = {uniform64(a), uniform64(b1), uniform64(b2), uniform64(c)};
   if (T.first_generic < P.n_outer) { // rare: batch axes with arbitrary extents
     long r = tile >> T.pow2_bits;
+    if (gc && gc->r == r) {
+      t.a += gc->a; t.b1 += gc->b1; t.b2 += gc->b2; t.c += gc->c;
+      return t;
+    }
+    const TileOff base = t;
+    const long r_key = r;
     for (int d = T.first_generic; d < P.n_outer; ++d) {
       const long ext = P.outer[d].ext;
       const long x = r % ext;
@@ -269,6 +282,10 @@ __device__ __forceinline__ TileOff tile_offsets(const PlanT &P, const OffTab &T,
       t.b2 += x * P.outer[d].sB2;
       t.c += x * P.outer[d].sC;
     }
+    if (gc) {
+      gc->r = r_key;
+      gc->a = uniform64(t.a - base.a); gc->b1 = uniform64(t.b1 - base.b1); gc->b2 = uniform64(t.b2 - base.b2); gc->c = uniform64(t.c - base.c);
+    }
   }
   return t;
 }
@@ -276,8 +293,8 @@ __device__ __forceinline__ TileOff tile_offsets(const PlanT &P, const OffTab &T,
 // offsets(tile + G) from offsets(tile): one 32-byte LDS lookup when the grid is a power of two
 template <bool GATHER = false, typename PlanT = ArtnBitsPlan>
 __device__ __forceinline__ TileOff next_offsets(const PlanT &P, const OffTab &T, const TileOff &cur, long tile,
-                                                long G) {
-  if (T.g_log2 < 0) return tile_offsets<GATHER>(P, T, tile + G);
+                                                long G, GenCache *gc = nullptr) {
+  if (T.g_log2 < 0) return tile_offsets<GATHER>(P, T, tile + G, gc);
   const unsigned hi = (unsigned)(tile >> T.g_log2);
   const int c = __builtin_ctz(~hi);
   const long *e = T.delta + c * 4;
@@ -1178,11 +1195,15 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     G = 1;
     n_tiles = t0 + per < P.n_tiles ? t0 + per : P.n_tiles;
   }
+  GenCache gcache = {-1, 0, 0, 0, 0};
+  // (the row-gather instantiations only: ten more live scalar registers in the tile loop of the others are not free;
+  //  grid-stride sequences change the batch row at every tile)
+  GenCache *const gc = (GATHER && P.blocked) ? &gcache : nullptr;
   if (t0 < n_tiles) {
-    off = tile_offsets<GATHER>(P, OT, t0);
+    off = tile_offsets<GATHER>(P, OT, t0, gc);
     copy_in_sync(reinterpret_cast<const char *>(A + off.a), in_hi, in_lane, R0, tid16, n_in_iters);
     if (t0 + G < n_tiles) {
-      noff = tile_offsets<GATHER>(P, OT, t0 + G);
+      noff = tile_offsets<GATHER>(P, OT, t0 + G, gc);
       if (pf_half) issue_loads<NV, NT, 0, NV / 2>(v, reinterpret_cast<const char *>(A + noff.a), in_hi, in_lane);
       else if (prefetch) issue_loads<NV, NT>(v, reinterpret_cast<const char *>(A + noff.a), in_hi, in_lane);
     }
@@ -1239,7 +1260,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     }
     const long next = tile + G, next2 = tile + 2 * G;
     TileOff n2off = noff;
-    if (next2 < n_tiles) n2off = next_offsets<GATHER>(P, OT, noff, next, G);
+    if (next2 < n_tiles) n2off = next_offsets<GATHER>(P, OT, noff, next, G, gc);
     STAMP(0); // W reload, offsets of the tile after next
     PHASE_MARK(0);
 
@@ -2419,6 +2440,20 @@ static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, v
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);
     }
     return hipGetLastError();
+  }
+  // memory-bound 3M steps (few free bits in the second operand: one block column per wave): operand loads two chunks ahead
+  if (g.m3 && g.nb_log2 == 0 && g.wk_log2 == 0 && g.n_ko >= 1 && g.n_ko <= 8 && g.ta_bits == 11 &&
+      g.pitch_log2 == ARTN_GEMM_PITCH_LOG2 && g.kc == ARTN_GEMM_KC && artn::tuning().gemm_deep) {
+#define ARTN_GEMM_LAUNCH_DEEP(MBV, NBIV)                                                             \
+  {                                                                                                  \
+    auto kern = artn_k_gemm_deep<MBV, 1, 4, NBIV>;                                                   \
+    if (hipError_t e = ensure_lds<artn_k_gemm_deep<MBV, 1, 4, NBIV>>(lds); e != hipSuccess) return e; \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
+    return hipGetLastError();                                                                        \
+  }
+    if (g.mb_log2 == 0 && g.tb_bits == 9) ARTN_GEMM_LAUNCH_DEEP(1, 1)
+    if (g.mb_log2 == 1 && g.tb_bits == 10 && artn::tuning().gemm_deep >= 2) ARTN_GEMM_LAUNCH_DEEP(2, 2)
+#undef ARTN_GEMM_LAUNCH_DEEP
   }
   if (g.m3) {
     switch (key) {

@@ -216,6 +216,8 @@ struct Tuning {
   int packed = 2;     // packed-operand GEMM (ArtnPackPlan): 1 reduced-precision mode only (2^9+ contracted values),
                       // 2 also complex64 arithmetic (3M on fp32 MFMA, 2^10+ contracted values), 0 never
   int bits128 = 1;         // complex128 on the state-streaming kernel: 0 never, 1 fused pairs (+ singles the GEMM declines), 2 singles first
+  int gemm_deep = 2;       // GEMM kernel, fp32 3M, one block column per wave: operand loads two chunks ahead (artn_k_gemm_deep); 2: also 64-row waves
+  int idle_to_gemm = 1;    // single steps whose state-streaming tile would leave waves idle go to the GEMM kernel
   int m3_frag = 96;        // 3M in fused pairs up to this many fragment registers (80: not in 5+6 / 6+5 pairs)
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
@@ -242,6 +244,8 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
     if (const char *e = getenv("ARTN_M3_FRAG")) x.m3_frag = atoi(e);
+    if (const char *e = getenv("ARTN_IDLE_TO_GEMM")) x.idle_to_gemm = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_GEMM_DEEP")) x.gemm_deep = atoi(e);
     if (const char *e = getenv("ARTN_BITS128")) x.bits128 = atoi(e);
     if (const char *e = getenv("ARTN_PACKED_MIN_K")) x.packed_min_k = std::max(6, atoi(e));
     if (const char *e = getenv("ARTN_PACKED_MIN_AI")) x.packed_min_ai = std::max(1, atoi(e));
@@ -1370,6 +1374,19 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   allow_gemm = allow_gemm && allow_bits && gather_label < 0 && tuning().gemm && d->dtype != ARTN_C128 && !ok;
   if (allow_gemm) ok = make_gemm(d, p, n_cu, min_tiles, tuning().gemm < 2);
   if (!ok) ok = allow_bits && (d->dtype != ARTN_C128 || gather_label < 0) && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
+  // A state-streaming tile with fewer than four (sub-tile, column block) units leaves waves without work -- and the busy
+  // waves of the two workgroups of a CU sit on the same SIMDs: a 6-bit step of the n53 slices with 16 result columns and
+  // 64-row tiles ran two of four matrix pipes (1.26 ms; the GEMM kernel, whose four waves share a tile's rows: 0.82 ms).
+  if (ok && allow_gemm && p.kernel == ARTN_KERNEL_BITS_MFMA && p.bits.st[0].k <= 6 && p.bits.st[0].k >= 5 &&
+      p.bits.st[0].m_bits - 5 + p.bits.st[0].wn_log2 < 2 && tuning().idle_to_gemm) {
+    ArtnPlan q;
+    memset(&q.info, 0, sizeof(q.info));
+    q.n_cu = n_cu;
+    if (make_gemm(d, q, n_cu, min_tiles, false)) {
+      q.why_generic = p.why_generic;
+      p = q;
+    }
+  }
   if (!ok && allow_gemm) { // what the state-streaming kernel declines
     const std::string why = p.why_generic;
     ok = make_gemm(d, p, n_cu, min_tiles, false);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-launch breakdown of one slice of a fixture: python tools/time_case.py <fixture.npz> [sparse]"""
+"""Per-launch breakdown of one slice of a fixture: [DTYPE=c128] [TOP=n] python tools/time_case.py <fixture.npz> [sparse]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +10,7 @@ from artensor_amd import _native as N
 from artensor_amd.fixtures import load_case
 case = load_case(os.path.join(ROOT, "tests", "golden", sys.argv[1]))
 sparse = len(sys.argv) > 2 and sys.argv[2] == "sparse"
-leaves = case.fresh_tensors(device="cuda")
+leaves = case.fresh_tensors(device="cuda", dtype=torch.complex128 if os.environ.get("DTYPE") == "c128" else torch.complex64)
 nb = len(case.slicing_indices or {})
 rec = []
 orig_q = C._query
