@@ -55,7 +55,7 @@ __device__ __forceinline__ void lds_write4(unsigned a, unsigned v) {
 // 6 real FLOP per complex multiply-add on the matrix pipe, the other 2 become one add per operand element
 // and three per result.  NB counts 32-column blocks in this mode.
 // TALL (single-block tiles, fp32): images of 2^6 contracted values x 2^5 rows (ArtnGemmPlan::pitch_log2 = 5, kc = 6)
-template <int MB, int NB, bool BF = false, bool M3 = false, bool TALL = false>
+template <int MB, int NB, bool BF = false, bool M3 = false, bool TALL = false, bool GATHER = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *__restrict__ A, const float2 *__restrict__ B,
                                                                  float2 *__restrict__ C, const ArtnGemmPlan P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
   TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
   const char *Ac = reinterpret_cast<const char *>(A), *Bc = reinterpret_cast<const char *>(B);
   if (t0 < n_tiles) {
-    off = tile_offsets<false>(P, OT, t0);
+    off = tile_offsets<GATHER>(P, OT, t0);
     issue(Ac + off.a * 8, Bc + off.b1 * 8);
     fill(0u);
   }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
   unsigned cur = 0;
   for (long tile = t0; tile < n_tiles; tile += G) {
     const bool more_tiles = tile + G < n_tiles;
-    if (more_tiles) noff = next_offsets<false>(P, OT, off, tile, G);
+    if (more_tiles) noff = next_offsets<GATHER>(P, OT, off, tile, G);
     constexpr int NACC = M3 ? 3 : 1;
     f32x16 acc[MB][NB * NACC];
 #pragma unroll
@@ -514,9 +514,14 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm(const float2 *
 // compiler cannot count what is in flight and falls back to s_waitcnt vmcnt(0) before the LDS fill, which waits for the
 // loads just issued as well -- one chunk in flight again.  Same plan, same images, same epilogue as artn_k_gemm; used for
 // 2..256 chunks per tile (no partial-sum flush inside a tile), one block column per wave, and images every thread moves
-// the same number of 16-byte pieces of (NA of the first operand's, NBI of the second's: compile-time constants).
+// the same number of 16-byte pieces of (NA of the first operand's, NBI of the second's: compile-time constants; where the
+// second operand's image has fewer than 256 pieces the upper threads load a piece again and do not store it).
+// M3 = false: the 4M arithmetic of blocks with 16 columns or fewer (chunk steps of the sparse executor: 8 columns).
+// DEPTH register sets (2 or 4): chunk c multiplies while chunks c + 1 .. c + DEPTH - 1 wait or fly and chunk c + DEPTH is
+// issued into the set chunk c came from.  Measured (A/B in one session): 4 sets are no faster than 2 on any workload
+// (n53 26.6 ms, n30 x 10 000 57.2 ms, rand2 13.4 ms either way); only DEPTH = 2 is instantiated.
 // ----------------------------------------------------------------------------------------
-template <int MB, int NB, int NA, int NBI>
+template <int MB, int NB, int NA, int NBI, bool GATHER = false, bool M3 = true, int DEPTH = 2>
 __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const float2 *__restrict__ A, const float2 *__restrict__ B,
                                                                       float2 *__restrict__ C, const ArtnGemmPlan P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
+  const int j = lane & 31, h = lane >> 5, ro = j & 1;
   const int mt = P.mt, nt = P.nt;
   constexpr int PITCH = ARTN_GEMM_PITCH_LOG2, KCB = ARTN_GEMM_KC;
   constexpr int NS = 1 << (KCB - 1);
@@ -541,7 +546,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
     kotab[2 * tid + 1] = P.ko_sB[tid] * 8;
   }
   const OffTab OT = build_offset_table(P, offtab, tid);
-  // (the launcher checked: 2^(ta_bits - 1) = 256 NA and 2^(tb_bits - 1) = 256 NBI 16-byte pieces per image)
+  // (the launcher checked: 2^(ta_bits - 1) = 256 NA and 2^(tb_bits - 1) <= 256 NBI 16-byte pieces per image)
+  const bool b_act = P.tb_bits - 1 >= 8 || tid < (1 << (P.tb_bits - 1));
   unsigned a_gl = 0, a_ll = 0, b_gl = 0, b_ll = 0;
 #pragma unroll
   for (int b = 1; b <= 8; ++b) {
@@ -561,9 +567,11 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
   }
   const unsigned a_pair = (unsigned)P.a_lds[0], b_pair = (unsigned)P.b_lds[0];
   const int wn = wave & ((1 << P.wn_log2) - 1), wm = (wave >> P.wn_log2) & ((1 << P.wm_log2) - 1);
-  constexpr int NBW = 32;
+  constexpr int NBW = M3 ? 32 : 16, NACC = M3 ? 3 : 1;
+  const int n_in = M3 ? j : j >> 1;
+  const bool w_valid = M3 || nt >= 4 || n_in < (1 << nt);
   const unsigned lane_x = (((unsigned)h << PITCH) + (unsigned)(wm * MB * 32 + j)) * 8u;
-  const unsigned lane_w = a_bytes + (((unsigned)h << PITCH) + (unsigned)(wn * NB * NBW) + (unsigned)j) * 8u;
+  const unsigned lane_w = a_bytes + (((unsigned)h << PITCH) + (unsigned)(wn * NB * NBW) + (unsigned)(w_valid ? n_in : 0)) * 8u;
   auto m_off = [&](int m_local) {
     unsigned o = 0;
 #pragma unroll
@@ -578,13 +586,14 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
       if (i < nt && ((n_local >> i) & 1)) o |= 1u << P.n_pos[i];
     return o;
   };
-  const unsigned lane_c = swz_gemm(m_off(wm * MB * 32 + j) | n_off(wn * NB * NBW + 4 * h), P);
+  const unsigned lane_c = swz_gemm(m_off(wm * MB * 32 + j) | n_off(wn * NB * NBW + (M3 ? 4 : 2) * h), P);
   unsigned c_mb[MB], c_nb[NB];
 #pragma unroll
   for (int q = 0; q < MB; ++q) c_mb[q] = swz_gemm(m_off(q * 32), P);
 #pragma unroll
   for (int q = 0; q < NB; ++q) c_nb[q] = swz_gemm(n_off(q * NBW), P);
-  const unsigned c_b0 = swz_gemm(n_off(1), P), c_b1 = swz_gemm(n_off(2), P), c_q0 = swz_gemm(n_off(8), P), c_q1 = swz_gemm(n_off(16), P);
+  const unsigned c_b0 = swz_gemm(n_off(1), P), c_b1 = swz_gemm(n_off(2), P), c_q0 = swz_gemm(n_off(M3 ? 8 : 4), P), c_q1 = swz_gemm(n_off(M3 ? 16 : 8), P);
+  const int n_lim = nt >= 4 ? 16 : 1 << nt; // 4M: valid columns of a block
   const int o_cb = epi_bits - 1;
   const int o_iters = o_cb > 8 ? 1 << (o_cb - 8) : 1;
   const bool o_act = o_cb >= 8 || tid < (1 << o_cb);
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
   const long pass_stride = P.tc_bits > epi_bits ? P.out_stride[epi_bits] * 8 : 0;
   const unsigned o_ll = swz_gemm((unsigned)tid * 2u, P) * 8u;
 
-  f32x4 va0[NVA], vb0[NVB], va1[NVA], vb1[NVB]; // two register sets: chunk parity 0 / 1
+  f32x4 va[DEPTH][NVA], vb[DEPTH][NVB]; // register sets: chunk q lives in set q mod DEPTH
   auto issue = [&](f32x4 (&va)[NVA], f32x4 (&vb)[NVB], const char *__restrict__ Ab, const char *__restrict__ Bb) {
     unsigned agl = a_gl, bgl = b_gl;
     OPAQUE_V(agl);
@@ -616,17 +625,19 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
   auto fill = [&](const f32x4 (&va)[NVA], const f32x4 (&vb)[NVB], unsigned buf) {
 #pragma unroll
     for (int u = 0; u < NVA; ++u) put(buf + a_ll + ((u & 1) ? a_li[0] : 0u) + ((u & 2) ? a_li[1] : 0u), a_pair, va[u]);
+    if (b_act) {
 #pragma unroll
-    for (int u = 0; u < NVB; ++u) put(buf + a_bytes + b_ll + ((u & 1) ? b_li[0] : 0u) + ((u & 2) ? b_li[1] : 0u), b_pair, vb[u]);
+      for (int u = 0; u < NVB; ++u) put(buf + a_bytes + b_ll + ((u & 1) ? b_li[0] : 0u) + ((u & 2) ? b_li[1] : 0u), b_pair, vb[u]);
+    }
   };
 
   long t0 = blockIdx.x;
   const long G = gridDim.x, n_tiles = P.n_tiles;
   if ((G & 7) == 0) t0 = (long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int n_chunks = 1 << P.n_ko; // even, 2..256 (checked by the launcher)
+  const int n_chunks = 1 << P.n_ko; // a multiple of DEPTH, at most 256 (checked by the launcher)
   __syncthreads();
   if (t0 >= n_tiles) return; // (never: the grid is at most n_tiles)
-  TileOff off = tile_offsets<false>(P, OT, t0), noff = off;
+  TileOff off = tile_offsets<GATHER>(P, OT, t0), noff = off;
   const char *Ac = reinterpret_cast<const char *>(A), *Bc = reinterpret_cast<const char *>(B);
   // (ka, kb): byte offsets of the most recently issued chunk inside its tile (Gray-code walk over the looped bits)
   long ka = 0, kb = 0;
@@ -638,30 +649,33 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
     ka = uniform64(ka);
     kb = uniform64(kb);
   };
-  issue(va0, vb0, Ac + off.a * 8, Bc + off.b1 * 8);
-  fill(va0, vb0, 0u);
-  advance(1);
-  issue(va1, vb1, Ac + off.a * 8 + ka, Bc + off.b1 * 8 + kb);
+  issue(va[0], vb[0], Ac + off.a * 8, Bc + off.b1 * 8);
+  fill(va[0], vb[0], 0u);
+#pragma unroll
+  for (int q = 1; q < DEPTH; ++q) {
+    advance(q);
+    issue(va[q], vb[q], Ac + off.a * 8 + ka, Bc + off.b1 * 8 + kb);
+  }
   __syncthreads();
   unsigned cur = 0;
   for (long tile = t0; tile < n_tiles; tile += G) {
     const bool more_tiles = tile + G < n_tiles;
-    if (more_tiles) noff = next_offsets<false>(P, OT, off, tile, G);
-    f32x16 acc[MB][NB * 3];
+    if (more_tiles) noff = next_offsets<GATHER>(P, OT, off, tile, G);
+    f32x16 acc[MB][NB * NACC];
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll
-      for (int b = 0; b < NB * 3; ++b)
+      for (int b = 0; b < NB * NACC; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    // one chunk: issue chunk c + 2 into the set that chunk c came from, multiply chunk c, then chunk c + 1 (the other set) -> LDS
+    // one chunk: issue chunk c + DEPTH into the set that chunk c came from, multiply chunk c, then chunk c + 1 (the next set) -> LDS
     auto step = [&](int c, f32x4 (&va_free)[NVA], f32x4 (&vb_free)[NVB], const f32x4 (&va_next)[NVA], const f32x4 (&vb_next)[NVB]) {
-      const int c2 = c + 2;
+      const int c2 = c + DEPTH;
       long base_a = off.a, base_b = off.b1;
       if (c2 < n_chunks) {
         advance(c2);
       } else {
-        if (c2 == n_chunks) { ka = 0; kb = 0; } else advance(1);
+        if (c2 == n_chunks) { ka = 0; kb = 0; } else advance(c2 - n_chunks);
         if (more_tiles) { base_a = noff.a; base_b = noff.b1; } // (else: a chunk of this tile again, never used)
       }
       issue(va_free, vb_free, Ac + base_a * 8 + ka, Bc + base_b * 8 + kb);
@@ -679,19 +693,36 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
       for (int s = 0; s < NS; ++s) {
         if (s + 1 < NS) load_ops(s + 1, X[(s + 1) & 1], Wr[(s + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        float xs[MB], wsum[NB];
+        if constexpr (M3) {
+          float xs[MB], wsum[NB];
 #pragma unroll
-        for (int a = 0; a < MB; ++a) xs[a] = X[s & 1][a].x + X[s & 1][a].y;
+          for (int a = 0; a < MB; ++a) xs[a] = X[s & 1][a].x + X[s & 1][a].y;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) wsum[b] = Wr[s & 1][b].x + Wr[s & 1][b].y;
+          for (int b = 0; b < NB; ++b) wsum[b] = Wr[s & 1][b].x + Wr[s & 1][b].y;
 #pragma unroll
-        for (int a = 0; a < MB; ++a)
+          for (int a = 0; a < MB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              acc[a][3 * b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].x, X[s & 1][a].x, acc[a][3 * b], 0, 0, 0);
+              acc[a][3 * b + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].y, X[s & 1][a].y, acc[a][3 * b + 1], 0, 0, 0);
+              acc[a][3 * b + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wsum[b], xs[a], acc[a][3 * b + 2], 0, 0, 0);
+            }
+        } else {
+          float W0[NB], W1[NB];
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
-            acc[a][3 * b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].x, X[s & 1][a].x, acc[a][3 * b], 0, 0, 0);
-            acc[a][3 * b + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wr[s & 1][b].y, X[s & 1][a].y, acc[a][3 * b + 1], 0, 0, 0);
-            acc[a][3 * b + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wsum[b], xs[a], acc[a][3 * b + 2], 0, 0, 0);
+            const v2f_t bv = Wr[s & 1][b];
+            W0[b] = w_valid ? (ro ? bv.y : bv.x) : 0.f;
+            W1[b] = w_valid ? (ro ? bv.x : -bv.y) : 0.f;
           }
+#pragma unroll
+          for (int a = 0; a < MB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(W0[b], X[s & 1][a].x, acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[b], X[s & 1][a].y, acc[a][b], 0, 0, 0);
+            }
+        }
       }
       if (c + 1 < n_chunks) {
         fill(va_next, vb_next, (cur ^ 1u) * stage_bytes);
@@ -705,17 +736,33 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
         __syncthreads();
         unsigned lc = lane_c;
         OPAQUE_V(lc);
+        if constexpr (M3) {
 #pragma unroll
-        for (int a = 0; a < MB; ++a)
+          for (int a = 0; a < MB; ++a)
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ ((r & 1) ? c_b0 : 0u) ^ ((r & 2) ? c_b1 : 0u) ^ ((r & 4) ? c_q0 : 0u) ^ ((r & 8) ? c_q1 : 0u);
-              const float t1 = acc[a][3 * b][r], t2 = acc[a][3 * b + 1][r], t3 = acc[a][3 * b + 2][r];
-              if ((int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
-                lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{t1 - t2, t3 - t1 - t2});
-            }
+              for (int r = 0; r < 16; ++r) {
+                const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ ((r & 1) ? c_b0 : 0u) ^ ((r & 2) ? c_b1 : 0u) ^ ((r & 4) ? c_q0 : 0u) ^ ((r & 8) ? c_q1 : 0u);
+                const float t1 = acc[a][3 * b][r], t2 = acc[a][3 * b + 1][r], t3 = acc[a][3 * b + 2][r];
+                if ((int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
+                  lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{t1 - t2, t3 - t1 - t2});
+              }
+        } else {
+#pragma unroll
+          for (int a = 0; a < MB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b0 = 0; b0 < 2; ++b0) {
+                  const int n_loc = b0 + 2 * h + 4 * q;
+                  const unsigned pos = lc ^ c_mb[a] ^ c_nb[b] ^ (b0 ? c_b0 : 0u) ^ ((q & 1) ? c_q0 : 0u) ^ ((q >> 1) ? c_q1 : 0u);
+                  if (n_loc < n_lim && (int)(pos >> ARTN_GEMM_EPI_BITS) == pass)
+                    lds_write8((pos & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u, v2f_t{acc[a][b][4 * q + 2 * b0], acc[a][b][4 * q + 2 * b0 + 1]});
+                }
+        }
         __syncthreads();
         char *Cp = Cb + pass * pass_stride;
         unsigned oll = o_ll ^ ((swz_gemm((unsigned)pass << ARTN_GEMM_EPI_BITS, P) & ((1u << ARTN_GEMM_EPI_BITS) - 1u)) * 8u), ogl = o_gl;
@@ -746,9 +793,9 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
       __syncthreads();
       cur = 0;
     };
-    for (int c = 0; c < n_chunks; c += 2) {
-      step(c, va0, vb0, va1, vb1);     // chunk c came from set 0; chunk c + 1 waits in set 1
-      step(c + 1, va1, vb1, va0, vb0);
+    for (int c = 0; c < n_chunks; c += DEPTH) {
+#pragma unroll
+      for (int q = 0; q < DEPTH; ++q) step(c + q, va[q], vb[q], va[(q + 1) % DEPTH], vb[(q + 1) % DEPTH]);
     }
     off = noff;
   }

@@ -2428,6 +2428,52 @@ static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, v
     return hipErrorInvalidValue;
   }
   const int key = g.mb_log2 * 4 + g.nb_log2;
+  if (g.gather_dim >= 0) { // row gather (artn_contract_gather): fp32, chunks of 2^4
+    if (g.split || g.kc != ARTN_GEMM_KC || g.pitch_log2 != ARTN_GEMM_PITCH_LOG2) return hipErrorInvalidValue;
+#define ARTN_GEMM_LAUNCH_G(MBV, NBV, M3V)                                                            \
+  {                                                                                                  \
+    auto kern = artn_k_gemm<MBV, NBV, false, M3V, false, true>;                                      \
+    if (hipError_t e = ensure_lds<artn_k_gemm<MBV, NBV, false, M3V, false, true>>(lds); e != hipSuccess) return e; \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
+    return hipGetLastError();                                                                        \
+  }
+#define ARTN_GEMM_LAUNCH_DEEP_G(MBV, NBIV)                                                           \
+  {                                                                                                  \
+    auto kern = artn_k_gemm_deep<MBV, 1, 4, NBIV, true>;                                             \
+    if (hipError_t e = ensure_lds<artn_k_gemm_deep<MBV, 1, 4, NBIV, true>>(lds); e != hipSuccess) return e; \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
+    return hipGetLastError();                                                                        \
+  }
+    if (g.m3) {
+      if (g.nb_log2 == 0 && g.wk_log2 == 0 && g.n_ko >= 1 && g.n_ko <= 8 && g.ta_bits == 11 && artn::tuning().gemm_deep) {
+        if (g.mb_log2 == 0 && g.tb_bits == 9) ARTN_GEMM_LAUNCH_DEEP_G(1, 1)
+        if (g.mb_log2 == 1 && g.tb_bits == 10 && artn::tuning().gemm_deep >= 2) ARTN_GEMM_LAUNCH_DEEP_G(2, 2)
+      }
+      switch (key) {
+        case 0: ARTN_GEMM_LAUNCH_G(1, 1, true)
+        case 1: ARTN_GEMM_LAUNCH_G(1, 2, true)
+        case 4: ARTN_GEMM_LAUNCH_G(2, 1, true)
+      }
+      return hipErrorInvalidValue;
+    }
+    if (key == 0 && g.wk_log2 == 0 && g.n_ko >= 1 && g.n_ko <= 8 && g.ta_bits == 11 && g.tb_bits <= 9 && artn::tuning().gemm_deep) {
+      // 4M, 16 columns or fewer: the chunk steps of the sparse executor
+      auto kern = artn_k_gemm_deep<1, 1, 4, 1, true, false>;
+      if (hipError_t e = ensure_lds<artn_k_gemm_deep<1, 1, 4, 1, true, false>>(lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);
+      return hipGetLastError();
+    }
+    switch (key) {
+      case 0: ARTN_GEMM_LAUNCH_G(1, 1, false)
+      case 1: ARTN_GEMM_LAUNCH_G(1, 2, false)
+      case 2: ARTN_GEMM_LAUNCH_G(1, 4, false)
+      case 5: ARTN_GEMM_LAUNCH_G(2, 2, false)
+      case 6: ARTN_GEMM_LAUNCH_G(2, 4, false)
+    }
+#undef ARTN_GEMM_LAUNCH_G
+#undef ARTN_GEMM_LAUNCH_DEEP_G
+    return hipErrorInvalidValue;
+  }
   if (g.kc == ARTN_GEMM_KC_TALL && !g.split) { // 32 x 32 tiles, chunks of 2^6 contracted values
     if (key != 0) return hipErrorInvalidValue;
     if (g.m3) {
@@ -2470,6 +2516,14 @@ static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, v
       case 5: ARTN_GEMM_LAUNCH_BF(2, 2)
     }
     return hipErrorInvalidValue;
+  }
+  if (key == 0 && g.wk_log2 == 0 && g.n_ko >= 1 && g.n_ko <= 8 && g.ta_bits == 11 && g.tb_bits <= 9 &&
+      g.pitch_log2 == ARTN_GEMM_PITCH_LOG2 && g.kc == ARTN_GEMM_KC && artn::tuning().gemm_deep) {
+    // 4M, memory-bound: operand loads two chunks ahead
+    auto kern = artn_k_gemm_deep<1, 1, 4, 1, false, false>;
+    if (hipError_t e = ensure_lds<artn_k_gemm_deep<1, 1, 4, 1, false, false>>(lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);
+    return hipGetLastError();
   }
   switch (key) {
     case 0: ARTN_GEMM_LAUNCH(1, 1)
@@ -2660,6 +2714,23 @@ int artn_contract_gather(const ArtnStepDesc *d, const void *A, const void *B, vo
   std::string err;
   int rc = artn::make_plan(d, p, err, g_ncu, true, 1, label);
   if (rc) return fail(rc, err);
+  if (p.kernel == ARTN_KERNEL_GEMM_MFMA) { // (the kernel's first operand is the caller's B when the plan swapped them)
+    if ((((uintptr_t)B) & 15) != 0) return fail(ARTN_E_UNSUPPORTED, "row gather needs 16-byte aligned operands");
+    const bool sw = p.gemm.swapped != 0;
+    p.gemm.rows_a = sw ? rows_b : rows_a;
+    p.gemm.rows_b = sw ? rows_a : rows_b;
+    p.gemm.src_rows_a = sw ? src_rows_b : src_rows_a;
+    p.gemm.src_rows_b = sw ? src_rows_a : src_rows_b;
+    p.gemm.gather_err = err_flag;
+    if (hipError_t e = launch_gemm(p, A, B, C, (hipStream_t)stream); e != hipSuccess) {
+      const ArtnGemmPlan &g = p.gemm;
+      return fail(ARTN_E_LAUNCH, std::string("row gather on the GEMM kernel (tile 2^") + std::to_string(g.mt) + " x 2^" + std::to_string(g.nt) +
+                                  ", chunk 2^" + std::to_string(g.kc) + ", blocks " + std::to_string(1 << g.mb_log2) + " x " +
+                                  std::to_string(1 << g.nb_log2) + (g.m3 ? ", 3M" : "") + ", lds " + std::to_string(p.info.lds_bytes) +
+                                  ", grid " + std::to_string(p.info.grid) + "): " + hipGetErrorString(e));
+    }
+    return ARTN_OK;
+  }
   p.bits.rows_a = rows_a;
   p.bits.rows_b = rows_b;
   p.bits.src_rows_a = src_rows_a;

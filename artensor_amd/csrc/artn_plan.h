@@ -218,6 +218,7 @@ struct Tuning {
   int bits128 = 1;         // complex128 on the state-streaming kernel: 0 never, 1 fused pairs (+ singles the GEMM declines), 2 singles first
   int gemm_deep = 2;       // GEMM kernel, fp32 3M, one block column per wave: operand loads two chunks ahead (artn_k_gemm_deep); 2: also 64-row waves
   int idle_to_gemm = 1;    // single steps whose state-streaming tile would leave waves idle go to the GEMM kernel
+  int gather_gemm = 2;     // row-gather steps with 7+ contracted bits on the GEMM kernel: 1 when the second operand has 5+ free bits, 2 always, 0 never
   int m3_frag = 96;        // 3M in fused pairs up to this many fragment registers (80: not in 5+6 / 6+5 pairs)
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
@@ -244,6 +245,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
     if (const char *e = getenv("ARTN_M3_FRAG")) x.m3_frag = atoi(e);
+    if (const char *e = getenv("ARTN_GATHER_GEMM")) x.gather_gemm = atoi(e);
     if (const char *e = getenv("ARTN_IDLE_TO_GEMM")) x.idle_to_gemm = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_DEEP")) x.gemm_deep = atoi(e);
     if (const char *e = getenv("ARTN_BITS128")) x.bits128 = atoi(e);
@@ -778,10 +780,11 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
 // (16-byte lanes, runs as long as the low address bits of each operand allow), every wave multiplies
 // its 32-row x 16-column MFMA blocks, accumulators stay in registers across all chunks.
 static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles, bool only_if_preferred,
-                             int use_3m = -1 /* -1: as tuning() says */) {
+                             int use_3m = -1 /* -1: as tuning() says */, int gather_label = -1) {
   if (d->dtype != ARTN_C64 && d->dtype != ARTN_C64_BF16) { p.why_generic = "dtype is not complex64"; return false; }
+  if (gather_label >= 0 && d->dtype != ARTN_C64) { p.why_generic = "row gather: complex64 arithmetic only"; return false; }
   std::vector<Axis> ax;
-  expand_axes(d, ax);
+  expand_axes(d, ax, gather_label);
   std::vector<int> K, M, N, O;
   for (int i = 0; i < (int)ax.size(); ++i) {
     const Axis &a = ax[i];
@@ -883,7 +886,8 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
   // tiles of one 32 x 32 block (closing steps: two big tensors down to a few amplitudes, 2^16 contracted values per
   // tile): the same 16 KiB images hold 2^6 contracted values of 2^5 rows instead of 2^4 of 2^7 -- a quarter of the
   // chunk iterations, each of them a latency chain (loads one chunk ahead), for the same bytes
-  if (!bf16 && mt <= 5 && nt <= 5 && k >= ARTN_GEMM_KC_TALL && (int)Kf.size() <= ARTN_GEMM_KC_TALL && tuning().gemm_tall) {
+  if (!bf16 && mt <= 5 && nt <= 5 && k >= ARTN_GEMM_KC_TALL && (int)Kf.size() <= ARTN_GEMM_KC_TALL && tuning().gemm_tall &&
+      gather_label < 0) { // (no row-gather instantiation of the tall-chunk kernel)
     kc = ARTN_GEMM_KC_TALL;
     pitch = ARTN_GEMM_PITCH_TALL_LOG2;
   }
@@ -1000,7 +1004,7 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
     od.sB1 = a.sB1 >= 0 ? a.sB1 : 0;
     od.sB2 = 0;
     od.sC = a.sC >= 0 ? a.sC : 0;
-    od.log2ext = ilog2_exact(a.ext);
+    od.log2ext = a.gathered ? -1 : ilog2_exact(a.ext); // the gathered axis is decoded the slow way, on its own
     od.pad_ = 0;
     g.n_tiles *= a.ext;
     if (a.sA < 0) a_rereads *= a.ext;
@@ -1015,8 +1019,10 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
       }
     }
     if (g.n_outer >= ARTN_MAX_OUTER) { p.why_generic = "too many outer axes"; return false; }
+    if (a.gathered) g.gather_dim = g.n_outer;
     g.outer[g.n_outer++] = od;
   }
+  if (gather_label >= 0 && g.gather_dim < 0) { p.why_generic = "gathered label is not an outer axis"; return false; }
   // ---- envelope: 16-byte lanes, 32-bit per-lane offsets
   for (int b = 1; b < g.ta_bits; ++b) if (g.a_stride[b] & 1) { p.why_generic = "odd A stride"; return false; }
   for (int b = 1; b < g.tb_bits; ++b) if (g.b_stride[b] & 1) { p.why_generic = "odd B stride"; return false; }
@@ -1373,6 +1379,19 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
     ok = make_gemm128(d, p, n_cu, min_tiles); // complex128: the f64 MFMA GEMM kernel, else the state-streaming one, else strided
   allow_gemm = allow_gemm && allow_bits && gather_label < 0 && tuning().gemm && d->dtype != ARTN_C128 && !ok;
   if (allow_gemm) ok = make_gemm(d, p, n_cu, min_tiles, tuning().gemm < 2);
+  // row gather (artn_contract_gather): chunk steps with 7-8 contracted bits whose second operand brings 5+ free bits run
+  // on the GEMM kernel (3M arithmetic, two workgroups per CU) -- the state-streaming kernel's big-K instantiation runs
+  // one workgroup per CU with 4M chains: 60 against 100+ TFLOP/s on the chunk steps of the n30 x 100 scheme
+  if (!ok && gather_label >= 0 && allow_bits && d->dtype == ARTN_C64 && tuning().gemm && tuning().gather_gemm) {
+    int kk = 0, nn = 0;
+    for (int l = 0; l < d->n_labels; ++l) {
+      if (l == gather_label || d->extent[l] < 2 || ilog2_exact(d->extent[l]) < 0) continue;
+      const int lg = ilog2_exact(d->extent[l]);
+      if (d->stride_a[l] >= 0 && d->stride_b[l] >= 0 && d->stride_c[l] < 0) kk += lg;
+      if (d->stride_a[l] < 0 && d->stride_b[l] >= 0 && d->stride_c[l] >= 0) nn += lg;
+    }
+    if (kk >= 7 && (nn >= 5 || tuning().gather_gemm >= 2)) ok = make_gemm(d, p, n_cu, min_tiles, false, -1, gather_label);
+  }
   if (!ok) ok = allow_bits && (d->dtype != ARTN_C128 || gather_label < 0) && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
   // A state-streaming tile with fewer than four (sub-tile, column block) units leaves waves without work -- and the busy
   // waves of the two workgroups of a CU sit on the same SIMDs: a 6-bit step of the n53 slices with 16 result columns and

@@ -300,7 +300,12 @@ static void run_gemm(const ArtnGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
       int64_t ext = P.outer[d].ext, x;
       if (P.outer[d].log2ext >= 0) { x = r & (ext - 1); r >>= P.outer[d].log2ext; }
       else { x = r % ext; r /= ext; }
-      offA += x * P.outer[d].sA; offB += x * P.outer[d].sB1; offC += x * P.outer[d].sC;
+      int64_t xa = x, xb = x;
+      if (d == P.gather_dim) { // row gather (host pointers here; rows_a belongs to the kernel's first operand)
+        if (P.rows_a) { xa = P.rows_a[x]; if (xa < 0 || xa >= P.src_rows_a) { xa = 0; if (P.gather_err) *P.gather_err = 1; } }
+        if (P.rows_b) { xb = P.rows_b[x]; if (xb < 0 || xb >= P.src_rows_b) { xb = 0; if (P.gather_err) *P.gather_err = 1; } }
+      }
+      offA += xa * P.outer[d].sA; offB += xb * P.outer[d].sB1; offC += x * P.outer[d].sC;
     }
     // accumulators of every (wave, block, lane, register)
     const int NACC = P.m3 ? 3 : 1, NBW = P.m3 ? 32 : 16;
@@ -771,6 +776,14 @@ extern "C" int artn_emulate_gather(const ArtnStepDesc *d, const void *A, const v
   std::string err;
   int rc = artn::make_plan(d, p, err, 256, true, 1, label);
   if (rc) return rc;
+  if (p.kernel == ARTN_KERNEL_GEMM_MFMA) { // (as artn_contract_gather: the kernel's first operand is B when the plan swapped them)
+    const bool sw = p.gemm.swapped != 0;
+    p.gemm.rows_a = sw ? rows_b : rows_a; p.gemm.rows_b = sw ? rows_a : rows_b;
+    p.gemm.src_rows_a = sw ? src_rows_b : src_rows_a; p.gemm.src_rows_b = sw ? src_rows_a : src_rows_b;
+    p.gemm.gather_err = err_flag;
+    run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);
+    return 2;
+  }
   p.bits.rows_a = rows_a; p.bits.rows_b = rows_b;
   p.bits.src_rows_a = src_rows_a; p.bits.src_rows_b = src_rows_b;
   p.bits.gather_err = err_flag;

@@ -345,7 +345,10 @@ def test_contract_gathered():
     index is flagged; a step the tiled kernel cannot take reports None."""
     from artensor_amd.contraction import contract_gathered
     rng = np.random.default_rng(23)
-    for (na, nb, n, free, kb, nn) in [(7, 5, 6, 12, 3, 2), (16, 16, 9, 13, 4, 3), (3, 9, 619, 10, 8, 3), (40, 1, 33, 11, 5, 5)]:
+    # (the last three take the GEMM kernel's row gather: 7-8 contracted bits, 5+ free bits in the second operand -- the chunk
+    #  steps of the n30 x 100 scheme; (4, 4, 6, 4, 7, 7) with the operands swapped inside the plan)
+    for (na, nb, n, free, kb, nn) in [(7, 5, 6, 12, 3, 2), (16, 16, 9, 13, 4, 3), (3, 9, 619, 10, 8, 3), (40, 1, 33, 11, 5, 5),
+                                      (9, 11, 100, 8, 8, 6), (6, 3, 37, 9, 7, 5), (4, 4, 6, 4, 7, 7)]:
         la = ["z"] + [chr(65 + x) for x in range(free + kb)]
         kl = la[1:1 + kb]
         nl = [chr(97 + x) for x in range(nn)]
@@ -381,6 +384,17 @@ def test_contract_gathered():
     assert rel(got.cpu().numpy(), want) < STEP_TOL
     assert contract_gathered("zab,zbc->zac", gpu(crandn(rng, (4, 2, 2))), torch.tensor([0, 1]),
                              gpu(crandn(rng, (4, 2, 2))), torch.tensor([1, 1])) is None
+    # the same edge cases on the GEMM kernel's gather (8 contracted bits, 5 free bits in the second operand)
+    eq_g = "zABCDEFGHIJKLMNOP,zPONMLKJIabcde->zABCDEFGHabcde"
+    a_np, b_np = crandn(rng, (7,) + (2,) * 16), crandn(rng, (5,) + (2,) * 13)
+    neg, rb = torch.tensor([-1, 0, -7, 3, 2]), torch.tensor([4, -5, 0, 2, -1])
+    got = contract_gathered(eq_g, gpu(a_np), neg, gpu(b_np), rb)
+    want = oracle.einsum_pair(eq_g, a_np[neg.numpy()], b_np[rb.numpy()])
+    assert rel(got.cpu().numpy(), want) < STEP_TOL
+    contract_gathered(eq_g, gpu(a_np), torch.tensor([0, 99, 1]), gpu(b_np), torch.tensor([0, 1, 2]), _validate=False)
+    with pytest.raises(RuntimeError, match="outside its operand"):
+        A.contraction.check_gather_flag("test")
+    A.contraction.check_gather_flag()
 
 
 def test_gather_axpy_normalize():
