@@ -194,6 +194,7 @@ struct ArtnPlan {
   ArtnGemmPlan gemm;
   ArtnGenericPlan gen;
   ArtnStepInfo info;
+  int64_t stage1_repeats = 1; // fused pairs: visits of one input tile = values of the second step's result bits outside the tile
   std::string why_generic;
 };
 
@@ -219,6 +220,9 @@ struct Tuning {
   int gemm_deep = 2;       // GEMM kernel, fp32 3M, one block column per wave: operand loads two chunks ahead (artn_k_gemm_deep); 2: also 64-row waves
   int idle_to_gemm = 1;    // single steps whose state-streaming tile would leave waves idle go to the GEMM kernel
   int gather_gemm = 2;     // row-gather steps with 7+ contracted bits on the GEMM kernel: 1 when the second operand has 5+ free bits, 2 always, 0 never
+  int fuse_max_rereads = 4;   // fused pairs: how often the first stage may be repeated per input tile (second-step result bits outside the
+                              // tile).  Measured (tools/ab_env.sh, ms per slice, limit none / 8 / 4 / 2): n53 m20 76.0 / 76.4 / 75.0 / 75.1;
+                              // n53, rand2, rand4, n30 x 10 000 within noise
   int m3_frag = 96;        // 3M in fused pairs up to this many fragment registers (80: not in 5+6 / 6+5 pairs)
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
@@ -245,6 +249,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
     if (const char *e = getenv("ARTN_M3_FRAG")) x.m3_frag = atoi(e);
+    if (const char *e = getenv("ARTN_FUSE_MAX_REREADS")) x.fuse_max_rereads = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_GATHER_GEMM")) x.gather_gemm = atoi(e);
     if (const char *e = getenv("ARTN_IDLE_TO_GEMM")) x.idle_to_gemm = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_DEEP")) x.gemm_deep = atoi(e);
@@ -663,7 +668,8 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   // ---- outer axes: N-outer fastest (tiles sharing an A tile run together), then M-outer by A
   //      stride, then batch / generic axes
   std::vector<int> outer;
-  for (int i : N2) if (!in_set(N2t, i)) outer.push_back(i);
+  p.stage1_repeats = 1;
+  for (int i : N2) if (!in_set(N2t, i)) { outer.push_back(i); p.stage1_repeats *= ax[i].ext; }
   for (int i : N1) if (!in_set(N1t, i)) outer.push_back(i);
   for (int i : M1) if (!in_set(Mt, i)) outer.push_back(i);
   std::sort(O.begin(), O.end(), [&](int x, int y) {
@@ -1445,6 +1451,9 @@ static inline int make_plan_fused(const ArtnStepDesc *d1, const ArtnStepDesc *d2
   memset(&p.info, 0, sizeof(p.info));
   p.n_cu = n_cu;
   if (!make_bits(d1, d2, p, n_cu, min_tiles)) { err = "not fusable: " + p.why_generic; return ARTN_E_UNSUPPORTED; }
+  // a fused pair whose second step has result bits outside the tile visits every input tile once per value of those
+  // bits -- and runs its FIRST stage again each time
+  if (p.stage1_repeats > tuning().fuse_max_rereads) { err = "not fusable: the first stage would run " + std::to_string(p.stage1_repeats) + " times per input tile"; return ARTN_E_UNSUPPORTED; }
   double f1, f2, a1, b1, c1, a2, b2, c2;
   step_cost(d1, f1, a1, b1, c1);
   step_cost(d2, f2, a2, b2, c2);

@@ -54,7 +54,8 @@ def kernel_source_sha16():
     counters were collected on (tools/summarize_profile.py)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("artn_kernels.hip", "artn_gemm_kernel.h", "artn_gemm128_kernel.h", "artn_pgemm_kernel.h", "artn_plan.h"):
+    for name in ("artn_kernels.hip", "artn_gemm_kernel.h", "artn_gemm128_kernel.h", "artn_bits128_kernel.h", "artn_pgemm_kernel.h",
+                 "artn_plan.h"):
         with open(os.path.join(ROOT, "artensor_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -121,7 +122,10 @@ def roofline_of(ks, gpu_ms, launches_div=1, f64_peak=None):
     ai = d["flops"] / d["bytes"] if d["bytes"] else float("inf")
     ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
     mfma_bound = ai >= ridge
-    r = {"bound": "mfma" if mfma_bound else "hbm", "kernel": KERNEL_NAMES.get(kid, str(kid)),
+    kname = KERNEL_NAMES.get(kid, str(kid))
+    if f64:   # (complex128 runs on its own kernels behind the same planner ids)
+        kname = {1: "artn_k_bits128", 2: "artn_k_gemm128"}.get(kid, kname)
+    r = {"bound": "mfma" if mfma_bound else "hbm", "kernel": kname,
          "achieved": tf if mfma_bound else gbs, "peak": peak if mfma_bound else HBM_PEAK_GBS,
          "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": (tf / peak) if mfma_bound else gbs / HBM_PEAK_GBS,
          "traffic": None, "arithmetic": "bf16 operands, fp32 accumulate" if bf16 else ("f64 MFMA (peak = measured back-to-back v_mfma_f64_16x16x4_f64 rate)" if f64 else "fp32 MFMA"),
@@ -364,9 +368,9 @@ def leg_sparse_whole(A, dev, steps, precision):
 
 
 def leg_n30_c128(A, dev):
-    """The headline scheme in complex128 (the reference takes any dtype, simulation.py:90): every big step is one pass of
-    artn_k_gemm128 on v_mfma_f64_16x16x4_f64 (no fused pairs, no state-streaming variant), the small ones run on the
-    strided kernel.  Priced against the f64 MFMA rate measured on this device."""
+    """The headline scheme in complex128 (the reference takes any dtype, simulation.py:90): the 13 fused pairs run on
+    artn_k_bits128 (state-streaming, v_mfma_f64_16x16x4_f64 stages, the intermediate stays in LDS), the growth steps on
+    artn_k_gemm128, the small ones on the strided kernel.  Priced against the f64 MFMA rate measured on this device."""
     from artensor_amd import contraction as C
     from artensor_amd.fixtures import load_case
     case = load_case(os.path.join(ROOT, "tests", "golden", "n30_dense.npz"))
