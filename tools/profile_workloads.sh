@@ -22,6 +22,11 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/n53m2
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY \
   --kernel-trace --output-format csv -d $OUT/n53m20b_bf16_pmc -- python3 bench.py --workload n53m20b --precision bf16 --slices 1 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/n53m20b_bf16_pmc.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/n53m20b_bf16_clk -- python3 bench.py --workload n53m20b --precision bf16 --slices 1 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/n53m20b_bf16_clk.log 2>&1
+# the headline scheme in complex128 (artn_k_bits128 pairs + artn_k_gemm128): kernel statistics and matrix-core counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/n30_c128 -- python3 tools/trace_c128.py 3 > $OUT/n30_c128.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY \
+  --kernel-trace --output-format csv -d $OUT/n30_c128_pmc -- python3 tools/trace_c128.py 1 > $OUT/n30_c128_pmc.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/n30_c128_clk -- python3 tools/trace_c128.py 1 > $OUT/n30_c128_clk.log 2>&1
 for t in n30_sparse10000 n30_sparse100; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$t -- python3 tools/trace_sparse.py $t > $OUT/$t.log 2>&1
 done

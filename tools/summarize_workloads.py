@@ -7,8 +7,8 @@ root = os.path.join(ROOT, "gpurun_out", f"profw_{R}")
 md = [f"# rocprofv3 kernel statistics of the secondary workloads, round {R}", "",
       f"`tools/profile_workloads.sh {R}` on one MI355X: `rocprofv3 --kernel-trace --stats` around",
       "`bench.py --workload W --slices 4 --steps 2 --warmup 1` (13 slices incl. warm-up and check) and around",
-      "`tools/trace_sparse.py` (3 runs of the n30 sparse fixtures).", ""]
-for w in ("n53", "n53m20", "n53m20b", "n53m20b_bf16", "rand2", "rand4", "n30_sparse10000", "n30_sparse100"):
+      "`tools/trace_sparse.py` (3 runs of the n30 sparse fixtures) and `tools/trace_c128.py` (3 runs of the n30 dense fixture in complex128).", ""]
+for w in ("n53", "n53m20", "n53m20b", "n53m20b_bf16", "rand2", "rand4", "n30_sparse10000", "n30_sparse100", "n30_c128"):
     fs = sorted(glob.glob(f"{root}/{w}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
     if not fs:
         continue
@@ -77,6 +77,33 @@ if pm:
         mf = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for d in sb)
         md += ["## artn_k_pgemm on the n53 m20 big-batch slice (15 contracted bits, bf16 operands packed once, LDS-DMA): PMC counters", "",
                f"* launches counted: {len(sb)}, {dur / len(sb) * 1e3:.1f} ms each (1.407e14 real FLOP: {1.407e14 / (dur / len(sb)) / 1e12:.0f} TFLOP/s)",
+               f"* SQ_VALU_MFMA_BUSY_CYCLES / (duration x 1024 SIMDs x clock): {mf / (dur * 1024 * (clk or 2.1e9)):.3f} (clock {clk / 1e9:.2f} GHz from GRBM_GUI_ACTIVE)",
+               f"* SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: {sum(d.get('SQ_LDS_BANK_CONFLICT', 0) for d in sb) / max(sum(d.get('SQ_LDS_IDX_ACTIVE', 0) for d in sb), 1):.3f}",
+               f"* SQ_WAIT_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}",
+               f"* SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_INST_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}", ""]
+# the complex128 state-streaming kernel: matrix-core counters of its big launches
+pm = glob.glob(f"{root}/n30_c128_pmc/**/*_counter_collection.csv", recursive=True)
+ck = glob.glob(f"{root}/n30_c128_clk/**/*_counter_collection.csv", recursive=True)
+if pm:
+    def load3(f):
+        per = collections.OrderedDict()
+        for r in csv.DictReader(open(f)):
+            if "artn_k_bits128" not in r["Kernel_Name"]:
+                continue
+            d = per.setdefault(r["Dispatch_Id"], {"t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        return [d for d in per.values() if d["t1"] - d["t0"] > 2e6]
+    sb = load3(pm[0])
+    clk = 0.0
+    if ck:
+        cb = load3(ck[0])
+        if cb:
+            clk = sum(d.get("GRBM_GUI_ACTIVE", 0) for d in cb) / 8 / (sum(d["t1"] - d["t0"] for d in cb) * 1e-9)
+    if sb:
+        dur = sum(d["t1"] - d["t0"] for d in sb) * 1e-9
+        mf = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for d in sb)
+        md += ["## artn_k_bits128 on the n30 contraction in complex128 (fused pairs, v_mfma_f64_16x16x4_f64): PMC counters", "",
+               f"* launches counted: {len(sb)} (longer than 2 ms), {dur * 1e3:.1f} ms together",
                f"* SQ_VALU_MFMA_BUSY_CYCLES / (duration x 1024 SIMDs x clock): {mf / (dur * 1024 * (clk or 2.1e9)):.3f} (clock {clk / 1e9:.2f} GHz from GRBM_GUI_ACTIVE)",
                f"* SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: {sum(d.get('SQ_LDS_BANK_CONFLICT', 0) for d in sb) / max(sum(d.get('SQ_LDS_IDX_ACTIVE', 0) for d in sb), 1):.3f}",
                f"* SQ_WAIT_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}",
