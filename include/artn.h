@@ -121,7 +121,9 @@ int artn_contract_ws(const ArtnStepDesc *d, const void *A, const void *B, void *
  * Replaces `tensors[i][batch_i[k]]`, `tensors[j][batch_j[k]]` followed by the batched einsum of
  * artensor/contraction.py:149-156 and :177-179 without materialising the gathered operands.
  * Out-of-range indices read row 0 and set *err_flag (if non-NULL).  Returns ARTN_E_UNSUPPORTED
- * when the step does not fit the tiled kernel; callers then gather with artn_gather_rows.
+ * when the step does not fit a tiled kernel; callers then gather with artn_gather_rows.
+ * (complex64 only.  Steps with 7+ contracted bits run on the two-operand GEMM kernel, the others on the
+ * state-streaming kernel; both resolve the rows inside their tile-offset computation.)
  */
 int artn_contract_gather(const ArtnStepDesc *d, const void *A, const void *B, void *C, int label,
                          const int64_t *rows_a, int64_t src_rows_a, const int64_t *rows_b, int64_t src_rows_b,
@@ -136,6 +138,8 @@ int artn_contract_gather(const ArtnStepDesc *d, const void *A, const void *B, vo
  * never written to memory: the second contraction runs on the tile while it is in LDS.
  * artn_contract2_query / artn_contract2 return ARTN_E_UNSUPPORTED when the pair does not
  * fit one LDS tile (artn_last_error() says why); callers then issue two artn_contract.
+ * complex64 (fp32 MFMA; bf16 operands under ARTN_C64_BF16) and complex128 (f64 MFMA, tiles of half as
+ * many elements); both descriptors must name the same dtype.
  */
 int artn_contract2_query(const ArtnStepDesc *d1, const ArtnStepDesc *d2, ArtnStepInfo *info);
 int artn_contract2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A, const void *B1,
