@@ -472,6 +472,23 @@ def test_sparse_schemes(name):
         assert (np.abs(out - g) / np.abs(g)).max() < 1e-3
 
 
+@pytest.mark.parametrize("name", ["n12_sparse5", "n30_sparse100"])
+def test_sparse_schemes_in_complex128(name):
+    """The sparse executor with complex128 leaves (reference simulation.py:90 takes any dtype): fused pairs on
+    artn_k_bits128, single steps on artn_k_gemm128 / the strided kernel, gathers through artn_gather_rows (the fused
+    row gather is complex64 only).  Against the reference's own complex128 run of the same scheme (c128_spread.npz)
+    and, for n30 x 100 bitstrings, the truth computed in round 3 with un-fused complex128 GEMM passes."""
+    case = load_case(os.path.join(GOLDEN, name + ".npz"))
+    out = A.tensor_contraction_sparse(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme).cpu().numpy()
+    assert out.dtype == np.complex128 and out.shape == case.arrays["final"].shape
+    meta, arrays = c128_spread()
+    want = arrays[name + "_c128"].reshape(out.shape)
+    assert np.abs(out - want).max() <= 1e-11 * np.abs(want).max()
+    if name == "n30_sparse100":
+        t = gpu_truth("n30_sparse100_final")
+        assert np.abs(out.reshape(-1) - t).max() <= 1e-11 * np.abs(t).max()
+
+
 def test_small_step_program(monkeypatch):
     """The launch-latency tail of a dense scheme as ONE launch (artn_program_*): n12 is 68 tiny steps and
     nothing else; with the program switched off the same scheme goes step by step through artn_contract.
