@@ -223,6 +223,7 @@ struct Tuning {
   int fuse_max_rereads = 4;   // fused pairs: how often the first stage may be repeated per input tile (second-step result bits outside the
                               // tile).  Measured (tools/ab_env.sh, ms per slice, limit none / 8 / 4 / 2): n53 m20 76.0 / 76.4 / 75.0 / 75.1;
                               // n53, rand2, rand4, n30 x 10 000 within noise
+  int grow_nt = 1;         // single growth steps: result bits beyond the contracted count taken into the tile (0 or 1)
   int m3_frag = 96;        // 3M in fused pairs up to this many fragment registers (80: not in 5+6 / 6+5 pairs)
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
@@ -249,6 +250,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
     if (const char *e = getenv("ARTN_M3_FRAG")) x.m3_frag = atoi(e);
+    if (const char *e = getenv("ARTN_GROW_NT")) x.grow_nt = atoi(e) != 0;
     if (const char *e = getenv("ARTN_FUSE_MAX_REREADS")) x.fuse_max_rereads = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_GATHER_GEMM")) x.gather_gemm = atoi(e);
     if (const char *e = getenv("ARTN_IDLE_TO_GEMM")) x.idle_to_gemm = atoi(e) != 0;
@@ -520,7 +522,10 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
       if (ax[i].sC < rout) N2t.push_back(i);
     // grow N tiles towards full 16-column MFMA tiles (lowest result positions first)
     const int n_cap = c128 ? 5 : 6, n_lo = c128 ? 3 : 4;
-    int n1_target = std::min(n1, std::min(n_cap, std::max(std::min(k1, n_cap), n_lo)));
+    // (grow_nt: a single step that doubles its tensor takes one more result bit into the tile -- a 2^11-element input
+    //  tile for a 2^12-element output tile, every input tile read once -- instead of visiting every input tile twice)
+    const int grow = (!fused && n1 > k1) ? tuning().grow_nt : 0;
+    int n1_target = std::min(n1, std::min(n_cap, std::max(std::min(k1 + grow, n_cap), n_lo)));
     for (int i : N1) { if ((int)N1t.size() >= n1_target) break; if (!in_set(N1t, i)) N1t.push_back(i); }
     int n2_target = std::min(n2, std::min(n_cap, std::max(k2, n_lo)));
     for (int i : N2) { if ((int)N2t.size() >= n2_target) break; if (!in_set(N2t, i)) N2t.push_back(i); }
