@@ -48,7 +48,8 @@ def test_n30_big_steps_surrogates():
 
 
 @pytest.mark.parametrize("k,n,ra", [(1, 1, 12), (2, 0, 13), (3, 3, 14), (4, 4, 15), (5, 5, 15), (6, 6, 16),
-                                    (4, 7, 13), (6, 2, 16), (1, 6, 12), (5, 1, 14), (7, 3, 15), (8, 4, 15), (7, 6, 16), (8, 0, 14)])
+                                    (4, 7, 13), (6, 2, 16), (1, 6, 12), (5, 1, 14), (7, 3, 15), (8, 4, 15), (7, 6, 16), (8, 0, 14),
+                                    (6, 7, 16), (6, 8, 15), (5, 6, 15)])   # (growth steps: 7 / 6 result bits in the tile)
 def test_random_bit_steps(k, n, ra):
     """Random bit permutations: K and N bits scattered, output order scrambled."""
     rng = np.random.default_rng(100 * k + n)
