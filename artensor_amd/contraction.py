@@ -339,8 +339,13 @@ def contract(eq, a, b, out=None):
         n_rows = 1
         for e in a.shape[:n_outer]:
             n_rows *= e
-        if out is None and _sum_leading_ok(a, n_rows):   # the temporary label leads: a plain column sum
-            return sum_leading(a, n_rows).reshape(a.shape[n_outer:])
+        if _sum_leading_ok(a, n_rows):   # the temporary label leads: a plain column sum
+            if out is None:
+                return sum_leading(a, n_rows).reshape(a.shape[n_outer:])
+            if out.is_contiguous() and out.dtype == a.dtype and tuple(out.shape) == tuple(a.shape[n_outer:]):
+                # (with out=: the chunk loop of the sparse executor in complex128 -- the sum went to the strided kernel)
+                sum_leading(a, n_rows, out=out.reshape(-1))
+                return out
     if a.dtype != b.dtype or a.dtype not in _DTYPES:
         raise RuntimeError(f"operands must both be complex64 or complex128, got {a.dtype} and {b.dtype}")
     if a.device != b.device:
