@@ -224,6 +224,7 @@ struct Tuning {
                               // tile).  Measured (tools/ab_env.sh, ms per slice, limit none / 8 / 4 / 2): n53 m20 76.0 / 76.4 / 75.0 / 75.1;
                               // n53, rand2, rand4, n30 x 10 000 within noise
   int grow_nt = 1;         // single growth steps: result bits beyond the contracted count taken into the tile (0 or 1)
+  int fuse_66 = 0;         // fused pairs of two 6-bit steps (complex64): 1 allows them
   int m3_frag = 96;        // 3M in fused pairs up to this many fragment registers (80: not in 5+6 / 6+5 pairs)
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
@@ -250,6 +251,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_TALL")) x.gemm_tall = atoi(e) != 0;
     if (const char *e = getenv("ARTN_M3_FRAG")) x.m3_frag = atoi(e);
+    if (const char *e = getenv("ARTN_FUSE_66")) x.fuse_66 = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GROW_NT")) x.grow_nt = atoi(e) != 0;
     if (const char *e = getenv("ARTN_FUSE_MAX_REREADS")) x.fuse_max_rereads = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_GATHER_GEMM")) x.gather_gemm = atoi(e);
@@ -1458,6 +1460,9 @@ static inline int make_plan_fused(const ArtnStepDesc *d1, const ArtnStepDesc *d2
   if (!make_bits(d1, d2, p, n_cu, min_tiles)) { err = "not fusable: " + p.why_generic; return ARTN_E_UNSUPPORTED; }
   // a fused pair whose second step has result bits outside the tile visits every input tile once per value of those
   // bits -- and runs its FIRST stage again each time
+  // 6 + 6 contracted bits: 128 fragment registers next to the accumulators -- the pair runs four-product chains with 480 bytes of
+  // scratch per lane (65 TFLOP/s); two single 3M steps are faster although they move the tensor twice
+  if (p.bits.st[0].k == 6 && p.bits.st[1].k == 6 && !p.bits.c128 && !tuning().fuse_66) { err = "not fusable: 6 + 6 contracted bits spill"; return ARTN_E_UNSUPPORTED; }
   if (p.stage1_repeats > tuning().fuse_max_rereads) { err = "not fusable: the first stage would run " + std::to_string(p.stage1_repeats) + " times per input tile"; return ARTN_E_UNSUPPORTED; }
   double f1, f2, a1, b1, c1, a2, b2, c2;
   step_cost(d1, f1, a1, b1, c1);
