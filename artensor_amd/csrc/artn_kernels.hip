@@ -402,6 +402,8 @@ struct StageConst {
   unsigned msub_tab;                  // LDS byte address of the table: sub-tile -> (input, output) byte offsets
   unsigned mo0x, mo0y, mo1x, mo1y;    // the table entries of this wave's first two sub-tiles (wm, wm + wm_count): the first
                                       // operand reads of a stage do not wait for a table read
+  unsigned hin, hout;                 // 3M on 16 x 16 x 4 blocks (4-bit stages of the 3M instantiations): byte offsets of column
+                                      // bit 4 of a 32-column sub-tile (its two 16-column halves) in the input / output tile
   int ksplit_wave;                    // >= 0: the waves split the chain of a big-K tile; this wave's share
   unsigned ksplit_scratch;            // LDS byte address of the 3 x 4 KiB partial blocks
 #if defined(ARTN_PHASES)
@@ -486,6 +488,41 @@ __device__ __forceinline__ StageConst<KB> stage_const(const ArtnStage &st, const
   L.o3 = st.nt > 3 ? swz(8u << st.n_out_pos[3], &st) : 0;
   L.o1 = st.nt > 1 ? swz(8u << st.n_out_pos[1], &st) : 0;
   L.o4 = st.nt > 4 ? swz(8u << st.n_out_pos[4], &st) : 0;
+  L.hin = L.hout = 0;
+  if constexpr (M3 && KB >= 2 && KB <= 4) {
+    // 2- to 4-bit stage of a 3M instantiation: blocks of 16 complex columns n x 16 tile columns m x 4 contracted values on
+    // v_mfma_f32_16x16x4_f32 (A[l & 15][l >> 4], B[l >> 4][l & 15]; D: column l & 15, rows 4 (l >> 4) + r): lane (jj, g) reads
+    // x[kc = 4 s + g][m = 16 half + jj], the W lane (n, g) holds w[kc = 4 s + g][n], accumulator register r is column
+    // n = 4 g + r; three products per complex product as in the 32-column stages, a quarter fewer MFMA cycles than 4M
+    const int ln = j | (h << 5), jj = ln & 15, g = ln >> 4;
+    unsigned li = ((unsigned)(g & 1) << (st.k_in_pos[0] + 3)) + ((unsigned)(g >> 1) << (st.k_in_pos[1] + 3)), lo = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if ((jj >> b) & 1) {
+        li += 8u << st.lane_in_pos[b];
+        lo += 8u << st.lane_out_pos[b];
+      }
+    }
+    if (st.nt > 2) lo += (unsigned)(g & 1) << (st.n_out_pos[2] + 3);
+    if (st.nt > 3) lo += (unsigned)(g >> 1) << (st.n_out_pos[3] + 3);
+    long lb = (long)(g & 1) * st.k_b_stride[0] * 8 + (long)(g >> 1) * st.k_b_stride[1] * 8;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b < L.nt_eff && ((jj >> b) & 1)) lb += st.n_b_stride[b] * 8;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (b < st.wn_log2 && ((wn >> b) & 1)) {
+        lo += 8u << st.n_out_pos[4 + b];
+        lb += st.n_b_stride[4 + b] * 8;
+      }
+    }
+    L.w_valid = (jj >> L.nt_eff) == 0;
+    L.lane_in = li;
+    L.lane_out = lo;
+    L.lane_b = lb;
+    L.hin = swz(8u << st.lane_in_pos[4], zin);
+    L.hout = swz(8u << st.lane_out_pos[4], &st);
+  }
   // region bases are multiples of the region size: XOR-ing them in equals adding them
   L.lane_in = swz(L.lane_in, zin) ^ in_base;
   L.lane_out = swz(L.lane_out, &st) ^ out_base;
@@ -559,6 +596,30 @@ __device__ __forceinline__ void load_w3(float (&W0)[1 << (KB - 1)], float (&W1)[
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// 2- to 4-bit stage of a 3M instantiation (16 x 16 x 4 blocks): W0[s] / W1[s] = re / im of w[kc = 4 s + g][n = lane & 15],
+// s < 2^(KB - 2)
+template <int KB>
+__device__ __forceinline__ void load_w4m3(float (&W0)[1 << (KB - 1)], float (&W1)[1 << (KB - 1)], const char *__restrict__ Bbase,
+                                          const StageConst<KB> &L) {
+  static_assert(KB >= 2 && KB <= 4, "16 x 16 x 4 blocks: 2- to 4-bit stages");
+  constexpr int NST = 1 << (KB - 2);
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+    long ko = 0;
+#pragma unroll
+    for (int b = 2; b < KB; ++b)
+      if ((s >> (b - 2)) & 1) ko += L.kb[b];
+    float2 bv = make_float2(0.f, 0.f);
+    if (L.w_valid) bv = *reinterpret_cast<const float2 *>(Bbase + ko + L.lane_b);
+    W0[s] = bv.x;
+    W1[s] = bv.y;
+  }
+#pragma unroll
+  for (int s = NST; s < (1 << (KB - 1)); ++s) { W0[s] = 0.f; W1[s] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < NST; ++s) asm volatile("" : "+v"(W0[s]), "+v"(W1[s])); // see load_w
+}
+
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) { // RNE, a in the low half
   v2f_t v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
@@ -654,6 +715,8 @@ struct StageRun {
   static constexpr int WSD = SPLIT ? (BIGK ? 4 : NP) : 1;
   static_assert(!(BIGK && NP > 1), "the 7-8 bit kernel has no three-piece split");
   static constexpr bool CAN3M = M3 && (KB == 5 || KB == 6) && !BIGK && NP == 0;
+  static constexpr bool K4M3 = M3 && KB >= 2 && KB <= 4 && !BIGK && NP == 0; // 3M on 16 x 16 x 4 blocks (stage_const)
+  static constexpr int NST4 = KB >= 2 && KB <= 4 ? 1 << (KB - 2) : 1;         // ... chain steps of 4 contracted values
   const StageConst<KB> &L;
   float (&W0)[S];
   float (&W1)[S];
@@ -1003,9 +1066,85 @@ struct StageRun {
     }
   }
 
+  // 2- to 4-bit stage of a 3M instantiation: per 32-column sub-tile two halves of 16 columns x 2^(KB - 2) chain steps x 3
+  // products on v_mfma_f32_16x16x4_f32 (4 bits: 24 MFMAs of 32 cycles = 768 cycles; the 4M chain: 16 of 64 = 1 024); the
+  // operands of the next sub-tile are read under the MFMAs of this one
+  __device__ __forceinline__ void run4() const {
+    int msub = L.wm;
+    if (msub >= L.msubs) return;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    v2f_t x[2][2][NST4]; // [buffer][half][step]
+    auto kx = [&](int s) {
+      unsigned k = 0;
+#pragma unroll
+      for (int b = 2; b < KB; ++b)
+        if ((s >> (b - 2)) & 1) k ^= L.kin[b];
+      return k;
+    };
+    auto load = [&](v2f_t (&b)[2][NST4], unsigned li) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int s = 0; s < NST4; ++s) b[hf][s] = lds_read8(li ^ (hf ? L.hin : 0u) ^ kx(s));
+    };
+    const int g = lane >> 4;
+    u2_t mo = u2_t{L.mo0x, L.mo0y};
+    load(x[0], L.lane_in ^ mo.x);
+    bool first = true;
+    auto body = [&](v2f_t (&cur)[2][NST4], v2f_t (&nxt)[2][NST4]) -> bool {
+      const unsigned lo = L.lane_out ^ mo.y;
+      const int nmsub = msub + L.wm_count;
+      const bool more = nmsub < L.msubs;
+      u2_t mo_n = mo;
+      if (more) mo_n = first ? u2_t{L.mo1x, L.mo1y} : lds_read_u2(L.msub_tab + nmsub * 8);
+      first = false;
+      if (more) load(nxt, L.lane_in ^ mo_n.x);
+      f32x4_t t[2][3];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t[hf][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NST4; ++s) {
+        const float ws = W0[s] + W1[s];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const float xs = cur[hf][s].x + cur[hf][s].y;
+#ifdef ARTN_ABLATE_MFMA
+          asm volatile("" ::"v"(cur[hf][s].x), "v"(cur[hf][s].y), "v"(xs), "v"(W0[s]), "v"(W1[s]), "v"(ws));
+#else
+          t[hf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W0[s], cur[hf][s].x, t[hf][0], 0, 0, 0);
+          t[hf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1[s], cur[hf][s].y, t[hf][1], 0, 0, 0);
+          t[hf][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws, xs, t[hf][2], 0, 0, 0);
+#endif
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned o = lo ^ (hf ? L.hout : 0u) ^ ((r & 1) ? L.o0 : 0u) ^ ((r & 2) ? L.o1 : 0u);
+          if (L.nt_eff == 4 || ((4 * g + r) >> L.nt_eff) == 0)
+            lds_write8(o, v2f_t{t[hf][0][r] - t[hf][1][r], t[hf][2][r] - t[hf][0][r] - t[hf][1][r]});
+        }
+      if (!more) return false;
+      msub = nmsub;
+      mo = mo_n;
+      return true;
+    };
+    for (;;) {
+      if (!body(x[0], x[1])) return;
+      if (!body(x[1], x[0])) return;
+    }
+  }
+
   __device__ __forceinline__ void run() const {
     if constexpr (CAN3M) {
       run3();
+      return;
+    }
+    if constexpr (K4M3) {
+      run4();
       return;
     }
     if constexpr (BIGK) { // 7 or 8 contracted bits: only instantiated for the single-stage KB = 6 kernel
@@ -1236,6 +1375,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       if constexpr (SP1 && BIGK) load_w_plane<KB1>(WS1[0], Bb + kb0, L1, ro);
       else if constexpr (SP1) load_w_split<KB1, (SP1 ? NP : 1)>(WS1, Bb, L1, ro);
       else if constexpr (C31) load_w3<KB1>(W10, W11, W12, Bb, L1);
+      else if constexpr (M3 && KB1 >= 2 && KB1 <= 4 && !BIGK && NP == 0) load_w4m3<KB1>(W10, W11, Bb, L1);
       else load_w<KB1>(W10, W11, Bb + kb0, L1, ro);
       if constexpr (BIGK) { // fragments of the looped-over contracted bits' values 1..3
 #pragma unroll
@@ -1256,6 +1396,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       prev_b2 = off.b2;
       if constexpr (SP2) load_w_split<KB2e, (SP2 ? NP : 1)>(WS2, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
       else if constexpr (C32) load_w3<KB2e>(W20, W21, W22, reinterpret_cast<const char *>(B2 + off.b2), L2);
+      else if constexpr (M3 && KB2 >= 2 && KB2 <= 4 && NP == 0) load_w4m3<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + off.b2), L2);
       else load_w<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
     }
     const long next = tile + G, next2 = tile + 2 * G;
@@ -1482,11 +1623,13 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
         prev_b1 = coff.b1;
         const char *Bb = reinterpret_cast<const char *>(B1 + coff.b1);
         if constexpr (C31) load_w3<KB1>(W10, W11, W12, Bb, L1);
+        else if constexpr (M3 && KB1 >= 2 && KB1 <= 4) load_w4m3<KB1>(W10, W11, Bb, L1);
         else load_w<KB1>(W10, W11, Bb, L1, ro);
       }
       if (KB2 > 0 && coff.b2 != prev_b2) {
         prev_b2 = coff.b2;
         if constexpr (C32) load_w3<KB2e>(W20, W21, W22, reinterpret_cast<const char *>(B2 + coff.b2), L2);
+        else if constexpr (M3 && KB2 >= 2 && KB2 <= 4) load_w4m3<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + coff.b2), L2);
         else load_w<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + coff.b2), L2, ro);
       }
 #if defined(ARTN_PHASES)

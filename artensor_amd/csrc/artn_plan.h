@@ -60,7 +60,8 @@ struct ArtnStage {
   // position 1..3 so the group spreads over the banks (at most 2-way conflicts remain).
   int32_t swz_n, swz_src[4], swz_dst[4]; // (complex128: units of 16 bytes, targets 0..3, up to four entries)
   int32_t m3; // 1: three real products per complex product (5 contracted bits, 32+ columns: a wave owns 32-column
-              // sub-tiles; wn_log2 = nt - 5; lane half h carries column bit 2)
+              // sub-tiles; wn_log2 = nt - 5; lane half h carries column bit 2); 2: the 4-bit stage of such a launch, on
+              // 16 x 16 x 4 blocks (lane group l >> 4 carries contracted bits 0, 1 and column bits 2, 3)
 };
 
 // Launch plan of the LDS-tiled bit-permuted complex GEMM (kernel argument, POD).
@@ -670,6 +671,11 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     if (!b.m3)
       for (int q = 0; q < b.n_stages; ++q)
         if (b.st[q].m3) { b.st[q].m3 = 0; b.st[q].wn_log2 = std::max(0, b.st[q].nt - 4); } // (never complex128: no 3M there)
+    // the 2- to 4-bit stage of a 3M pair runs three products too, on 16 x 16 x 4 blocks (ArtnStage::m3 = 2: the M3 instantiations
+    // treat every such stage that way; waves split column blocks of 16 as in the 4M chains)
+    if (b.m3)
+      for (int q = 0; q < b.n_stages; ++q)
+        if (b.st[q].k >= 2 && b.st[q].k <= 4) b.st[q].m3 = 2;
   }
 
   // ---- outer axes: N-outer fastest (tiles sharing an A tile run together), then M-outer by A

@@ -32,6 +32,54 @@ static void run_stage(const ArtnStage &st, const ArtnStage *zin, const cf *in, c
       int oi = 0, oo = 0;
       for (int b = 0; b < st.m_bits - 5; ++b)
         if ((msub >> b) & 1) { oi += 1 << st.msub_in_pos[b]; oo += 1 << st.msub_out_pos[b]; }
+      if (st.m3 == 2) { // 4-bit stage of a 3M launch: v_mfma_f32_16x16x4_f32 blocks (A[l & 15][l >> 4], B[l >> 4][l & 15]; D: column
+                        // l & 15, rows 4 (l >> 4) + r), two halves of 16 columns per 32-column sub-tile, three products
+        for (int half = 0; half < 2; ++half) {
+          float t1[64][4] = {}, t2[64][4] = {}, t3[64][4] = {};
+          int lane_out4[64];
+          for (int s = 0; s < (1 << (KB - 2)); ++s) { // chain steps of 4 contracted values (KB = 2..4)
+            float wre[64], wim[64], ax[64], ay[64];
+            for (int lane = 0; lane < 64; ++lane) {
+              const int jj = lane & 15, g = lane >> 4;
+              int li = ((g & 1) << st.k_in_pos[0]) + ((g >> 1) << st.k_in_pos[1]);
+              for (int b = 2; b < KB; ++b) if ((s >> (b - 2)) & 1) li += 1 << st.k_in_pos[b];
+              int lo = 0;
+              for (int b = 0; b < 4; ++b) if ((jj >> b) & 1) { li += 1 << st.lane_in_pos[b]; lo += 1 << st.lane_out_pos[b]; }
+              if (half) { li += 1 << st.lane_in_pos[4]; lo += 1 << st.lane_out_pos[4]; }
+              if (st.nt > 2) lo += (g & 1) << st.n_out_pos[2];
+              if (st.nt > 3) lo += (g >> 1) << st.n_out_pos[3];
+              int64_t lb = (int64_t)(g & 1) * st.k_b_stride[0] + (int64_t)(g >> 1) * st.k_b_stride[1];
+              for (int b = 2; b < KB; ++b) if ((s >> (b - 2)) & 1) lb += st.k_b_stride[b];
+              for (int b = 0; b < nt_eff; ++b) if ((jj >> b) & 1) lb += st.n_b_stride[b];
+              for (int b = 0; b < st.wn_log2; ++b) if ((wn >> b) & 1) { lo += 1 << st.n_out_pos[4 + b]; lb += st.n_b_stride[4 + b]; }
+              lane_out4[lane] = lo;
+              cf bv(0.f, 0.f);
+              if ((jj >> nt_eff) == 0) bv = B[offB + lb];
+              wre[lane] = bv.real(); wim[lane] = bv.imag();
+              const cf a = in[swz(li + oi, zin)];
+              ax[lane] = a.real(); ay[lane] = a.imag();
+            }
+            for (int lane = 0; lane < 64; ++lane)
+              for (int r = 0; r < 4; ++r) {
+                const int i = 4 * (lane >> 4) + r, jc = lane & 15;
+                for (int kk = 0; kk < 4; ++kk) {
+                  t1[lane][r] += wre[i + 16 * kk] * ax[jc + 16 * kk];
+                  t2[lane][r] += wim[i + 16 * kk] * ay[jc + 16 * kk];
+                  t3[lane][r] += (wre[i + 16 * kk] + wim[i + 16 * kk]) * (ax[jc + 16 * kk] + ay[jc + 16 * kk]);
+                }
+              }
+          }
+          for (int lane = 0; lane < 64; ++lane)
+            for (int r = 0; r < 4; ++r) {
+              const int n = 4 * (lane >> 4) + r;
+              if ((n >> nt_eff) != 0) continue;
+              const int o = lane_out4[lane] + oo + ((r & 1) && st.nt > 0 ? 1 << st.n_out_pos[0] : 0) + ((r & 2) && st.nt > 1 ? 1 << st.n_out_pos[1] : 0);
+              const float a1 = t1[lane][r], a2 = t2[lane][r], a3 = t3[lane][r];
+              out[swz(o, &st)] = cf(a1 - a2, a3 - a1 - a2);
+            }
+        }
+        continue;
+      }
       if (st.m3) { // three real products per complex product: rows = 32 columns n of the small operand
         std::vector<float> t1(64 * 16, 0.f), t2(64 * 16, 0.f), t3(64 * 16, 0.f);
         int lane_out3[64];

@@ -963,6 +963,48 @@ def test_complex128_n30_dense_full_size_against_committed_truth():
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("k1,k2", [(5, 2), (5, 3), (5, 4), (6, 2), (6, 3), (6, 4), (2, 5), (3, 5), (4, 5), (2, 6), (3, 6), (4, 6)])
+def test_fused_pairs_3m_with_a_narrow_stage(k1, k2, monkeypatch):
+    """3M pairs whose other stage contracts 2-4 bits (that stage on v_mfma_f32_16x16x4_f32 blocks, three products): full
+    tiles (2^22-element state: the FULL / artn_k_alt instantiations) and smaller ones, size-preserving, growing and
+    narrow-column stages, against a complex128 einsum on the host."""
+    from artensor_amd.contraction import contract2, pair_info
+    monkeypatch.setenv("ARTN_FORCE_BITS", "1")
+    rng = np.random.default_rng(100 * k1 + k2)
+    gen = torch.Generator(device=DEV).manual_seed(k1 * 10 + k2)
+    done = 0
+    for trial in range(5):
+        ra = 22 if trial == 0 else int(rng.integers(15, 19))
+        n1 = k1 + (1 if (trial == 2 and k1 <= 4) else 0) - (1 if (trial == 3 and k1 <= 4) else 0)
+        n2 = k2 + (1 if (trial == 2 and k2 <= 4) else 0) - (1 if (trial == 3 and k2 <= 4) else 0)
+        la = [chr(65 + x) for x in range(ra)]
+        kl1 = list(rng.choice(la, size=k1, replace=False))
+        nl1 = [chr(97 + x) for x in range(n1)]
+        lb1 = kl1 + nl1
+        rng.shuffle(lb1)
+        lo1 = [x for x in la if x not in kl1] + nl1
+        rng.shuffle(lo1)
+        kl2 = list(rng.choice(lo1, size=k2, replace=False))
+        nl2 = [chr(110 + x) for x in range(n2)]
+        lb2 = kl2 + nl2
+        rng.shuffle(lb2)
+        lo2 = [x for x in lo1 if x not in kl2] + nl2
+        rng.shuffle(lo2)
+        eq1 = "".join(la) + "," + "".join(lb1) + "->" + "".join(lo1)
+        eq2 = "".join(lo1) + "," + "".join(lb2) + "->" + "".join(lo2)
+        mk = lambda n: torch.view_as_complex(torch.randn((2,) * n + (2,), device=DEV, generator=gen))
+        a, b1, b2 = mk(ra), mk(len(lb1)), mk(len(lb2))
+        got = contract2(eq1, a, b1, eq2, b2)
+        if got is None:
+            continue
+        info = pair_info(eq1, (2,) * ra, (2,) * len(lb1), eq2, (2,) * len(lb2))
+        want = torch.einsum(eq2, torch.einsum(eq1, a.cpu().to(torch.complex128), b1.cpu().to(torch.complex128)), b2.cpu().to(torch.complex128))
+        err = float((got.cpu().to(torch.complex128) - want).abs().max() / want.abs().max())
+        assert err < STEP_TOL, (eq1, eq2, err)
+        done += info is not None and info["arith"] == 1
+    assert done >= 2, done
+
+
 def test_randomised_single_steps_pairs_and_gathers():
     """tools/stress_random.py: 120 random single steps, fused pairs and gathered steps (random label orders, 1-8 contracted
     bits, 0-7 new bits, ragged batch labels; complex64 and complex128) through contract / contract2 / contract_gathered

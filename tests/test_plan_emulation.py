@@ -498,3 +498,41 @@ def test_complex128_n30_fused_pairs_surrogates():
         want = np.einsum(e2, np.einsum(e1, a, b1), b2)
         assert np.abs(got - want).max() / np.abs(want).max() < 1e-13, (n, m)
     assert planned >= 10 and fused >= 8, (planned, fused)
+
+
+@pytest.mark.parametrize("k1,k2", [(5, 2), (5, 3), (5, 4), (6, 2), (6, 3), (6, 4), (2, 5), (3, 5), (4, 5), (2, 6), (3, 6), (4, 6)])
+def test_fused_pairs_3m_with_a_narrow_stage(k1, k2):
+    """3M pairs whose other stage contracts 2-4 bits: that stage runs three products too, on v_mfma_f32_16x16x4_f32 blocks
+    (ArtnStage::m3 = 2: lane group l >> 4 carries contracted bits 0, 1 and column bits 2, 3; two 16-column halves per
+    sub-tile).  Size-preserving steps, a growing narrow stage and one with fewer than 16 columns."""
+    from helpers import emulate2
+    rng = np.random.default_rng(100 * k1 + k2)
+    done = 0
+    for trial in range(4):
+        ra = int(rng.integers(15, 17))
+        n1 = k1 + (1 if (trial == 1 and k1 <= 4) else 0) - (1 if (trial == 2 and k1 <= 4) else 0)
+        n2 = k2 + (1 if (trial == 1 and k2 <= 4) else 0) - (1 if (trial == 2 and k2 <= 4) else 0)
+        la = [chr(65 + x) for x in range(ra)]
+        kl1 = list(rng.choice(la, size=k1, replace=False))
+        nl1 = [chr(97 + x) for x in range(n1)]
+        lb1 = kl1 + nl1
+        rng.shuffle(lb1)
+        lo1 = [x for x in la if x not in kl1] + nl1
+        rng.shuffle(lo1)
+        kl2 = list(rng.choice(lo1, size=k2, replace=False))
+        nl2 = [chr(110 + x) for x in range(n2)]
+        lb2 = kl2 + nl2
+        rng.shuffle(lb2)
+        lo2 = [x for x in lo1 if x not in kl2] + nl2
+        rng.shuffle(lo2)
+        eq1 = "".join(la) + "," + "".join(lb1) + "->" + "".join(lo1)
+        eq2 = "".join(lo1) + "," + "".join(lb2) + "->" + "".join(lo2)
+        a, b1, b2 = crandn(rng, (2,) * ra), crandn(rng, (2,) * len(lb1)), crandn(rng, (2,) * len(lb2))
+        got, info = emulate2(eq1, a, b1, eq2, b2)
+        if got is None:
+            continue
+        want = oracle.einsum_pair(eq2, oracle.einsum_pair(eq1, a, b1), b2)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (eq1, eq2)
+        if info["arith"] == 1:
+            done += 1
+    assert done >= 2, done   # at least two of the trials really ran the 3M plan
