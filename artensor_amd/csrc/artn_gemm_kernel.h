@@ -669,7 +669,19 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     // one chunk: issue chunk c + DEPTH into the set that chunk c came from, multiply chunk c, then chunk c + 1 (the next set) -> LDS
+#if defined(ARTN_PHASES)
+    const long it_ = (tile - t0) / G;
+#define GMARK(k)                                                                                                          \
+  if (tid == 0 && blockIdx.x < 64 && it_ == 3 && (c == 2 || c == 3)) {                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    artn_phase_buf[blockIdx.x * 16 + (c - 2) * 8 + (k)] = __builtin_amdgcn_s_memtime();                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+#else
+#define GMARK(k)
+#endif
     auto step = [&](int c, f32x4 (&va_free)[NVA], f32x4 (&vb_free)[NVB], const f32x4 (&va_next)[NVA], const f32x4 (&vb_next)[NVB]) {
+      GMARK(0);
       const int c2 = c + DEPTH;
       long base_a = off.a, base_b = off.b1;
       if (c2 < n_chunks) {
@@ -679,6 +691,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
         if (more_tiles) { base_a = noff.a; base_b = noff.b1; } // (else: a chunk of this tile again, never used)
       }
       issue(va_free, vb_free, Ac + base_a * 8 + ka, Bc + base_b * 8 + kb);
+      GMARK(1);
       const unsigned base = cur * stage_bytes;
       const unsigned xa = base + lane_x, wa = base + lane_w;
       v2f_t X[2][MB], Wr[2][NB];
@@ -724,9 +737,16 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm_deep(const flo
             }
         }
       }
+      GMARK(2);
       if (c + 1 < n_chunks) {
+#if defined(ARTN_PHASES)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVA + NVB) : "memory");
+#endif
+        GMARK(3);
         fill(va_next, vb_next, (cur ^ 1u) * stage_bytes);
+        GMARK(4);
         __syncthreads();
+        GMARK(5);
         cur ^= 1u;
         return;
       }
