@@ -21,8 +21,14 @@ carry it, so the slabs cost more than 1/N of the whole: the line reports that ov
 line carries, under "sliced", the slice-sharded workload north_star names -- Sycamore n53 m14,
 slices dealt round-robin to the ranks, ONE all-reduce over RCCL closing the timed region.
 
-Exit code 1 when a result check fails (the JSON line is still printed, with "check": "FAILED").
-Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with N > 1 as a PLAIN command (no WORLD_SIZE in the environment) starts its own N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a CHILD process, before
+this process has touched the GPU) and exits with their status; launched by torch.distributed.run it is a rank.
+
+Output (rank 0): one line per secondary workload leg as it finishes (`{"leg": ...}`), the full record in
+`bench_detail.json` next to this script (and under gpurun_out/ when that directory exists), and as the LAST stdout line
+ONE compact JSON object (< 1.5 KB: metric, value, roofline, cpu_baseline, one [value, frac, check] triple per leg).
+Exit code 1 when a result check fails (the line is still printed, with "check": "FAILED").
 """
 import argparse
 import json
@@ -103,12 +109,41 @@ def mfma_rate_probe(kind, dev):
     return _probe[kind]
 
 
-def roofline_of(ks, gpu_ms, launches_div=1, f64_peak=None):
+_traffic = []
+
+
+def traffic_record():
+    """profiles/rNN_traffic.json of the newest round -- HBM bytes from rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950,
+    WRITE_SIZE; tools/profile_traffic.sh) -- if it was collected on THESE kernel sources; else (None, why)."""
+    if not _traffic:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+        if not files:
+            _traffic.append((None, "no profiles/r*_traffic.json"))
+        else:
+            with open(files[-1]) as f:
+                tj = json.load(f)
+            name = os.path.basename(files[-1])
+            if tj.get("kernel_source_sha16") == kernel_source_sha16():
+                _traffic.append((tj, f"{name} (same kernel sources)"))
+            else:   # counters belong to the sources they were collected on: a stale file is not quoted
+                _traffic.append((None, f"{name} was collected on other kernel sources "
+                                       f"({tj.get('kernel_source_sha16')} != {kernel_source_sha16()}): not quoted"))
+    return _traffic[0]
+
+
+FAMILY_KEYS = {0: "generic", 1: "bits", 2: "gemm", 3: "program", 4: "pgemm"}   # keys of rNN_traffic.json's per-leg tables
+
+
+def roofline_of(ks, gpu_ms, launches_div=1, f64_peak=None, leg=None, units=1):
     """roofline block of a workload leg from per-launch HIP-event timings (KernelTimes.summarize()): the kernel
-    family that takes most of the GPU time, its nominal FLOP / its time against the MFMA peak of its arithmetic,
-    the FLOP the matrix pipe really executes (3M stages: 6 of the 8 counted per complex multiply-add), and its
-    algorithmic bytes / its time against the HBM peak; `bound` is whichever of the two the family's arithmetic
-    intensity puts it under."""
+    family that takes most of the GPU time; `bound` is whichever roof the family's arithmetic intensity puts it
+    under.  HBM-bound: algorithmic bytes / time against 8 TB/s.  MFMA-bound: `achieved` is the NOMINAL rate (8 FLOP
+    per complex multiply-add, the metric's count) and `peak` the nominal rate at which the matrix pipe would be
+    saturated by this family's mix of arithmetic -- spec peak / (executed FLOP / nominal FLOP): 3M stages execute 6 of
+    the 8 counted FLOP, so a pure-3M kernel can reach 4/3 of the spec peak in nominal terms -- so that `frac` is the
+    executed-FLOP fraction of the matrix pipe and can never exceed 1; the nominal fraction of the SPEC peak is beside
+    it (`mfma_frac_nominal`).  `traffic`: HBM bytes per launch from the PMC counters of profiles/rNN_traffic.json."""
     if not ks:
         return None
     kid = max(ks, key=lambda k: ks[k]["ms"])
@@ -125,13 +160,29 @@ def roofline_of(ks, gpu_ms, launches_div=1, f64_peak=None):
     kname = KERNEL_NAMES.get(kid, str(kid))
     if f64:   # (complex128 runs on its own kernels behind the same planner ids)
         kname = {1: "artn_k_bits128", 2: "artn_k_gemm128"}.get(kid, kname)
+    exec_frac = d["mfma_flops"] / d["flops"] if d["flops"] and d["mfma_flops"] else 1.0
+    eff_peak = peak / exec_frac
+    alg_per_launch = d["bytes"] / max(d["launches"], 1)
+    traffic, ratio, tnote = None, None, None
+    tj, tnote = traffic_record()
+    if tj is not None and leg is not None:
+        fam = (tj.get("workloads", {}).get(leg) or {}).get(FAMILY_KEYS.get(kid, str(kid)))
+        if fam:   # bytes per contraction (slice) of this family / its contract calls per contraction
+            traffic = fam["hbm_bytes_per_unit"] / (d["launches"] / launches_div / units)
+            ratio = traffic / alg_per_launch if alg_per_launch else None
+        else:
+            tnote += f": no entry for {leg}/{FAMILY_KEYS.get(kid, kid)}"
     r = {"bound": "mfma" if mfma_bound else "hbm", "kernel": kname,
-         "achieved": tf if mfma_bound else gbs, "peak": peak if mfma_bound else HBM_PEAK_GBS,
-         "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": (tf / peak) if mfma_bound else gbs / HBM_PEAK_GBS,
-         "traffic": None, "arithmetic": "bf16 operands, fp32 accumulate" if bf16 else ("f64 MFMA (peak = measured back-to-back v_mfma_f64_16x16x4_f64 rate)" if f64 else "fp32 MFMA"),
+         "achieved": tf if mfma_bound else gbs, "peak": eff_peak if mfma_bound else HBM_PEAK_GBS,
+         "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": (tf / eff_peak) if mfma_bound else gbs / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_over_algorithmic": ratio, "traffic_source": tnote,
+         "algorithmic_bytes_per_launch": alg_per_launch,
+         "peak_is": ((f"{peak:.1f} TFLOP/s matrix peak / {exec_frac:.3f} (share of the counted FLOP this family executes on the "
+                      "matrix pipe: 3M stages run 6 of 8)") if mfma_bound else "HBM3E spec"),
+         "arithmetic": "bf16 operands, fp32 accumulate" if bf16 else ("f64 MFMA (peak = measured back-to-back v_mfma_f64_16x16x4_f64 rate)" if f64 else "fp32 MFMA"),
          "nominal_TFLOPs": tf, "mfma_peak_TFLOPs": peak, "mfma_frac_nominal": tf / peak,
-         "executed_mfma_flop_frac": d["mfma_flops"] / d["flops"] if d["flops"] else 0.0,
-         "mfma_frac_executed": d["mfma_flops"] / sec / 1e12 / peak if sec else 0.0,
+         "executed_mfma_flop_frac": exec_frac,
+         "mfma_frac_executed": tf * exec_frac / peak,
          "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "flop_per_byte": ai, "ridge_flop_per_byte": ridge,
          "launches": d["launches"] / launches_div, "avg_launch_ms": d["ms"] / max(d["launches"], 1),
          "kernel_ms": d["ms"] / launches_div, "share_of_gpu_time": d["ms"] / gpu_ms if gpu_ms else None,
@@ -207,7 +258,7 @@ def cpu_baseline(case_n30, case_n12, budget_s=25.0):
         "sample": (f"torch-CPU einsum loop over the n30 m14 scheme, steps 0..{r30['steps_done'] - 1} of {len(case_n30.scheme)} in order "
                    f"({100 * frac:.1f} % of the scheme's FLOPs, {r30['flops_done']:.3e} FLOP in {r30['seconds']:.1f} s, "
                    f"torch.set_num_threads({threads})); budget {budget_s:.0f} s"),
-        "n30_fraction_of_flops": frac, "n30_seconds": r30["seconds"],
+        "n30_fraction_of_flops": frac, "n30_seconds": r30["seconds"], "n30_steps_done": r30["steps_done"],
         "n12_ms": best["seconds"] * 1e3, "n12_gflops": best["flops_done"] / best["seconds"] / 1e9,
     }
 
@@ -312,6 +363,7 @@ def run_sliced(A, name, dev, world, rank, dist, steps, warmup, per_step, precisi
         "parallelism": (f"slices sharded round-robin over {world} rank(s), one all-reduce ({dist.get_backend() if world > 1 else 'none'})"
                         if n_b else ("replicas" if world > 1 else "single")),
         "ranks_in_collective": world, "frac_mfma_peak": value / world / MFMA_F32_PEAK_TFLOPS,
+        "slices_executed_in_process": 1 + (warmup + steps + (1 if profile else 0)) * per_step,
         "slice0_err_rel_to_max_abs_or_rms": loose, "slice0_rel_err_strict_over_1e-3rms": strict,
         "slice0_fidelity_vs_reference": fid, "check": "ok" if ok else "FAILED",
         "partial_sum_abs": float(acc.abs().sum().item()),
@@ -445,11 +497,21 @@ def leg_n30_sliced3(A, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = 2 ** n_b
+    # the 8 slices once more with per-launch HIP events (outside the timed region): the leg's roofline block
+    from artensor_amd import contraction as C
+    prof = KernelTimes()
+    C.profiler = prof
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    runner.run(range(2 ** n_b))
+    e1.record()
+    torch.cuda.synchronize()
+    C.profiler = None
     return {"workload": "Sycamore n30 m14 full-amplitude, 3 inner bonds sliced (8 slices of 2^30 amplitudes), tests/golden/n30_dense_sliced3.npz",
             "value": n * flops_slice / dt / 1e12, "unit": "TFLOP/s", "ms_per_step": dt * 1e3, "ms_per_slice_per_rank": dt / n * 1e3,
             "flops_per_slice": flops_slice, "slices": n, "executed_flop_over_unsliced": n * flops_slice / (8.0 * 10 ** dense.meta["log10_tc"]),
             "sum_of_slices_err_rel_to_max_abs_or_rms_vs_truth": err, "check": "ok" if ok else "FAILED",
-            "kernel_times_": None, "case_": case}
+            "kernel_times_": (prof.summarize(), e0.elapsed_time(e1)), "profiled_units_": n, "case_": case}
 
 
 # secondary workloads of the default run: key -> (BASELINE config, runner, precision, slices per step, sparse, sliced)
@@ -492,7 +554,7 @@ def run_workloads(A, dev, cpu_budget, only=None):
             f64_peak = mfma_rate_probe(2, dev) if kind == "c128" else None
             if res["kernel_times_"] is not None:
                 ks, gpu_ms = res["kernel_times_"]
-                roof = roofline_of(ks, gpu_ms, 1, f64_peak)
+                roof = roofline_of(ks, gpu_ms, 1, f64_peak, leg=key, units=res.get("profiled_units_", units))
             else:
                 ks, gpu_ms, roof = None, 0.0, None
             peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else (f64_peak if kind == "c128" else MFMA_F32_PEAK_TFLOPS)
@@ -501,7 +563,7 @@ def run_workloads(A, dev, cpu_budget, only=None):
                      "frac_of_peak": res["value"] / peak, "peak_TFLOPs": peak,
                      "dtype": ("c64 in memory, bf16 MFMA operands, fp32 accumulate" if precision == "bf16"
                                else ("c128 (f64 MFMA)" if kind == "c128" else "c64 (fp32 MFMA)")),
-                     "roofline": roof, "profiled_step_gpu_ms": gpu_ms / units,
+                     "roofline": roof, "profiled_step_gpu_ms": gpu_ms / res.get("profiled_units_", units),
                      "check": {k: v for k, v in strip_private(res).items() if k not in ("value", "unit", "ms_per_step", "workload")},
                      "workload": res["workload"]}
             if kind == "c128":
@@ -518,10 +580,12 @@ def run_workloads(A, dev, cpu_budget, only=None):
                                          "its CPU executor runs this workload in complex64 (see that entry)"}
             entry["leg_seconds"] = time.perf_counter() - t_leg
             out[key] = entry
+            print(json.dumps({"leg": key, **entry}), flush=True)   # (the LAST line of the run is the compact headline)
         except Exception as e:   # a leg that cannot run must not take the headline with it; it is reported as failed
             import traceback
             out[key] = {"config": config, "check": {"check": "FAILED"}, "error": f"{type(e).__name__}: {e}",
                         "traceback": traceback.format_exc()[-800:]}
+            print(json.dumps({"leg": key, **out[key]}), flush=True)
         torch.cuda.empty_cache()
     return out
 
@@ -532,7 +596,8 @@ def bench_sliced(args, A, dev, world, rank, dist):
     if rank == 0:
         kt = res.pop("kernel_times_", None)
         res = strip_private(res)
-        roof = roofline_of(*kt) if kt else None
+        leg = args.workload + ("_bf16" if args.precision == "bf16" else "")
+        roof = roofline_of(*kt, leg=leg, units=args.slices) if kt else None
         line = {
             "metric": f"contracted TFLOP/s, {args.workload} sliced contraction (8 real FLOP per complex MAC)"
                       + (", bf16 operands" if args.precision == "bf16" else ""),
@@ -547,7 +612,24 @@ def bench_sliced(args, A, dev, world, rank, dist):
             fixture, sparse, _ = SLICED_WORKLOADS[args.workload]
             line["cpu_baseline"] = cpu_leg(load_case(os.path.join(ROOT, "tests", "golden", fixture)), sparse, True,
                                            args.cpu_budget_workloads, "slice 0 of " + args.workload)
-        print(json.dumps(line), flush=True)
+        write_detail(line)
+        # the LAST line stays under COMPACT_LIMIT: rounded numbers, the roofline block's essentials
+        short = dict(line)
+        short["value"], short["ms_per_step"] = sig(line["value"], 6), sig(line["ms_per_step"], 6)
+        cfg = line["config"]
+        short["config"] = {k: sig(cfg[k], 5) for k in ("workload", "ms_per_slice_per_rank", "slices_per_rank_per_step", "slices_timed",
+                                                       "slices_executed_in_process", "flops_per_slice", "parallelism", "ranks_in_collective",
+                                                       "frac_mfma_peak", "slice0_err_rel_to_max_abs_or_rms",
+                                                       "slice0_rel_err_strict_over_1e-3rms", "slice0_fidelity_vs_reference", "check") if k in cfg}
+        if roof:
+            short["roofline"] = {k: sig(roof[k], 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                              "traffic_over_algorithmic", "mfma_frac_nominal", "hbm_frac",
+                                                              "algorithmic_bytes_per_launch", "launches", "kernel_ms", "share_of_gpu_time")}
+        if "cpu_baseline" in line:
+            cb = line["cpu_baseline"]
+            short["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                     "sample": f"torch-CPU einsum loop, slice 0, steps 0..{cb['steps_done'] - 1} in {cb['seconds']:.0f} s"}
+        print(json.dumps(short), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0 if res["check"] == "ok" else 1
@@ -570,6 +652,98 @@ def n12_latency(A, dev, reps=20):
         best = min(best, time.perf_counter() - t0)
     err = float(np.abs(out.cpu().numpy() - case.arrays["raw"]).max() / np.abs(case.arrays["raw"]).max())
     return {"n12_gpu_us": best * 1e6, "n12_err": err}, case
+
+
+def sig(x, n=4):
+    """x rounded to n significant digits (the compact line carries no 17-digit floats)."""
+    if isinstance(x, bool) or not isinstance(x, (int, float)):
+        return x
+    if x == 0 or x != x or x in (float("inf"), float("-inf")):
+        return x
+    if isinstance(x, int) or float(x).is_integer() and abs(x) < 1e15:
+        return int(x)
+    return float(f"{x:.{n}g}")
+
+
+COMPACT_LIMIT = 1500   # bytes: the driver keeps a 2 000-character tail of stdout
+
+
+def compact_line(full):
+    """The LAST stdout line: what the driver parses.  Everything else of `full` goes to bench_detail.json and the
+    per-leg lines.  Keys are dropped from the least important end until the line fits COMPACT_LIMIT."""
+    cfg, roof = full.get("config", {}), full.get("roofline") or {}
+    vt = cfg.get("vs_c128_truth") or {}
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data") if k in full}
+    line["value"], line["ms_per_step"] = sig(full["value"], 6), sig(full["ms_per_step"], 6)
+    c = {"workload": cfg.get("workload"), "flops_per_step": sig(cfg.get("flops_per_step"), 6), "parallelism": cfg.get("parallelism"),
+         "check": cfg.get("check"), "frac_mfma_peak": sig(cfg.get("frac_mfma_peak")),
+         "err_loose": sig(vt.get("hip_loose", cfg.get("err_rel_to_max_abs_or_rms")), 3),
+         "err_strict": sig(vt.get("hip_strict", cfg.get("rel_err_strict_over_1e-3rms")), 3),
+         "ref_c64_loose": sig(vt.get("reference_c64_loose"), 3), "ref_c64_strict": sig(vt.get("reference_c64_strict"), 3),
+         "err_vs": "c128 truth" if vt else "reference c64", "n12_gpu_us": sig(cfg.get("n12_gpu_us")),
+         "ms_per_step_unprofiled": sig(cfg.get("ms_per_step_unprofiled"), 6)}
+    if cfg.get("failed_workloads"):
+        c["failed_workloads"] = cfg["failed_workloads"]
+    line["config"] = {k: v for k, v in c.items() if v is not None}
+    rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "mfma_frac_executed",
+          "hbm_frac", "algorithmic_bytes_per_launch", "launches_per_step", "avg_launch_ms", "kernel_ms_per_step")
+    line["roofline"] = {k: sig(roof.get(k), 5) for k in rk if k in roof}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": (f"torch-CPU einsum loop, n30 scheme steps 0..{cb.get('n30_steps_done', '?')}"
+                                           f" ({100 * cb.get('n30_fraction_of_flops', 0):.0f}% of its FLOP) in {cb.get('n30_seconds', 0):.0f} s"),
+                                "n12_ms": sig(cb.get("n12_ms"))}
+    sl = full.get("sliced")
+    if sl:
+        line["sliced"] = {"workload": "n53 m14 slice-sharded, one all-reduce", "value": sig(sl["value"], 6), "unit": "TFLOP/s",
+                          "ms_per_slice_per_rank": sig(sl.get("ms_per_slice_per_rank"), 5), "slices_timed": sl.get("slices_timed"),
+                          "ranks_in_collective": sl.get("ranks_in_collective"), "backend": sl.get("backend"), "check": sl.get("check")}
+    wl = full.get("workloads")
+    if wl:   # [TFLOP/s, roofline fraction of the dominant kernel (executed FLOP or bytes: never above 1), check]
+        line["workloads"] = {k: [sig(v.get("value"), 4), sig((v.get("roofline") or {}).get("frac"), 3), (v.get("check") or {}).get("check")]
+                             for k, v in wl.items()}
+    line["detail"] = "bench_detail.json; one {\"leg\":...} line per workload above"
+    for drop in (("detail",), ("config", "n12_gpu_us"), ("roofline", "avg_launch_ms"), ("config", "parallelism"),
+                 ("cpu_baseline", "n12_ms"), ("roofline", "launches_per_step"), ("workloads",)):
+        if len(json.dumps(line)) <= COMPACT_LIMIT:
+            break
+        d = line
+        for k in drop[:-1]:
+            d = d.get(k, {})
+        d.pop(drop[-1], None)
+    return line
+
+
+def write_detail(full):
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    json.dump(full, f, indent=1)
+            except OSError:
+                pass
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` as a plain command: start the N ranks as a CHILD process (never exec, and before this
+    process has initialised the GPU: torch.cuda.device_count() does not), relay their output, exit with their status."""
+    import socket
+    import subprocess
+    if "ARTN_BENCH_DEVICE" not in os.environ:   # (the one-GPU self-test knob runs every rank on that device)
+        have = torch.cuda.device_count()
+        if have < n:
+            print(json.dumps({"error": f"--gpus {n}: this node has {have} visible GPU(s)", "n_gpus": n}), flush=True)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -600,6 +774,9 @@ def main():
                          "reported as its own metric, checked by state fidelity)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)   # (nothing above this line has touched the GPU)
+
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -615,8 +792,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    elif args.gpus > 1:
-        sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -734,17 +909,31 @@ def main():
     C.profiler = None
     del out
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    # the same steps once more WITHOUT the per-launch events (what the 2 events per launch inside the timed region cost)
+    n_plain = max(1, min(args.steps, 5))
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(n_plain):
+        out = one_step()
+    barrier()
+    dt_plain = time.perf_counter() - t1
+    del out
+
+    t = torch.tensor([dt, dt_plain], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt, dt_plain = float(t[0].item()), float(t[1].item())
 
+    # the slice-sharded workload north_star's ">= 6x at 8 GPUs" refers to, at EVERY N with the same parameters (weak
+    # scaling: slices per rank fixed; at N = 1 no collective): sliced.value(N) / sliced.value(1) is that speed-up
     sliced = None
-    if world > 1 and not args.no_sliced:
+    if not args.no_sliced and not (world == 1 and args.no_workloads):
         del leaves
+        leaves = None
         torch.cuda.empty_cache()
-        sliced = strip_private(run_sliced(A, "n53", dev, world, rank, dist, max(1, min(args.steps, 3)), 1, args.slices, args.precision))
+        sliced = strip_private(run_sliced(A, "n53", dev, world, rank, dist, 3, 1, args.slices, args.precision))
         sliced["series"] = "n53 m14 slice-sharded, one all-reduce (the workload north_star's >= 6x at 8 GPUs refers to)"
+        sliced["backend"] = dist.get_backend() if world > 1 else None
         ok = ok and sliced["check"] == "ok"
 
     if rank == 0 and args.detail:
@@ -775,19 +964,11 @@ def main():
         hbm_gbs = bits["bytes"] / (bits["ms"] * 1e-3) / 1e9 if bits["ms"] else 0.0
         # HBM bytes per launch of the dominant kernel come from separate rocprofv3 PMC passes
         # (tools/profile_round.sh -> profiles/rNN_traffic.json); bench.py cannot run them itself
-        traffic, traffic_note = None, "no profiles/r*_traffic.json"
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-        if tfiles and world == 1:
-            with open(tfiles[-1]) as f:
-                tj = json.load(f)
-            # the counters belong to the kernel sources they were collected on: a traffic file recorded on other
-            # sources is stale and is not quoted
-            if tj.get("kernel_source_sha16") == kernel_source_sha16():
-                traffic, traffic_note = tj.get("hbm_bytes_per_launch"), f"{os.path.basename(tfiles[-1])} (same kernel sources)"
-            else:
-                traffic_note = (f"{os.path.basename(tfiles[-1])} was collected on other kernel sources "
-                                f"({tj.get('kernel_source_sha16')} != {kernel_source_sha16()}): not quoted")
+        traffic, traffic_note = None, "N > 1: not collected"
+        if world == 1:
+            tj, traffic_note = traffic_record()
+            if tj is not None:
+                traffic = tj.get("hbm_bytes_per_launch")
         line = {
             "metric": "contracted TFLOP/s, Sycamore n30 m14 full-amplitude (8 real FLOP per complex MAC)"
                       + (", bf16 operands" if bf16 else ""),
@@ -806,6 +987,8 @@ def main():
                                   if world > 1 else "n30 m14 full amplitude, one GPU"),
                        "ranks_in_collective": 0 if world > 1 else None,
                        "frac_mfma_peak": value / world / MFMA_F32_PEAK_TFLOPS,
+                       "ms_per_step_unprofiled": dt_plain / n_plain * 1e3,
+                       "ms_per_step_unprofiled_is": f"{n_plain} more steps with the per-launch HIP events of the roofline block switched off",
                        "check": "ok" if ok else "FAILED",
                        "checked_amplitudes": "Google's 10 000 bitstrings (examples/amplitudes_n30_m14...txt positions) vs the "
                                              "reference's complex64 CPU run",
@@ -815,6 +998,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+                "traffic_over_algorithmic": (traffic / (bits["bytes"] / max(bits["launches"], 1))) if traffic and bits["bytes"] else None,
                 "frac_is": "nominal FLOP (8 per complex multiply-add) / kernel time / fp32 MFMA spec peak",
                 "executed_mfma_flop_frac": bits["mfma_flops"] / bits["flops"] if bits["flops"] else 0.0,
                 "mfma_frac_executed": (bits["mfma_flops"] / (bits["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if bits["ms"] else 0.0,
@@ -835,7 +1019,7 @@ def main():
             lat, case12 = n12_latency(A, dev)
             line["config"].update(lat)
             if not args.no_workloads and not bf16:
-                del leaves
+                leaves = None
                 torch.cuda.empty_cache()
                 only = set(args.only_workloads.split(",")) if args.only_workloads else None
                 line["workloads"] = run_workloads(A, dev, 0.0 if args.no_cpu_baseline else args.cpu_budget_workloads, only)
@@ -846,7 +1030,8 @@ def main():
                     line["config"]["failed_workloads"] = bad
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(case, case12, args.cpu_budget)
-        print(json.dumps(line), flush=True)
+        write_detail(line)
+        print(json.dumps(compact_line(line)), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1

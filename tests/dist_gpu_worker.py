@@ -3,7 +3,10 @@ world_size-2 group (gloo rendezvous on 127.0.0.1; both ranks on cuda:0, which RC
 product code path does not care) running the PRODUCT slice loop -- real HIP executors, real
 accumulate, one all_reduce -- and writing its result for the parent to compare.
 
-    python tests/dist_gpu_worker.py RANK WORLD PORT OUT_DIR
+    python tests/dist_gpu_worker.py RANK WORLD PORT OUT_DIR [BACKEND [DEVICE]]
+
+BACKEND nccl (= RCCL; one GPU per rank: DEVICE defaults to RANK) is what a multi-GPU node runs
+(test_two_gpu_rccl_sliced_contraction, skipped on one-GPU boxes).
 """
 import os
 import sys
@@ -15,13 +18,19 @@ import torch
 import torch.distributed as dist
 
 rank, world, port, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
+device = int(sys.argv[6]) if len(sys.argv) > 6 else (rank if backend == "nccl" else 0)
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-dist.init_process_group("gloo", rank=rank, world_size=world)
+if backend == "nccl":
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 import artensor_amd as A
 from artensor_amd.fixtures import load_case
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-dev = "cuda:0"
+dev = f"cuda:{device}"
 try:
     # (1) a whole sliced contraction, sharded over the two ranks, all_reduce at the end
     case = load_case(os.path.join(GOLDEN, "n12_sparse_sliced.npz"))

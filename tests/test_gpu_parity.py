@@ -15,6 +15,7 @@ computed too (`amp_strict`) and asserted against the reference's own spread: tes
 c128_spread.npz holds complex128 runs of the reference's executors on the same leaves and schemes
 (tests/golden/make_golden.py c128_spread) and how far the reference's complex64 results are from
 them; the HIP results have to stay within STRICT_FACTOR x that distance of the complex128 truth."""
+import json
 import os
 import sys
 
@@ -786,6 +787,73 @@ def test_two_process_sliced_contraction(tmp_path):
     r0, r1 = np.load(tmp_path / "n53_0.npy"), np.load(tmp_path / "n53_1.npy")
     assert np.abs(r0 - single).max() <= 1e-5 * np.abs(single).max()      # reduce to root: rank 0 holds the sum
     assert np.abs(r1 - single).max() > 1e-3 * np.abs(single).max()       # rank 1 keeps its partial sum
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than 2")
+def test_two_gpu_rccl_sliced_contraction(tmp_path):
+    """The same two-rank run over backend "nccl" (= RCCL over xGMI), one GPU per rank: n12 sliced with its all_reduce and
+    8 slices of n53 m14 reduced to rank 0 (reference simulation.py:107-114, the loop being sharded)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gpu_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path), "nccl"], env=env) for r in range(2)]
+    codes = [p.wait(timeout=600) for p in procs]
+    assert codes == [0, 0], codes
+    case = load_case(os.path.join(GOLDEN, "n12_sparse_sliced.npz"))
+    for r in range(2):
+        assert amp_rel(np.load(tmp_path / f"n12_{r}.npy"), case.arrays["final"]) < 1e-5
+    case = load_case(os.path.join(GOLDEN, "n53_m14_sliced.npz"))
+    single = A.sliced_contraction(case.fresh_tensors(device=DEV), case.scheme, case.slicing_indices, (1,), sparse=True,
+                                  device=DEV, slices=list(range(8))).cpu().numpy()
+    assert np.abs(np.load(tmp_path / "n53_0.npy") - single).max() <= 1e-5 * np.abs(single).max()
+
+
+def _bench_last_line(args, env_extra, timeout=900):
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    return lines, json.loads(lines[-1])
+
+
+def test_bench_gpus_2_as_a_plain_command():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts its own two ranks as a child process and relays
+    rank 0's compact line (here: gloo, both ranks on cuda:0 through the self-test knobs -- a one-GPU box cannot run RCCL;
+    on a multi-GPU node the same command runs backend nccl, test_bench_gpus_2_rccl).  The line must fit the driver's tail."""
+    lines, line = _bench_last_line(["--gpus", "2", "--steps", "1", "--warmup", "1", "--slices", "2"],
+                                   {"ARTN_BENCH_BACKEND": "gloo", "ARTN_BENCH_DEVICE": "0"})
+    assert len(lines[-1]) < 2000
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["check"] == "ok"
+    assert line["sliced"]["ranks_in_collective"] == 2 and line["sliced"]["backend"] == "gloo" and line["sliced"]["check"] == "ok"
+    assert line["sliced"]["slices_timed"] == 2 * 3 * 2
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than 2")
+def test_bench_gpus_2_rccl():
+    lines, line = _bench_last_line(["--gpus", "2", "--steps", "2", "--warmup", "1"], {})
+    assert len(lines[-1]) < 2000 and line["n_gpus"] == 2 and line["config"]["check"] == "ok"
+    assert line["sliced"]["ranks_in_collective"] == 2 and line["sliced"]["backend"] == "nccl" and line["sliced"]["check"] == "ok"
+
+
+def test_bench_default_line_is_compact():
+    """N = 1: every leg on an earlier line, the LAST line under 2 000 characters with value, roofline and (here skipped)
+    cpu_baseline; roofline fractions never above 1."""
+    lines, line = _bench_last_line(["--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert len(lines[-1]) < 2000 and line["n_gpus"] == 1 and line["config"]["check"] == "ok"
+    assert 0.3 < line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] == "mfma"
+    legs = [json.loads(ln) for ln in lines[:-1] if ln.startswith('{"leg"')]
+    assert {leg["leg"] for leg in legs} == set(line["workloads"]) and len(legs) >= 9
+    for leg in legs:
+        assert leg["check"]["check"] == "ok", leg["leg"]
+        assert leg["roofline"] is not None and 0.0 < leg["roofline"]["frac"] <= 1.0, (leg["leg"], leg["roofline"])
+    assert line["sliced"]["ranks_in_collective"] == 1
 
 
 def test_output_partitioned_contraction():
