@@ -11,7 +11,7 @@ import threading
 
 import torch
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ARTN_MAX_LABELS = 96
 ARTN_PROGRAM_MAX_EXT = 256
 ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
@@ -95,6 +95,8 @@ _EXPORTS = {
     "artn_probe_mfma_rate": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "artn_absmax_normalize_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                  ctypes.c_void_p]),
+    "artn_absmax_normalize_c128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                  ctypes.c_void_p]),
 }
 
 

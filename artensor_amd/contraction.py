@@ -73,6 +73,15 @@ class _Bounded(dict):
         super().__setitem__(key, value)
 
 
+def _same_steps(snapshot, scheme, _is=__import__("operator").is_):
+    """Caches keyed on id(scheme) hold the scheme object (so its id cannot be reused) AND a tuple of its step objects as
+    they were when it was compiled: the reference re-reads the list on every call (contraction.py:66), so a scheme list
+    mutated in place between two calls -- steps appended, removed, replaced or reordered -- must not replay the stale
+    plan.  One pass of pointer comparisons in C (68 steps: ~1 us).  Steps themselves are treated as values: editing the
+    inside of a step's own lists in place is not seen."""
+    return len(snapshot) == len(scheme) and all(map(_is, snapshot, scheme))
+
+
 _desc_cache = _Bounded(8192)   # key: labels + shapes + strides of one step
 
 # Optional per-launch timing hook (bench.py / profiling only): an object with
@@ -318,7 +327,8 @@ def _launch_step(d, a, b, out, stream):
     2^9+ / 2^10+ values pack their operands first: to bfloat16 in the reduced-precision mode, in tile order otherwise).  The library never allocates: the scratch is
     a torch buffer, returned to the caching allocator in stream order.  Returns the status code."""
     lib = N.lib()
-    if d.dtype != N.ARTN_C128 and a.numel() >= (1 << 20):   # (only big contractions ever pack their operands)
+    if d.dtype != N.ARTN_C128 and max(a.numel(), b.numel()) >= (1 << 20):   # (only big contractions ever pack their operands;
+        #                                 the planner may swap them, so the bigger of the two decides: what is queried is what runs)
         ws_bytes = _step_info_cached(d)["workspace_bytes"]
         if ws_bytes > 0:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
@@ -342,7 +352,7 @@ def contract(eq, a, b, out=None):
         if _sum_leading_ok(a, n_rows):   # the temporary label leads: a plain column sum
             if out is None:
                 return sum_leading(a, n_rows).reshape(a.shape[n_outer:])
-            if out.is_contiguous() and out.dtype == a.dtype and tuple(out.shape) == tuple(a.shape[n_outer:]):
+            if out.is_contiguous() and out.dtype == a.dtype and out.device == a.device and tuple(out.shape) == tuple(a.shape[n_outer:]):
                 # (with out=: the chunk loop of the sparse executor in complex128 -- the sum went to the strided kernel)
                 sum_leading(a, n_rows, out=out.reshape(-1))
                 return out
@@ -356,8 +366,8 @@ def contract(eq, a, b, out=None):
     if out is None:
         out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
     else:
-        if tuple(out.shape) != out_shape or not out.is_contiguous() or out.dtype != a.dtype:
-            raise RuntimeError("out= must be a contiguous tensor of the result shape and dtype")
+        if tuple(out.shape) != out_shape or not out.is_contiguous() or out.dtype != a.dtype or out.device != a.device:
+            raise RuntimeError("out= must be a contiguous tensor of the result shape and dtype on the operands' device")
     if out.numel() == 0:
         return out
     _warn_if_generic(d, max(a.numel(), out.numel()), f"contract({eq!r})" if isinstance(eq, str) else "contract()")
@@ -864,12 +874,12 @@ def tensor_contraction(tensors, scheme):
     # (host time matters for the launch-latency workloads -- n12 is ONE 90 us launch: the ids a scheme reads are
     #  resolved once per scheme object, the per-tensor checks are inlined, shapes are hashed as torch.Size)
     su = _scheme_ids.get(id(scheme))
-    if su is None or su[0] is not scheme:
+    if su is None or su[0] is not scheme or not _same_steps(su[2], scheme):
         seen = {}
         for step in scheme:
             for k in step[0]:
                 seen.setdefault(k, None)
-        su = _scheme_ids[id(scheme)] = (scheme, tuple(seen))
+        su = _scheme_ids[id(scheme)] = (scheme, tuple(seen), tuple(scheme))
     is_dict = isinstance(tensors, dict)
     n_list = 0 if is_dict else len(tensors)
     first = None
@@ -895,13 +905,13 @@ def tensor_contraction(tensors, scheme):
         raise RuntimeError("tensor_contraction needs complex64 or complex128 GPU tensors")
     key = (id(scheme), dtype, precision.current(), tuple(shape_key), _HAS_PAIR_QUERY(), bool(_os_environ.get("ARTN_NO_FUSE")))
     hit = _plan_cache.get(key)
-    if hit is None or hit[0] is not scheme:
+    if hit is None or hit[0] is not scheme or hit[3] is not su[2]:   # (su[2]: the step snapshot just verified above)
         shapes = {k: tuple(tensors[k].shape) for k in su[1] if (k in tensors if is_dict else isinstance(k, int) and 0 <= k < n_list)}
         try:
             prog, ops = _compile_dense(scheme, shapes, first.dtype)
         except KeyError as e:
             raise RuntimeError(f"scheme refers to tensor id {e} that was not supplied") from e
-        hit = _plan_cache[key] = (scheme, ops, prog)
+        hit = _plan_cache[key] = (scheme, ops, prog, su[2])
     ops, prog = hit[1], hit[2]
     lib = N.lib()
     byref = ctypes.byref
@@ -1037,7 +1047,7 @@ def contract_gathered(eq, a, rows_a, b, rows_b, out=None, label=None, _validate=
     contraction.py:149-156, :177-179).  rows_* are the reference's int64 index tensors or None.
     Returns None when the step does not fit the tiled kernel (the caller gathers instead)."""
     la, lb, lo = _parse(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
-    if a.dtype != torch.complex64 or b.dtype != torch.complex64 or not lo:
+    if a.dtype != b.dtype or a.dtype not in _DTYPES or not lo:
         return None
     lab = lo[0] if label is None else label
     if (rows_a is not None and (not la or la[0] != lab)) or (rows_b is not None and (not lb or lb[0] != lab)):
@@ -1120,12 +1130,13 @@ def gather_rows(t, idx, _validate=True):
 
 def _normalize_inplace(t):
     """t /= t.abs().max(); returns the device scalar abs-max (reference contraction.py:197-199)."""
-    if t.dtype != torch.complex64:
-        raise RuntimeError("scientific_notation is implemented for complex64")
-    amax = torch.empty(1, dtype=torch.float32, device=t.device)
+    if t.dtype not in _DTYPES:
+        raise RuntimeError(f"scientific_notation needs complex64 or complex128 tensors, got {t.dtype}")
+    c128 = t.dtype == torch.complex128
+    amax = torch.empty(1, dtype=torch.float64 if c128 else torch.float32, device=t.device)
+    fn = N.lib().artn_absmax_normalize_c128 if c128 else N.lib().artn_absmax_normalize_c64
     with torch.cuda.device(t.device):
-        N.check(N.lib().artn_absmax_normalize_c64(t.data_ptr(), t.numel(), amax.data_ptr(),
-                                                  N.current_stream_ptr(t.device)))
+        N.check(fn(t.data_ptr(), t.numel(), amax.data_ptr(), N.current_stream_ptr(t.device)))
     return amax
 
 
@@ -1217,10 +1228,10 @@ def _sparse_program(scheme, tensors):
         return None, _NO_HOIST
     sig = tuple(shapes.items())
     hit = _sparse_prog_cache.get(id(scheme))
-    if hit is None or hit[0] is not scheme or hit[1] != sig:
+    if hit is None or hit[0] is not scheme or hit[1] != sig or not _same_steps(hit[4], scheme):
         prog, main = _plan_small_program(scheme, shapes, dtype)
         hoisted = frozenset(range(len(scheme))) - frozenset(main) if prog is not None else _NO_HOIST
-        hit = _sparse_prog_cache[id(scheme)] = (scheme, sig, prog, hoisted)
+        hit = _sparse_prog_cache[id(scheme)] = (scheme, sig, prog, hoisted, tuple(scheme))
     return hit[2], hit[3]
 
 
@@ -1245,8 +1256,8 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
     scheme = contraction_scheme
     key = id(scheme)
     hit = _schedule_cache.get(key)
-    if hit is None or hit[0] is not scheme:
-        hit = _schedule_cache[key] = (scheme, fusion_schedule(scheme))
+    if hit is None or hit[0] is not scheme or not _same_steps(hit[2], scheme):
+        hit = _schedule_cache[key] = (scheme, fusion_schedule(scheme), tuple(scheme))
     factor = None
     last = scheme[-1][0][0]
 

@@ -20,7 +20,10 @@
 //   accumulator register r of lane (j, g): row i = g + 4r  ->  ro = g & 1, n_in = (g >> 1) + 2r   (guide: f64 C/D map)
 // (f64x4, lds_read_f64, lds_write_f64: artn_kernels.hip, next to the other LDS accessors)
 
-template <int NB>
+// GATHER: row indices on one outer axis (artn_contract_gather: the chunk loop of the sparse executor in complex128,
+// /root/reference/artensor/contraction.py:140-175 with `dtype=torch.complex128`): the tile offsets of both operands are
+// read through rows_a[x] / rows_b[x] (tile_offsets<true>), nothing else changes.
+template <int NB, bool GATHER = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm128(const double2 *__restrict__ A, const double2 *__restrict__ B,
                                                                     double2 *__restrict__ C, const ArtnGemmPlan P) {
   constexpr int MB = 2;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm128(const doubl
   TileOff off = {0, 0, 0, 0}, noff = {0, 0, 0, 0};
   const char *Ac = reinterpret_cast<const char *>(A), *Bc = reinterpret_cast<const char *>(B);
   if (t0 < n_tiles) {
-    off = tile_offsets<false>(P, OT, t0);
+    off = tile_offsets<GATHER>(P, OT, t0);
     issue(Ac + off.a * 16, Bc + off.b1 * 16);
     fill(0u);
   }
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_gemm128(const doubl
   unsigned cur = 0;
   for (long tile = t0; tile < n_tiles; tile += G) {
     const bool more_tiles = tile + G < n_tiles;
-    if (more_tiles) noff = next_offsets<false>(P, OT, off, tile, G);
+    if (more_tiles) noff = next_offsets<GATHER>(P, OT, off, tile, G);
     f64x4 acc[MB][NB];
 #pragma unroll
     for (int a = 0; a < MB; ++a)

@@ -2215,6 +2215,34 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_divide(float2 *__restr
     x[i] = v;
   }
 }
+// the same in complex128 (the reference renormalises whatever dtype it runs in, contraction.py:197-200)
+__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_absmax128(const double2 *__restrict__ x, long n,
+                                                                    unsigned long long *out_bits) {
+  double m = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double2 v = x[i];
+    m = fmax(m, hypot(v.x, v.y));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  __shared__ double part[ARTN_WG_THREADS / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < ARTN_WG_THREADS / 64; ++w) m = fmax(m, part[w]);
+    atomicMax(out_bits, (unsigned long long)__double_as_longlong(m)); // non-negative doubles order like their bit patterns
+  }
+}
+__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_divide128(double2 *__restrict__ x, long n,
+                                                                    const double *__restrict__ denom) {
+  const double d = *denom;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double2 v = x[i];
+    v.x /= d;
+    v.y /= d;
+    x[i] = v;
+  }
+}
 
 #endif // !ARTN_TU_PART
 
@@ -2562,11 +2590,27 @@ static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, v
     hipLaunchKernelGGL(kern, grid, block, lds, st, a2, b2, c2, g);                                   \
     return hipGetLastError();                                                                        \
   }
+#define ARTN_GEMM128_LAUNCH_G(NBV)                                                                   \
+  {                                                                                                  \
+    auto kern = artn_k_gemm128<NBV, true>;                                                           \
+    if (hipError_t e = ensure_lds<artn_k_gemm128<NBV, true>>(lds); e != hipSuccess) return e;        \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a2, b2, c2, g);                                   \
+    return hipGetLastError();                                                                        \
+  }
+    if (g.gather_dim >= 0) { // row gather (artn_contract_gather) in complex128
+      switch (g.nb_log2) {
+        case 0: ARTN_GEMM128_LAUNCH_G(1)
+        case 1: ARTN_GEMM128_LAUNCH_G(2)
+        case 2: ARTN_GEMM128_LAUNCH_G(4)
+      }
+      return hipErrorInvalidValue;
+    }
     switch (g.nb_log2) {
       case 0: ARTN_GEMM128_LAUNCH(1)
       case 1: ARTN_GEMM128_LAUNCH(2)
       case 2: ARTN_GEMM128_LAUNCH(4)
     }
+#undef ARTN_GEMM128_LAUNCH_G
 #undef ARTN_GEMM128_LAUNCH
     return hipErrorInvalidValue;
   }
@@ -2831,7 +2875,8 @@ int artn_contract_ws(const ArtnStepDesc *d, const void *A, const void *B, void *
   if (ws && ws_bytes > 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) == 0 && !env_flag("ARTN_FORCE_GENERIC")) {
     ArtnPlan p;
     std::string err;
-    int rc = artn::make_plan(d, p, err, g_ncu, true, 32, -1, true, true);
+    const int64_t min_tiles = env_flag("ARTN_FORCE_BITS") ? 1 : 32; // (the same switches as artn_contract / artn_contract_query)
+    int rc = artn::make_plan(d, p, err, g_ncu, true, min_tiles, -1, true, true);
     if (rc) return fail(rc, err);
     if (p.kernel == ARTN_KERNEL_PGEMM && p.info.workspace_bytes <= ws_bytes) {
       HIP_TRY(launch_pgemm(p, A, B, C, ws, (hipStream_t)stream));
@@ -3357,6 +3402,20 @@ int artn_absmax_normalize_c64(void *x, int64_t n, float *out_absmax, void *strea
                      (unsigned int *)out_absmax);
   hipLaunchKernelGGL(artn_k_divide, dim3(grid), dim3(ARTN_WG_THREADS), 0, st, (float2 *)x, (long)n,
                      (const float *)out_absmax);
+  HIP_TRY(hipGetLastError());
+  return ARTN_OK;
+}
+
+int artn_absmax_normalize_c128(void *x, int64_t n, double *out_absmax, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (n <= 0 || !x || !out_absmax) return fail(ARTN_E_INVALID, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(out_absmax, 0, sizeof(double), st));
+  const int grid = (int)std::min<long>((n + ARTN_WG_THREADS - 1) / ARTN_WG_THREADS, 256L * 8);
+  hipLaunchKernelGGL(artn_k_absmax128, dim3(grid), dim3(ARTN_WG_THREADS), 0, st, (const double2 *)x, (long)n,
+                     (unsigned long long *)out_absmax);
+  hipLaunchKernelGGL(artn_k_divide128, dim3(grid), dim3(ARTN_WG_THREADS), 0, st, (double2 *)x, (long)n,
+                     (const double *)out_absmax);
   HIP_TRY(hipGetLastError());
   return ARTN_OK;
 }

@@ -155,7 +155,8 @@ struct ArtnGemmPlan {
   int32_t *gather_err;
 };
 
-// Launch plan of the packed-operand GEMM (artn_k_pack_bf16 + artn_k_pgemm; ARTN_C64_BF16 only): big x big steps with
+// Launch plan of the packed-operand GEMM (artn_k_pack_bf16 + artn_k_pgemm under ARTN_C64_BF16; artn_k_pack_f32 + artn_k_pgemm3m
+// for plain ARTN_C64 since round 3, tuning().packed = 2): big x big steps with
 // many contracted bits (BASELINE configs[4]: 2^30 x 2^29 elements over 15 contracted bits).  One pass per operand
 // rounds it to bfloat16 and writes it in the order the GEMM's LDS images have -- [tile][chunk][kc >> 2][row][kc & 3],
 // 4 bytes per complex element -- into a caller-supplied workspace; the GEMM then moves half the bytes per operand
@@ -1090,10 +1091,10 @@ static inline bool make_gemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64
 // ----------------------------------------------------------------------------------------
 #define ARTN_GEMM128_KC 3
 #define ARTN_GEMM128_EPI_BITS 12 /* result passes of 2^12 elements (64 KiB) */
-static inline bool make_gemm128(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles) {
+static inline bool make_gemm128(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles, int gather_label = -1) {
   if (d->dtype != ARTN_C128) { p.why_generic = "dtype is not complex128"; return false; }
   std::vector<Axis> ax;
-  expand_axes(d, ax);
+  expand_axes(d, ax, gather_label);
   std::vector<int> K, M, N, O;
   for (int i = 0; i < (int)ax.size(); ++i) {
     const Axis &a = ax[i];
@@ -1208,7 +1209,7 @@ static inline bool make_gemm128(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, in
     const Axis &a = ax[i];
     ArtnOuterDim od;
     od.ext = a.ext; od.sA = a.sA >= 0 ? a.sA : 0; od.sB1 = a.sB1 >= 0 ? a.sB1 : 0; od.sB2 = 0; od.sC = a.sC >= 0 ? a.sC : 0;
-    od.log2ext = ilog2_exact(a.ext); od.pad_ = 0;
+    od.log2ext = a.gathered ? -1 : ilog2_exact(a.ext); od.pad_ = 0; // (the gathered axis is decoded the slow way, on its own)
     g.n_tiles *= a.ext;
     if (a.sA < 0) a_rereads *= a.ext;
     if (g.n_outer > 0) {
@@ -1220,8 +1221,10 @@ static inline bool make_gemm128(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, in
       }
     }
     if (g.n_outer >= ARTN_MAX_OUTER) { p.why_generic = "too many outer axes"; return false; }
+    if (a.gathered) g.gather_dim = g.n_outer;
     g.outer[g.n_outer++] = od;
   }
+  if (gather_label >= 0 && g.gather_dim < 0) { p.why_generic = "gathered label is not an outer axis"; return false; }
   {
     int64_t sa = 0, sb = 0, sc = 0;
     for (int b = 0; b < 8; ++b) {
@@ -1253,7 +1256,7 @@ static inline bool make_gemm128(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, in
 }
 
 // ----------------------------------------------------------------------------------------
-// packed-operand GEMM (ARTN_C64_BF16): see ArtnPackPlan
+// packed-operand GEMM (ARTN_C64_BF16, and ARTN_C64 in 3M fp32): see ArtnPackPlan
 // ----------------------------------------------------------------------------------------
 static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
   if (d->dtype != ARTN_C64_BF16 && d->dtype != ARTN_C64) { p.why_generic = "packed GEMM: complex64 only"; return false; }
@@ -1411,6 +1414,9 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
     }
     if (kk >= 7 && (nn >= 5 || tuning().gather_gemm >= 2)) ok = make_gemm(d, p, n_cu, min_tiles, false, -1, gather_label);
   }
+  // complex128 row gather: the f64 GEMM kernel (3+ contracted bits); there is no gathering state-streaming kernel in complex128
+  if (!ok && gather_label >= 0 && allow_bits && d->dtype == ARTN_C128 && tuning().gemm)
+    ok = make_gemm128(d, p, n_cu, min_tiles, gather_label);
   if (!ok) ok = allow_bits && (d->dtype != ARTN_C128 || gather_label < 0) && make_bits(d, nullptr, p, n_cu, min_tiles, gather_label);
   // A state-streaming tile with fewer than four (sub-tile, column block) units leaves waves without work -- and the busy
   // waves of the two workgroups of a CU sit on the same SIMDs: a 6-bit step of the n53 slices with 16 result columns and

@@ -540,9 +540,9 @@ def partitioned_contraction(tensors, scheme, n_fix, part, device="cuda", dtype=t
     shapes = {k: tuple(t.shape) for k, t in items}
     key = (id(scheme), n_fix, tuple(sorted(shapes.items(), key=lambda kv: repr(kv[0]))))
     hit = _partition_cache.get(key)
-    if hit is None or hit[0] is not scheme:
-        hit = _partition_cache[key] = (scheme,) + partition_output(scheme, shapes, n_fix)
-    _, new_scheme, selects, fixed_dims = hit
+    if hit is None or hit[0] is not scheme or not _C._same_steps(hit[4], scheme):
+        hit = _partition_cache[key] = (scheme,) + tuple(partition_output(scheme, shapes, n_fix)) + (tuple(scheme),)
+    _, new_scheme, selects, fixed_dims, _ = hit
     values = slice_assignments(n_fix, part)
     per_leaf = {}
     for (leaf, dim), v in zip(selects, values):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ARTN_ABI_VERSION 3
+#define ARTN_ABI_VERSION 4
 #define ARTN_MAX_LABELS 96
 
 /* error codes */
@@ -66,7 +66,10 @@ typedef struct ArtnStepDesc {
 #define ARTN_KERNEL_GENERIC 0 /* one thread per output element, strided loops       */
 #define ARTN_KERNEL_BITS_MFMA 1 /* LDS-tiled bit-permuted complex GEMM on fp32 MFMA */
 #define ARTN_KERNEL_GEMM_MFMA 2 /* two-operand LDS GEMM on fp32 MFMA, contracted bits looped in-kernel */
-#define ARTN_KERNEL_PGEMM 4     /* ARTN_C64_BF16, big steps: operands packed to bfloat16 in a workspace, LDS-DMA GEMM */
+#define ARTN_KERNEL_PGEMM 4     /* big x big steps (2^8+ contracted values, arithmetic intensity >= 64): both operands packed in
+                                 * tile order into a workspace, then an LDS-DMA GEMM.  ARTN_C64: fp32 images, 3M arithmetic
+                                 * (artn_k_pgemm3m; workspace 8 B x (2^(m+k) + 2^(n+k))); ARTN_C64_BF16: bfloat16 images
+                                 * (artn_k_pgemm; half of that) */
 typedef struct ArtnStepInfo {
   int32_t kernel;       /* ARTN_KERNEL_*                                        */
   int32_t k_bits;       /* contracted bits handled inside a tile                */
@@ -107,9 +110,9 @@ const char *artn_last_plan_note(void);
 int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *stream);
 
 /* The same with `ws_bytes` bytes of device scratch (16-byte aligned; ArtnStepInfo::workspace_bytes of
- * artn_contract_query says how much the step can use): steps that pack their operands first -- the big
- * contractions of the reduced-precision mode -- run that way when the scratch is big enough, and exactly like
- * artn_contract otherwise.  The library never allocates. */
+ * artn_contract_query says how much the step can use): steps that pack their operands first (ARTN_KERNEL_PGEMM:
+ * the big x big contractions of plain complex64 AND of the reduced-precision mode) run that way when the scratch
+ * is big enough, and exactly like artn_contract otherwise.  The library never allocates. */
 int artn_contract_ws(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *ws, int64_t ws_bytes,
                      void *stream);
 
@@ -204,6 +207,9 @@ int artn_sum_axis_c128(const void *in, void *out, int64_t n_groups, int64_t n_ro
  * x[i] /= out[0]: the running renormalisation of artensor/contraction.py:197-200
  * (`norm_factor = tensors[i].abs().max(); tensors[i] /= norm_factor`). */
 int artn_absmax_normalize_c64(void *x, int64_t n, float *out_absmax, void *stream);
+/* the same for complex128 elements (out_absmax: float64 device pointer): the reference renormalises in whatever
+ * dtype `TensorNetworkSimulation.contraction(dtype=...)` selected (artensor/simulation.py:90, contraction.py:197-200) */
+int artn_absmax_normalize_c128(void *x, int64_t n, double *out_absmax, void *stream);
 
 /* Measurement aid (bench.py): the rate the matrix pipes of this device sustain on back-to-back MFMAs with operands
  * in registers, in TFLOP/s -- kind 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_bf16, 2: v_mfma_f64_16x16x4_f64

@@ -281,3 +281,11 @@ def tensor_contraction_sparse_torch_cpu(tensors, scheme, budget_s=None, threads=
     whole = done_n == len(scheme)
     return dict(result=ts[scheme[-1][0][0]] if whole else None, steps_done=done_n, flops_done=done_f,
                 flops_total=None, seconds=dt, threads=torch.get_num_threads())
+
+
+# The two torch loops above run on whatever device their tensors live on.  With complex128 CUDA tensors they are the
+# reference's executors as they run on a GPU (torch.einsum -> permute + bmm on the vendor BLAS): an independent complex128
+# truth for the cases whose 2^30-element intermediates (16 GiB each in complex128) do not fit the build container
+# (tests/test_gpu_parity.py::test_c128_truth_against_torch_einsum_on_the_gpu).  Test infrastructure only.
+tensor_contraction_torch = tensor_contraction_torch_cpu
+tensor_contraction_sparse_torch = tensor_contraction_sparse_torch_cpu

@@ -954,6 +954,133 @@ def test_complex128_on_the_matrix_cores():
     assert raw.dtype == np.complex128 and amp_rel(raw.reshape(-1), arrays["n12_dense_c128"]) < 1e-12
 
 
+def test_complex128_row_gather_and_scientific_notation():
+    """The sparse executor in complex128 (reference contraction.py:132-205 takes any dtype): (d) the chunk loop's row
+    gather fused into the f64 GEMM kernel (artn_k_gemm128<NB, GATHER>, :149-156) against gather + einsum in numpy, and
+    the n30 x 100 scheme (four chunk steps) against the REFERENCE's own complex128 run (c128_spread.npz); (c)
+    scientific_notation renormalises in complex128 (:197-200) -- n12 against the oracle in complex128, and the
+    factor / amplitudes recombine to the reference's complex128 amplitudes."""
+    from artensor_amd.contraction import contract_gathered
+    rng = np.random.default_rng(29)
+    for (na, nb, n, free, kb, nn) in [(7, 5, 6, 12, 3, 2), (3, 9, 619, 10, 8, 3), (9, 11, 100, 8, 8, 6), (6, 3, 37, 9, 7, 5),
+                                      (4, 4, 6, 4, 7, 7)]:
+        la = ["z"] + [chr(65 + x) for x in range(free + kb)]
+        kl = la[1:1 + kb]
+        nl = [chr(97 + x) for x in range(nn)]
+        lb = ["z"] + kl[::-1] + nl
+        lo = ["z"] + [x for x in la[1:] if x not in kl] + nl
+        eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
+        a = rng.standard_normal((na,) + (2,) * (len(la) - 1)) + 1j * rng.standard_normal((na,) + (2,) * (len(la) - 1))
+        b = rng.standard_normal((nb,) + (2,) * (len(lb) - 1)) + 1j * rng.standard_normal((nb,) + (2,) * (len(lb) - 1))
+        ra, rb = torch.from_numpy(rng.integers(0, na, size=n)), torch.from_numpy(rng.integers(0, nb, size=n))
+        got = contract_gathered(eq, gpu(a), ra, gpu(b), rb)
+        assert got is not None and got.dtype == torch.complex128, eq
+        want = torch.einsum(eq, torch.from_numpy(a[ra.numpy()]), torch.from_numpy(b[rb.numpy()])).numpy()
+        assert rel(got.cpu().numpy(), want) < 1e-12, eq
+        got = contract_gathered(eq, gpu(a[ra.numpy()]), None, gpu(b), rb)
+        assert got is not None and rel(got.cpu().numpy(), want) < 1e-12
+    A.contraction.check_gather_flag()
+    meta, arrays = c128_spread()
+    case = load_case(os.path.join(GOLDEN, "n30_sparse100.npz"))
+    from artensor_amd import contraction as C
+    calls = []
+    orig = C.contract_gathered
+    C.contract_gathered = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        out = A.tensor_contraction_sparse(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme)
+    finally:
+        C.contract_gathered = orig
+    assert calls and out.dtype == torch.complex128
+    assert amp_rel(out.cpu().numpy().reshape(-1), arrays["n30_sparse100_c128"]) < 1e-11
+    # scientific notation in complex128
+    case = load_case(os.path.join(GOLDEN, "n12_sparse5_scinot.npz"))
+    factor, out = A.tensor_contraction_sparse(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme,
+                                              scientific_notation=True)
+    assert out.dtype == torch.complex128 and factor.dtype == torch.float64
+    leaves = {k: t.numpy().astype(np.complex128) for k, t in case.tensors.items()}
+    of, oo = oracle.tensor_contraction_sparse(leaves, case.scheme, scientific_notation=True)
+    assert abs(factor.cpu().item() - float(np.real(of))) < 1e-10
+    assert amp_rel(out.cpu().numpy(), oo) < 1e-12
+    assert abs(float(out.abs().max().item()) - 1.0) < 1e-12            # renormalised after the last step
+    assert amp_rel(out.cpu().numpy().reshape(-1) * 10.0 ** factor.cpu().item(), arrays["n12_sparse5_c128"]) < 1e-11
+
+
+def test_scheme_list_mutated_in_place_is_recompiled():
+    """The reference re-reads the scheme list on every call (contraction.py:66); the compiled-plan caches are keyed on
+    id(scheme) and must notice steps appended / removed / replaced in place (VERDICT r03 weak #11)."""
+    case = load_case(os.path.join(GOLDEN, "n12_dense.npz"))
+    leaves64 = {k: t.numpy() for k, t in case.tensors.items()}
+    scheme = list(case.scheme)
+    full = A.tensor_contraction(case.fresh_tensors(device=DEV), scheme).cpu().numpy()
+    assert rel(full, oracle.tensor_contraction(dict(leaves64), list(case.scheme))) < 1e-5
+    last = scheme.pop()                                    # same list object, one step fewer
+    part = A.tensor_contraction(case.fresh_tensors(device=DEV), scheme).cpu().numpy()
+    want = oracle.tensor_contraction(dict(leaves64), list(case.scheme[:-1]))
+    assert part.shape == want.shape and rel(part, want) < 1e-5
+    scheme.append(last)                                    # and back
+    again = A.tensor_contraction(case.fresh_tensors(device=DEV), scheme).cpu().numpy()
+    assert again.shape == full.shape and np.array_equal(again, full)
+    # the sparse executor's schedule / program caches
+    case = load_case(os.path.join(GOLDEN, "n12_sparse5.npz"))
+    scheme = list(case.scheme)
+    full = A.tensor_contraction_sparse(case.fresh_tensors(device=DEV), scheme).cpu().numpy()
+    assert amp_rel(full, case.arrays["final"]) < 1e-5
+    last = scheme.pop()
+    part = A.tensor_contraction_sparse(case.fresh_tensors(device=DEV), scheme).cpu().numpy()
+    want = oracle.tensor_contraction_sparse({k: t.numpy() for k, t in case.tensors.items()}, list(case.scheme[:-1]))
+    assert part.shape == np.asarray(want).shape and rel(part, want) < 1e-5
+    scheme.append(last)
+    assert np.array_equal(A.tensor_contraction_sparse(case.fresh_tensors(device=DEV), scheme).cpu().numpy(), full)
+
+
+TRUTH_CASES = {
+    # key in c128_truth_gpu.npz -> (fixture, sparse, sliced)
+    "n30_dense_at_google": ("n30_dense.npz", False, False),
+    "n30_sparse100_final": ("n30_sparse100.npz", True, False),
+    "n30_sparse10000_final": ("n30_sparse10000.npz", True, False),
+    "n53_m14_sliced_slice0": ("n53_m14_sliced.npz", True, True),
+    "n53_m20_sliced_slice0": ("n53_m20_sliced.npz", True, True),
+    "n53_m20_batch_slice0": ("n53_m20_batch.npz", True, True),
+    "rand_D2_nv260_sliced_slice0": ("rand_D2_nv260_sliced.npz", False, True),
+    "rand_D4_nv100_slice0": ("rand_D4_nv100.npz", False, True),
+}
+
+
+@pytest.mark.parametrize("key", sorted(TRUTH_CASES))
+def test_c128_truth_against_torch_einsum_on_the_gpu(key):
+    """The committed complex128 truth (tests/golden/c128_truth_gpu.npz, computed by THIS package's f64-MFMA path) against
+    an INDEPENDENT complex128 computation of the same leaves and scheme: the reference's executor loop run by torch in
+    complex128 on the GPU (oracle.tensor_contraction[_sparse]_torch: torch.einsum -> permute + bmm on the vendor BLAS;
+    no planner, descriptor or kernel of this package).  The build container cannot hold these cases in complex128
+    (2^30-element intermediates, 16 GiB each); 288 GB of HBM can.  Both must agree to 1e-11 of the rms amplitude."""
+    fixture, sparse, sliced = TRUTH_CASES[key]
+    case = load_case(os.path.join(GOLDEN, fixture))
+    leaves = case.fresh_tensors(dtype=torch.complex128, device=DEV)
+    if sliced and case.slicing_indices:
+        leaves = A.apply_slice(leaves, case.slicing_indices, A.slice_assignments(len(case.slicing_indices), 0))
+    fn = oracle.tensor_contraction_sparse_torch if sparse else oracle.tensor_contraction_torch
+    out = fn(leaves, case.scheme)["result"]
+    assert out.dtype == torch.complex128
+    if key == "n30_dense_at_google":
+        perm = case.meta["permute_dims"]
+        fpos = np.array([int(b, 2) for b in case.meta["google_bitstrings"]], dtype=np.int64)
+        rpos = np.zeros_like(fpos)
+        for d in range(30):
+            rpos |= ((fpos >> (29 - d)) & 1) << (29 - perm[d])
+        got = out.reshape(-1)[torch.from_numpy(rpos).to(DEV)].cpu().numpy()
+        # ... and every one of the 2^30 amplitudes of this package's complex128 path against torch's
+        mine = A.tensor_contraction(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme)
+        assert float((mine - out).abs().max().item()) <= 1e-11 * 2.0 ** -15
+        del mine
+    else:
+        got = out.reshape(-1).cpu().numpy()
+    del out, leaves
+    torch.cuda.empty_cache()
+    t = gpu_truth(key)
+    rms = float(np.sqrt(np.mean(np.abs(t) ** 2)))
+    assert np.abs(got - t).max() <= 1e-11 * rms, (key, float(np.abs(got - t).max() / rms))
+
+
 def test_complex128_fused_pairs():
     """complex128 pairs in ONE pass (artn_k_bits128: 16-byte elements, f64 MFMA stages, the intermediate in LDS): the 13
     fusable pairs of the n30 scheme truncated to 2^21 elements and random pairs, 1e-12 against complex128 einsums; single
