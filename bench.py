@@ -665,54 +665,60 @@ def sig(x, n=4):
     return float(f"{x:.{n}g}")
 
 
-COMPACT_LIMIT = 1500   # bytes: the driver keeps a 2 000-character tail of stdout
+COMPACT_LIMIT = 1700   # bytes: the driver keeps a 2 000-character tail of stdout
 
 
 def compact_line(full):
-    """The LAST stdout line: what the driver parses.  Everything else of `full` goes to bench_detail.json and the
-    per-leg lines.  Keys are dropped from the least important end until the line fits COMPACT_LIMIT."""
+    """The LAST stdout line: what the driver parses (it keeps a 2 000-character tail).  Everything else of `full` goes to
+    bench_detail.json and the per-leg lines.  Optional keys are dropped from the least important end until the line fits
+    COMPACT_LIMIT; metric, value, roofline, cpu_baseline and the per-leg triples are never dropped."""
     cfg, roof = full.get("config", {}), full.get("roofline") or {}
     vt = cfg.get("vs_c128_truth") or {}
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data") if k in full}
     line["value"], line["ms_per_step"] = sig(full["value"], 6), sig(full["ms_per_step"], 6)
-    c = {"workload": cfg.get("workload"), "flops_per_step": sig(cfg.get("flops_per_step"), 6), "parallelism": cfg.get("parallelism"),
+    par = cfg.get("parallelism")
+    c = {"workload": "Sycamore n30 m14 full-amplitude, complex64, no slicing (tests/golden/n30_dense.npz)",
+         "flops_per_step": sig(cfg.get("flops_per_step"), 6), "parallelism": par if par in (None, "single") else par.split(":")[0],
          "check": cfg.get("check"), "frac_mfma_peak": sig(cfg.get("frac_mfma_peak")),
          "err_loose": sig(vt.get("hip_loose", cfg.get("err_rel_to_max_abs_or_rms")), 3),
          "err_strict": sig(vt.get("hip_strict", cfg.get("rel_err_strict_over_1e-3rms")), 3),
          "ref_c64_loose": sig(vt.get("reference_c64_loose"), 3), "ref_c64_strict": sig(vt.get("reference_c64_strict"), 3),
          "err_vs": "c128 truth" if vt else "reference c64", "n12_gpu_us": sig(cfg.get("n12_gpu_us")),
-         "ms_per_step_unprofiled": sig(cfg.get("ms_per_step_unprofiled"), 6)}
+         "ms_unprofiled": sig(cfg.get("ms_per_step_unprofiled"), 6)}
     if cfg.get("failed_workloads"):
         c["failed_workloads"] = cfg["failed_workloads"]
     line["config"] = {k: v for k, v in c.items() if v is not None}
     rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "mfma_frac_executed",
-          "hbm_frac", "algorithmic_bytes_per_launch", "launches_per_step", "avg_launch_ms", "kernel_ms_per_step")
-    line["roofline"] = {k: sig(roof.get(k), 5) for k in rk if k in roof}
+          "hbm_frac", "algorithmic_bytes_per_launch", "launches_per_step", "kernel_ms_per_step")
+    line["roofline"] = {k: sig(roof.get(k), 5) for k in rk if k in roof and (roof.get(k) is not None or k == "traffic")}
     cb = full.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                                "sample": (f"torch-CPU einsum loop, n30 scheme steps 0..{cb.get('n30_steps_done', '?')}"
-                                           f" ({100 * cb.get('n30_fraction_of_flops', 0):.0f}% of its FLOP) in {cb.get('n30_seconds', 0):.0f} s"),
+                                "sample": (f"torch-CPU einsum loop, n30 scheme steps 0..{cb.get('n30_steps_done', 0) - 1}"
+                                           f" ({100 * cb.get('n30_fraction_of_flops', 0):.0f}% of its FLOP), {cb.get('n30_seconds', 0):.0f} s"),
                                 "n12_ms": sig(cb.get("n12_ms"))}
     sl = full.get("sliced")
     if sl:
-        line["sliced"] = {"workload": "n53 m14 slice-sharded, one all-reduce", "value": sig(sl["value"], 6), "unit": "TFLOP/s",
-                          "ms_per_slice_per_rank": sig(sl.get("ms_per_slice_per_rank"), 5), "slices_timed": sl.get("slices_timed"),
+        line["sliced"] = {"workload": "n53 m14, slices sharded, one all-reduce", "value": sig(sl["value"], 6),
+                          "ms_per_slice": sig(sl.get("ms_per_slice_per_rank"), 5), "slices": sl.get("slices_timed"),
                           "ranks_in_collective": sl.get("ranks_in_collective"), "backend": sl.get("backend"), "check": sl.get("check")}
     wl = full.get("workloads")
     if wl:   # [TFLOP/s, roofline fraction of the dominant kernel (executed FLOP or bytes: never above 1), check]
         line["workloads"] = {k: [sig(v.get("value"), 4), sig((v.get("roofline") or {}).get("frac"), 3), (v.get("check") or {}).get("check")]
                              for k, v in wl.items()}
-    line["detail"] = "bench_detail.json; one {\"leg\":...} line per workload above"
-    for drop in (("detail",), ("config", "n12_gpu_us"), ("roofline", "avg_launch_ms"), ("config", "parallelism"),
-                 ("cpu_baseline", "n12_ms"), ("roofline", "launches_per_step"), ("workloads",)):
+    line["detail"] = "bench_detail.json + one {\"leg\":..} line per workload"
+    for drop in (("detail",), ("config", "n12_gpu_us"), ("cpu_baseline", "n12_ms"), ("roofline", "launches_per_step"),
+                 ("config", "parallelism"), ("config", "err_vs"), ("sliced", "workload"), ("roofline", "algorithmic_bytes_per_launch"),
+                 ("config", "ref_c64_loose"), ("config", "flops_per_step"), ("sliced", "slices"), ("config", "failed_workloads")):
         if len(json.dumps(line)) <= COMPACT_LIMIT:
             break
         d = line
         for k in drop[:-1]:
             d = d.get(k, {})
         d.pop(drop[-1], None)
+    if len(json.dumps(line)) > COMPACT_LIMIT and "workloads" in line:   # (many legs: value and check only)
+        line["workloads"] = {k: [v[0], v[2]] for k, v in line["workloads"].items()}
     return line
 
 

@@ -531,7 +531,12 @@ static void run_gemm128(const ArtnGemmPlan &P, const cd *A0, const cd *B0, cd *C
       int64_t ext = P.outer[d].ext, x;
       if (P.outer[d].log2ext >= 0) { x = r & (ext - 1); r >>= P.outer[d].log2ext; }
       else { x = r % ext; r /= ext; }
-      offA += x * P.outer[d].sA; offB += x * P.outer[d].sB1; offC += x * P.outer[d].sC;
+      int64_t xa = x, xb = x;
+      if (d == P.gather_dim) { // fused row gather (tile_offsets<true> of the GATHER instantiation)
+        if (P.rows_a) { xa = P.rows_a[x]; if (xa < 0 || xa >= P.src_rows_a) { xa = 0; if (P.gather_err) *P.gather_err = 1; } }
+        if (P.rows_b) { xb = P.rows_b[x]; if (xb < 0 || xb >= P.src_rows_b) { xb = 0; if (P.gather_err) *P.gather_err = 1; } }
+      }
+      offA += xa * P.outer[d].sA; offB += xb * P.outer[d].sB1; offC += x * P.outer[d].sC;
     }
     std::vector<double> acc((size_t)4 * MB * NB * 64 * 4, 0.0);
     auto ACC = [&](int wave, int a, int b, int lane, int rr) -> double & { return acc[((((size_t)wave * MB + a) * NB + b) * 64 + lane) * 4 + rr]; };
@@ -829,9 +834,11 @@ extern "C" int artn_emulate_gather(const ArtnStepDesc *d, const void *A, const v
     p.gemm.rows_a = sw ? rows_b : rows_a; p.gemm.rows_b = sw ? rows_a : rows_b;
     p.gemm.src_rows_a = sw ? src_rows_b : src_rows_a; p.gemm.src_rows_b = sw ? src_rows_a : src_rows_b;
     p.gemm.gather_err = err_flag;
-    run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);
+    if (d->dtype == ARTN_C128) run_gemm128(p.gemm, (const cd *)A, (const cd *)B, (cd *)C);
+    else run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);
     return 2;
   }
+  if (d->dtype == ARTN_C128) return ARTN_E_UNSUPPORTED; // (no gathering state-streaming kernel in complex128)
   p.bits.rows_a = rows_a; p.bits.rows_b = rows_b;
   p.bits.src_rows_a = src_rows_a; p.bits.src_rows_b = src_rows_b;
   p.bits.gather_err = err_flag;

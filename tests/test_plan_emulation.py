@@ -251,6 +251,54 @@ def test_fused_row_gather_emulated():
         assert np.abs(out - want).max() / np.abs(want).max() < 1e-5, eq
 
 
+def test_row_gather_emulated_complex128():
+    """The complex128 chunk loop's fused row gather (artn_k_gemm128<NB, GATHER>, reference contraction.py:149-156 in
+    complex128) replayed on the CPU from the plan make_plan builds for artn_contract_gather: 3 to 8 contracted bits, ragged
+    row counts, operands exchanged inside the plan; fewer than 3 contracted bits are declined (the caller gathers)."""
+    import ctypes
+    import torch
+    from artensor_amd import contraction as C
+    from helpers import emulator
+    emu = emulator()
+    emu.artn_emulate_gather.restype = ctypes.c_int
+    rng = np.random.default_rng(19)
+    for (na, nb, n, free, kb, nn) in [(3, 9, 20, 10, 2, 4), (7, 5, 6, 11, 3, 2), (16, 16, 9, 10, 4, 3), (5, 4, 7, 8, 8, 6),
+                                      (6, 3, 5, 7, 7, 5), (4, 4, 6, 4, 7, 7)]:
+        la = ["z"] + [chr(65 + x) for x in range(free + kb)]
+        kl = la[1:1 + kb]
+        nl = [chr(97 + x) for x in range(nn)]
+        lb = ["z"] + kl[::-1] + nl
+        lo = ["z"] + [x for x in la[1:] if x not in kl] + nl
+        eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
+        a = (rng.standard_normal((na,) + (2,) * (len(la) - 1)) + 1j * rng.standard_normal((na,) + (2,) * (len(la) - 1)))
+        b = (rng.standard_normal((nb,) + (2,) * (len(lb) - 1)) + 1j * rng.standard_normal((nb,) + (2,) * (len(lb) - 1)))
+        ra = rng.integers(0, na, size=n).astype(np.int64)
+        rb = rng.integers(0, nb, size=n).astype(np.int64)
+        want = oracle.einsum_pair(eq, a[ra], b[rb])
+        ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+        d, out_shape = C._descriptor(tuple(la), tuple(lb), tuple(lo), (n,) + tuple(a.shape[1:]), tuple(ta.stride()),
+                                     (n,) + tuple(b.shape[1:]), tuple(tb.stride()), torch.complex128)
+        out = np.zeros(out_shape, dtype=np.complex128)
+        flag = ctypes.c_int32(0)
+        rc = emu.artn_emulate_gather(ctypes.byref(d), a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                                     out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(0),
+                                     ra.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(na),
+                                     rb.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(nb), ctypes.byref(flag))
+        if kb < 3:
+            assert rc < 0, rc    # declined: fewer contracted bits than one chunk of the f64 GEMM kernel
+            continue
+        assert rc == 2, (eq, rc)
+        assert flag.value == 0
+        assert np.abs(out - want).max() / np.abs(want).max() < 1e-13, eq
+    # an index outside the operand reads row 0 and raises the flag
+    bad = ra.copy()
+    bad[0] = 99
+    emu.artn_emulate_gather(ctypes.byref(d), a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                            out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(0), bad.ctypes.data_as(ctypes.c_void_p),
+                            ctypes.c_int64(na), rb.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(nb), ctypes.byref(flag))
+    assert flag.value == 1
+
+
 def _random_gemm_step(rng, m, n, k, batch=0):
     ml = [f"m{x}" for x in range(m)]
     kl = [f"k{x}" for x in range(k)]
