@@ -50,7 +50,32 @@ tools/bw_probe: tools/bw_probe.hip
 tools/bw_probe2: tools/bw_probe2.hip
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) $< -o $@
 
+# CPU sanitizer build (SURVEY section 5 hook; AddressSanitizer + UBSan on the HOST side only -- GPU ASan is not available
+# on this pool): the library's host half (planner artn_plan.h, every extern "C" entry point, the program builder) compiled
+# with --offload-host-only and linked against a stand-in for the device fat binary (never launched: no GPU here), plus the
+# CPU plan emulator; then the CPU test suite and the planner stress run on them.  Log: profiles/rNN_asan.log.
+ASAN_RT := $(firstword $(wildcard /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so))
+ASAN_DIR := build/asan
+ASAN_FLAGS := -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared-libsan -fPIC -Iinclude -I$(CSRC)
+ASAN_LOG ?= profiles/r04_asan.log
+asan: $(SRCS) tests/csrc/plan_emulate.cpp
+	@mkdir -p $(ASAN_DIR)
+	$(HIPCC) $(ASAN_FLAGS) --offload-host-only -c $(CSRC)/artn_kernels.hip -o $(ASAN_DIR)/host.o
+	echo "__attribute__((aligned(4096))) const char $$(nm -u $(ASAN_DIR)/host.o | grep -o '__hip_fatbin_[0-9a-f]*' | head -1)[4096] = {0};" > $(ASAN_DIR)/fatbin_stub.c
+	/opt/rocm/lib/llvm/bin/clang -fPIC -c $(ASAN_DIR)/fatbin_stub.c -o $(ASAN_DIR)/fatbin_stub.o
+	$(HIPCC) -fsanitize=address,undefined -shared-libsan -fPIC -shared $(ASAN_DIR)/host.o $(ASAN_DIR)/fatbin_stub.o -o $(ASAN_DIR)/libartn_host_asan.so
+	/opt/rocm/lib/llvm/bin/clang++ $(ASAN_FLAGS) -shared tests/csrc/plan_emulate.cpp -o $(ASAN_DIR)/libplan_emulate_asan.so
+	( echo "# make asan: $$(date -u +%FT%TZ), sources $$(python3 -c 'import bench; print(bench.kernel_source_sha16())')"; \
+	  echo "# sanitizer symbols referenced: libartn_host_asan.so $$(nm -D $(ASAN_DIR)/libartn_host_asan.so | grep -c '__asan_\|__ubsan_'), libplan_emulate_asan.so $$(nm -D $(ASAN_DIR)/libplan_emulate_asan.so | grep -c '__asan_\|__ubsan_')"; \
+	  LD_PRELOAD=$(ASAN_RT) ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+	  ARTN_LIB=$(ASAN_DIR)/libartn_host_asan.so ARTN_EMU_LIB=$(ASAN_DIR)/libplan_emulate_asan.so \
+	  python3 -m pytest tests/test_abi_cpu.py tests/test_plan_emulation.py tests/test_slice_runner.py tests/test_scheme_compilers.py \
+	      tests/test_distributed.py -q -m "not gpu" -p no:cacheprovider 2>&1; \
+	  LD_PRELOAD=$(ASAN_RT) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+	  ARTN_LIB=$(ASAN_DIR)/libartn_host_asan.so python3 tools/stress_planner.py 3000 0 2>&1 ) | tee $(ASAN_LOG)
+	@! grep -E "ERROR: AddressSanitizer|runtime error:" $(ASAN_LOG)
+
 clean:
 	rm -f $(LIB)
 	rm -rf $(OBJDIR)
-.PHONY: all clean probes stamps phases ablate single
+.PHONY: all clean probes stamps phases ablate single asan

@@ -58,6 +58,10 @@ def emulator():
     global _emu
     if _emu is not None:
         return _emu
+    if os.environ.get("ARTN_EMU_LIB"):   # a prebuilt emulator (make asan: the AddressSanitizer / UBSan build)
+        _emu = ctypes.CDLL(os.environ["ARTN_EMU_LIB"])
+        _emu.artn_emulate.restype = ctypes.c_int
+        return _emu
     build = os.path.join(ROOT, "tests", "_build")
     os.makedirs(build, exist_ok=True)
     so = os.path.join(build, "libplan_emulate.so")
