@@ -832,7 +832,7 @@ def test_bench_gpus_2_as_a_plain_command():
     assert len(lines[-1]) < 2000
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["check"] == "ok"
     assert line["sliced"]["ranks_in_collective"] == 2 and line["sliced"]["backend"] == "gloo" and line["sliced"]["check"] == "ok"
-    assert line["sliced"]["slices_timed"] == 2 * 3 * 2
+    assert line["sliced"]["slices"] == 2 * 3 * 2
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than 2")
@@ -1034,14 +1034,10 @@ def test_scheme_list_mutated_in_place_is_recompiled():
 
 
 TRUTH_CASES = {
-    # key in c128_truth_gpu.npz -> (fixture, sparse, sliced)
-    "n30_dense_at_google": ("n30_dense.npz", False, False),
-    "n30_sparse100_final": ("n30_sparse100.npz", True, False),
+    # key in c128_truth_gpu.npz -> (fixture, sparse, sliced): the cases torch's GPU einsum can run (tensors of up to 25
+    # dims: its copy kernels refuse or crawl on the rank-30 operands of the other fixtures -- those are pinned by the torch-CPU
+    # run of tests/golden/make_c128_truth_cpu.py instead, tests/test_oracle.py::test_gpu_truth_equals_the_independent_cpu_truth)
     "n30_sparse10000_final": ("n30_sparse10000.npz", True, False),
-    "n53_m14_sliced_slice0": ("n53_m14_sliced.npz", True, True),
-    "n53_m20_sliced_slice0": ("n53_m20_sliced.npz", True, True),
-    "n53_m20_batch_slice0": ("n53_m20_batch.npz", True, True),
-    "rand_D2_nv260_sliced_slice0": ("rand_D2_nv260_sliced.npz", False, True),
     "rand_D4_nv100_slice0": ("rand_D4_nv100.npz", False, True),
 }
 
@@ -1049,10 +1045,9 @@ TRUTH_CASES = {
 @pytest.mark.parametrize("key", sorted(TRUTH_CASES))
 def test_c128_truth_against_torch_einsum_on_the_gpu(key):
     """The committed complex128 truth (tests/golden/c128_truth_gpu.npz, computed by THIS package's f64-MFMA path) against
-    an INDEPENDENT complex128 computation of the same leaves and scheme: the reference's executor loop run by torch in
-    complex128 on the GPU (oracle.tensor_contraction[_sparse]_torch: torch.einsum -> permute + bmm on the vendor BLAS;
-    no planner, descriptor or kernel of this package).  The build container cannot hold these cases in complex128
-    (2^30-element intermediates, 16 GiB each); 288 GB of HBM can.  Both must agree to 1e-11 of the rms amplitude."""
+    an INDEPENDENT complex128 computation of the same leaves and scheme, live: the reference's executor loop run by torch
+    in complex128 on the GPU (oracle.tensor_contraction[_sparse]_torch: torch.einsum -> permute + bmm on the vendor BLAS;
+    no planner, descriptor or kernel of this package).  Both must agree to 1e-11 of the rms amplitude."""
     fixture, sparse, sliced = TRUTH_CASES[key]
     case = load_case(os.path.join(GOLDEN, fixture))
     leaves = case.fresh_tensors(dtype=torch.complex128, device=DEV)
@@ -1061,19 +1056,7 @@ def test_c128_truth_against_torch_einsum_on_the_gpu(key):
     fn = oracle.tensor_contraction_sparse_torch if sparse else oracle.tensor_contraction_torch
     out = fn(leaves, case.scheme)["result"]
     assert out.dtype == torch.complex128
-    if key == "n30_dense_at_google":
-        perm = case.meta["permute_dims"]
-        fpos = np.array([int(b, 2) for b in case.meta["google_bitstrings"]], dtype=np.int64)
-        rpos = np.zeros_like(fpos)
-        for d in range(30):
-            rpos |= ((fpos >> (29 - d)) & 1) << (29 - perm[d])
-        got = out.reshape(-1)[torch.from_numpy(rpos).to(DEV)].cpu().numpy()
-        # ... and every one of the 2^30 amplitudes of this package's complex128 path against torch's
-        mine = A.tensor_contraction(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme)
-        assert float((mine - out).abs().max().item()) <= 1e-11 * 2.0 ** -15
-        del mine
-    else:
-        got = out.reshape(-1).cpu().numpy()
+    got = out.reshape(-1).cpu().numpy()
     del out, leaves
     torch.cuda.empty_cache()
     t = gpu_truth(key)
