@@ -745,9 +745,19 @@ def tensor_network_contraction(tensors, tensor_bonds, bond_dims, final_qubits, b
     # children do not share: ONE rank plans (simplified leaves included: their numbering follows the plan) and
     # the plan is broadcast, so every rank contracts slices of the same slicing.
     if distributed:
-        box = [plan() if dist.get_rank(group) == 0 else None]
+        # (a planner failure on rank 0 -- import error, an inconsistent scheme, out of memory while simplifying -- must not
+        #  leave the other ranks waiting in the broadcast for ever: the exception travels in the plan's place and every
+        #  rank raises.  With backend nccl the pickled plan moves through the current CUDA device: set it per rank first.)
+        box = [None]
+        if dist.get_rank(group) == 0:
+            try:
+                box = [("plan", plan())]
+            except Exception as e:   # noqa: BLE001 -- re-raised on every rank below
+                box = [("error", f"{type(e).__name__}: {e}")]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        leaves, scheme, slicing, shape, sparse, perm, sorted_bits = box[0]
+        if box[0][0] == "error":
+            raise RuntimeError(f"planning failed on rank 0: {box[0][1]}")
+        leaves, scheme, slicing, shape, sparse, perm, sorted_bits = box[0][1]
     else:
         leaves, scheme, slicing, shape, sparse, perm, sorted_bits = plan()
     out = sliced_contraction(leaves, scheme, slicing, shape, sparse=sparse, permute_dims=perm, dtype=dtype,

@@ -184,3 +184,41 @@ def test_one_rank_plans_and_the_plan_is_broadcast(tmp_path):
     r0, r1 = (open(tmp_path / f"plan_{r}.txt").read().split(" ", 2) for r in range(2))
     assert r0[0] == "1" and r1[0] == "0"          # only rank 0 compiled a scheme
     assert r0[1:] == r1[1:]                        # both execute the same scheme on the same slicing
+
+
+def _worker_plan_fails(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from artensor_amd import simulation as S
+        from artensor_amd import contraction as C
+        case = load_case(os.path.join(GOLDEN, "rand_D2_closed_sliced.npz"))
+        orig = C.contraction_scheme
+
+        def boom(ctree, labels="einsum"):
+            raise ValueError("planner exploded")
+        C.contraction_scheme = boom
+        try:
+            bonds = {k: [f"b{k}_{d}" for d in range(t.dim())] for k, t in case.tensors.items()}
+            try:
+                S.tensor_network_contraction(case.tensors, bonds, {}, [], planner=_FakePlanner(case, rank), device="cpu")
+                msg = "no error"
+            except RuntimeError as e:
+                msg = str(e)
+        finally:
+            C.contraction_scheme = orig
+        with open(os.path.join(out_dir, f"fail_{rank}.txt"), "w") as f:
+            f.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_planner_failure_on_rank_0_raises_on_every_rank(tmp_path):
+    """only rank 0 plans; if it raises, the other ranks must not wait in the broadcast for ever -- the error
+    travels in the plan's place and every rank raises RuntimeError."""
+    port = _free_port()
+    mp.spawn(_worker_plan_fails, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        msg = open(tmp_path / f"fail_{r}.txt").read()
+        assert "planning failed on rank 0" in msg and "planner exploded" in msg, (r, msg)

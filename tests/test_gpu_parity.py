@@ -60,13 +60,16 @@ def amp_strict(got, want):
 
 
 STRICT_FACTOR = 2.0   # HIP-vs-complex128 strict error allowed, in units of the reference's own complex64-vs-complex128 one
-# Where the checked amplitudes include a handful far below the typical magnitude (the 1 024-amplitude big-batch slice:
-# 9 of them under 0.1 rms, the smallest at 0.02 rms) the strict figure IS the absolute error on the smallest one divided
-# by it -- 0.9e-6 rms for the reference's complex64 run, 2.4e-6 rms for this package -- and as a maximum over a few
-# samples it moves by 2x with any reordering of fp32 additions (6.3e-5, 8.0e-5, 1.2e-4 for three builds of this package,
-# tests/golden/c128_truth_report.json for the first two).  assert_contract therefore allows STRICT_FACTOR_MAX there and
-# pins the statistically stable figure beside it: the rms error over all amplitudes within 2x the reference's own.
-STRICT_FACTOR_MAX = 4.0
+# The factor is 2 everywhere except where a measured reason is written down here (profiles/r03_truth_report.md has every
+# figure with 3M arithmetic on and off; the same table is regenerated per round by tools/truth_round.sh):
+#   n53_m20_batch_slice0 -- 1 024 amplitudes of which 9 lie under 0.1 rms, the smallest at 0.02 rms: the strict figure IS the
+#       absolute error on that one amplitude divided by it (0.9e-6 rms for the reference's complex64 run, 2.4e-6 rms here), a
+#       maximum over a handful of samples that moved 6.3e-5 / 8.0e-5 / 1.2e-4 (1.5x / 1.9x / 2.9x the reference's 4.15e-5) over
+#       three builds that only reordered fp32 additions, with 4M arithmetic 8.0e-5 as well.  Allowed: 4x; the statistically
+#       stable figure -- rms error over all amplitudes within 2x the reference's -- is asserted beside it for every key.
+# (n30_dense_block_sums, 2.2x with 3M / 1.7x with 4M, is not asserted through this function: the block sums are checked
+#  in complex128 only.)
+STRICT_EXCEPTIONS = {"n53_m20_batch_slice0": 4.0}
 _spread = None
 
 
@@ -95,13 +98,14 @@ def assert_contract(got, ref_c64, key, rms=None):
     """The north_star contract (complex64, <= 1e-5 relative) against the complex128 TRUTH of the same leaves and
     scheme, with the reference's own complex64 value measured beside it:
       loose  |got - truth| <= 1e-5 max(|truth|, rms) for every amplitude;
-      strict max relative error over |truth| >= 1e-3 rms within STRICT_FACTOR x the reference's own;
+      strict max relative error over |truth| >= 1e-3 rms within STRICT_FACTOR (2) x the reference's own (STRICT_EXCEPTIONS: one key, 4);
       and the HIP value is no farther from the reference's than 1e-5 + the reference's distance to the truth."""
     t = gpu_truth(key)
     got, ref_c64 = np.asarray(got).reshape(-1), np.asarray(ref_c64).reshape(-1)
     ref_loose, ref_strict = amp_rel(ref_c64, t, rms), amp_strict(ref_c64, t)
     assert amp_rel(got, t, rms) <= 1e-5, (key, amp_rel(got, t, rms))
-    assert amp_strict(got, t) <= STRICT_FACTOR_MAX * max(ref_strict, 5e-6), (key, amp_strict(got, t), ref_strict)
+    # (floor 5e-6: the single-amplitude slices, where the reference's own figure is as low as 8e-7 by luck of one rounding)
+    assert amp_strict(got, t) <= STRICT_EXCEPTIONS.get(key, STRICT_FACTOR) * max(ref_strict, 5e-6), (key, amp_strict(got, t), ref_strict)
     typ = rms if rms is not None else np.sqrt(np.mean(np.abs(t) ** 2))
     rms_err = lambda x: np.sqrt(np.mean(np.abs(x - t) ** 2)) / typ
     if t.size >= 100:   # (a statistic: not for the single-amplitude slices, where it is the loose figure again)
