@@ -2542,12 +2542,15 @@ static hipError_t launch_pgemm(const ArtnPlan &p, const void *A, const void *B, 
   if (g.arith == 0) {
     hipLaunchKernelGGL(artn_k_pack_bf16, blocks(a_units), dim3(ARTN_WG_THREADS), 0, st, a, (u32x4_t *)Ap, g.a, g.n_ko, a_units);
     hipLaunchKernelGGL(artn_k_pack_bf16, blocks(b_units), dim3(ARTN_WG_THREADS), 0, st, b, (u32x4_t *)Bp, g.b, g.n_ko, b_units);
-    if (artn::tuning().pgemm16) {
-      if (hipError_t e = ensure_lds<artn_k_pgemm<true>>(lds); e != hipSuccess) return e;
-      hipLaunchKernelGGL(artn_k_pgemm<true>, dim3(p.info.grid), dim3(ARTN_PG_THREADS), lds, st, Ap, Bp, (float2 *)C, g);
+    if (artn::tuning().pgemm16 >= 2) {
+      if (hipError_t e = ensure_lds<artn_k_pgemm<2>>(lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL(artn_k_pgemm<2>, dim3(p.info.grid), dim3(ARTN_PG_THREADS), lds, st, Ap, Bp, (float2 *)C, g);
+    } else if (artn::tuning().pgemm16 == 1) {
+      if (hipError_t e = ensure_lds<artn_k_pgemm<1>>(lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL(artn_k_pgemm<1>, dim3(p.info.grid), dim3(ARTN_PG_THREADS), lds, st, Ap, Bp, (float2 *)C, g);
     } else {
-      if (hipError_t e = ensure_lds<artn_k_pgemm<false>>(lds); e != hipSuccess) return e;
-      hipLaunchKernelGGL(artn_k_pgemm<false>, dim3(p.info.grid), dim3(ARTN_PG_THREADS), lds, st, Ap, Bp, (float2 *)C, g);
+      if (hipError_t e = ensure_lds<artn_k_pgemm<0>>(lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL(artn_k_pgemm<0>, dim3(p.info.grid), dim3(ARTN_PG_THREADS), lds, st, Ap, Bp, (float2 *)C, g);
     }
   } else {
     hipLaunchKernelGGL(artn_k_pack_f32, blocks(a_units), dim3(ARTN_WG_THREADS), 0, st, a, (f32x4 *)Ap, g.a, g.n_ko, a_units);

@@ -74,9 +74,15 @@ __device__ __forceinline__ void pg_glds16(const void *gsrc, unsigned lds_dst) {
 //   X side (MFMA B operand): column j = lane & 15 = m_in_block; 16 bytes of the first operand's image [4s + g][m], conjugated
 //                            (re accumulator) or with re / im swapped (im accumulator)
 //   accumulator register r of lane (j, g): row i = 4g + r = n_in_block.
-template <bool S16>
+// MODE 2 (round 4): the S16 arithmetic on a RING of six half-chunk slots (16 contracted values: 16 + 8 KiB) instead of
+// three chunk buffers: one raw barrier per half-chunk, at which the DMA of the NEXT half-chunk is waited for (counted
+// vmcnt: three younger half-chunks stay in flight) -- so the half-chunk after the one being multiplied is already visible
+// to every wave and its first operand fragments are read under the MFMAs of this one: no LDS round trip after a barrier.
+// DMA budget: a half-chunk is issued five barriers before it is needed by a ds_read (2.5 chunk periods).
+template <int MODE>
 __global__ __launch_bounds__(ARTN_PG_THREADS, 1) void artn_k_pgemm(const unsigned char *__restrict__ Ap, const unsigned char *__restrict__ Bp,
                                                                    float2 *__restrict__ C, const ArtnPackPlan P) {
+  constexpr bool S16 = MODE >= 1, RING = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if ((unsigned)(unsigned long)(lds_byte_t *)smem != 0) __builtin_trap(); // LDS is addressed by raw byte offsets
   const int tid = threadIdx.x;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(ARTN_PG_THREADS, 1) void artn_k_pgemm(const unsigne
   constexpr int MB = S16 ? 4 : 2, NB = 4;
   constexpr unsigned RA = 1u << ARTN_PG_MT, RB = 1u << ARTN_PG_NT;
   const unsigned lane_x = ((unsigned)h * RA + (unsigned)(wm * 64 + j)) * 16u;
-  const unsigned lane_w = ARTN_PG_A_BYTES + ((unsigned)h * RB + (unsigned)(wn * 64 + (S16 ? j : (j >> 1)))) * 16u;
+  const unsigned lane_w = (RING ? ARTN_PG_A_BYTES / 2 : ARTN_PG_A_BYTES) + ((unsigned)h * RB + (unsigned)(wn * 64 + (S16 ? j : (j >> 1)))) * 16u;
   const unsigned w_sel = ro ? 0x01000302u : 0x03020100u, w_sign = ro ? 0u : 0x80000000u; // (im, re) / (re, -im)
   const int n_chunks = 1 << P.n_ko;
 
@@ -172,6 +178,69 @@ __global__ __launch_bounds__(ARTN_PG_THREADS, 1) void artn_k_pgemm(const unsigne
           if constexpr (S16) acci[a][b][e] = 0.f;
         }
     // (every wave is past the previous tile's last LDS read: the epilogue ends with a barrier)
+    if constexpr (RING) {
+      constexpr unsigned SLOT = ARTN_PG_STAGE / 2; // 24 KiB: [A half: 4 planes x 256 rows x 16 B][B half: 4 planes x 128 rows x 16 B]
+      const int n_half = 2 * n_chunks;
+      // half-chunk q -> slot q % 6: 2 + 1 LDS-DMA instructions per thread (the packed images are contiguous in q)
+      auto stage_half = [&](int q, unsigned slot) {
+        const unsigned char *ga = At + (long)q * (ARTN_PG_A_BYTES / 2) + tid * 16, *gb = Bt + (long)q * (ARTN_PG_B_BYTES / 2) + tid * 16;
+        const unsigned dst = slot * SLOT + (unsigned)wave * 1024u;
+        pg_glds16(ga, dst);
+        pg_glds16(ga + 8192, dst + 8192u);
+        pg_glds16(gb, dst + ARTN_PG_A_BYTES / 2);
+      };
+      for (int q = 0; q < 5 && q < n_half; ++q) stage_half(q, (unsigned)q);
+      u32x4_t Xf[2], Wf[2][NB];
+      auto read_x = [&](unsigned slot, int a_) { return __builtin_bit_cast(u32x4_t, lds_read16(slot * SLOT + lane_x + (unsigned)a_ * 256u)); };
+      auto read_w = [&](unsigned slot, int b_) { return __builtin_bit_cast(u32x4_t, lds_read16(slot * SLOT + lane_w + (unsigned)b_ * 256u)); };
+      unsigned slot = 0;
+      for (int qq = 0; qq < n_half; qq += 2) { // (n_half is even: two half-chunks per chunk; unrolled by two so that the
+#pragma unroll                                  //  W fragment buffer of a half-chunk is a compile-time choice)
+      for (int par = 0; par < 2; ++par) {
+        const int q = qq + par;
+        // half-chunk q + 1 (and, at q = 0, half-chunk 0) has landed for this wave: at most 3 younger half-chunks in flight ...
+        const int younger = (n_half - 1 < q + 4 ? n_half - 1 : q + 4) - (q + 1); // half-chunks issued after q + 1
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and after the barrier everybody's has; everybody is also done with half-chunk q - 1, whose slot takes q + 5
+        __builtin_amdgcn_s_barrier();
+        if (q + 5 < n_half) stage_half(q + 5, slot == 0 ? 5u : slot - 1);
+        const unsigned nslot = slot == 5 ? 0u : slot + 1;
+        // (after the tile's last half-chunk the "next" fragments are stale bytes of the ring, read and never used:
+        //  unconditional reads keep the loop body free of branches)
+        if (q == 0) { // the very first fragments of the tile
+#pragma unroll
+          for (int b = 0; b < NB; ++b) Wf[0][b] = read_w(0u, b);
+          Xf[0] = read_x(0u, 0);
+        }
+#pragma unroll
+        for (int a_ = 0; a_ < 4; ++a_) {
+          // next X fragment: the next row block of this half-chunk, or the first of the next one (visible since this barrier)
+          if (a_ < 3) Xf[(a_ + 1) & 1] = read_x(slot, a_ + 1);
+          else Xf[0] = read_x(nslot, 0);
+          Wf[par ^ 1][a_] = read_w(nslot, a_); // one of the next half-chunk's W fragments per row block
+          __builtin_amdgcn_sched_barrier(0);             // (the reads are ISSUED here, a row block of MFMAs ahead of their use)
+          u32x4_t Xc, Xs; // (re, -im) and (im, re) of this row block's X fragment: a dword is (lo: re, hi: im) in bfloat16
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned d = Xf[a_ & 1][e];
+            Xc[e] = d ^ 0x80000000u;
+            Xs[e] = __builtin_amdgcn_alignbit(d, d, 16);
+          }
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            acc[a_][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Wf[par][b]), __builtin_bit_cast(bf16x8_t, Xc), acc[a_][b], 0, 0, 0);
+            acci[a_][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Wf[par][b]), __builtin_bit_cast(bf16x8_t, Xs), acci[a_][b], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = nslot;
+      }
+      }
+    }
+    if constexpr (!RING) {
     stage(0, 0u);
     if (n_chunks > 1) stage(1, 1u);
     unsigned cur = 0;
@@ -249,6 +318,7 @@ __global__ __launch_bounds__(ARTN_PG_THREADS, 1) void artn_k_pgemm(const unsigne
       }
       cur = cur == 2 ? 0u : cur + 1;
     }
+    } // !RING
     // ---- epilogue: accumulators -> C-ordered LDS image (2^13 elements per pass) -> 16-byte coalesced stores
     char *Cb = reinterpret_cast<char *>(C) + c_off * 8;
     for (int pass = 0; pass < (1 << (TC - EPI)); ++pass) {

@@ -228,7 +228,7 @@ struct Tuning {
   int grow_nt = 1;         // single growth steps: result bits beyond the contracted count taken into the tile (0 or 1)
   int fuse_66 = 0;         // fused pairs of two 6-bit steps (complex64): 1 allows them
   int m3_frag = 96;        // 3M in fused pairs up to this many fragment registers (80: not in 5+6 / 6+5 pairs)
-  int pgemm16 = 1;         // reduced-precision packed GEMM on v_mfma_f32_16x16x32_bf16 (1) or 32x32x16 (0): ARTN_PGEMM16
+  int pgemm16 = 1;         // reduced-precision packed GEMM: 0 v_mfma_f32_32x32x16_bf16, 1 16x16x32 (three chunk buffers), 2 16x16x32 on a ring of six half-chunk slots: ARTN_PGEMM16
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
   int packed_min_ai = 64;  // ... and the FLOP per byte of the step it needs
@@ -261,7 +261,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_IDLE_TO_GEMM")) x.idle_to_gemm = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_DEEP")) x.gemm_deep = atoi(e);
     if (const char *e = getenv("ARTN_BITS128")) x.bits128 = atoi(e);
-    if (const char *e = getenv("ARTN_PGEMM16")) x.pgemm16 = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_PGEMM16")) x.pgemm16 = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_PACKED_MIN_K")) x.packed_min_k = std::max(6, atoi(e));
     if (const char *e = getenv("ARTN_PACKED_MIN_AI")) x.packed_min_ai = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_PACKED")) x.packed = std::min(2, std::max(0, atoi(e)));

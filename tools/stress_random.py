@@ -23,8 +23,6 @@ def main(cases=200, seed=0):
         dtype = torch.complex128 if rng.random() < 0.3 else torch.complex64
         tol = 1e-11 if dtype == torch.complex128 else 2e-5
         kind = rng.choice(["single", "pair", "gather"], p=[0.45, 0.35, 0.2])
-        if kind == "gather" and dtype == torch.complex128:
-            kind = "single"
         ra = int(rng.integers(10, 21))
         k1 = int(rng.integers(1, 9))
         n1 = int(rng.integers(0, 8))

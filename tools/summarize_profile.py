@@ -107,5 +107,6 @@ json.dump({"round": R, "kernel": "artn_k_bits", "kernel_source_sha16": bench.ker
            "hbm_bytes_per_launch_over_1ms": (fetch / n + write / max(len(wb), 1)),
            "fetch_bytes_per_launch_over_1ms": fetch / n, "write_bytes_per_launch_over_1ms": write / max(len(wb), 1),
            "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE in separate passes"},
-          open(os.path.join(DST, f"{R}_traffic.json"), "w"), indent=1)
+          open(os.path.join(DST, f"{R}_traffic_headline.json"), "w"), indent=1)   # (bench.py quotes {R}_traffic.json: every leg,
+#                                                                     tools/profile_traffic.sh + tools/summarize_traffic.py)
 print("\n".join(md))
