@@ -11,7 +11,7 @@ import threading
 
 import torch
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 ARTN_MAX_LABELS = 96
 ARTN_PROGRAM_MAX_EXT = 256
 ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
@@ -54,6 +54,8 @@ class ArtnStepInfo(ctypes.Structure):
         ("arith", ctypes.c_int32),
         ("mfma_flops", ctypes.c_double),
         ("workspace_bytes", ctypes.c_int64),
+        ("k3_bits", ctypes.c_int32),
+        ("reserved_", ctypes.c_int32),
     ]
 
 
@@ -82,6 +84,9 @@ _EXPORTS = {
     "artn_program_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int64]),
+    "artn_contract3_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "artn_contract3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_program_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                         ctypes.c_void_p, ctypes.c_void_p]),
     "artn_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

@@ -425,6 +425,82 @@ def _pair_descriptors(eq1, a, b1, eq2, b2, mid_view=None):
     return d1, d2, out_shape
 
 
+def _triple_descriptors(eq1, a, b1, eq2, b2, eq3, b3):
+    """Descriptors of three consecutive steps on the same first operand: every later step sees the result before it as
+    a dense tensor in that result's label order."""
+    la1, lb1, lo1 = _parse(eq1) if isinstance(eq1, str) else tuple(map(tuple, eq1))
+    la2, lb2, lo2 = _parse(eq2) if isinstance(eq2, str) else tuple(map(tuple, eq2))
+    la3, lb3, lo3 = _parse(eq3) if isinstance(eq3, str) else tuple(map(tuple, eq3))
+    d1, s1 = _descriptor(la1, lb1, lo1, tuple(a.shape), tuple(a.stride()), tuple(b1.shape), tuple(b1.stride()), a.dtype)
+    if len(la2) != len(s1):
+        raise RuntimeError("second equation's first operand does not match the first result")
+    d2, s2 = _descriptor(la2, lb2, lo2, s1, _dense_strides(s1), tuple(b2.shape), tuple(b2.stride()), a.dtype)
+    if len(la3) != len(s2):
+        raise RuntimeError("third equation's first operand does not match the second result")
+    d3, s3 = _descriptor(la3, lb3, lo3, s2, _dense_strides(s2), tuple(b3.shape), tuple(b3.stride()), a.dtype)
+    return d1, d2, d3, s3
+
+
+_triple_cache = _Bounded(4096)
+
+
+def contract3(eq1, a, b1, eq2, b2, eq3, b3):
+    """einsum(eq3, einsum(eq2, einsum(eq1, a, b1), b2), b3) in ONE pass over HBM through artn_contract3: neither
+    intermediate leaves LDS (three consecutive steps of reference contraction.py:66-70 on the state tensor).  Returns None
+    when the planner declines the triple (the caller falls back to a pair and a single step)."""
+    for t in (a, b1, b2, b3):
+        N.require_gpu(t, "contract3")
+    if not (a.dtype == b1.dtype == b2.dtype == b3.dtype == torch.complex64) or not a.is_contiguous() or precision.current() not in (None, "fp32"):
+        return None
+    b1, b2, b3 = _as_operand(b1), _as_operand(b2), _as_operand(b3)
+    d1, d2, d3, out_shape = _triple_descriptors(eq1, a, b1, eq2, b2, eq3, b3)
+    key = (id(d1), id(d2), id(d3))
+    hit = _triple_cache.get(key)
+    info = hit[3] if hit is not None and hit[0] is d1 and hit[1] is d2 and hit[2] is d3 else None
+    if info is None:
+        q = N.ArtnStepInfo()
+        rc = N.lib().artn_contract3_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), ctypes.byref(q))
+        if rc == -2:
+            info = False
+        else:
+            N.check(rc)
+            info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
+        _triple_cache[key] = (d1, d2, d3, info)
+    if info is False:
+        return None
+    out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        e0 = e1 = None
+        if profiler is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        N.check(N.lib().artn_contract3(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), a.data_ptr(), b1.data_ptr(),
+                                       b2.data_ptr(), b3.data_ptr(), out.data_ptr(), N.current_stream_ptr(a.device)))
+        if profiler is not None:
+            e1.record()
+            profiler.record(info, e0, e1)
+    return out
+
+
+def triple_info(eq1, a_shape, b1_shape, eq2, b2_shape, eq3, b3_shape):
+    """Planner decision for fusing three consecutive steps (host only); None if the triple does not fit."""
+    class _S:  # shape/stride carrier
+        def __init__(self, shape):
+            self.shape, self._st, self.dtype = tuple(shape), _dense_strides(tuple(shape)), torch.complex64
+
+        def stride(self):
+            return self._st
+    d1, d2, d3, out_shape = _triple_descriptors(eq1, _S(a_shape), _S(b1_shape), eq2, _S(b2_shape), eq3, _S(b3_shape))
+    info = N.ArtnStepInfo()
+    rc = N.lib().artn_contract3_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), ctypes.byref(info))
+    if rc == -2:
+        return None
+    N.check(rc)
+    res = {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+    res["out_shape"] = out_shape
+    return res
+
+
 def pair_info(eq1, a_shape, b1_shape, eq2, b2_shape, dtype=torch.complex64):
     """Planner decision for fusing two consecutive steps (host only); None if not fusable."""
     class _S:  # shape/stride carrier
@@ -550,13 +626,149 @@ def fusion_schedule(scheme):
     return order
 
 
+def chain_schedule(scheme):
+    """Execution order with CHAINS: maximal runs s0 < s1 < ... of steps on the same first operand such that no step in
+    between reads or writes that tensor or any of the chain's second operands (the steps in between only build later small
+    operands from other tensors and are moved in front of the chain: they do not depend on it).  Returns a list of
+    ("one", n) / ("chain", [s0, s1, ...]) entries (chains have two or more members) covering every step exactly once.
+    A chain is what one, two or three stages per pass over HBM are cut from (_compile_dense)."""
+    order, done = [], set()
+    n_steps = len(scheme)
+    for n in range(n_steps):
+        if n in done:
+            continue
+        i, j = scheme[n][0]
+        chain, js, moved = [n], {j}, []
+        last = n
+        while True:
+            partner, between = None, []
+            for m in range(last + 1, n_steps):
+                if m in done:
+                    continue
+                i2, j2 = scheme[m][0]
+                if i2 == i:
+                    partner = m
+                    break
+                if j2 == i or i2 in js or j2 in js:
+                    break
+                between.append(m)
+            if partner is None:
+                break
+            moved += between
+            done.update(between)
+            chain.append(partner)
+            js.add(scheme[partner][0][1])
+            last = partner
+        for m in moved:
+            order.append(("one", m))
+        if len(chain) == 1:
+            order.append(("one", n))
+        else:
+            order.append(("chain", chain))
+        done.update(chain)
+    return order
+
+
+def triple_schedule(scheme, shapes, dtype=torch.complex64):
+    """Host-only: how _compile_dense would cut the chains of a dense scheme -- a list of ("one", n) / ("pair", n, n') /
+    ("triple", n, n', n'') in execution order (the small-step program is ignored: every step appears)."""
+    out = []
+    shapes = dict(shapes)
+    for entry in chain_schedule(scheme):
+        members = [entry[1]] if entry[0] == "one" else entry[1]
+        for g in _cut_chain(scheme, members, shapes, dtype, set()):
+            out.append((("one", "pair", "triple")[len(g[0]) - 1],) + tuple(g[0]))
+    return out
+
+
+def _cut_chain(scheme, members, shapes, dtype, skip):
+    """Cut one chain into groups of one, two or three consecutive steps, minimising the bytes the chain's tensor moves
+    through HBM (elements in + elements out per group; dynamic programme over the planner's host-only answers).
+    `shapes` is advanced past the chain.  Returns [(steps, planner info or None, descriptors or None, out_shape)];
+    members in `skip` (taken by the small-step program) are dropped."""
+    members = [n for n in members if n not in skip]
+    if not members:
+        return []
+    i = scheme[members[0]][0][0]
+    # shapes of the chain's tensor before / after every member
+    seq = [tuple(shapes[i])]
+    for n in members:
+        (_, j), eq = scheme[n][0], scheme[n][1]
+        la, lb, lo = _labels(eq)
+        ext = dict(zip(la, seq[-1]))
+        ext.update(zip(lb, shapes[j]))
+        seq.append(tuple(ext[x] for x in lo))
+
+    def numel(shape):
+        r = 1
+        for e in shape:
+            r *= e
+        return r
+    fuse_ok = dtype in _DTYPES
+    fuse3_ok = dtype == torch.complex64 and precision.current() in (None, "fp32") and N.lib().artn_contract3_query is not None
+    L = len(members)
+    cand = {}   # (p, g) -> (info, descriptors, out_shape)
+
+    def desc(p, shape_in):
+        (_, j), eq = scheme[members[p]][0], scheme[members[p]][1]
+        la, lb, lo = _labels(eq)
+        if len(la) != len(shape_in):
+            return None, None
+        return _descriptor(la, lb, lo, shape_in, _dense_strides(shape_in), shapes[j], _dense_strides(shapes[j]), dtype)
+    for p in range(L):
+        if not fuse_ok or numel(seq[p]) < FUSE_MIN_NUMEL:
+            continue
+        if p + 1 < L and numel(seq[p + 1]) * FUSE_MIN_MID >= numel(seq[p]):
+            d1, mid = desc(p, seq[p])
+            d2, out = desc(p + 1, mid) if d1 is not None else (None, None)
+            if d2 is not None:
+                q = N.ArtnStepInfo()
+                rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
+                if rc == 0:
+                    cand[(p, 2)] = ({name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}, (d1, d2), out)
+                elif rc != -2:
+                    N.check(rc)
+                if fuse3_ok and p + 2 < L:
+                    d3, out3 = desc(p + 2, out)
+                    if d3 is not None:
+                        q = N.ArtnStepInfo()
+                        rc = N.lib().artn_contract3_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), ctypes.byref(q))
+                        if rc == 0:
+                            cand[(p, 3)] = ({name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}, (d1, d2, d3), out3)
+                        elif rc != -2:
+                            N.check(rc)
+    # best[p]: least elements moved for members p..; at equal bytes a pair beats a single step (fewer launches) and a
+    # triple must SAVE bytes to be taken (a tiny surcharge: the pair kernels are the measured ones; n30 m14's two fitting
+    # triples sit at an odd distance, so they would only trade a pair for a triple and a single step)
+    best = [0.0] * (L + 1)
+    take = [1] * L
+    for p in range(L - 1, -1, -1):
+        best[p], take[p] = numel(seq[p]) + numel(seq[p + 1]) + best[p + 1], 1
+        for g in (2, 3):
+            if (p, g) in cand:
+                c = numel(seq[p]) + numel(seq[p + g]) + best[p + g] + (1.0 if g == 3 else 0.0)
+                if c <= best[p]:
+                    best[p], take[p] = c, g
+    groups, p = [], 0
+    while p < L:
+        g = take[p]
+        if g == 1:
+            groups.append(((members[p],), None, None, seq[p + 1]))
+        else:
+            info, ds, out = cand[(p, g)]
+            groups.append((tuple(members[p:p + g]), info, ds, out))
+        p += g
+    shapes[i] = seq[-1]
+    return groups
+
+
 _plan_cache = _Bounded(64)
 _schedule_cache = _Bounded(64)
 
 
 class _Op:
-    """One launch of a compiled dense scheme: a single step or a fused pair."""
-    __slots__ = ("steps", "i", "j", "j2", "d1", "d2", "out_shape", "info", "sum_rows")
+    """One launch of a compiled dense scheme: a single step, a fused pair or a fused triple."""
+    __slots__ = ("steps", "i", "j", "j2", "j3", "d1", "d2", "d3", "out_shape", "info", "sum_rows")
 
 
 
@@ -771,7 +983,7 @@ def _compile_dense(scheme, shapes, dtype):
 
     def emit(n, i, j, la, lb, lo, sa, sb, warn=True):
         op = _Op()
-        op.steps, op.i, op.j, op.j2, op.d2 = (n,), i, j, None, None
+        op.steps, op.i, op.j, op.j2, op.d2, op.j3, op.d3 = (n,), i, j, None, None, None, None
         op.d1, op.out_shape = _descriptor(la, lb, lo, sa, _dense_strides(sa), sb, _dense_strides(sb), dtype)
         op.info = None
         op.sum_rows = 0
@@ -800,51 +1012,30 @@ def _compile_dense(scheme, shapes, dtype):
         else:
             shapes[i] = emit(n, i, j, la, lb, lo, shapes[i], shapes[j])
 
-    # (the pairing is decided on the whole scheme, as if there were no program: steps the program has
-    #  taken are simply skipped -- they ran before everything else)
-    for entry in fusion_schedule(scheme):
+    # (the chains are found on the whole scheme, as if there were no program: steps the program has taken are simply
+    #  skipped -- they ran before everything else)
+    for entry in chain_schedule(scheme):
         if entry[0] == "one":
             if entry[1] not in in_prog:
                 single(entry[1])
             continue
-        n, m = entry[1], entry[2]
-        if n in in_prog or m in in_prog:
-            for q in (n, m):
-                if q not in in_prog:
-                    single(q)
-            continue
-        (i, j), eq1 = scheme[n][0], scheme[n][1]
-        (_, j2), eq2 = scheme[m][0], scheme[m][1]
-        numel = 1
-        for e in shapes[i]:
-            numel *= e
-        info = None
-        if fuse_ok and numel >= FUSE_MIN_NUMEL:
-            la1, lb1, lo1 = _labels(eq1)
-            la2, lb2, lo2 = _labels(eq2)
-            d1, mid = _descriptor(la1, lb1, lo1, shapes[i], _dense_strides(shapes[i]), shapes[j],
-                                  _dense_strides(shapes[j]), dtype)
-            mid_numel = 1
-            for e in mid:
-                mid_numel *= e
-            if len(la2) == len(mid) and mid_numel * FUSE_MIN_MID >= numel:
-                d2, out_shape = _descriptor(la2, lb2, lo2, mid, _dense_strides(mid), shapes[j2],
-                                            _dense_strides(shapes[j2]), dtype)
-                q = N.ArtnStepInfo()
-                rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
-                if rc == 0:
-                    info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
-                elif rc != -2:
-                    N.check(rc)
-        if info is None:
-            single(n)
-            single(m)
-            continue
-        op = _Op()
-        op.steps, op.i, op.j, op.j2, op.d1, op.d2, op.out_shape, op.info = (n, m), i, j, j2, d1, d2, out_shape, info
-        op.sum_rows = 0
-        shapes[i] = out_shape
-        ops.append(op)
+        i = scheme[entry[1][0]][0][0]
+        before = dict(shapes)
+        for steps, info, ds, out_shape in _cut_chain(scheme, entry[1], shapes, dtype, in_prog):
+            if len(steps) == 1:
+                shapes[i] = before[i]
+                single(steps[0])
+                before[i] = shapes[i]
+                continue
+            op = _Op()
+            op.steps, op.i, op.out_shape, op.info, op.sum_rows = steps, i, out_shape, info, 0
+            op.j, op.j2 = scheme[steps[0]][0][1], scheme[steps[1]][0][1]
+            op.j3 = scheme[steps[2]][0][1] if len(steps) == 3 else None
+            op.d1, op.d2 = ds[0], ds[1]
+            op.d3 = ds[2] if len(steps) == 3 else None
+            before[i] = out_shape
+            ops.append(op)
+        shapes[i] = before[i]
     return prog, ops
 
 
@@ -931,10 +1122,14 @@ def tensor_contraction(tensors, scheme):
                 e0.record()
             if op.d2 is None:
                 rc = _launch_step(op.d1, a, b, out, stream) if out.numel() else 0
-            else:
+            elif op.d3 is None:
                 b2 = tensors[op.j2]
                 rc = lib.artn_contract2(byref(op.d1), byref(op.d2), a.data_ptr(), b.data_ptr(), b2.data_ptr(),
                                         out.data_ptr(), stream)
+            else:
+                b2, b3 = tensors[op.j2], tensors[op.j3]
+                rc = lib.artn_contract3(byref(op.d1), byref(op.d2), byref(op.d3), a.data_ptr(), b.data_ptr(), b2.data_ptr(),
+                                        b3.data_ptr(), out.data_ptr(), stream)
             if rc != 0:
                 msg = lib.artn_last_error()
                 raise RuntimeError(f"tensor_contraction failed at step(s) {op.steps} "

@@ -1724,8 +1724,12 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 // artn_launch_bits_kK(), -DARTN_TU_B128 only artn_k_bits128<*, *> behind artn_launch_bits128(), -DARTN_TU_MAIN
 // everything else and calls those; with none of the macros (diagnostic and development builds) the file is one
 // translation unit as before.
-#if defined(ARTN_TU_BITS) || defined(ARTN_TU_B128)
+#if defined(ARTN_TU_BITS) || defined(ARTN_TU_B128) || defined(ARTN_TU_BITS3)
 #define ARTN_TU_PART 1
+#endif
+// (-DARTN_TU_BITS3=K: only artn_k_bits3<K, *, *> behind artn_launch_bits3_kK())
+#if defined(ARTN_TU_BITS3) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
+#include "artn_bits3_kernel.h"
 #endif
 #if defined(ARTN_TU_B128) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
 #include "artn_bits128_kernel.h"
@@ -2484,7 +2488,46 @@ hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1,
 
 #define ARTN_CAT2(a, b) a##b
 #define ARTN_CAT(a, b) ARTN_CAT2(a, b)
-#if defined(ARTN_TU_B128)
+// fused triples (make_bits3): artn_k_bits3<KB1, KB2, KB3, M3>, 3..5 contracted bits per stage, fragments of at most 80 registers;
+// M3 exactly when a stage contracts 5 bits
+#if defined(ARTN_TU_BITS3) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
+template <int KB1>
+static hipError_t launch_bits3_k(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, const float2 *B3, float2 *C,
+                                 hipStream_t st) {
+  dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
+  const size_t lds = (size_t)p.info.lds_bytes;
+  const int k2 = p.bits.st[1].k, k3 = p.bits.st[2].k;
+#define ARTN_B3_GO(K2, K3)                                                                                \
+  if (k2 == K2 && k3 == K3) {                                                                             \
+    if constexpr ((1 << KB1) + (1 << K2) + (1 << K3) <= 80) {                                             \
+      constexpr bool M3V = KB1 == 5 || K2 == 5 || K3 == 5;                                                \
+      if ((p.bits.m3 != 0) != M3V) return hipErrorInvalidValue;                                           \
+      if (p.bits.nt_loads) {                                                                              \
+        auto kern = artn_k_bits3<KB1, K2, K3, M3V, true>;                                                 \
+        if (hipError_t e = ensure_lds<artn_k_bits3<KB1, K2, K3, M3V, true>>(lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, B3, C, p.bits);                         \
+      } else {                                                                                            \
+        auto kern = artn_k_bits3<KB1, K2, K3, M3V, false>;                                                \
+        if (hipError_t e = ensure_lds<artn_k_bits3<KB1, K2, K3, M3V, false>>(lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, B3, C, p.bits);                         \
+      }                                                                                                   \
+      return hipGetLastError();                                                                           \
+    }                                                                                                     \
+  }
+  ARTN_B3_GO(3, 3) ARTN_B3_GO(3, 4) ARTN_B3_GO(3, 5)
+  ARTN_B3_GO(4, 3) ARTN_B3_GO(4, 4) ARTN_B3_GO(4, 5)
+  ARTN_B3_GO(5, 3) ARTN_B3_GO(5, 4) ARTN_B3_GO(5, 5)
+#undef ARTN_B3_GO
+  return hipErrorInvalidValue;
+}
+#endif
+#if defined(ARTN_TU_BITS3)
+hipError_t ARTN_CAT(artn_launch_bits3_k, ARTN_TU_BITS3)(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2,
+                                                       const float2 *B3, float2 *C, hipStream_t st) {
+  return launch_bits3_k<ARTN_TU_BITS3>(p, A, B1, B2, B3, C, st);
+}
+#endif
+#if defined(ARTN_TU_B128) || defined(ARTN_TU_BITS3)
 // (nothing else in this translation unit)
 #elif defined(ARTN_TU_BITS)
 hipError_t ARTN_CAT(artn_launch_bits_k, ARTN_TU_BITS)(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, float2 *C,
@@ -2500,6 +2543,28 @@ hipError_t artn_launch_bits_k4(const ArtnPlan &, const float2 *, const float2 *,
 hipError_t artn_launch_bits_k5(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
 hipError_t artn_launch_bits_k6(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
 #endif
+#ifdef ARTN_TU_MAIN
+hipError_t artn_launch_bits3_k3(const ArtnPlan &, const float2 *, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits3_k4(const ArtnPlan &, const float2 *, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits3_k5(const ArtnPlan &, const float2 *, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+#endif
+static hipError_t launch_bits3(const ArtnPlan &p, const void *A, const void *B1, const void *B2, const void *B3, void *C, hipStream_t st) {
+  const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2, *b3 = (const float2 *)B3;
+  float2 *c = (float2 *)C;
+  switch (p.bits.st[0].k) {
+#ifdef ARTN_TU_MAIN
+    case 3: return artn_launch_bits3_k3(p, a, b1, b2, b3, c, st);
+    case 4: return artn_launch_bits3_k4(p, a, b1, b2, b3, c, st);
+    case 5: return artn_launch_bits3_k5(p, a, b1, b2, b3, c, st);
+#else
+    case 3: return launch_bits3_k<3>(p, a, b1, b2, b3, c, st);
+    case 4: return launch_bits3_k<4>(p, a, b1, b2, b3, c, st);
+    case 5: return launch_bits3_k<5>(p, a, b1, b2, b3, c, st);
+#endif
+  }
+  return hipErrorInvalidValue;
+}
+
 static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C,
                               hipStream_t st) {
   if (p.bits.c128) return artn_launch_bits128(p, A, B1, B2, C, st);
@@ -2960,6 +3025,31 @@ int artn_contract2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A
   int rc = artn::make_plan_fused(d1, d2, p, err, g_ncu, min_tiles);
   if (rc) return fail(rc, err);
   HIP_TRY(launch_bits(p, A, B1, B2, C, (hipStream_t)stream));
+  return ARTN_OK;
+}
+
+int artn_contract3_query(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const ArtnStepDesc *d3, ArtnStepInfo *info) {
+  if (!info || !d1 || !d2 || !d3) return fail(ARTN_E_INVALID, "null argument");
+  if (env_flag("ARTN_NO_FUSE")) return fail(ARTN_E_UNSUPPORTED, "not fusable: ARTN_NO_FUSE is set");
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::make_plan_fused3(d1, d2, d3, p, err, g_ncu);
+  if (rc) return fail(rc, err);
+  *info = p.info;
+  return ARTN_OK;
+}
+
+int artn_contract3(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const ArtnStepDesc *d3, const void *A, const void *B1,
+                   const void *B2, const void *B3, void *C, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (!d1 || !d2 || !d3 || !A || !B1 || !B2 || !B3 || !C) return fail(ARTN_E_INVALID, "null pointer");
+  if ((((uintptr_t)A | (uintptr_t)C) & 15) != 0) return fail(ARTN_E_UNSUPPORTED, "not fusable: operands not 16-byte aligned");
+  if (env_flag("ARTN_NO_FUSE")) return fail(ARTN_E_UNSUPPORTED, "not fusable: ARTN_NO_FUSE is set");
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::make_plan_fused3(d1, d2, d3, p, err, g_ncu);
+  if (rc) return fail(rc, err);
+  HIP_TRY(launch_bits3(p, A, B1, B2, B3, C, (hipStream_t)stream));
   return ARTN_OK;
 }
 

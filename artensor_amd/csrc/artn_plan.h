@@ -66,9 +66,11 @@ struct ArtnStage {
 
 // Launch plan of the LDS-tiled bit-permuted complex GEMM (kernel argument, POD).
 struct ArtnBitsPlan {
-  int32_t n_stages;
-  int32_t T_in, T_mid, T_out; // log2 elements: input tile, tile between the stages, output tile
+  int32_t n_stages;           // 1, 2 (fused pair) or 3 (fused triple: artn_k_bits3)
+  int32_t T_in, T_mid, T_out; // log2 elements: input tile, tile between the (first two) stages, output tile
+  int32_t T_mid2;             // three stages: the tile between the second and the third (region 0 again)
   int32_t r0_bits;            // LDS region 0 holds 2^r0_bits elements (region 1 follows it)
+  int32_t r1_bits;            // region 1 holds 2^r1_bits elements (= T_mid for one or two stages)
   int32_t run_in, run_out;    // tile-local bits [0,run) are global bits [0,run)
   int32_t n_outer;
   int32_t stage_prio;         // 1: one of the two co-resident workgroups runs its MFMA stages at s_setprio 2
@@ -80,7 +82,7 @@ struct ArtnBitsPlan {
   int32_t split;              // MFMA arithmetic: 0 fp32; 3 fp32-grade from three bf16 pieces; 1 plain bf16 operands
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
-  ArtnStage st[2];
+  ArtnStage st[3];
   ArtnOuterDim outer[ARTN_MAX_OUTER];
   // fused row gather (artn_contract_gather, read by the GATHER instantiations only): along outer axis
   // `gather_dim` operand A is read at row rows_a[x] and the small operand at rows_b[x] instead of x
@@ -228,6 +230,9 @@ struct Tuning {
   int grow_nt = 1;         // single growth steps: result bits beyond the contracted count taken into the tile (0 or 1)
   int fuse_66 = 0;         // fused pairs of two 6-bit steps (complex64): 1 allows them
   int m3_frag = 96;        // 3M in fused pairs up to this many fragment registers (80: not in 5+6 / 6+5 pairs)
+  int fuse3_frag = 80;     // triples: fragment registers of the three stages (ARTN_FUSE3_FRAG); fuse3_run: shortest input run (log2 elements)
+  int fuse3_run = 4;
+  int fuse3 = 1;           // three consecutive steps on one tensor in one pass where they fit a 2^12 tile (artn_k_bits3): ARTN_FUSE3
   int pgemm16 = 1;         // reduced-precision packed GEMM: 0 v_mfma_f32_32x32x16_bf16, 1 16x16x32 (three chunk buffers), 2 16x16x32 on a ring of six half-chunk slots: ARTN_PGEMM16
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
@@ -261,6 +266,9 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_IDLE_TO_GEMM")) x.idle_to_gemm = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM_DEEP")) x.gemm_deep = atoi(e);
     if (const char *e = getenv("ARTN_BITS128")) x.bits128 = atoi(e);
+    if (const char *e = getenv("ARTN_FUSE3")) x.fuse3 = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_FUSE3_FRAG")) x.fuse3_frag = atoi(e);
+    if (const char *e = getenv("ARTN_FUSE3_RUN")) x.fuse3_run = atoi(e);
     if (const char *e = getenv("ARTN_PGEMM16")) x.pgemm16 = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_PACKED_MIN_K")) x.packed_min_k = std::max(6, atoi(e));
     if (const char *e = getenv("ARTN_PACKED_MIN_AI")) x.packed_min_ai = std::max(1, atoi(e));
@@ -593,6 +601,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   b.n_stages = fused ? 2 : 1;
   b.T_in = T_in; b.T_mid = T_mid; b.T_out = T_out;
   b.r0_bits = fused ? std::max(T_in, T_out) : T_in;
+  b.r1_bits = T_mid; b.T_mid2 = 0;
   b.run_in = run_in; b.run_out = run_out;
   b.stage_prio = tuning().stage_prio;
   b.c128 = c128 ? 1 : 0;
@@ -1485,6 +1494,267 @@ static inline int make_plan_fused(const ArtnStepDesc *d1, const ArtnStepDesc *d2
   p.info.bytes = (d1->dtype == ARTN_C128 ? 16.0 : 8.0) * (a1 + b1 + b2 + c2); // the intermediate C1 never touches HBM
   p.info.arith = p.bits.c128 ? 3 : (p.bits.split == 1 ? 2 : ((p.bits.st[0].m3 || p.bits.st[1].m3) ? 1 : 0));
   p.info.mfma_flops = f1 * (p.bits.st[0].m3 ? 0.75 : 1.0) + f2 * (p.bits.st[1].m3 ? 0.75 : 1.0);
+  return ARTN_OK;
+}
+
+
+// ----------------------------------------------------------------------------------------
+// THREE consecutive steps on the same first operand in one pass over HBM (artn_k_bits3; round 4).
+//
+// The state tensor is operand 0 of every step that touches it (reference contraction.py:41-46), and consecutive gates of a
+// circuit act on overlapping qubits: most contracted bits of the second and third step are bits the step before has just
+// produced, and those live inside the tile by construction.  A triple therefore needs only
+//     K1  u  (old bits among K2, K3)  u  the low run bits of A  u  the old bits among the low run bits of C3
+// in the 2^12-element input tile -- tools/fusion_depth.py counts how often that holds on the committed schemes (n30 m14:
+// three triples, 13 -> 11 passes over the 2^30-amplitude state).  Scope (everything else is left to pairs and single steps):
+// complex64, power-of-two extents, no batch label, every result bit of every step inside the tile, all four tiles 2^12
+// elements (each step brings as many bits as it contracts: the rank-preserving steps of a full-amplitude run), 3..5
+// contracted bits per step, small operands whose fragments fit the register file next to the accumulators.
+// Stage s reads region (s - 1) & 1 and writes region s & 1; the result leaves from region 1.
+// ----------------------------------------------------------------------------------------
+struct ChainBit {
+  int born = 0, dead = 0;        // stage whose small operand brings the bit (0: a bit of A) / contracts it (0: it reaches C3)
+  int64_t sBn = -1, sBk = -1;    // element stride in the small operand that brings it / that contracts it
+  int64_t pos[4] = {-1, -1, -1, -1}; // element stride in A (pos[0]) and in the results C1, C2, C3; -1 where the bit does not exist
+  bool seen = false;
+};
+
+static inline bool chain3_bits(const ArtnStepDesc *const d[3], std::vector<ChainBit> &bits, std::string &why) {
+  for (int s = 1; s <= 3; ++s) {
+    const ArtnStepDesc *ds = d[s - 1];
+    for (auto &b : bits) b.seen = false;
+    for (int l = 0; l < ds->n_labels; ++l) {
+      const int64_t e = ds->extent[l];
+      if (e == 1) continue;
+      const int lg = ilog2_exact(e);
+      if (lg < 0) { why = "triple: non power-of-two extent"; return false; }
+      const int64_t sa = ds->stride_a[l], sb = ds->stride_b[l], sc = ds->stride_c[l];
+      for (int jb = 0; jb < lg; ++jb) {
+        if (sa >= 0) {
+          int idx = -1;
+          if (s == 1) {
+            ChainBit nb;
+            nb.pos[0] = sa << jb;
+            bits.push_back(nb);
+            idx = (int)bits.size() - 1;
+          } else {
+            for (int i = 0; i < (int)bits.size(); ++i)
+              if (bits[i].dead == 0 && !bits[i].seen && bits[i].pos[s - 1] == (sa << jb)) { idx = i; break; }
+            if (idx < 0) { why = "triple: a step does not carry the axes of the result before it"; return false; }
+          }
+          ChainBit &b = bits[idx];
+          b.seen = true;
+          if (sb >= 0 && sc < 0) { b.dead = s; b.sBk = sb << jb; }
+          else if (sb < 0 && sc >= 0) b.pos[s] = sc << jb;
+          else { why = "triple: batch label or label summed out of one operand"; return false; }
+        } else {
+          if (!(sb >= 0 && sc >= 0)) { why = "triple: label summed out of one operand"; return false; }
+          ChainBit nb;
+          nb.born = s; nb.sBn = sb << jb; nb.pos[s] = sc << jb; nb.seen = true;
+          bits.push_back(nb);
+        }
+      }
+    }
+    for (const auto &b : bits)
+      if (!b.seen && b.dead == 0 && b.born < s) { why = "triple: a step does not carry every axis of the result before it"; return false; }
+  }
+  return true;
+}
+
+static inline bool make_bits3(const ArtnStepDesc *const d[3], ArtnPlan &p, int n_cu, int64_t min_tiles = 1 << 14) {
+  for (int s = 0; s < 3; ++s)
+    if (d[s]->dtype != ARTN_C64) { p.why_generic = "triple: complex64 arithmetic only"; return false; }
+  if (!tuning().fuse3 || tuning().split != 0 || !tuning().nt) { p.why_generic = "triple: switched off"; return false; }
+  std::vector<ChainBit> bits;
+  if (!chain3_bits(d, bits, p.why_generic)) return false;
+  const int T = ARTN_TILE_BITS_TARGET;
+  std::vector<int> K[4], N[4];
+  for (int i = 0; i < (int)bits.size(); ++i) {
+    if (bits[i].dead) K[bits[i].dead].push_back(i);
+    if (bits[i].born) N[bits[i].born].push_back(i);
+  }
+  int frag = 0;
+  bool wide = false;
+  for (int s = 1; s <= 3; ++s) {
+    const int k = (int)K[s].size(), n = (int)N[s].size();
+    if (k < 3 || k > 5) { p.why_generic = "triple: 3..5 contracted bits per step"; return false; }
+    if (n != k) { p.why_generic = "triple: a step changes the size of its tensor"; return false; }
+    frag += 2 << (k - 1);
+    wide = wide || k == 5;
+  }
+  // (fragments of three stages next to three accumulators and the prefetched tile: 80 registers -- 5+5+4 -- is the most that
+  //  compiles without spills)
+  if (frag > std::min(tuning().m3_frag, tuning().fuse3_frag)) { p.why_generic = "triple: small-operand fragments exceed the register budget"; return false; }
+  auto in_set = [](const std::vector<int> &v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+  // ---- the input tile: forced old bits, then the lowest free A bits up to 2^T
+  std::vector<int> old_free; // bits of A that reach C3
+  for (int i = 0; i < (int)bits.size(); ++i) if (bits[i].born == 0 && bits[i].dead == 0) old_free.push_back(i);
+  std::sort(old_free.begin(), old_free.end(), [&](int x, int y) { return bits[x].pos[0] < bits[y].pos[0]; });
+  auto run_len = [&](int which) { // contiguous run at the bottom of A (which = 0) / of C3 (which = 3), over bits alive there
+    int r = 0;
+    for (; r < tuning().run_max; ++r) {
+      bool found = false;
+      for (const auto &b : bits) if (b.pos[which] == (int64_t(1) << r)) { found = true; break; }
+      if (!found) break;
+    }
+    return r;
+  };
+  const int r_in0 = run_len(0), r_out0 = run_len(3);
+  if (r_in0 < 1 || r_out0 < 1) { p.why_generic = "triple: no contiguous 16-byte run at the bottom of A or C"; return false; }
+  std::vector<int> told;
+  int run_in = 0, run_out = 0;
+  bool done = false;
+  for (int cut = 0; cut <= 4 && !done; ++cut) {       // total bits shaved off the two runs (128-byte runs first)
+    for (int co = (cut + 1) / 2; co >= 0 && !done; --co) {
+      const int ri = r_in0 - (cut - co), ro = r_out0 - co;
+      if (ri < std::min(r_in0, 2) || ro < std::min(r_out0, 2) || ri < 1 || ro < 1) continue;
+      std::vector<int> t;
+      for (int i = 0; i < (int)bits.size(); ++i) {
+        const ChainBit &b = bits[i];
+        if (b.born != 0) continue;
+        if (b.dead != 0 || b.pos[0] < (int64_t(1) << ri) || (b.pos[3] >= 0 && b.pos[3] < (int64_t(1) << ro))) t.push_back(i);
+      }
+      if ((int)t.size() > T) continue;
+      for (int i : old_free) { if ((int)t.size() >= T) break; if (!in_set(t, i)) t.push_back(i); }
+      if ((int)t.size() != T) continue;                 // (a tensor of fewer than 2^12 elements is not worth a triple)
+      told = t; run_in = ri; run_out = ro; done = true;
+    }
+  }
+  if (!done) { p.why_generic = "triple: forced tile bits exceed the 2^12 tile"; return false; }
+  if (run_in < tuning().fuse3_run) { p.why_generic = "triple: input runs shorter than 128 bytes"; return false; } // (the NT instantiations only)
+
+  // ---- tile-local orders of the four tiles
+  std::vector<int> tile[4];
+  tile[0] = told;
+  std::sort(tile[0].begin(), tile[0].end(), [&](int x, int y) { return bits[x].pos[0] < bits[y].pos[0]; });
+  for (int s = 1; s <= 3; ++s) {
+    for (int i : tile[s - 1]) if (bits[i].dead != s) tile[s].push_back(i);
+    tile[s].insert(tile[s].end(), N[s].begin(), N[s].end());
+    std::sort(tile[s].begin(), tile[s].end(), [&](int x, int y) { return bits[x].pos[s] < bits[y].pos[s]; });
+    if ((int)tile[s].size() != T) { p.why_generic = "internal: triple tile size"; return false; }
+  }
+  ArtnBitsPlan &b = p.bits;
+  memset(&b, 0, sizeof(b));
+  b.n_stages = 3;
+  b.T_in = b.T_mid = b.T_mid2 = b.T_out = T;
+  b.r0_bits = b.r1_bits = T;
+  b.run_in = run_in; b.run_out = run_out;
+  b.stage_prio = tuning().stage_prio;
+  auto pos = [](const std::vector<int> &v, int x) { return (int)(std::find(v.begin(), v.end(), x) - v.begin()); };
+  for (int i = 0; i < T; ++i) { b.in_stride[i] = bits[tile[0][i]].pos[0]; b.out_stride[i] = bits[tile[3][i]].pos[3]; }
+  for (int i = 0; i < run_in; ++i) if (b.in_stride[i] != (int64_t(1) << i)) { p.why_generic = "internal: input run broken"; return false; }
+  for (int i = 0; i < run_out; ++i) if (b.out_stride[i] != (int64_t(1) << i)) { p.why_generic = "internal: output run broken"; return false; }
+  const bool use_3m = tuning().bits_3m != 0 && wide;
+  for (int s = 1; s <= 3; ++s) {
+    ArtnStage &st = b.st[s - 1];
+    const std::vector<int> &tin = tile[s - 1], &tout = tile[s];
+    std::vector<int> Kx(K[s]), Nx(N[s]), Mx;
+    std::sort(Kx.begin(), Kx.end(), [&](int x, int y) { return pos(tin, x) < pos(tin, y); });
+    std::sort(Nx.begin(), Nx.end(), [&](int x, int y) { return pos(tout, x) < pos(tout, y); });
+    for (int i : tin) if (bits[i].dead != s) Mx.push_back(i); // (in tile-input order)
+    st.k = (int)Kx.size();
+    st.nt = (int)Nx.size();
+    st.wn_log2 = std::max(0, st.nt - 4);
+    st.m3 = (use_3m && st.k == 5 && st.nt >= 5) ? 1 : 0;
+    if (st.m3) st.wn_log2 = st.nt - 5;
+    st.m_bits = (int)Mx.size();
+    for (int i = 0; i < 5; ++i) { st.lane_in_pos[i] = pos(tin, Mx[i]); st.lane_out_pos[i] = pos(tout, Mx[i]); }
+    for (int i = 5; i < st.m_bits; ++i) { st.msub_in_pos[i - 5] = pos(tin, Mx[i]); st.msub_out_pos[i - 5] = pos(tout, Mx[i]); }
+    for (int i = 0; i < st.k; ++i) { st.k_in_pos[i] = pos(tin, Kx[i]); st.k_b_stride[i] = bits[Kx[i]].sBk; }
+    for (int i = 0; i < st.nt; ++i) { st.n_out_pos[i] = pos(tout, Nx[i]); st.n_b_stride[i] = bits[Nx[i]].sBn; }
+    st.swz_n = 0;
+    bool taken[4] = {true, false, false, false};
+    for (int i = 0; i < 4; ++i) if (st.lane_out_pos[i] < 4) taken[st.lane_out_pos[i]] = true;
+    for (int i = 0; i < 4 && tuning().swizzle; ++i) {
+      if (st.lane_out_pos[i] < 4) continue;
+      int f = -1;
+      for (int c = 0; c < 4; ++c) if (!taken[c]) { f = c; break; }
+      if (f < 0) break;
+      taken[f] = true;
+      st.swz_src[st.swz_n] = st.lane_out_pos[i];
+      st.swz_dst[st.swz_n] = f;
+      ++st.swz_n;
+    }
+  }
+  // 3M: every 5-bit stage or none (the M3 instantiation), the narrow stages of such a launch on 16 x 16 x 4 blocks
+  {
+    bool any = false, all = true;
+    for (int q = 0; q < 3; ++q) if (b.st[q].k == 5) { any = any || b.st[q].m3; all = all && b.st[q].m3; }
+    b.m3 = (any && all) ? 1 : 0;
+    for (int q = 0; q < 3; ++q) {
+      if (!b.m3 && b.st[q].m3) { b.st[q].m3 = 0; b.st[q].wn_log2 = std::max(0, b.st[q].nt - 4); }
+      if (b.m3 && b.st[q].k >= 2 && b.st[q].k <= 4) b.st[q].m3 = 2;
+    }
+    if (wide && !b.m3) { p.why_generic = "triple: a 5-bit stage without the 3M arithmetic"; return false; } // (four-product chains of three stages spill)
+  }
+  // ---- outer axes: the free bits of A outside the tile, by A stride
+  b.n_tiles = 1;
+  b.gather_dim = -1;
+  for (int i : old_free) {
+    if (in_set(told, i)) continue;
+    ArtnOuterDim od;
+    od.ext = 2; od.sA = bits[i].pos[0]; od.sB1 = 0; od.sB2 = 0; od.sC = bits[i].pos[3]; od.log2ext = 1; od.pad_ = 0;
+    b.n_tiles *= 2;
+    if (b.n_outer > 0) {
+      ArtnOuterDim &pr = b.outer[b.n_outer - 1];
+      if (od.sA == pr.sA * pr.ext && od.sC == pr.sC * pr.ext && pr.log2ext + 1 < 31) { pr.ext *= 2; pr.log2ext += 1; continue; }
+    }
+    if (b.n_outer >= ARTN_MAX_OUTER) { p.why_generic = "too many outer axes"; return false; }
+    b.outer[b.n_outer++] = od;
+  }
+  if (b.n_tiles < min_tiles) { p.why_generic = "triple: fewer than 2^14 tiles"; return false; } // (the big launches only: the NT instantiations)
+  b.nt_loads = run_in >= 4 ? 1 : 0; // (shorter runs: two tiles share a 128-byte line, which must stay in L2 for the second)
+  b.blocked = 0;
+  for (int i = 1; i < T; ++i) if ((b.in_stride[i] & 1) || (b.out_stride[i] & 1)) { p.why_generic = "odd stride"; return false; }
+  for (int i = 0; i < b.n_outer; ++i) if ((b.outer[i].sA & 1) || (b.outer[i].sC & 1)) { p.why_generic = "odd outer stride"; return false; }
+  {
+    int64_t si = 0, so = 0;
+    for (int i = 1; i <= 8; ++i) { si += b.in_stride[i]; so += b.out_stride[i]; }
+    const int64_t lim = (int64_t(1) << 28) - 1;
+    if (si > lim || so > lim) { p.why_generic = "lane offsets exceed 32 bits"; return false; }
+    int pow2_bits = 0;
+    for (int i = 0; i < b.n_outer; ++i) pow2_bits += b.outer[i].log2ext;
+    if (pow2_bits > 32) { p.why_generic = "more than 2^32 tiles"; return false; }
+  }
+  p.kernel = ARTN_KERNEL_BITS_MFMA;
+  ArtnStepInfo &f = p.info;
+  f.kernel = ARTN_KERNEL_BITS_MFMA;
+  f.k_bits = b.st[0].k; f.m_tile_bits = b.st[0].m_bits; f.n_tile_bits = b.st[0].nt;
+  f.k2_bits = b.st[1].k; f.n2_tile_bits = b.st[1].nt; f.k3_bits = b.st[2].k;
+  f.tile_in_bits = T; f.tile_mid_bits = T; f.tile_out_bits = T;
+  f.run_in_bits = run_in; f.run_out_bits = run_out;
+  int64_t tabs = 0;
+  for (int q = 0; q < 3; ++q) tabs += 8LL << (b.st[q].m_bits - 5);
+  f.lds_bytes = (int32_t)((16LL << T) + tabs + 512LL * 8 + 32 * 32);
+  f.n_tiles = b.n_tiles;
+  f.a_rereads = 1;
+  const int wg_per_cu = std::max(1, std::min(tuning().wg_per_cu, (160 * 1024) / f.lds_bytes));
+  f.grid = (int32_t)std::min<int64_t>(b.n_tiles, (int64_t)n_cu * wg_per_cu);
+  return true;
+}
+
+static inline int make_plan_fused3(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const ArtnStepDesc *d3, ArtnPlan &p,
+                                   std::string &err, int n_cu = 256, int64_t min_tiles = 1 << 14) {
+  const ArtnStepDesc *const d[3] = {d1, d2, d3};
+  for (int s = 0; s < 3; ++s)
+    if (int rc = validate(d[s], err)) return rc;
+  memset(&p.info, 0, sizeof(p.info));
+  p.n_cu = n_cu;
+  if (!make_bits3(d, p, n_cu, min_tiles)) { err = "not fusable: " + p.why_generic; return ARTN_E_UNSUPPORTED; }
+  p.info.flops = 0.0;
+  p.info.mfma_flops = 0.0;
+  double a_in = 0, c_out = 0, small = 0;
+  for (int s = 0; s < 3; ++s) {
+    double f, na, nb, nc;
+    step_cost(d[s], f, na, nb, nc);
+    p.info.flops += f;
+    p.info.mfma_flops += f * (p.bits.st[s].m3 ? 0.75 : 1.0);
+    small += nb;
+    if (s == 0) a_in = na;
+    if (s == 2) c_out = nc;
+  }
+  p.info.bytes = 8.0 * (a_in + small + c_out); // neither intermediate touches HBM
+  p.info.arith = p.bits.m3 ? 1 : 0;
   return ARTN_OK;
 }
 

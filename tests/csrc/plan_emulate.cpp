@@ -166,8 +166,8 @@ static void run_stage(const ArtnStage &st, const ArtnStage *zin, const cf *in, c
   }
 }
 
-static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf *B2, cf *C) {
-  std::vector<cf> R0((size_t)1 << P.r0_bits), R1((size_t)1 << P.T_mid);
+static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf *B2, cf *C, const cf *B3 = nullptr) {
+  std::vector<cf> R0((size_t)1 << P.r0_bits), R1((size_t)1 << P.r1_bits);
   const int n_in_iters = 1 << (P.T_in - 9), n_out_iters = P.T_out >= 9 ? 1 << (P.T_out - 9) : 1;
   for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
     int64_t r = tile, offA = 0, offB1 = 0, offB2 = 0, offC = 0;
@@ -196,10 +196,15 @@ static void run_bits(const ArtnBitsPlan &P, const cf *A, const cf *B1, const cf 
     run_stage(P.st[0], nullptr, R0.data(), R1.data(), B1, offB1);
     const cf *outr = R1.data();
     const ArtnStage *zout = &P.st[0];
-    if (P.n_stages == 2) {
+    if (P.n_stages >= 2) {
       run_stage(P.st[1], &P.st[0], R1.data(), R0.data(), B2, offB2);
       outr = R0.data();
       zout = &P.st[1];
+    }
+    if (P.n_stages == 3) { // artn_k_bits3: the third stage reads region 0 and leaves the result in region 1
+      run_stage(P.st[2], &P.st[1], R0.data(), R1.data(), B3, 0);
+      outr = R1.data();
+      zout = &P.st[2];
     }
     for (int tid = 0; tid < 256; ++tid) {
       if (P.T_out < 9 && tid >= (1 << (P.T_out - 1))) continue;
@@ -875,6 +880,18 @@ extern "C" int artn_emulate2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, con
 
 // Diagnostic: LDS cycles per ds_read_b64 of the stage-1 operand reads (1 = conflict free): the 32
 // lanes of a half wave read 8 bytes each, bank = (byte address / 4) mod 64.
+// Fused triple.  Returns ARTN_E_UNSUPPORTED when the planner declines.
+extern "C" int artn_emulate3(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const ArtnStepDesc *d3, const void *A, const void *B1,
+                             const void *B2, const void *B3, void *C, ArtnStepInfo *info) {
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::make_plan_fused3(d1, d2, d3, p, err, 256, A ? 1 : (1 << 14)); // (emulated on tensors of 2^16+ elements)
+  if (rc) return rc;
+  if (info) *info = p.info;
+  if (A) run_bits(p.bits, (const cf *)A, (const cf *)B1, (const cf *)B2, (cf *)C, (const cf *)B3);
+  return 0;
+}
+
 extern "C" int artn_read_conflicts(const ArtnStepDesc *d1, const ArtnStepDesc *d2, int *stage1, int *stage2) {
   ArtnPlan p;
   std::string err;

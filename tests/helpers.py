@@ -188,6 +188,67 @@ def shrink_pair(eq1, a_shape, b1_shape, eq2, b2_shape, max_log2=17):
             "".join(la2) + "," + lb2 + "->" + "".join(lo2), tuple(b2_shape))
 
 
+def shrink_triple(eq1, a_shape, b1_shape, eq2, b2_shape, eq3, b3_shape, max_log2=17):
+    """Surrogate of three consecutive big steps (each later first operand is the result before it, matched by position):
+    drop axes that are free in ALL three steps, highest A positions first."""
+    def parse(eq):
+        lhs, lo = eq.split("->")
+        la, lb = lhs.split(",")
+        return list(la), lb, list(lo)
+    la1, lb1, lo1 = parse(eq1)
+    la2, lb2, lo2 = parse(eq2)
+    la3, lb3, lo3 = parse(eq3)
+    a_shape = list(a_shape)
+    numel = int(np.prod(a_shape))
+    pos = 0
+    while numel > 2 ** max_log2 and pos < len(la1):
+        lab = la1[pos]
+        if lab not in lb1 and lab in lo1:
+            lab2 = la2[lo1.index(lab)]
+            if lab2 not in lb2 and lab2 in lo2:
+                lab3 = la3[lo2.index(lab2)]
+                if lab3 not in lb3 and lab3 in lo3:
+                    numel //= a_shape[pos]
+                    la1.pop(pos)
+                    a_shape.pop(pos)
+                    k = lo1.index(lab)
+                    lo1.pop(k)
+                    la2.pop(k)
+                    k2 = lo2.index(lab2)
+                    lo2.pop(k2)
+                    la3.pop(k2)
+                    lo3.remove(lab3)
+                    continue
+        pos += 1
+    return ("".join(la1) + "," + lb1 + "->" + "".join(lo1), tuple(a_shape), tuple(b1_shape),
+            "".join(la2) + "," + lb2 + "->" + "".join(lo2), tuple(b2_shape),
+            "".join(la3) + "," + lb3 + "->" + "".join(lo3), tuple(b3_shape))
+
+
+def emulate3(eq1, a, b1, eq2, b2, eq3, b3, run=True):
+    """Fused triple through the emulator (artn_k_bits3 replayed stage by stage from make_bits3's plan); returns
+    (result or None if the planner declines, planner info).  run=False: plan only (full-size tensors: a is a shape carrier)."""
+    import torch
+    from artensor_amd import contraction as C
+    from artensor_amd import _native as N
+    emu = emulator()
+    emu.artn_emulate3.restype = ctypes.c_int
+    ta, tb1, tb2, tb3 = (torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in (a, b1, b2, b3))
+    d1, d2, d3, out_shape = C._triple_descriptors(eq1, ta, tb1, eq2, tb2, eq3, tb3)
+    info = N.ArtnStepInfo()
+    if not run:
+        rc = emu.artn_emulate3(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), None, None, None, None, None, ctypes.byref(info))
+        return (None if rc else True), {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+    out = np.zeros(out_shape, dtype=np.complex64)
+    rc = emu.artn_emulate3(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), a.ctypes.data_as(ctypes.c_void_p),
+                           b1.ctypes.data_as(ctypes.c_void_p), b2.ctypes.data_as(ctypes.c_void_p), b3.ctypes.data_as(ctypes.c_void_p),
+                           out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info))
+    if rc == -2:
+        return None, None
+    assert rc == 0, rc
+    return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}
+
+
 def emulate2(eq1, a, b1, eq2, b2):
     """Fused pair through the emulator; returns the result or None if the planner declines."""
     import torch

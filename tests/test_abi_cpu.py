@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # sizes the C side was compiled with (ArtnStepDesc: 2 int32 + 4 arrays of 96 int64)
     assert ctypes.sizeof(N.ArtnStepDesc) == 8 + 4 * 96 * 8
-    assert ctypes.sizeof(N.ArtnStepInfo) == 10 * 4 + 2 * 8 + 2 * 8 + 4 * 4 + 8 + 8
+    assert ctypes.sizeof(N.ArtnStepInfo) == 10 * 4 + 2 * 8 + 2 * 8 + 4 * 4 + 8 + 8 + 2 * 4   # (+ k3_bits, reserved_: ABI version 5)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the CPU-only refusal")
@@ -59,6 +59,8 @@ def test_no_cpu_fallback_anywhere():
     assert N.lib().artn_sum_axis_c64(p, p, 1, 2, 2, None) == -4
     assert N.lib().artn_contract_gather(ctypes.byref(d), p, p, p, 0, None, 0, None, 0, None, None) == -4
     assert N.lib().artn_contract2(ctypes.byref(d), ctypes.byref(d), p, p, p, p, None) == -4
+    assert N.lib().artn_contract3(ctypes.byref(d), ctypes.byref(d), ctypes.byref(d), p, p, p, p, p, None) == -4
+    assert N.lib().artn_absmax_normalize_c128(p, 4, p, None) == -4
     assert N.lib().artn_gather_rows(p, p, p, 1, 8, 1, None, None) == -4
     assert N.lib().artn_absmax_normalize_c64(p, 4, p, None) == -4
 

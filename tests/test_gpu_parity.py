@@ -1069,6 +1069,34 @@ def test_c128_truth_against_torch_einsum_on_the_gpu(key):
     assert np.abs(got - t).max() <= 1e-11 * rms, (key, float(np.abs(got - t).max() / rms))
 
 
+def test_fused_triples_on_the_gpu(monkeypatch):
+    """artn_contract3 (artn_k_bits3: three steps of reference contraction.py:66-70 on one tensor in ONE pass; region 0 -> 1
+    -> 0 -> 1) against three oracle steps: the two triples of the n30 scheme that fit a 2^12 tile with 128-byte runs, on
+    surrogates of 2^26 elements (the planner takes triples only for launches of 2^14+ tiles), four-product and 3M
+    instantiations, against the same three steps run one by one (the lane-by-lane replay against the ORACLE is
+    tests/test_plan_emulation.py::test_fused_triples_emulated / test_n30_triples_planned_and_emulated)."""
+    from artensor_amd.contraction import contract3, triple_info
+    from helpers import shrink_triple
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    rng = np.random.default_rng(31)
+    for (n1, n2, n3) in [(125, 128, 131), (149, 155, 159)]:
+        (eq1, sa, sb1), (eq2, _, sb2), (eq3, _, sb3) = steps[n1], steps[n2], steps[n3]
+        assert triple_info(eq1, sa, sb1, eq2, sb2, eq3, sb3) is not None
+        e1, sa_, sb1_, e2, sb2_, e3, sb3_ = shrink_triple(eq1, sa, sb1, eq2, sb2, eq3, sb3, max_log2=26)
+        info = triple_info(e1, sa_, sb1_, e2, sb2_, e3, sb3_)
+        assert info is not None and info["n_tiles"] >= 2 ** 14, (n1, info)
+        a = crandn(rng, sa_)
+        b1, b2, b3 = crandn(rng, sb1_), crandn(rng, sb2_), crandn(rng, sb3_)
+        got = contract3(e1, gpu(a), gpu(b1), e2, gpu(b2), e3, gpu(b3))
+        assert got is not None, (n1, n2, n3)
+        # the same three steps one by one on the GPU (single-step kernels: green against the oracle elsewhere)
+        ref = A.contract(e3, A.contract(e2, A.contract(e1, gpu(a), gpu(b1)), gpu(b2)), gpu(b3))
+        assert float((got - ref).abs().max().item()) <= 2e-6 * float(ref.abs().max().item()), (n1, n2, n3)
+        del got, ref
+        torch.cuda.empty_cache()
+
+
 def test_complex128_fused_pairs():
     """complex128 pairs in ONE pass (artn_k_bits128: 16-byte elements, f64 MFMA stages, the intermediate in LDS): the 13
     fusable pairs of the n30 scheme truncated to 2^21 elements and random pairs, 1e-12 against complex128 einsums; single

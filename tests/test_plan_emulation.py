@@ -584,3 +584,107 @@ def test_fused_pairs_3m_with_a_narrow_stage(k1, k2):
         if info["arith"] == 1:
             done += 1
     assert done >= 2, done   # at least two of the trials really ran the 3M plan
+
+
+def _random_triple(rng, ra, ks, reuse=0.6):
+    """Three consecutive rank-preserving steps on a rank-`ra` tensor; with probability `reuse` a contracted label of a later
+    step is one the step before has just produced (consecutive gates on overlapping qubits: what makes triples fit)."""
+    labels = [chr(65 + x) for x in range(ra)]
+    fresh = iter("abcdefghijklmnopqrstuvwxyz")
+    eqs, shapes = [], []
+    cur, last_new = list(labels), []
+    for k in ks:
+        pick = []
+        for x in last_new:
+            if len(pick) < k and rng.random() < reuse:
+                pick.append(x)
+        rest = [x for x in cur if x not in pick]
+        pick += [str(x) for x in rng.choice(rest, size=k - len(pick), replace=False)]
+        new = [next(fresh) for _ in range(k)]
+        lb = pick + new
+        rng.shuffle(lb)
+        lo = [x for x in cur if x not in pick] + new
+        rng.shuffle(lo)
+        eqs.append("".join(cur) + "," + "".join(lb) + "->" + "".join(lo))
+        shapes.append((2,) * len(lb))
+        cur, last_new = lo, new
+    return eqs, shapes
+
+
+@pytest.mark.parametrize("ks", [(4, 3, 4), (4, 4, 5), (3, 3, 3), (5, 4, 3), (3, 5, 4), (5, 5, 4), (4, 4, 4), (5, 3, 5)])
+def test_fused_triples_emulated(ks):
+    """Three steps in one pass (artn_k_bits3: region 0 -> 1 -> 0 -> 1; plan make_bits3), replayed stage by stage on the CPU
+    from the same ArtnBitsPlan the kernel gets: random label orders with later steps contracting bits the step before has
+    just produced; 3M instantiations (a 5-bit stage: three products there, 16 x 16 x 4 blocks in the narrow stages) and
+    four-product ones; against three oracle steps.  Triples that do not fit a 2^12 tile are declined."""
+    from helpers import emulate3
+    rng = np.random.default_rng(1000 * ks[0] + 100 * ks[1] + 10 * ks[2])
+    done = declined = 0
+    for trial in range(6):
+        ra = int(rng.integers(14, 17))
+        eqs, bshapes = _random_triple(rng, ra, ks, reuse=0.5 + 0.1 * trial)
+        a = crandn(rng, (2,) * ra)
+        bs = [crandn(rng, sh) for sh in bshapes]
+        got, info = emulate3(eqs[0], a, bs[0], eqs[1], bs[1], eqs[2], bs[2])
+        if got is None:
+            declined += 1
+            continue
+        want = oracle.einsum_pair(eqs[2], oracle.einsum_pair(eqs[1], oracle.einsum_pair(eqs[0], a, bs[0]), bs[1]), bs[2])
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, eqs
+        assert (info["k_bits"], info["k2_bits"], info["k3_bits"]) == ks and info["tile_in_bits"] == 12
+        assert info["arith"] == (1 if 5 in ks else 0)
+        done += 1
+    assert done >= 2, (done, declined)
+
+
+def test_triples_that_do_not_fit_are_declined():
+    from helpers import emulate3
+    rng = np.random.default_rng(5)
+    # 5 + 5 + 5: fragments of 96 registers; 6-bit stages; a step that grows its tensor; twelve old contracted bits
+    for ks, grow in [((5, 5, 5), 0), ((6, 3, 3), 0), ((4, 4, 4), 1)]:
+        ra = 16
+        eqs, bshapes = _random_triple(rng, ra, ks, reuse=1.0)
+        if grow:   # the second step brings one more bit than it contracts
+            lhs, lo = eqs[1].split("->")
+            la, lb = lhs.split(",")
+            eqs[1] = la + "," + lb + "Z->" + lo + "Z"
+            bshapes[1] = bshapes[1] + (2,)
+            lhs3, lo3 = eqs[2].split("->")
+            la3, lb3 = lhs3.split(",")
+            eqs[2] = la3 + "Z," + lb3 + "->" + lo3 + "Z"
+        a = crandn(rng, (2,) * ra)
+        bs = [crandn(rng, sh) for sh in bshapes]
+        got, info = emulate3(eqs[0], a, bs[0], eqs[1], bs[1], eqs[2], bs[2])
+        assert got is None, ks
+    eqs, bshapes = _random_triple(rng, 16, (5, 4, 4), reuse=0.0)   # 13 old contracted bits cannot share a 2^12 tile
+    got, _ = emulate3(eqs[0], crandn(rng, (2,) * 16), crandn(rng, bshapes[0]), eqs[1], crandn(rng, bshapes[1]), eqs[2], crandn(rng, bshapes[2]))
+    assert got is None
+
+
+def test_n30_triples_planned_and_emulated():
+    """The n30 m14 scheme: the two runs of three consecutive rank-30 steps whose contracted old bits and 128-byte runs fit
+    one 2^12 tile -- steps (125, 128, 131) and (149, 155, 159) -- planned at full size and replayed on surrogates
+    truncated to 2^16 elements; every other run of three is declined with 128-byte runs (the planner's answer: this is why
+    three-step fusion does not shorten THIS scheme: 26 chain members = 2 triples + 10 pairs would need the triples to
+    sit at even distances; tools/fusion_depth.py)."""
+    from helpers import emulate3, shrink_triple
+    from artensor_amd.contraction import triple_info
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    big = [n for n, (eq, sa, sb) in enumerate(steps) if len(sa) == 30]
+    fit = []
+    for p in range(len(big) - 2):
+        (e1, sa, sb1), (e2, _, sb2), (e3, _, sb3) = (steps[n] for n in big[p:p + 3])
+        if triple_info(e1, sa, sb1, e2, sb2, e3, sb3) is not None:
+            fit.append(tuple(big[p:p + 3]))
+    assert fit == [(125, 128, 131), (149, 155, 159)], fit
+    rng = np.random.default_rng(3)
+    for n1, n2, n3 in fit:
+        (eq1, sa, sb1), (eq2, _, sb2), (eq3, _, sb3) = steps[n1], steps[n2], steps[n3]
+        e1, sa_, sb1_, e2, sb2_, e3, sb3_ = shrink_triple(eq1, sa, sb1, eq2, sb2, eq3, sb3, max_log2=16)
+        a, b1, b2, b3 = crandn(rng, sa_), crandn(rng, sb1_), crandn(rng, sb2_), crandn(rng, sb3_)
+        got, info = emulate3(e1, a, b1, e2, b2, e3, b3)
+        assert got is not None, (n1, n2, n3)
+        want = oracle.einsum_pair(e3, oracle.einsum_pair(e2, oracle.einsum_pair(e1, a, b1), b2), b3)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (n1, n2, n3)
