@@ -51,7 +51,7 @@ bits = [r for r in rows if "artn_k_bits" in r["Name"] or "artn_k_alt" in r["Name
 tot_ns = sum(float(r["TotalDurationNs"]) for r in bits)
 tot_calls = sum(int(r["Calls"]) for r in bits)
 md += ["", f"All `artn_k_bits<KB1,KB2>` instantiations together: {tot_calls} launches, {tot_ns / 1e6:.2f} ms, "
-           f"average {tot_ns / tot_calls / 1e3:.1f} us per launch (4 contractions: 1 warm-up + 3 timed).", ""]
+           f"average {tot_ns / tot_calls / 1e3:.1f} us per launch ({tot_calls // 20} contractions: warm-up, check, 3 timed with per-launch events, 3 without).", ""]
 
 fb, wb = big(fe), big(wr)
 fetch = sum(d.get("FETCH_SIZE", 0) for d in fb) * 1024 * 2  # KB -> B; gfx950 halves wide reads (guide)
