@@ -749,6 +749,18 @@ def _cut_chain(scheme, members, shapes, dtype, skip):
                 c = numel(seq[p]) + numel(seq[p + g]) + best[p + g] + (1.0 if g == 3 else 0.0)
                 if c <= best[p]:
                     best[p], take[p] = c, g
+    # the cut of rounds 1-3 -- pairs from the left, as fusion_schedule forms them -- stays unless the dynamic programme finds a
+    # triple that saves bytes: re-pairing alone is not a reason to leave the measured launch lists (it cost the random
+    # D = 2 network 8 %: fewer launches, but pairs whose first stage is re-run for every value of an outer result bit)
+    p, uses_triple = 0, False
+    while p < L:
+        uses_triple = uses_triple or take[p] == 3
+        p += take[p]
+    if not uses_triple:
+        p = 0
+        while p < L:
+            take[p] = 2 if (p, 2) in cand else 1
+            p += take[p]
     groups, p = [], 0
     while p < L:
         g = take[p]
@@ -1012,30 +1024,95 @@ def _compile_dense(scheme, shapes, dtype):
         else:
             shapes[i] = emit(n, i, j, la, lb, lo, shapes[i], shapes[j])
 
-    # (the chains are found on the whole scheme, as if there were no program: steps the program has taken are simply
-    #  skipped -- they ran before everything else)
-    for entry in chain_schedule(scheme):
+    # Three-step fusion (artn_contract3) changes the launch list only where a triple SAVES bytes (section 4.1c of DESIGN.md: on
+    # no committed workload); everywhere else the pairing of rounds 1-3 -- fusion_schedule, pairs from the left -- is kept
+    # exactly: re-pairing alone cost the random D = 2 network 8 % (pairs the old schedule never formed).
+    use_chains = False
+    if dtype == torch.complex64 and precision.current() in (None, "fp32") and not _os_environ.get("ARTN_NO_FUSE"):
+        probe = dict(shapes)
+        for entry in chain_schedule(scheme):
+            if entry[0] == "chain":
+                if any(len(g[0]) == 3 for g in _cut_chain(scheme, entry[1], probe, dtype, in_prog)):
+                    use_chains = True
+                    break
+            elif entry[1] not in in_prog:
+                (ci, cj), ceq = scheme[entry[1]][0], scheme[entry[1]][1]
+                cla, clb, clo = _labels(ceq)
+                cext = dict(zip(cla, probe[ci]))
+                cext.update(zip(clb, probe[cj]))
+                probe[ci] = tuple(cext[x] for x in clo)
+    if use_chains:
+        # (the chains are found on the whole scheme, as if there were no program: steps the program has taken are simply
+        #  skipped -- they ran before everything else)
+        for entry in chain_schedule(scheme):
+            if entry[0] == "one":
+                if entry[1] not in in_prog:
+                    single(entry[1])
+                continue
+            i = scheme[entry[1][0]][0][0]
+            before = dict(shapes)
+            for steps, info, ds, out_shape in _cut_chain(scheme, entry[1], shapes, dtype, in_prog):
+                if len(steps) == 1:
+                    shapes[i] = before[i]
+                    single(steps[0])
+                    before[i] = shapes[i]
+                    continue
+                op = _Op()
+                op.steps, op.i, op.out_shape, op.info, op.sum_rows = steps, i, out_shape, info, 0
+                op.j, op.j2 = scheme[steps[0]][0][1], scheme[steps[1]][0][1]
+                op.j3 = scheme[steps[2]][0][1] if len(steps) == 3 else None
+                op.d1, op.d2 = ds[0], ds[1]
+                op.d3 = ds[2] if len(steps) == 3 else None
+                before[i] = out_shape
+                ops.append(op)
+            shapes[i] = before[i]
+        return prog, ops
+    # (the pairing is decided on the whole scheme, as if there were no program: steps the program has
+    #  taken are simply skipped -- they ran before everything else)
+    for entry in fusion_schedule(scheme):
         if entry[0] == "one":
             if entry[1] not in in_prog:
                 single(entry[1])
             continue
-        i = scheme[entry[1][0]][0][0]
-        before = dict(shapes)
-        for steps, info, ds, out_shape in _cut_chain(scheme, entry[1], shapes, dtype, in_prog):
-            if len(steps) == 1:
-                shapes[i] = before[i]
-                single(steps[0])
-                before[i] = shapes[i]
-                continue
-            op = _Op()
-            op.steps, op.i, op.out_shape, op.info, op.sum_rows = steps, i, out_shape, info, 0
-            op.j, op.j2 = scheme[steps[0]][0][1], scheme[steps[1]][0][1]
-            op.j3 = scheme[steps[2]][0][1] if len(steps) == 3 else None
-            op.d1, op.d2 = ds[0], ds[1]
-            op.d3 = ds[2] if len(steps) == 3 else None
-            before[i] = out_shape
-            ops.append(op)
-        shapes[i] = before[i]
+        n, m = entry[1], entry[2]
+        if n in in_prog or m in in_prog:
+            for q in (n, m):
+                if q not in in_prog:
+                    single(q)
+            continue
+        (i, j), eq1 = scheme[n][0], scheme[n][1]
+        (_, j2), eq2 = scheme[m][0], scheme[m][1]
+        numel = 1
+        for e in shapes[i]:
+            numel *= e
+        info = None
+        if fuse_ok and numel >= FUSE_MIN_NUMEL:
+            la1, lb1, lo1 = _labels(eq1)
+            la2, lb2, lo2 = _labels(eq2)
+            d1, mid = _descriptor(la1, lb1, lo1, shapes[i], _dense_strides(shapes[i]), shapes[j],
+                                  _dense_strides(shapes[j]), dtype)
+            mid_numel = 1
+            for e in mid:
+                mid_numel *= e
+            if len(la2) == len(mid) and mid_numel * FUSE_MIN_MID >= numel:
+                d2, out_shape = _descriptor(la2, lb2, lo2, mid, _dense_strides(mid), shapes[j2],
+                                            _dense_strides(shapes[j2]), dtype)
+                q = N.ArtnStepInfo()
+                rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
+                if rc == 0:
+                    info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
+                elif rc != -2:
+                    N.check(rc)
+        if info is None:
+            single(n)
+            single(m)
+            continue
+        op = _Op()
+        op.steps, op.i, op.j, op.j2, op.d1, op.d2, op.out_shape, op.info = (n, m), i, j, j2, d1, d2, out_shape, info
+        op.j3 = op.d3 = None
+        op.sum_rows = 0
+        shapes[i] = out_shape
+        ops.append(op)
     return prog, ops
 
 
