@@ -702,13 +702,16 @@ def compact_line(full):
         line["sliced"] = {"workload": "n53 m14, slices sharded, one all-reduce", "value": sig(sl["value"], 6),
                           "ms_per_slice": sig(sl.get("ms_per_slice_per_rank"), 5), "slices": sl.get("slices_timed"),
                           "ranks_in_collective": sl.get("ranks_in_collective"), "backend": sl.get("backend"), "check": sl.get("check")}
+        r2 = sl.get("rand2")
+        if r2:   # [TFLOP/s, ms per slice per rank, fraction of N x the fp32 MFMA peak, check]: random network D = 2, same sharding
+            line["sliced"]["rand_D2"] = [sig(r2["value"], 5), sig(r2.get("ms_per_slice_per_rank"), 4), sig(r2.get("frac_mfma_peak"), 3), r2.get("check")]
     wl = full.get("workloads")
     if wl:   # [TFLOP/s, roofline fraction of the dominant kernel (executed FLOP or bytes: never above 1), check]
         line["workloads"] = {k: [sig(v.get("value"), 4), sig((v.get("roofline") or {}).get("frac"), 3), (v.get("check") or {}).get("check")]
                              for k, v in wl.items()}
     line["detail"] = "bench_detail.json + one {\"leg\":..} line per workload"
     for drop in (("detail",), ("config", "n12_gpu_us"), ("cpu_baseline", "n12_ms"), ("roofline", "launches_per_step"),
-                 ("config", "parallelism"), ("config", "err_vs"), ("sliced", "workload"), ("roofline", "algorithmic_bytes_per_launch"),
+                 ("sliced", "workload"), ("config", "parallelism"), ("config", "err_vs"), ("roofline", "algorithmic_bytes_per_launch"),
                  ("config", "ref_c64_loose"), ("config", "flops_per_step"), ("sliced", "slices"), ("config", "failed_workloads")):
         if len(json.dumps(line)) <= COMPACT_LIMIT:
             break
@@ -940,6 +943,15 @@ def main():
         sliced["series"] = "n53 m14 slice-sharded, one all-reduce (the workload north_star's >= 6x at 8 GPUs refers to)"
         sliced["backend"] = dist.get_backend() if world > 1 else None
         ok = ok and sliced["check"] == "ok"
+        # north_star: "throughput on random tensor networks of stated bond dimension ... at 1/2/4/8 GPUs": the sliced random
+        # 3-regular network of bond dimension 2 (260 tensors, 12 sliced bonds) the same way -- slices sharded, one all-reduce
+        # (the bond-dimension-4 network is unsliced: it does not shard and is a leg of the N = 1 run only)
+        torch.cuda.empty_cache()
+        rand2 = strip_private(run_sliced(A, "rand2", dev, world, rank, dist, 3, 1, args.slices, args.precision))
+        rand2["series"] = "random 3-regular network, bond dimension 2, slice-sharded, one all-reduce"
+        rand2["backend"] = sliced["backend"]
+        ok = ok and rand2["check"] == "ok"
+        sliced["rand2"] = rand2
 
     if rank == 0 and args.detail:
         per = {}

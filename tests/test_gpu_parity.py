@@ -837,6 +837,7 @@ def test_bench_gpus_2_as_a_plain_command():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["check"] == "ok"
     assert line["sliced"]["ranks_in_collective"] == 2 and line["sliced"]["backend"] == "gloo" and line["sliced"]["check"] == "ok"
     assert line["sliced"]["slices"] == 2 * 3 * 2
+    assert line["sliced"]["rand_D2"][3] == "ok" and line["sliced"]["rand_D2"][0] > 10   # the random-network series, same sharding
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than 2")
