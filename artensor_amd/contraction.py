@@ -1433,13 +1433,65 @@ def _fusable_kind(step):
     return not (len(bi) == 1 and len(bj) == 1)
 
 
+LAZY_SELECT_MIN_NUMEL = 1 << 24   # a row select of a tensor at least this big is deferred to its consumer (_RowsOf)
+_lazy_state = threading.local()    # .on: set by tensor_contraction_sparse around its step loop (never under scientific_notation)
+_compose_cache = _Bounded(1024)   # (id(select), id(rows)) -> (select, rows, select[rows])
+
+
+class _RowsOf:
+    """`base[idx]` along dim 0, NOT yet materialised: the row select that ends a branch-(C) step (reference
+    contraction.py:187, `tensors[i] = tensors[i][batch_i[0]]`) when the tensor is big.  The steps that follow a select in
+    the reference's sparse schemes are the chunk loop (A) and the gathered step (B), which index the rows of their operands
+    anyway (`tensors[i][batch_i[k]]`, :149-150, :177): `base[idx][rows] == base[idx[rows]]`, so they read the un-selected
+    tensor through composed indices inside the contraction kernel and the select's copy of the whole tensor -- 2 x 7.8 GB
+    on the n30 x 10 000 scheme -- never happens.  Any other consumer materialises it (`rows_of`)."""
+    __slots__ = ("base", "idx")
+
+    def __init__(self, base, idx):
+        self.base, self.idx = base, idx
+
+    @property
+    def shape(self):
+        return (len(self.idx),) + tuple(self.base.shape[1:])
+
+
+def rows_of(t):
+    """The tensor itself, or the materialised rows of a deferred select."""
+    return gather_rows(t.base, t.idx) if isinstance(t, _RowsOf) else t
+
+
+def _composed(sel, rows):
+    """sel[rows] as a CPU int64 tensor, cached per (select, rows) pair: the scheme's index tensors live as long as the scheme."""
+    key = (id(sel), id(rows))
+    hit = _compose_cache.get(key)
+    if hit is None or hit[0] is not sel or hit[1] is not rows:
+        s_ = torch.as_tensor(sel, dtype=torch.int64).reshape(-1)
+        r_ = torch.as_tensor(rows, dtype=torch.int64).reshape(-1)
+        if r_.numel() and (int(r_.min()) < -len(s_) or int(r_.max()) >= len(s_)):
+            raise RuntimeError(f"row index out of range: indices span [{int(r_.min())}, {int(r_.max())}] but the operand has {len(s_)} rows "
+                               "(IndexError in the reference, contraction.py:192-195)")
+        hit = _compose_cache[key] = (sel, rows, s_[r_])
+    return hit[2]
+
+
 def _sparse_step(tensors, step):
     """One step of the sparse executor: the four branches of reference contraction.py:140-191."""
     i, j = step[0]
     eq = step[1]
     batch_i, batch_j = step[2]
+    if isinstance(tensors[j], _RowsOf):
+        tensors[j] = rows_of(tensors[j])
+    lazy_i = tensors[i] if isinstance(tensors[i], _RowsOf) else None
+    if lazy_i is not None and not (len(batch_i) > 1 or (len(step) > 3 and len(batch_i) == len(batch_j) == 1)):
+        tensors[i] = rows_of(lazy_i)   # (a consumer that does not index rows itself)
+        lazy_i = None
     if len(batch_i) > 1:
         src_i, src_j = tensors[i], tensors[j]
+        if lazy_i is not None:   # rows of a deferred select: compose the indices, read the un-selected tensor
+            src_i = lazy_i.base
+            rows_i = [_composed(lazy_i.idx, x) for x in batch_i]
+        else:
+            rows_i = batch_i
         la, lb, lo = _labels(eq)
         rows = [len(x) for x in batch_i]
         first = None
@@ -1451,8 +1503,8 @@ def _sparse_step(tensors, step):
                 first = torch.empty((sum(rows),) + tuple(ext[x] for x in lo[1:]), dtype=src_i.dtype, device=src_i.device)
             dst = first[r0:r0 + rows[k]]
             # rows gathered inside the contraction kernel; two gathers + contraction otherwise
-            if contract_gathered(eq, src_i, batch_i[k], src_j, batch_j[k], out=dst) is None:
-                contract(eq, gather_rows(src_i, batch_i[k]), gather_rows(src_j, batch_j[k]), out=dst)
+            if contract_gathered(eq, src_i, rows_i[k], src_j, batch_j[k], out=dst) is None:
+                contract(eq, gather_rows(src_i, rows_i[k]), gather_rows(src_j, batch_j[k]), out=dst)
             r0 += rows[k]
         if step[3]:
             first = first.reshape((-1,) + tuple(step[3][1:]))
@@ -1460,12 +1512,15 @@ def _sparse_step(tensors, step):
         tensors[i] = first
     elif len(step) > 3 and len(batch_i) == len(batch_j) == 1:
         fused = None
+        rows_i0 = batch_i[0]
+        if lazy_i is not None:
+            tensors[i], rows_i0 = lazy_i.base, _composed(lazy_i.idx, batch_i[0])
         plain = (isinstance(tensors[i], torch.Tensor) and isinstance(tensors[j], torch.Tensor)
-                 and _is_identity(batch_i[0], tensors[i].shape[0]) and _is_identity(batch_j[0], tensors[j].shape[0]))
+                 and _is_identity(rows_i0, tensors[i].shape[0]) and _is_identity(batch_j[0], tensors[j].shape[0]))
         if not plain and isinstance(tensors[i], torch.Tensor) and tensors[i].numel() >= (1 << 20):
-            fused = contract_gathered(eq, tensors[i], batch_i[0], tensors[j], batch_j[0])
+            fused = contract_gathered(eq, tensors[i], rows_i0, tensors[j], batch_j[0])
         if fused is None:
-            tensors[i] = gather_rows(tensors[i], batch_i[0])
+            tensors[i] = gather_rows(tensors[i], rows_i0)
             tensors[j] = gather_rows(tensors[j], batch_j[0])
             fused = contract(eq, tensors[i], tensors[j])
         # (the reference leaves the gathered operand in tensors[j]; here it keeps its rows when the
@@ -1474,7 +1529,13 @@ def _sparse_step(tensors, step):
     elif len(step) > 3:
         tensors[i] = contract(eq, tensors[i], tensors[j]).reshape(step[3])
         if len(batch_i) == 1:
-            tensors[i] = gather_rows(tensors[i], batch_i[0])
+            t = tensors[i]
+            if (getattr(_lazy_state, "on", False) and t.numel() >= LAZY_SELECT_MIN_NUMEL and t.dim() > 0
+                    and not _is_identity(batch_i[0], t.shape[0])):
+                _device_index(batch_i[0], t.device, t.shape[0])   # (validated now, as gather_rows would: out of range raises here)
+                tensors[i] = _RowsOf(t, batch_i[0])               # deferred: see _RowsOf
+            else:
+                tensors[i] = gather_rows(t, batch_i[0])
         tensors[j] = []
     else:
         tensors[i] = contract(eq, tensors[i], tensors[j])
@@ -1563,7 +1624,23 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
             j = scheme[n][0][1]
             if j not in prog.outputs:
                 tensors[j] = []
-    for entry in hit[1]:
+    _lazy_state.on = not _os_environ.get("ARTN_NO_LAZY_SELECT")
+    try:
+        _run_sparse_main(tensors, scheme, hit[1], hoisted, one)
+    finally:
+        _lazy_state.on = False
+    if isinstance(tensors[last], _RowsOf):
+        tensors[last] = rows_of(tensors[last])
+    # abort-on-failure semantics of the reference (contraction.py:192-195) for the one failure the
+    # kernels cannot raise themselves: one flag read per scheme (the slice loop defers it to its end)
+    if _flags_used() and not getattr(_defer, "flag_check", False):
+        check_gather_flag("tensor_contraction_sparse")
+    return tensors[last]
+
+
+def _run_sparse_main(tensors, scheme, schedule, hoisted, one):
+    """The step loop of tensor_contraction_sparse after the small-step program: single steps and fused pairs."""
+    for entry in schedule:
         if entry[0] == "one":
             if entry[1] not in hoisted:
                 one(entry[1])
@@ -1576,6 +1653,9 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
             continue
         s1, s2 = scheme[n], scheme[m]
         fused = None
+        for t in (s1[0][1], s2[0][1]):   # (second operands are never read through a deferred select)
+            if isinstance(tensors[t], _RowsOf):
+                tensors[t] = rows_of(tensors[t])
         a = tensors[s1[0][0]]
         if (_fusable_kind(s1) and _fusable_kind(s2)
                 and isinstance(a, torch.Tensor) and a.is_cuda and a.numel() >= FUSE_MIN_NUMEL
@@ -1597,15 +1677,15 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
             if len(s2) > 3:  # branch (C) of the second step: free reshape, optional row select
                 fused = fused.reshape(s2[3])
                 if len(s2[2][0]) == 1:
-                    fused = gather_rows(fused, s2[2][0][0])
+                    if (getattr(_lazy_state, "on", False) and fused.numel() >= LAZY_SELECT_MIN_NUMEL
+                            and not _is_identity(s2[2][0][0], fused.shape[0])):
+                        _device_index(s2[2][0][0], fused.device, fused.shape[0])
+                        fused = _RowsOf(fused, s2[2][0][0])
+                    else:
+                        fused = gather_rows(fused, s2[2][0][0])
             tensors[s1[0][0]] = fused
             tensors[s1[0][1]] = []
             tensors[s2[0][1]] = []
-    # abort-on-failure semantics of the reference (contraction.py:192-195) for the one failure the
-    # kernels cannot raise themselves: one flag read per scheme (the slice loop defers it to its end)
-    if _flags_used() and not getattr(_defer, "flag_check", False):
-        check_gather_flag("tensor_contraction_sparse")
-    return tensors[last]
 
 
 # ----------------------------------------------------------------------------------------

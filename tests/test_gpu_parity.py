@@ -526,6 +526,43 @@ def test_small_step_program(monkeypatch):
     C._plan_cache.clear()
 
 
+def test_deferred_row_select(monkeypatch):
+    """A branch-(C) row select of a big tensor (reference contraction.py:187) is deferred to its consumer: the chunk loop
+    that follows it in the n30 x 10 000 scheme reads the un-selected tensor through composed indices (`base[idx][rows] ==
+    base[idx[rows]]`), the 2 x 7.8 GB copy of the select never happens.  Same bits as the eager order, against the reference's
+    amplitudes, and the big gather is gone."""
+    from artensor_amd import contraction as C
+    case = load_case(os.path.join(GOLDEN, "n30_sparse10000.npz"))
+    seen = []
+    orig = C.gather_rows
+
+    def spy(t, idx, _validate=True):
+        seen.append(int(t.numel()))
+        return orig(t, idx, _validate)
+    monkeypatch.setattr(C, "gather_rows", spy)
+    lazy = A.tensor_contraction_sparse(case.fresh_tensors(device=DEV), case.scheme).cpu().numpy()
+    big_lazy = [n for n in seen if n >= C.LAZY_SELECT_MIN_NUMEL]
+    seen.clear()
+    monkeypatch.setenv("ARTN_NO_LAZY_SELECT", "1")
+    eager = A.tensor_contraction_sparse(case.fresh_tensors(device=DEV), case.scheme).cpu().numpy()
+    big_eager = [n for n in seen if n >= C.LAZY_SELECT_MIN_NUMEL]
+    # (the eager order gathers the 2^30-element result of step 145; deferred, only the 2^24.3-element gather of a later
+    #  gathered step is left)
+    assert max(big_eager) >= 2 ** 29 and max(big_lazy + [0]) < 2 ** 26 and len(big_lazy) == len(big_eager) - 1, (big_eager, big_lazy)
+    assert np.array_equal(lazy, eager)
+    assert amp_rel(lazy.reshape(-1), case.arrays["final"].reshape(-1)) <= 1e-5
+    # composed indices: cached per (select, rows) pair, out-of-range rows refused like the reference's IndexError
+    sel, rows = torch.tensor([5, 3, 9, 1]), torch.tensor([2, 0, -1])
+    assert C._composed(sel, rows).tolist() == [9, 5, 1] and C._composed(sel, rows) is C._composed(sel, rows)
+    with pytest.raises(RuntimeError, match="row index out of range"):
+        C._composed(sel, torch.tensor([4]))
+    # a deferred select that nobody indexes is materialised: (big select) then a plain step
+    rng = np.random.default_rng(8)
+    a = gpu(crandn(rng, (64,) + (2,) * 18))
+    lz = C._RowsOf(a, torch.tensor([3, 1, 60]))
+    assert lz.shape == (3,) + (2,) * 18 and torch.equal(C.rows_of(lz), a[[3, 1, 60]])
+
+
 def test_sparse_scientific_notation():
     case = load_case(os.path.join(GOLDEN, "n12_sparse5_scinot.npz"))
     factor, out = A.tensor_contraction_sparse(case.fresh_tensors(device=DEV), case.scheme, scientific_notation=True)
