@@ -109,6 +109,38 @@ def test_fusion_schedule_covers_every_step_once():
                     assert when[m] <= when[n], (name, m, n)
 
 
+def test_chain_schedule_covers_every_step_once_and_keeps_dependencies():
+    """chain_schedule (what triples are cut from): every step exactly once, and a step never runs before an earlier step
+    that touches one of its tensors -- steps moved in front of a chain are independent of it; the cut of every chain
+    (_cut_chain through triple_schedule) keeps the members in order and is, without a byte-saving triple, the pairing of
+    fusion_schedule restricted to pairs the planner accepts."""
+    from artensor_amd.contraction import chain_schedule, triple_schedule
+    for name in ["n12_dense", "n30_dense", "n30_dense_sliced3", "rand_D2_closed", "rand_D2_nv260_sliced", "rand_D4_nv100", "n53_m14_sliced"]:
+        case = load_case(os.path.join(GOLDEN, name + ".npz"))
+        scheme = [(s[0], s[1]) for s in case.scheme]
+        sched = chain_schedule(scheme)
+        seen, when = [], {}
+        for t, e in enumerate(sched):
+            members = [e[1]] if e[0] == "one" else list(e[1])
+            assert members == sorted(members)
+            if e[0] == "chain":
+                assert len(members) >= 2 and len({scheme[n][0][0] for n in members}) == 1
+            for n in members:
+                seen.append(n)
+                when[n] = (t, n)
+        assert sorted(seen) == list(range(len(scheme))), name
+        for n, step in enumerate(scheme):
+            for m in range(n):
+                if set(step[0]) & set(scheme[m][0]):
+                    assert when[m] <= when[n], (name, m, n)
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    cut = triple_schedule(case.scheme, {k: tuple(t.shape) for k, t in case.tensors.items()})
+    flat = [n for e in cut for n in e[1:]]
+    assert sorted(flat) == list(range(len(case.scheme)))
+    assert not [e for e in cut if e[0] == "triple"]              # as shipped: no triple saves bytes on n30 (DESIGN 4.1c)
+    assert len([e for e in cut if e[0] == "pair"]) == 13
+
+
 def test_n30_fused_pairs_surrogates():
     """Every fusable pair of big n30 steps, both steps truncated consistently to 2^16."""
     from artensor_amd.contraction import fusion_schedule, pair_info
