@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session of several bounded pieces (every piece under its own `timeout`: a hung piece must not eat the call).
-# usage (through gpurun): tools/gpu_session.sh <name> ; pieces are read from tools/gpu_session_<name>.txt, one per line:
+# usage (through gpurun): tools/gpu_session.sh <name> ; pieces are read from tools/gpu_session_<name>.txt (profile: the four profiling scripts of a round; example: tests, an A/B, the independent truth), one per line:
 #   <seconds> <log name> <command ...>
 set -u
 N=${1:-a}
