@@ -20,7 +20,7 @@ from artensor_amd import contraction as C  # noqa: E402
 
 def main(cases=1000, seed=0):
     rng = np.random.default_rng(seed)
-    kernels, fused, declined = {}, 0, 0
+    kernels, fused, declined, triples = {}, 0, 0, 0
     t0 = time.time()
     for case in range(cases):
         dtype = torch.complex128 if rng.random() < 0.3 else torch.complex64
@@ -74,8 +74,45 @@ def main(cases=1000, seed=0):
                         fused += pi is not None
                     except RuntimeError:
                         declined += 1
+                    # ... and a third step: the triple query (artn_contract3_query / make_bits3)
+                    cand3 = [x for x in lo2 if x != "z"]
+                    k3 = int(rng.integers(1, 7))
+                    if dtype == torch.complex64 and len(cand3) >= k3:
+                        kl3 = [str(x) for x in rng.choice(cand3, size=k3, replace=False)]
+                        nl3 = [f"p{x}" for x in range(int(rng.integers(0, 8)))]
+                        lb3 = kl3 + nl3
+                        rng.shuffle(lb3)
+                        lo3 = [x for x in lo2 if x not in kl3] + nl3
+                        try:
+                            ti = C.triple_info((tuple(la), tuple(lb1), tuple(lo1)), a_shape, ext(lb1), (tuple(lo1), tuple(lb2), tuple(lo2)),
+                                               ext(lb2), (tuple(lo2), tuple(lb3), tuple(lo3)), ext(lb3))
+                            triples += ti is not None
+                        except RuntimeError:
+                            declined += 1
+    # triples the planner can accept: rank 26..30, rank-preserving steps of 3..5 contracted bits, later steps contracting
+    # bits the step before has just produced (consecutive gates on overlapping qubits)
+    for case in range(max(1, cases // 10)):
+        ra = int(rng.integers(26, 31))
+        cur, last_new, eqs, shapes_b = [f"a{x}" for x in range(ra)], [], [], []
+        for st in range(3):
+            k = int(rng.integers(3, 6))
+            pick = [x for x in last_new if rng.random() < 0.7][:k]
+            rest = [x for x in cur if x not in pick]
+            pick += [str(x) for x in rng.choice(rest, size=k - len(pick), replace=False)]
+            new = [f"s{st}n{x}" for x in range(k)]
+            lb = pick + new
+            rng.shuffle(lb)
+            lo = [x for x in cur if x not in pick] + new
+            rng.shuffle(lo)
+            eqs.append((tuple(cur), tuple(lb), tuple(lo)))
+            shapes_b.append((2,) * len(lb))
+            cur, last_new = lo, new
+        ti = C.triple_info(eqs[0], (2,) * ra, shapes_b[0], eqs[1], shapes_b[1], eqs[2], shapes_b[2])
+        if ti is not None:
+            triples += 1
+            assert ti["tile_in_bits"] == 12 and ti["k3_bits"] in (3, 4, 5) and ti["n_tiles"] >= 1 << 14
     print(f"stress_planner: {cases} cases in {time.time() - t0:.1f} s; kernels {dict(sorted(kernels.items()))}, "
-          f"{fused} pairs fused, {declined} descriptors refused; OK")
+          f"{fused} pairs fused, {triples} triples fused, {declined} descriptors refused; OK")
 
 
 if __name__ == "__main__":
