@@ -599,12 +599,16 @@ def fusion_schedule(scheme):
     ("one", n) / ("pair", n, n') entries covering every step exactly once."""
     order, done = [], set()
     n_steps = len(scheme)
+    unpaired = set()
+    shift = _os_environ.get("ARTN_PAIR_SHIFT")   # experiment: leave step <n> single, so that the pairs after it shift by one
+    if shift:
+        unpaired = {int(x) for x in shift.split(",")}
     for n in range(n_steps):
         if n in done:
             continue
         i, j = scheme[n][0]
         partner = None
-        for m in range(n + 1, n_steps):
+        for m in range(n + 1, n_steps if n not in unpaired else 0):
             if m in done:
                 continue
             i2, j2 = scheme[m][0]
