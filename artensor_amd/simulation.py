@@ -372,7 +372,7 @@ class SliceRunner:
 
 def sliced_contraction(tensors, scheme, slicing_indices, out_shape, sparse=False, permute_dims=None,
                        dtype=torch.complex64, device="cuda", group=None, slices=None, reduce="all",
-                       graph=False, reuse_small=True, runner=None):
+                       graph=False, reuse_small=True, runner=None, checkpoint=None, checkpoint_every=256):
     """The slice loop (reference simulation.py:101-116) on one rank of `group`.
 
     tensors         leaf tensors (dict or list) already on `device` or movable to it
@@ -384,13 +384,47 @@ def sliced_contraction(tensors, scheme, slicing_indices, out_shape, sparse=False
                     in Gray-code order
     graph           True: replay whole slices from a captured HIP graph instead
     runner          a SliceRunner to reuse across calls (its accumulator is zeroed first)
+    checkpoint      path prefix: this rank's partial sum and the slices it covers are written to
+                    `<checkpoint>.rank<r>of<w>.pt` every `checkpoint_every` slices (atomically: write + rename) and when the
+                    shard is done; a later call with the same plan, shard and path resumes after the last saved slice (a
+                    16 384-slice n53 run is minutes per GPU, a 2^29-slice one is not a single sitting).  The reference has no
+                    such thing (simulation.py:107-114 is one uninterrupted loop).
     """
     if runner is None:
         runner = SliceRunner(tensors, scheme, slicing_indices, out_shape, sparse=sparse, dtype=dtype, device=device,
                              graph=graph, reuse_small=reuse_small)
     else:
         runner.collect.zero_()
-    return _shard_and_reduce(runner, permute_dims, group, slices, reduce)
+    return _shard_and_reduce(runner, permute_dims, group, slices, reduce, checkpoint, checkpoint_every)
+
+
+def _checkpoint_path(prefix, rank, world):
+    return f"{prefix}.rank{rank}of{world}.pt"
+
+
+def load_checkpoint(path, fingerprint, my_slices):
+    """(slices done, partial sum as a CPU tensor) of a checkpoint written for THIS plan and THIS shard, or (0, None).
+    A file of another plan (fingerprint) or another shard (slice list) is refused: resuming it would sum slices of a
+    different network, or the same slices twice."""
+    import os
+    if not os.path.exists(path):
+        return 0, None
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    if ck.get("fingerprint") != fingerprint:
+        raise RuntimeError(f"{path} was written for another plan (scheme / sliced bonds / output order differ): not resumed")
+    done = int(ck["done"])
+    if ck.get("n_slices") != len(my_slices) or ck.get("head") != [int(x) for x in my_slices[:done][-8:]]:
+        raise RuntimeError(f"{path} was written for another shard of the slices: not resumed")
+    return done, ck["partial"]
+
+
+def save_checkpoint(path, fingerprint, my_slices, done, collect):
+    """Atomic: the previous checkpoint stays valid until the new one is complete on disk."""
+    import os
+    tmp = path + ".tmp"
+    torch.save({"fingerprint": fingerprint, "n_slices": len(my_slices), "done": int(done),
+                "head": [int(x) for x in my_slices[:done][-8:]], "partial": collect.detach().cpu()}, tmp)
+    os.replace(tmp, path)
 
 
 def plan_fingerprint(scheme, slicing_indices, permute_dims=None):
@@ -431,7 +465,7 @@ def _check_same_plan(runner, permute_dims, group):
     runner._plan_checked = id(group)
 
 
-def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce="all"):
+def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce="all", checkpoint=None, checkpoint_every=256):
     """Sharding + the single reduction of sliced_contraction around a ready SliceRunner (also the entry
     of the CPU tests, which hand in a runner built by SliceRunner._with_seams)."""
     import torch.distributed as dist
@@ -442,7 +476,21 @@ def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce
         _check_same_plan(runner, permute_dims, group)
     if slices is None:
         slices = rank_slices(2 ** runner.n_bonds, rank, world, gray=runner.reuse_small)
-    collect = runner.run(slices)
+    if checkpoint is None:
+        collect = runner.run(slices)
+    else:   # resumable: the shard in pieces of `checkpoint_every` slices, the partial sum saved after each
+        slices = [int(x) for x in slices]
+        fp = plan_fingerprint(runner.scheme, runner.slicing_indices, permute_dims)
+        path = _checkpoint_path(checkpoint, rank, world)
+        done, partial = load_checkpoint(path, fp, slices)
+        if partial is not None:
+            runner.collect.copy_(partial.to(runner.collect.device).reshape(runner.collect.shape))
+        every = max(1, int(checkpoint_every))
+        while done < len(slices):
+            runner.run(slices[done:done + every])
+            done = min(done + every, len(slices))
+            save_checkpoint(path, fp, slices, done, runner.collect)
+        collect = runner.collect
     if distributed and reduce is not None:
         buf = torch.view_as_real(collect)
         if reduce == "all":
@@ -693,7 +741,8 @@ class TensorNetworkSimulation:
         return cls(case.tensors, case.scheme, case.slicing_indices, m.get("output_bonds", []),
                    m.get("pattern", "normal"), m.get("bitstrings_sorted"), m.get("permute_dims"))
 
-    def contraction(self, tensors=None, dtype=torch.complex64, device="cuda", group=None, reduce="all"):
+    def contraction(self, tensors=None, dtype=torch.complex64, device="cuda", group=None, reduce="all", checkpoint=None,
+                    checkpoint_every=256):
         src = self.tensors if tensors is None else tensors
         if self.pattern == "sparse":
             shape = [len(self.bitstrings_sorted)] + [2] * len(self.output_bonds)
@@ -701,7 +750,8 @@ class TensorNetworkSimulation:
             shape = [2] * len(self.output_bonds)
         permute = getattr(self, "permute_dims", None) if len(self.output_bonds) > 0 else None
         return sliced_contraction(src, self.scheme, self.slicing_indices, shape, sparse=self.pattern == "sparse",
-                                  permute_dims=permute, dtype=dtype, device=device, group=group, reduce=reduce)
+                                  permute_dims=permute, dtype=dtype, device=device, group=group, reduce=reduce,
+                                  checkpoint=checkpoint, checkpoint_every=checkpoint_every)
 
 
 def tensor_network_contraction(tensors, tensor_bonds, bond_dims, final_qubits, bitstrings=[], sc_target=31,

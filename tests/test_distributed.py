@@ -222,3 +222,54 @@ def test_a_planner_failure_on_rank_0_raises_on_every_rank(tmp_path):
     for r in range(2):
         msg = open(tmp_path / f"fail_{r}.txt").read()
         assert "planning failed on rank 0" in msg and "planner exploded" in msg, (r, msg)
+
+
+def test_checkpoint_and_resume_of_the_slice_loop(tmp_path, monkeypatch):
+    """SURVEY section 5 (optional hook): the slice loop writes its partial sum every few slices and a later call resumes after
+    the last saved slice -- same result as the uninterrupted loop; a checkpoint of another plan or another shard is refused.
+    (Single process, CPU oracle through the test seams: what is exercised is the product's checkpoint logic.)"""
+    from artensor_amd import simulation as S
+    case = load_case(os.path.join(GOLDEN, "rand_D2_closed_sliced.npz"))     # 6 sliced bonds: 64 slices
+    want = case.arrays["final"]
+
+    def runner():
+        return S.SliceRunner._with_seams(case.tensors, case.scheme, case.slicing_indices, want.shape, False,
+                                         torch.complex64, "cpu", _oracle_execute(False), _cpu_add)
+    full = S._shard_and_reduce(runner(), reduce=None).numpy().copy()
+    assert np.abs(full - want).max() <= 1e-5 * np.abs(want).max()
+    prefix = str(tmp_path / "ck")
+    # an interrupted run: the 4th save never happens
+    saves = []
+    orig = S.save_checkpoint
+
+    def dying(path, fp, sl, done, collect):
+        if len(saves) == 3:
+            raise KeyboardInterrupt
+        saves.append(done)
+        orig(path, fp, sl, done, collect)
+    monkeypatch.setattr(S, "save_checkpoint", dying)
+    with pytest.raises(KeyboardInterrupt):
+        S._shard_and_reduce(runner(), reduce=None, checkpoint=prefix, checkpoint_every=10)
+    assert saves == [10, 20, 30] and os.path.exists(prefix + ".rank0of1.pt") and not os.path.exists(prefix + ".rank0of1.pt.tmp")
+    monkeypatch.setattr(S, "save_checkpoint", orig)
+    # resumed: only slices 30.. are contracted again
+    r = runner()
+    ran = []
+    orig_run = r.run
+    r.run = lambda sl: (ran.append(list(sl)), orig_run(sl))[1]
+    resumed = S._shard_and_reduce(r, reduce=None, checkpoint=prefix, checkpoint_every=10).numpy()
+    assert [len(x) for x in ran] == [10, 10, 10, 4] and sum(len(x) for x in ran) == 64 - 30
+    assert np.abs(resumed - full).max() <= 1e-6 * np.abs(full).max()
+    # a finished checkpoint resumes to "nothing left": no slice is contracted twice
+    r = runner()
+    r.run = lambda sl: (_ for _ in ()).throw(AssertionError("nothing should run"))
+    again = S._shard_and_reduce(r, reduce=None, checkpoint=prefix, checkpoint_every=10).numpy()
+    assert np.abs(again - full).max() <= 1e-6 * np.abs(full).max()
+    # another shard of the same plan, and another plan: refused
+    with pytest.raises(RuntimeError, match="another shard"):
+        S._shard_and_reduce(runner(), reduce=None, slices=list(range(5, 40)), checkpoint=prefix, checkpoint_every=10)
+    other = load_case(os.path.join(GOLDEN, "rand_D2_open_sliced.npz"))
+    r2 = S.SliceRunner._with_seams(other.tensors, other.scheme, other.slicing_indices, other.arrays["final"].shape, False,
+                                   torch.complex64, "cpu", _oracle_execute(False), _cpu_add)
+    with pytest.raises(RuntimeError, match="another plan"):
+        S._shard_and_reduce(r2, reduce=None, checkpoint=prefix, checkpoint_every=10)
