@@ -9,9 +9,9 @@ all: $(LIB)
 # eight objects from ONE source (see "Translation units" in artn_kernels.hip): `make -j8` builds in about a
 # minute and a half instead of four
 SRCS := $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_pgemm_kernel.h \
-        $(CSRC)/artn_bits128_kernel.h $(CSRC)/artn_bits3_kernel.h $(CSRC)/artn_plan.h include/artn.h
+        $(CSRC)/artn_bits128_kernel.h $(CSRC)/artn_bits3_kernel.h $(CSRC)/artn_wide_kernel.h $(CSRC)/artn_plan.h include/artn.h
 OBJDIR := build/obj
-OBJS := $(OBJDIR)/main.o $(OBJDIR)/b128.o $(foreach k,1 2 3 4 5 6,$(OBJDIR)/bits_k$(k).o) $(foreach k,3 4 5,$(OBJDIR)/bits3_k$(k).o)
+OBJS := $(OBJDIR)/main.o $(OBJDIR)/b128.o $(OBJDIR)/wide.o $(foreach k,1 2 3 4 5 6,$(OBJDIR)/bits_k$(k).o) $(foreach k,3 4 5,$(OBJDIR)/bits3_k$(k).o)
 FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -I$(CSRC)
 
 $(OBJDIR)/main.o: $(SRCS)
@@ -20,6 +20,9 @@ $(OBJDIR)/main.o: $(SRCS)
 $(OBJDIR)/b128.o: $(SRCS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -DARTN_TU_B128 -c $< -o $@
+$(OBJDIR)/wide.o: $(SRCS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FLAGS) -DARTN_TU_WIDE -c $< -o $@
 $(OBJDIR)/bits3_k%.o: $(SRCS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -DARTN_TU_BITS3=$* -c $< -o $@

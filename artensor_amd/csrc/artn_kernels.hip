@@ -1724,8 +1724,12 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 // artn_launch_bits_kK(), -DARTN_TU_B128 only artn_k_bits128<*, *> behind artn_launch_bits128(), -DARTN_TU_MAIN
 // everything else and calls those; with none of the macros (diagnostic and development builds) the file is one
 // translation unit as before.
-#if defined(ARTN_TU_BITS) || defined(ARTN_TU_B128) || defined(ARTN_TU_BITS3)
+#if defined(ARTN_TU_BITS) || defined(ARTN_TU_B128) || defined(ARTN_TU_BITS3) || defined(ARTN_TU_WIDE)
 #define ARTN_TU_PART 1
+#endif
+// (-DARTN_TU_WIDE: only artn_k_wide<*, *> behind artn_launch_wide())
+#if defined(ARTN_TU_WIDE) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
+#include "artn_wide_kernel.h"
 #endif
 // (-DARTN_TU_BITS3=K: only artn_k_bits3<K, *, *> behind artn_launch_bits3_kK())
 #if defined(ARTN_TU_BITS3) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
@@ -2486,6 +2490,31 @@ hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1,
 hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st);
 #endif
 
+// fused pairs of 2^12-element tiles (ArtnBitsPlan::wide8): artn_k_wide<KB1, KB2>, 3..6 contracted bits per stage
+#if defined(ARTN_TU_WIDE) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
+hipError_t artn_launch_wide(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st) {
+  dim3 grid(p.info.grid), block(ARTN_WIDE_THREADS);
+  const size_t lds = (size_t)p.info.lds_bytes;
+  const int k1 = p.bits.st[0].k, k2 = p.bits.st[1].k;
+  const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2;
+  float2 *c = (float2 *)C;
+#define ARTN_WIDE_GO(K1, K2)                                                                        \
+  if (k1 == K1 && k2 == K2) {                                                                       \
+    auto kern = artn_k_wide<K1, K2>;                                                                \
+    if (hipError_t e = ensure_lds<artn_k_wide<K1, K2>>(lds); e != hipSuccess) return e;             \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b1, b2, c, p.bits);                           \
+    return hipGetLastError();                                                                       \
+  }
+#define ARTN_WIDE_ROW(K1) ARTN_WIDE_GO(K1, 3) ARTN_WIDE_GO(K1, 4) ARTN_WIDE_GO(K1, 5) ARTN_WIDE_GO(K1, 6)
+  ARTN_WIDE_ROW(3) ARTN_WIDE_ROW(4) ARTN_WIDE_ROW(5) ARTN_WIDE_ROW(6)
+#undef ARTN_WIDE_ROW
+#undef ARTN_WIDE_GO
+  return hipErrorInvalidValue;
+}
+#elif defined(ARTN_TU_MAIN)
+hipError_t artn_launch_wide(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st);
+#endif
+
 #define ARTN_CAT2(a, b) a##b
 #define ARTN_CAT(a, b) ARTN_CAT2(a, b)
 // fused triples (make_bits3): artn_k_bits3<KB1, KB2, KB3, M3>, 3..5 contracted bits per stage, fragments of at most 80 registers;
@@ -2527,7 +2556,7 @@ hipError_t ARTN_CAT(artn_launch_bits3_k, ARTN_TU_BITS3)(const ArtnPlan &p, const
   return launch_bits3_k<ARTN_TU_BITS3>(p, A, B1, B2, B3, C, st);
 }
 #endif
-#if defined(ARTN_TU_B128) || defined(ARTN_TU_BITS3)
+#if defined(ARTN_TU_B128) || defined(ARTN_TU_BITS3) || defined(ARTN_TU_WIDE)
 // (nothing else in this translation unit)
 #elif defined(ARTN_TU_BITS)
 hipError_t ARTN_CAT(artn_launch_bits_k, ARTN_TU_BITS)(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, float2 *C,
@@ -2568,6 +2597,7 @@ static hipError_t launch_bits3(const ArtnPlan &p, const void *A, const void *B1,
 static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C,
                               hipStream_t st) {
   if (p.bits.c128) return artn_launch_bits128(p, A, B1, B2, C, st);
+  if (p.bits.wide8) return artn_launch_wide(p, A, B1, B2, C, st);
   const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2;
   float2 *c = (float2 *)C;
 #ifdef ARTN_DEV_FEW // development builds only: one family of artn_k_bits instantiations (compiles in under a minute)

@@ -80,6 +80,8 @@ struct ArtnBitsPlan {
   int32_t c128;               // 1: complex128 elements -- artn_k_bits128 (16-column sub-tiles: 4 lane bits, f64 MFMA)
   int32_t ksplit;             // 1: 7-8 contracted bits, one 32 x 16 block per tile: the four waves split the chain
   int32_t split;              // MFMA arithmetic: 0 fp32; 3 fp32-grade from three bf16 pieces; 1 plain bf16 operands
+  int32_t wide8;              // 1: fused pair of 2^12-element tiles run by artn_k_wide (one 8-wave workgroup per CU, every stage 3M on
+  int32_t pad8_;              //    16 x 16 x 4 blocks, tiles by LDS-DMA); the plan itself is the one artn_k_bits would run
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
   ArtnStage st[3];
@@ -237,6 +239,9 @@ struct Tuning {
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
   int packed_min_ai = 64;  // ... and the FLOP per byte of the step it needs
+  int wide = 0;       // fused pairs of 2^12-element tiles: 1: artn_k_wide (ArtnBitsPlan::wide8) -- an experiment that lost:
+                      // 56.5 ms on n30 against 53.5
+  int wide_min_tiles = 0; // ... for launches of at least this many tiles (0: 8 per CU)
   int alt = 2;        // big launches of the state-streaming kernel: 1: one 8-wave workgroup per CU, two groups alternating
                       // between MFMA stages and copy phases (artn_k_alt); 0: two independent workgroups per CU (artn_k_bits);
                       // 2: artn_k_alt where a tile's OUTPUT runs are shorter than a 128-byte line (its stores, slow
@@ -274,6 +279,8 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_PACKED_MIN_AI")) x.packed_min_ai = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_PACKED")) x.packed = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_ALT")) x.alt = std::min(2, std::max(0, atoi(e)));
+    if (const char *e = getenv("ARTN_WIDE")) x.wide = atoi(e);
+    if (const char *e = getenv("ARTN_WIDE_MIN_TILES")) x.wide_min_tiles = atoi(e);
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
     return x;
@@ -1470,6 +1477,24 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   return ARTN_OK;
 }
 
+// artn_k_wide runs a fused pair when all three tiles are 2^12 complex64 elements (so every stage brings as many bits as it
+// contracts and 8 waves have two 16 x 16 blocks each), 3..6 contracted bits per stage, fp32 arithmetic, no row gather, and
+// the launch is big enough for one workgroup per CU to matter.
+static inline bool wide_eligible(const ArtnPlan &p) {
+  const ArtnBitsPlan &b = p.bits;
+  if (!tuning().wide || b.c128 || b.split != 0 || b.n_stages != 2 || b.gather_dim >= 0) return false;
+  if (b.T_in != ARTN_TILE_BITS_TARGET || b.T_mid != ARTN_TILE_BITS_TARGET || b.T_out != ARTN_TILE_BITS_TARGET) return false;
+  for (int q = 0; q < 2; ++q) {
+    const ArtnStage &s = b.st[q];
+    if (s.k < 3 || s.k > 6 || s.nt != s.k || s.m_bits != ARTN_TILE_BITS_TARGET - s.k) return false;
+  }
+  if (b.n_tiles < (tuning().wide_min_tiles > 0 ? (int64_t)tuning().wide_min_tiles : (int64_t)p.n_cu * 8)) return false;
+  int64_t si = 0, so = 0; // per-lane byte offsets of the copies span tile bits 1..9 and are 32-bit
+  for (int i = 1; i <= 9; ++i) { si += b.in_stride[i]; so += b.out_stride[i]; }
+  if (si > (int64_t(1) << 28) - 1 || so > (int64_t(1) << 28) - 1) return false;
+  return true;
+}
+
 // Two consecutive steps on the same big operand, d2's A being d1's C, in ONE pass.
 // Fails with ARTN_E_UNSUPPORTED (err says why) when the pair does not fit one LDS tile;
 // the caller then runs the two steps one after the other.
@@ -1494,6 +1519,15 @@ static inline int make_plan_fused(const ArtnStepDesc *d1, const ArtnStepDesc *d2
   p.info.bytes = (d1->dtype == ARTN_C128 ? 16.0 : 8.0) * (a1 + b1 + b2 + c2); // the intermediate C1 never touches HBM
   p.info.arith = p.bits.c128 ? 3 : (p.bits.split == 1 ? 2 : ((p.bits.st[0].m3 || p.bits.st[1].m3) ? 1 : 0));
   p.info.mfma_flops = f1 * (p.bits.st[0].m3 ? 0.75 : 1.0) + f2 * (p.bits.st[1].m3 ? 0.75 : 1.0);
+  if (wide_eligible(p)) {
+    // artn_k_wide: the same plan, one 512-thread workgroup per CU, a ring of three input regions + the middle one
+    ArtnBitsPlan &b = p.bits;
+    b.wide8 = 1;
+    p.info.grid = (int32_t)std::min<int64_t>(b.n_tiles, (int64_t)n_cu);
+    p.info.lds_bytes = (int32_t)(4 * (8 << ARTN_TILE_BITS_TARGET) + (8 << (b.st[0].m_bits - 5)) + (8 << (b.st[1].m_bits - 5)) + 512 * 8 + 32 * 32);
+    p.info.arith = 1;
+    p.info.mfma_flops = 0.75 * (f1 + f2);
+  }
   return ARTN_OK;
 }
 

@@ -17,6 +17,7 @@ c128_spread.npz holds complex128 runs of the reference's executors on the same l
 them; the HIP results have to stay within STRICT_FACTOR x that distance of the complex128 truth."""
 import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -1133,6 +1134,16 @@ def test_fused_triples_on_the_gpu(monkeypatch):
         assert float((got - ref).abs().max().item()) <= 2e-6 * float(ref.abs().max().item()), (n1, n2, n3)
         del got, ref
         torch.cuda.empty_cache()
+
+
+def test_wide_kernel_pairs():
+    """artn_k_wide (ARTN_WIDE=1: one 8-wave workgroup per CU on one tile, LDS-DMA ring, every stage 3M on 16 x 16 x 4 blocks --
+    an opt-in experiment) against the oracle, in a process of its own because the planner reads its
+    tuning once: tests/wide_worker.py."""
+    env = dict(os.environ, ARTN_WIDE="1", ARTN_WIDE_MIN_TILES="1")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "wide_worker.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "wide ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_complex128_fused_pairs():

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Per-kernel PMC summary of tools/pmc_case.sh (launches longer than 1 ms, averaged per instantiation)."""
+import collections, csv, glob, os, sys
+out = sys.argv[1]
+for sub in ("a", "b"):
+    files = glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True)
+    if not files:
+        print(sub, "no counters:", open(os.path.join(out, sub + ".log")).read()[-600:])
+        continue
+    per = collections.OrderedDict()
+    for r in csv.DictReader(open(files[0])):
+        d = per.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"].split("(")[0].replace("void ", ""), "t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    agg = collections.OrderedDict()
+    for d in per.values():
+        if d["t"] < 1e6: continue
+        a = agg.setdefault(d["name"], collections.Counter())
+        a["n"] += 1
+        for k, v in d.items():
+            if k != "name": a[k] += v
+    for name, a in agg.items():
+        n = a["n"]
+        print(f"{name[:60]:60s} n={n} ms={a['t']/n/1e6:.2f} " + " ".join(f"{k}={v/n:.3g}" for k, v in a.items() if k not in ("n", "t")))

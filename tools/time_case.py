@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-launch breakdown of one slice of a fixture: [DTYPE=c128] [TOP=n] python tools/time_case.py <fixture.npz> [sparse]"""
+"""Per-launch breakdown of one slice of a fixture: [DTYPE=c128] [PRECISION=bf16] [TOP=n] python tools/time_case.py <fixture.npz> [sparse]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,7 +25,11 @@ def q(d):
     info["shape"] = dict(cnt)
     return info
 C._query = q
+import contextlib
+def ctx():
+    return C.precision(os.environ["PRECISION"]) if os.environ.get("PRECISION") else contextlib.nullcontext()
 def one(s):
+  with ctx():
     sl = A.apply_slice(leaves, case.slicing_indices, A.slice_assignments(nb, s)) if nb else dict(leaves)
     return (A.tensor_contraction_sparse if sparse else A.tensor_contraction)(sl, case.scheme)
 one(0); torch.cuda.synchronize()
