@@ -11,7 +11,7 @@ import threading
 
 import torch
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ARTN_MAX_LABELS = 96
 ARTN_PROGRAM_MAX_EXT = 256
 ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
@@ -79,6 +79,10 @@ _EXPORTS = {
                                             ctypes.POINTER(ArtnStepInfo)]),
     "artn_contract2": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "artn_contract_acc": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
+    "artn_contract2_acc": (ctypes.c_int, [ctypes.POINTER(ArtnStepDesc), ctypes.POINTER(ArtnStepDesc), ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_program_record_bytes": (ctypes.c_int64, []),
     "artn_program_image_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]),
     "artn_program_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -784,7 +784,8 @@ _schedule_cache = _Bounded(64)
 
 class _Op:
     """One launch of a compiled dense scheme: a single step, a fused pair or a fused triple."""
-    __slots__ = ("steps", "i", "j", "j2", "j3", "d1", "d2", "d3", "out_shape", "info", "sum_rows")
+    __slots__ = ("steps", "i", "j", "j2", "j3", "d1", "d2", "d3", "out_shape", "info", "sum_rows", "acc")
+    # (acc: False once artn_contract[2]_acc has declined this launch -- see tensor_contraction(accumulate_into=...))
 
 
 
@@ -1132,10 +1133,24 @@ def _HAS_PAIR_QUERY():
     return _pair_query[0]
 
 
-def tensor_contraction(tensors, scheme):
+def _axpy(acc, x):
+    """acc += x (artn_axpy_c64 / _c128) on acc's device and the current stream"""
+    x = x.contiguous()
+    axpy = N.lib().artn_axpy_c64 if acc.dtype == torch.complex64 else N.lib().artn_axpy_c128
+    with torch.cuda.device(acc.device):
+        N.check(axpy(acc.data_ptr(), x.data_ptr(), acc.numel(), N.current_stream_ptr(acc.device)))
+
+
+def tensor_contraction(tensors, scheme, accumulate_into=None):
     """Run a dense scheme: for each ((i, j), eq): tensors[i] <- contract(eq, tensors[i],
     tensors[j]); returns the last tensors[i] (reference contraction.py:62-76; `tensors` is
     mutated the same way).
+
+    accumulate_into: a contiguous tensor of the result's dtype and number of elements (the slice loop's
+    `collect_tensor`, reference simulation.py:114): the result is ADDED to it and it is returned.  When the last launch of
+    the scheme is a state-streaming step or pair the add happens in that launch's store phase (artn_contract_acc /
+    artn_contract2_acc: the slice's result never exists in memory); otherwise the scheme runs as usual and the result is
+    added with artn_axpy_c64.
 
     Behind the unchanged entry point the scheme is compiled once (per scheme object and leaf
     shapes) into a launch list; two consecutive steps on the same big tensor execute as ONE
@@ -1191,17 +1206,48 @@ def tensor_contraction(tensors, scheme):
         stream = N.current_stream_ptr(device)
         if prog is not None:   # every step that only combines small leaf-derived tensors: one launch
             _run_program(prog, tensors, dtype, device, stream)
+        last_op = ops[-1] if ops else None
+        done_acc = False
+        acc_ok = False
+        if accumulate_into is not None:
+            if not (isinstance(accumulate_into, torch.Tensor) and accumulate_into.is_cuda and accumulate_into.device == device
+                    and accumulate_into.is_contiguous() and accumulate_into.dtype == dtype):
+                raise RuntimeError("accumulate_into must be a contiguous tensor of the scheme's dtype on its device")
+            acc_ok = (last_op is not None and dtype == torch.complex64 and precision.current() in (None, "fp32")
+                      and last_op.steps and last_op.steps[-1] == len(scheme) - 1
+                      and int(np.prod(last_op.out_shape, dtype=np.int64)) == accumulate_into.numel())
         for op in ops:
             a = tensors[op.i]
             if op.sum_rows and _sum_leading_ok(a, op.sum_rows):
                 tensors[op.i] = sum_leading(a, op.sum_rows).reshape(op.out_shape)
                 continue
             b = _one_scalar(dtype, device) if op.j is _ONE else tensors[op.j]
-            out = torch.empty(op.out_shape, dtype=dtype, device=device)
-            if profiler is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            if op.d2 is None:
+            fused_acc = False
+            if op is last_op and acc_ok and op.d3 is None and getattr(op, "acc", None) is not False:
+                # the slice loop's `collect += result` in the store phase of the last launch
+                if profiler is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                if op.d2 is None:
+                    rc = lib.artn_contract_acc(byref(op.d1), a.data_ptr(), b.data_ptr(), accumulate_into.data_ptr(), stream)
+                else:
+                    rc = lib.artn_contract2_acc(byref(op.d1), byref(op.d2), a.data_ptr(), b.data_ptr(), tensors[op.j2].data_ptr(),
+                                                accumulate_into.data_ptr(), stream)
+                if rc == -2:
+                    op.acc = False   # (this plan's store phase cannot add: remembered per compiled op)
+                else:
+                    fused_acc = True
+                    out = accumulate_into
+            if fused_acc:
+                pass
+            else:
+                out = torch.empty(op.out_shape, dtype=dtype, device=device)
+                if profiler is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+            if fused_acc:
+                pass
+            elif op.d2 is None:
                 rc = _launch_step(op.d1, a, b, out, stream) if out.numel() else 0
             elif op.d3 is None:
                 b2 = tensors[op.j2]
@@ -1221,7 +1267,15 @@ def tensor_contraction(tensors, scheme):
                     op.info = _query(op.d1)
                 profiler.record(op.info, e0, e1)
             tensors[op.i] = out
-    return tensors[scheme[-1][0][0]]
+            done_acc = done_acc or fused_acc
+    res = tensors[scheme[-1][0][0]]
+    if accumulate_into is None:
+        return res
+    if not done_acc:
+        if res.numel() != accumulate_into.numel() or res.dtype != accumulate_into.dtype:
+            raise RuntimeError("accumulate_into does not match the result")
+        _axpy(accumulate_into, res.reshape(accumulate_into.shape))
+    return accumulate_into
 
 
 # ----------------------------------------------------------------------------------------

@@ -1452,6 +1452,28 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       }
       PHASE_MARK(4);
       STAMP(2);
+      // C += result (ArtnBitsPlan::accumulate: the slice loop's `collect += ...` in the store phase of a slice's last launch):
+      // the accumulator's chunks are read into registers the refill has just freed and added before the stores.  (Each
+      // element belongs to exactly one lane of one tile: plain loads and stores.  global_atomic_add_f32 instead -- four per
+      // chunk, no registers -- ran the launch at a FIFTH of the speed: 42.4 ms per n30_sliced3 slice against 22.4.)
+#ifndef ARTN_ABLATE_MEM
+      if (P.accumulate) {
+        f32x4 c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (i < n_out_iters && out_active) {
+            long o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              if ((i >> b) & 1) o += out_hi[b];
+            c[i] = *reinterpret_cast<const f32x4 *>(Cbase + o + lo_out);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < n_out_iters && out_active) x[i] += c[i];
+      }
+#endif
       // stores of this tile, then the loads of the tile after next
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -2370,7 +2392,7 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
   // the big launches (2^12-element tiles, fp32 chains, grid-stride tiles): one 8-wave workgroup per CU whose two
   // groups alternate between the MFMA stages and the copy phases (artn_k_alt)
   if constexpr (KB1 >= 3) {
-    if (full && p.bits.T_mid == 12 && split == 0 && p.bits.gather_dim < 0 && !p.bits.blocked && p.bits.st[0].k <= 6 &&
+    if (full && p.bits.T_mid == 12 && split == 0 && p.bits.gather_dim < 0 && !p.bits.blocked && p.bits.st[0].k <= 6 && !p.bits.accumulate &&
         (artn::tuning().alt == 1 || (artn::tuning().alt == 2 && p.bits.run_out < 4)) &&
         p.bits.n_tiles >= 64 && (k2 == 0 || k2 >= 3)) {
       const long half_tiles = (long)((p.bits.n_tiles + 1) / 2);
@@ -3055,6 +3077,40 @@ int artn_contract2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A
   int rc = artn::make_plan_fused(d1, d2, p, err, g_ncu, min_tiles);
   if (rc) return fail(rc, err);
   HIP_TRY(launch_bits(p, A, B1, B2, C, (hipStream_t)stream));
+  return ARTN_OK;
+}
+
+int artn_contract2_acc(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A, const void *B1, const void *B2,
+                       void *C, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (!A || !B1 || !B2 || !C) return fail(ARTN_E_INVALID, "null operand pointer");
+  if ((((uintptr_t)A | (uintptr_t)C) & 15) != 0) return fail(ARTN_E_UNSUPPORTED, "not fusable: operands not 16-byte aligned");
+  if (env_flag("ARTN_NO_FUSE") || env_flag("ARTN_NO_ACC")) return fail(ARTN_E_UNSUPPORTED, "not fusable: ARTN_NO_FUSE / ARTN_NO_ACC is set");
+  ArtnPlan p;
+  std::string err;
+  const int64_t min_tiles = env_flag("ARTN_FORCE_BITS") ? 1 : 32;
+  int rc = artn::make_plan_fused(d1, d2, p, err, g_ncu, min_tiles);
+  if (rc) return fail(rc, err);
+  if (p.bits.wide8) return fail(ARTN_E_UNSUPPORTED, "accumulate: not in artn_k_wide");
+  if (!artn::bits_can_accumulate(p)) return fail(ARTN_E_UNSUPPORTED, "accumulate: this pair's store phase cannot add");
+  p.bits.accumulate = 1;
+  HIP_TRY(launch_bits(p, A, B1, B2, C, (hipStream_t)stream));
+  return ARTN_OK;
+}
+
+int artn_contract_acc(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *stream) {
+  if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
+  if (!A || !B || !C) return fail(ARTN_E_INVALID, "null operand pointer");
+  if (env_flag("ARTN_NO_ACC")) return fail(ARTN_E_UNSUPPORTED, "accumulate: ARTN_NO_ACC is set");
+  ArtnPlan p;
+  std::string err;
+  const bool aligned = (((uintptr_t)A | (uintptr_t)C) & 15) == 0;
+  const int64_t min_tiles = env_flag("ARTN_FORCE_BITS") ? 1 : 32;
+  int rc = artn::make_plan(d, p, err, g_ncu, aligned && !env_flag("ARTN_FORCE_GENERIC"), min_tiles);
+  if (rc) return fail(rc, err);
+  if (!artn::bits_can_accumulate(p)) return fail(ARTN_E_UNSUPPORTED, "accumulate: this step's kernel cannot add in its store phase");
+  p.bits.accumulate = 1;
+  HIP_TRY(launch_bits(p, A, B, nullptr, C, (hipStream_t)stream));
   return ARTN_OK;
 }
 

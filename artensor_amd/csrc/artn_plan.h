@@ -81,7 +81,10 @@ struct ArtnBitsPlan {
   int32_t ksplit;             // 1: 7-8 contracted bits, one 32 x 16 block per tile: the four waves split the chain
   int32_t split;              // MFMA arithmetic: 0 fp32; 3 fp32-grade from three bf16 pieces; 1 plain bf16 operands
   int32_t wide8;              // 1: fused pair of 2^12-element tiles run by artn_k_wide (one 8-wave workgroup per CU, every stage 3M on
-  int32_t pad8_;              //    16 x 16 x 4 blocks, tiles by LDS-DMA); the plan itself is the one artn_k_bits would run
+  int32_t accumulate;         //    16 x 16 x 4 blocks, tiles by LDS-DMA); the plan itself is the one artn_k_bits would run
+                              // accumulate = 1: C += result (artn_contract_acc / artn_contract2_acc: the store phase reads the
+                              // accumulator's chunk and adds -- every result element belongs to exactly one lane of one tile; set
+                              // by the entry point on plans for which bits_can_accumulate() holds
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
   ArtnStage st[3];
@@ -1493,6 +1496,17 @@ static inline bool wide_eligible(const ArtnPlan &p) {
   for (int i = 1; i <= 9; ++i) { si += b.in_stride[i]; so += b.out_stride[i]; }
   if (si > (int64_t(1) << 28) - 1 || so > (int64_t(1) << 28) - 1) return false;
   return true;
+}
+
+// C += result in the store phase of artn_k_bits (reference simulation.py:114, `collect_tensor += tensor_contraction(...)`, without
+// writing the slice's result and reading it back): the register-prefetch tile loop of the complex64 kernel (input tiles of
+// 2^12 or 2^11 elements, output tiles of at most 2^12), fp32 or split chains, no row gather, not the 7-8 bit instantiation.
+static inline bool bits_can_accumulate(const ArtnPlan &p) {
+  if (p.kernel != ARTN_KERNEL_BITS_MFMA) return false;
+  const ArtnBitsPlan &b = p.bits;
+  if (b.c128 || b.wide8 || b.n_stages > 2 || b.gather_dim >= 0 || b.st[0].k > 6) return false;
+  const int n_in = 1 << (b.T_in - 9);
+  return b.T_in >= 9 && (n_in == 8 || n_in == 4) && b.T_out <= 12;
 }
 
 // Two consecutive steps on the same big operand, d2's A being d1's C, in ONE pass.

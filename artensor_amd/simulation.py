@@ -191,6 +191,10 @@ class SliceRunner:
         self.n_bonds = len(self.slicing_indices)
         self.collect = torch.zeros(tuple(out_shape), dtype=dtype, device=device)
         seams = _execute is not None or _accumulate is not None
+        # dense complex64 schemes: `collect += result` rides in the store phase of the slice's last launch where that launch is
+        # a state-streaming step or pair (tensor_contraction(accumulate_into=...)); ARTN_NO_ACC=1 keeps the separate add
+        self._fused_add = (not seams and not sparse and dtype == torch.complex64 and self.device.type == "cuda"
+                           and __import__("os").environ.get("ARTN_NO_ACC", "0") in ("", "0"))
         on_gpu = not seams and self.device.type == "cuda" and self.n_bonds > 0
         self.use_graph = graph is True and on_gpu
         self._selects = {}    # tensor id -> {dim: position of the bond in the slice configuration}
@@ -245,6 +249,9 @@ class SliceRunner:
             self._static[tid].copy_(self.leaves[tid][self._index(tid, cfg)])
 
     def _one(self, inputs):
+        if self._fused_add:   # dense schemes: `collect += result` in the store phase of the slice's last launch
+            self.execute(inputs, self.scheme, accumulate_into=self.collect)
+            return
         res = self.execute(inputs, self.scheme)
         self.add(self.collect, res.reshape(self.collect.shape))
 
@@ -322,6 +329,9 @@ class SliceRunner:
             self.small_steps_run += 1
             cur[i] = val
         flush()
+        if self._main and self._fused_add:
+            self.execute(cur, self._main, accumulate_into=self.collect)
+            return
         res = self.execute(cur, self._main) if self._main else cur[self._last_id]
         self.add(self.collect, res.reshape(self.collect.shape))
 

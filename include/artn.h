@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ARTN_ABI_VERSION 5
+#define ARTN_ABI_VERSION 6
 #define ARTN_MAX_LABELS 96
 
 /* error codes */
@@ -149,6 +149,19 @@ int artn_contract_gather(const ArtnStepDesc *d, const void *A, const void *B, vo
 int artn_contract2_query(const ArtnStepDesc *d1, const ArtnStepDesc *d2, ArtnStepInfo *info);
 int artn_contract2(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A, const void *B1,
                    const void *B2, void *C, void *stream);
+
+/*
+ * C += contract(...) in the store phase of the last launch of a slice: the reference's slice loop ends every slice with
+ * `collect_tensor += tensor_contraction(...)` (artensor/simulation.py:114); with a dense output the separate add reads the
+ * slice's result and the accumulator and writes the accumulator again (3 x the output), the fused form reads and writes the
+ * accumulator once and the result never exists in memory.  Every element of C belongs to exactly one lane of one tile
+ * of the launch (plain loads and stores; C must not alias A), so C's value does not depend on scheduling.  complex64 state-streaming
+ * plans only (artn_k_bits, single steps and fused pairs, register-prefetch tile loop); ARTN_E_UNSUPPORTED (-2) otherwise:
+ * the caller then contracts into a temporary and calls artn_axpy_c64.
+ */
+int artn_contract_acc(const ArtnStepDesc *d, const void *A, const void *B, void *C, void *stream);
+int artn_contract2_acc(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A, const void *B1,
+                       const void *B2, void *C, void *stream);
 
 /* THREE consecutive steps on the same first operand in one pass (round 4): C = step3(step2(step1(A, B1), B2), B3), neither
  * intermediate leaves LDS -- the loop body of artensor/contraction.py:66-70 three times on one tensors[i].  d2 / d3

@@ -59,6 +59,8 @@ def test_no_cpu_fallback_anywhere():
     assert N.lib().artn_sum_axis_c64(p, p, 1, 2, 2, None) == -4
     assert N.lib().artn_contract_gather(ctypes.byref(d), p, p, p, 0, None, 0, None, 0, None, None) == -4
     assert N.lib().artn_contract2(ctypes.byref(d), ctypes.byref(d), p, p, p, p, None) == -4
+    assert N.lib().artn_contract2_acc(ctypes.byref(d), ctypes.byref(d), p, p, p, p, None) == -4
+    assert N.lib().artn_contract_acc(ctypes.byref(d), p, p, p, None) == -4
     assert N.lib().artn_contract3(ctypes.byref(d), ctypes.byref(d), ctypes.byref(d), p, p, p, p, p, None) == -4
     assert N.lib().artn_absmax_normalize_c128(p, 4, p, None) == -4
     assert N.lib().artn_gather_rows(p, p, p, 1, 8, 1, None, None) == -4

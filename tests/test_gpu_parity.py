@@ -1136,6 +1136,76 @@ def test_fused_triples_on_the_gpu(monkeypatch):
         torch.cuda.empty_cache()
 
 
+def test_accumulate_in_the_store_phase():
+    """`collect_tensor += tensor_contraction(...)` (reference simulation.py:114) with the add in the store phase of the last
+    launch (artn_contract2_acc / artn_contract_acc): the 13 fusable pairs of the n30 scheme and its big single steps on
+    surrogates of 2^22 elements, against accumulator + the same launch without the add (one fp32 add per element either
+    way: equal to the last bit), and through tensor_contraction(accumulate_into=...) with a scheme whose last launch can and
+    one whose last launch cannot add."""
+    from artensor_amd.contraction import fusion_schedule, contract2, _pair_descriptors, _descriptor
+    from helpers import shrink_pair
+    import ctypes
+    lib = N.lib()
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    pairs = [e for e in fusion_schedule(case.scheme) if e[0] == "pair" and np.prod(steps[e[1]][1]) >= 2 ** 22]
+    fused = 0
+    stream = N.current_stream_ptr(torch.device("cuda:0"))
+    for _, n, m in pairs:
+        eq1, sa, sb1 = steps[n]
+        eq2, _, sb2 = steps[m]
+        e1, a_s, b1_s, e2, b2_s = shrink_pair(eq1, sa, sb1, eq2, sb2, max_log2=22)
+        rng = np.random.default_rng(100 + n)
+        a, b1, b2 = gpu(crandn(rng, a_s)), gpu(crandn(rng, b1_s)), gpu(crandn(rng, b2_s))
+        plain = contract2(e1, a, b1, e2, b2)
+        if plain is None:
+            continue
+        acc0 = gpu(crandn(rng, tuple(plain.shape)))
+        acc = acc0.clone()
+        d1, d2, _ = _pair_descriptors(e1, a, b1, e2, b2)
+        rc = lib.artn_contract2_acc(ctypes.byref(d1), ctypes.byref(d2), a.data_ptr(), b1.data_ptr(), b2.data_ptr(), acc.data_ptr(), stream)
+        if rc == -2:
+            continue
+        assert rc == 0, lib.artn_last_error()
+        assert torch.equal(acc, acc0 + plain), (n, m)
+        fused += 1
+        # ... and through the executor: a two-step scheme whose last launch is this pair
+        tensors = {0: a.clone(), 1: b1, 2: b2}
+        scheme = [((0, 1), e1), ((0, 2), e2)]
+        acc2 = acc0.clone()
+        got = A.tensor_contraction(tensors, scheme, accumulate_into=acc2)
+        assert got is acc2 and torch.equal(acc2, acc0 + plain), (n, m)
+    assert fused >= 10, fused
+    # single big steps
+    singles = 0
+    for n in (75, 93, 108, 139, 172):
+        eq, sa, sb = steps[n]
+        e, a_s, b_s = shrink_step(eq, sa, sb, max_log2=22)
+        rng = np.random.default_rng(200 + n)
+        a, b = gpu(crandn(rng, a_s)), gpu(crandn(rng, b_s))
+        plain = A.contract(e, a, b)
+        acc0 = gpu(crandn(rng, tuple(plain.shape)))
+        acc = acc0.clone()
+        la, rest = e.split(",")
+        lb, lo = rest.split("->")
+        d, _ = _descriptor(tuple(la), tuple(lb), tuple(lo), tuple(a.shape), tuple(a.stride()), tuple(b.shape), tuple(b.stride()), torch.complex64)
+        rc = lib.artn_contract_acc(ctypes.byref(d), a.data_ptr(), b.data_ptr(), acc.data_ptr(), stream)
+        if rc == -2:
+            continue
+        assert rc == 0, lib.artn_last_error()
+        assert torch.equal(acc, acc0 + plain), n
+        singles += 1
+    assert singles >= 3, singles
+    # a scheme whose last launch cannot add (a tiny step: strided kernel) falls back to the separate add
+    a, b = gpu(crandn(np.random.default_rng(5), (2, 2, 2))), gpu(crandn(np.random.default_rng(6), (2, 2)))
+    acc0 = gpu(crandn(np.random.default_rng(7), (2, 2, 2)))
+    acc = acc0.clone()
+    got = A.tensor_contraction({0: a.clone(), 1: b}, [((0, 1), "abc,cd->abd")], accumulate_into=acc)
+    assert got is acc and float((acc - (acc0 + torch.einsum("abc,cd->abd", a, b))).abs().max()) < 1e-5
+    with pytest.raises(RuntimeError, match="accumulate_into"):
+        A.tensor_contraction({0: a.clone(), 1: b}, [((0, 1), "abc,cd->abd")], accumulate_into=acc[:1])
+
+
 def test_wide_kernel_pairs():
     """artn_k_wide (ARTN_WIDE=1: one 8-wave workgroup per CU on one tile, LDS-DMA ring, every stage 3M on 16 x 16 x 4 blocks --
     an opt-in experiment) against the oracle, in a process of its own because the planner reads its
