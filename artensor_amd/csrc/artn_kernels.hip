@@ -1456,8 +1456,11 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
       // the accumulator's chunks are read into registers the refill has just freed and added before the stores.  (Each
       // element belongs to exactly one lane of one tile: plain loads and stores.  global_atomic_add_f32 instead -- four per
       // chunk, no registers -- ran the launch at a FIFTH of the speed: 42.4 ms per n30_sliced3 slice against 22.4.)
+      // (FULL instantiations only -- bits_can_accumulate(): behind the run-time tile sizes of the others the conditional loads
+      //  cost every launch 40 %, accumulating or not)
+      if (!FULL && P.accumulate) __builtin_trap();
 #ifndef ARTN_ABLATE_MEM
-      if (P.accumulate) {
+      if (FULL && P.accumulate) {
         f32x4 c[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

@@ -1499,14 +1499,19 @@ static inline bool wide_eligible(const ArtnPlan &p) {
 }
 
 // C += result in the store phase of artn_k_bits (reference simulation.py:114, `collect_tensor += tensor_contraction(...)`, without
-// writing the slice's result and reading it back): the register-prefetch tile loop of the complex64 kernel (input tiles of
-// 2^12 or 2^11 elements, output tiles of at most 2^12), fp32 or split chains, no row gather, not the 7-8 bit instantiation.
+// writing the slice's result and reading it back): the FULL instantiations of the complex64 kernel (input and output tiles of
+// 2^12 elements, fp32 chains, no row gather).
 static inline bool bits_can_accumulate(const ArtnPlan &p) {
   if (p.kernel != ARTN_KERNEL_BITS_MFMA) return false;
   const ArtnBitsPlan &b = p.bits;
-  if (b.c128 || b.wide8 || b.n_stages > 2 || b.gather_dim >= 0 || b.st[0].k > 6) return false;
-  const int n_in = 1 << (b.T_in - 9);
-  return b.T_in >= 9 && (n_in == 8 || n_in == 4) && b.T_out <= 12;
+  if (b.c128 || b.wide8 || b.n_stages > 2 || b.gather_dim >= 0 || b.st[0].k > 6 || b.split != 0) return false;
+  if (b.T_in != 12 || b.T_out != 12) return false;
+  // ... and the launch must be one of the FULL instantiations (launch_bits_k2): 3M pairs / steps, or non-temporal loads with
+  // 3+ contracted bits per stage
+  const int k1 = b.st[0].k, k2 = b.n_stages == 2 ? b.st[1].k : 0;
+  const bool wide_stage = k1 == 5 || k1 == 6 || k2 == 5 || k2 == 6;
+  if (wide_stage && !((k1 >= 5 && k2 >= 5) && k1 + k2 > 11) && b.m3) return true;
+  return k1 >= 3 && (k2 == 0 || k2 >= 3) && b.nt_loads != 0;
 }
 
 // Two consecutive steps on the same big operand, d2's A being d1's C, in ONE pass.
