@@ -1265,7 +1265,11 @@ def tensor_contraction(tensors, scheme, accumulate_into=None):
                 e1.record()
                 if op.info is None:
                     op.info = _query(op.d1)
-                profiler.record(op.info, e0, e1)
+                info = op.info
+                if fused_acc:   # the launch also reads the accumulator
+                    info = dict(info)
+                    info["bytes"] = info["bytes"] + float(out.numel() * out.element_size())
+                profiler.record(info, e0, e1)
             tensors[op.i] = out
             done_acc = done_acc or fused_acc
     res = tensors[scheme[-1][0][0]]
