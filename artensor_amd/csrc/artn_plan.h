@@ -242,8 +242,10 @@ struct Tuning {
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
   int packed_min_ai = 64;  // ... and the FLOP per byte of the step it needs
-  int wide = 0;       // fused pairs of 2^12-element tiles: 1: artn_k_wide (ArtnBitsPlan::wide8) -- an experiment that lost:
-                      // 56.5 ms on n30 against 53.5
+  int wide = 2;       // fused pairs of 2^12-element tiles on artn_k_wide (ArtnBitsPlan::wide8): 0 never; 1 all of them (loses:
+                      // 56.5 ms on n30 against 53.5); 2 (default) the pairs with 11+ contracted bits -- 5+6, 6+5, 6+6 -- whose
+                      // fragments artn_k_bits cannot hold next to three accumulators (it runs them as four-product chains, or not
+                      // at all): the 5+6 pair of n30 x 10 000 7.50 -> 6.05 ms
   int wide_min_tiles = 0; // ... for launches of at least this many tiles (0: 8 per CU)
   int alt = 2;        // big launches of the state-streaming kernel: 1: one 8-wave workgroup per CU, two groups alternating
                       // between MFMA stages and copy phases (artn_k_alt); 0: two independent workgroups per CU (artn_k_bits);
@@ -282,7 +284,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_PACKED_MIN_AI")) x.packed_min_ai = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_PACKED")) x.packed = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_ALT")) x.alt = std::min(2, std::max(0, atoi(e)));
-    if (const char *e = getenv("ARTN_WIDE")) x.wide = atoi(e);
+    if (const char *e = getenv("ARTN_WIDE")) x.wide = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_WIDE_MIN_TILES")) x.wide_min_tiles = atoi(e);
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
@@ -1486,6 +1488,7 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
 static inline bool wide_eligible(const ArtnPlan &p) {
   const ArtnBitsPlan &b = p.bits;
   if (!tuning().wide || b.c128 || b.split != 0 || b.n_stages != 2 || b.gather_dim >= 0) return false;
+  if (tuning().wide == 2 && b.st[0].k + b.st[1].k < 11) return false;
   if (b.T_in != ARTN_TILE_BITS_TARGET || b.T_mid != ARTN_TILE_BITS_TARGET || b.T_out != ARTN_TILE_BITS_TARGET) return false;
   for (int q = 0; q < 2; ++q) {
     const ArtnStage &s = b.st[q];
@@ -1529,7 +1532,8 @@ static inline int make_plan_fused(const ArtnStepDesc *d1, const ArtnStepDesc *d2
   // bits -- and runs its FIRST stage again each time
   // 6 + 6 contracted bits: 128 fragment registers next to the accumulators -- the pair runs four-product chains with 480 bytes of
   // scratch per lane (65 TFLOP/s); two single 3M steps are faster although they move the tensor twice
-  if (p.bits.st[0].k == 6 && p.bits.st[1].k == 6 && !p.bits.c128 && !tuning().fuse_66) { err = "not fusable: 6 + 6 contracted bits spill"; return ARTN_E_UNSUPPORTED; }
+  // (artn_k_wide holds them -- 16 x 16 x 4 blocks need 3 x 16 fragment registers per stage: wide_eligible() below)
+  if (p.bits.st[0].k == 6 && p.bits.st[1].k == 6 && !p.bits.c128 && !tuning().fuse_66 && !wide_eligible(p)) { err = "not fusable: 6 + 6 contracted bits spill"; return ARTN_E_UNSUPPORTED; }
   if (p.stage1_repeats > tuning().fuse_max_rereads) { err = "not fusable: the first stage would run " + std::to_string(p.stage1_repeats) + " times per input tile"; return ARTN_E_UNSUPPORTED; }
   double f1, f2, a1, b1, c1, a2, b2, c2;
   step_cost(d1, f1, a1, b1, c1);

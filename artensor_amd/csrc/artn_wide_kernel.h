@@ -18,11 +18,17 @@
 //   * the result of tile t is read back from its own input region (the second stage writes there) into 4 x 16 bytes per lane
 //     and stored from registers; the stores drain under the first stage of tile t + 1.
 //
-//   iteration t:   stage 1: ring[t % 3] -> mid | barrier A | DMA of tile t + 2 -> ring[(t + 2) % 3] (its previous tenant, tile
-//                  t - 1, was read out before barrier A) | stage 2: mid -> ring[t % 3] | wait for the DMA of tile t + 1 (issued
-//                  a period ago) | barrier B | result -> registers -> global stores
+//   iteration t:   result of tile t - 1 -> registers | stage 1: ring[t % 3] -> mid, with the stores of tile t - 1 and the offsets
+//                  of tile t + 2 in pieces behind its first chain steps | barrier A | stage 2: mid -> ring[t % 3], with the four
+//                  LDS-DMA passes of tile t + 2 -> ring[(t + 2) % 3] (tile t - 1's region, read out before barrier A) behind its
+//                  first chain steps | wait for the DMA of tile t + 1 (issued a period ago) | barrier B
 //
-// Two barriers per tile; between them nothing but MFMA chains and their LDS operands.
+// Two barriers per tile.  On the pairs artn_k_bits runs with three products it is SLOWER (ARTN_WIDE=1: 56.5 against 53.5 ms on
+// n30 -- with one workgroup per CU the operand waits, scatters and bookkeeping of both waves of a SIMD coincide at every barrier;
+// DESIGN section 4.1d has the ablation, counter and in-kernel-mark evidence).  It is the default (ARTN_WIDE=2) where artn_k_bits
+// cannot: pairs with 11+ contracted bits (5+6, 6+5, 6+6), whose 96-128 fragment registers do not fit next to three 32 x 32
+// accumulators -- here a stage needs 3 x 2^(k-2) -- so they ran as four-product chains or as two single steps: the 5+6 pair of
+// n30 x 10 000 bitstrings 7.50 -> 6.05 ms.
 #define ARTN_WIDE_THREADS 512
 #define ARTN_WIDE_REGION (8u << ARTN_TILE_BITS_TARGET) /* 32 KiB */
 #define ARTN_WIDE_NBUF 3

@@ -1208,7 +1208,7 @@ def test_accumulate_in_the_store_phase():
 
 def test_wide_kernel_pairs():
     """artn_k_wide (ARTN_WIDE=1: one 8-wave workgroup per CU on one tile, LDS-DMA ring, every stage 3M on 16 x 16 x 4 blocks --
-    an opt-in experiment) against the oracle, in a process of its own because the planner reads its
+    the default only for pairs with 11+ contracted bits) on EVERY pair shape against the oracle, in a process of its own because the planner reads its
     tuning once: tests/wide_worker.py."""
     env = dict(os.environ, ARTN_WIDE="1", ARTN_WIDE_MIN_TILES="1")
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "wide_worker.py")], env=env,

@@ -29,7 +29,7 @@ def counters(sub):
     f = one(f"{sub}/**/*_counter_collection.csv")
     per = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
-        if "artn_k_bits" not in r["Kernel_Name"] and "artn_k_alt" not in r["Kernel_Name"]:
+        if not any(k in r["Kernel_Name"] for k in ("artn_k_bits", "artn_k_alt", "artn_k_wide")):
             continue
         d = per.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"].split("(")[0].replace("void ", ""),
                                               "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
@@ -47,7 +47,7 @@ md = [f"# rocprofv3 summary, round {R}", "",
 for r in rows[:12]:
     name = r["Name"].split("(")[0].replace("void ", "")[:60]
     md.append(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
-bits = [r for r in rows if "artn_k_bits" in r["Name"] or "artn_k_alt" in r["Name"]]
+bits = [r for r in rows if any(k in r["Name"] for k in ("artn_k_bits", "artn_k_alt", "artn_k_wide"))]
 tot_ns = sum(float(r["TotalDurationNs"]) for r in bits)
 tot_calls = sum(int(r["Calls"]) for r in bits)
 md += ["", f"All `artn_k_bits<KB1,KB2>` instantiations together: {tot_calls} launches, {tot_ns / 1e6:.2f} ms, "
@@ -85,7 +85,7 @@ if sb:
         e["mf"] += d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
         e["conf"] += d.get("SQ_LDS_BANK_CONFLICT", 0)
         e["act"] += d.get("SQ_LDS_IDX_ACTIVE", 0)
-    md += ["## Per instantiation (launches > 1 ms; template arguments KB1, KB2, BIGK, NP, GATHER, NT, M3, FULL -- artn_k_alt: KB1, KB2, NT, M3)", "",
+    md += ["## Per instantiation (launches > 1 ms; template arguments KB1, KB2, BIGK, NP, GATHER, NT, M3, FULL -- artn_k_alt: KB1, KB2, NT, M3; artn_k_wide: KB1, KB2)", "",
            "| kernel | launches | avg ms | SQ_VALU_MFMA_BUSY | LDS conflict / active |", "|---|---|---|---|---|"]
     for name, e in per_name.items():
         md.append(f"| `{name[:70]}` | {e['n']} | {e['t'] / e['n'] * 1e3:.2f} | {e['mf'] / (e['t'] * 1024 * clk_eff):.3f} | {e['conf'] / max(e['act'], 1):.3f} |")

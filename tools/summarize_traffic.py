@@ -18,7 +18,7 @@ import bench  # noqa: E402
 
 
 def family(name):
-    if "artn_k_bits" in name or "artn_k_alt" in name:
+    if "artn_k_bits" in name or "artn_k_alt" in name or "artn_k_wide" in name:
         return "bits"          # (artn_k_bits128 too: the complex128 leg's planner id 1)
     if "artn_k_pgemm" in name or "artn_k_pack" in name:
         return "pgemm"         # packing passes + the packed GEMM: one artn_contract_ws call
