@@ -720,3 +720,44 @@ def test_n30_triples_planned_and_emulated():
         assert got is not None, (n1, n2, n3)
         want = oracle.einsum_pair(e3, oracle.einsum_pair(e2, oracle.einsum_pair(e1, a, b1), b2), b3)
         assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (n1, n2, n3)
+
+
+def _synthetic_pair(k1, k2, rank=24):
+    """a fused pair on a 2^rank state: k1 contracted bits (the low ones bar the 4-bit run), then k2 of the bits just produced"""
+    la = [chr(65 + x) for x in range(rank)]
+    kl1 = la[4:4 + k1]
+    nl1 = [chr(97 + x) for x in range(k1)]
+    lo1 = la[:4] + nl1 + la[4 + k1:]
+    kl2 = nl1[:k2] if k2 <= k1 else nl1 + la[4 + k1:4 + k1 + (k2 - k1)]
+    nl2 = [chr(110 + x) for x in range(k2)]
+    lo2 = [x for x in lo1 if x not in kl2]
+    lo2 = lo2[:4] + nl2 + lo2[4:]
+    e1 = "".join(la) + "," + "".join(kl1 + nl1) + "->" + "".join(lo1)
+    e2 = "".join(lo1) + "," + "".join(kl2 + nl2) + "->" + "".join(lo2)
+    return e1, (2,) * rank, (2,) * (2 * k1), e2, (2,) * (2 * k2)
+
+
+def test_wide_kernel_is_planned_for_pairs_with_11_or_more_contracted_bits():
+    """ArtnBitsPlan::wide8 (artn_k_wide, DESIGN section 4.1d): the default sends the fused pairs whose fragments artn_k_bits cannot
+    hold -- 5+6, 6+5, 6+6 -- to the one-workgroup-per-CU kernel (four 32 KiB regions, one workgroup per CU, three-product
+    arithmetic) and nothing else; with ARTN_WIDE=0 a 6+6 pair does not fuse at all (checked in a process of its own: the
+    planner reads its tuning once)."""
+    from artensor_amd.contraction import pair_info
+    is_wide = lambda info: info["lds_bytes"] >= 4 * 32768 and info["grid"] <= 256
+    for k1, k2, want in ((5, 6, True), (6, 5, True), (6, 6, True), (5, 5, False), (6, 4, False), (4, 4, False)):
+        info = pair_info(*_synthetic_pair(k1, k2))
+        assert info is not None and (info["k_bits"], info["k2_bits"]) == (k1, k2), (k1, k2, info)
+        assert info["tile_in_bits"] == 12 and info["tile_out_bits"] == 12
+        assert is_wide(info) == want, (k1, k2, info)
+        if want:
+            assert info["arith"] == 1 and abs(info["mfma_flops"] - 0.75 * info["flops"]) < 1.0
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_plan_emulation import _synthetic_pair\n"
+            "from artensor_amd.contraction import pair_info\n"
+            "print('66', pair_info(*_synthetic_pair(6, 6)) is None)\n"
+            "i = pair_info(*_synthetic_pair(5, 6)); print('56', i['lds_bytes'] < 4 * 32768)\n") % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ARTN_WIDE="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "66 True" in out.stdout and "56 True" in out.stdout, out.stdout + out.stderr[-2000:]
