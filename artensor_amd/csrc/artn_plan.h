@@ -241,7 +241,9 @@ struct Tuning {
   int pgemm16 = 1;         // reduced-precision packed GEMM: 0 v_mfma_f32_32x32x16_bf16, 1 16x16x32 (three chunk buffers), 2 16x16x32 on a ring of six half-chunk slots: ARTN_PGEMM16
   int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
                            // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
-  int packed_min_ai = 64;  // ... and the FLOP per byte of the step it needs
+  int packed_min_ai = 160; // ... and the FLOP per byte of the step it needs (64 until round 4: the 2^20 x 2^8 x 2^8 step of an n53 m14 slice --
+                           // 128 FLOP per byte, a quarter of its time in the packing passes -- takes 4.65 ms packed and 4.25 on
+                           // artn_k_gemm; the 2^8- and 2^10-deep steps of the D = 4 random network (204-205) stay packed: 1.00 against 1.08 ms)
   int wide = 2;       // fused pairs of 2^12-element tiles on artn_k_wide (ArtnBitsPlan::wide8): 0 never; 1 all of them (loses:
                       // 56.5 ms on n30 against 53.5); 2 (default) the pairs with 11+ contracted bits -- 5+6, 6+5, 6+6 -- whose
                       // fragments artn_k_bits cannot hold next to three accumulators (it runs them as four-product chains, or not
@@ -1281,7 +1283,8 @@ static inline bool make_gemm128(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, in
 // ----------------------------------------------------------------------------------------
 // packed-operand GEMM (ARTN_C64_BF16, and ARTN_C64 in 3M fp32): see ArtnPackPlan
 // ----------------------------------------------------------------------------------------
-static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
+static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, bool any_intensity = false) {
+  // (any_intensity: the plan emulator replays the mechanics of small steps the routing rule below would send elsewhere)
   if (d->dtype != ARTN_C64_BF16 && d->dtype != ARTN_C64) { p.why_generic = "packed GEMM: complex64 only"; return false; }
   const bool bf = d->dtype == ARTN_C64_BF16;
   const int KC = bf ? ARTN_PG_KC : ARTN_PG_KC - 1; // the stage holds the same bytes either way
@@ -1305,7 +1308,7 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu) {
   // worth two packing passes: 2^9+ contracted values (fp32, whose MFMAs are 16 times slower per FLOP and whose packed copy
   // saves no bytes: 2^10+), and enough tiles for every CU
   if (k < (bf ? 9 : tuning().packed_min_k) || m < ARTN_PG_MT || n < ARTN_PG_NT) { p.why_generic = "packed GEMM: too few contracted or free bits"; return false; }
-  if (!bf) { // the packing passes move every operand element twice more: only where the GEMM itself is far from memory-bound
+  if (!bf && !any_intensity) { // the packing passes move every operand element twice more: only where the GEMM itself is far from memory-bound
     const double flops = 8.0 * (double)(int64_t(1) << (m + n)) * (double)(int64_t(1) << k);
     const double bytes = 8.0 * ((double)(int64_t(1) << (m + k)) + (double)(int64_t(1) << (n + k)) + (double)(int64_t(1) << (m + n)));
     if (flops / bytes < tuning().packed_min_ai) { p.why_generic = "packed GEMM: too few FLOP per byte to pay for the packing passes"; return false; }

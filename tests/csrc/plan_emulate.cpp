@@ -786,7 +786,7 @@ extern "C" int artn_emulate_pgemm(const ArtnStepDesc *d, const void *A, const vo
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
   const char *e = getenv("ARTN_EMU_NCU");
-  if (!artn::make_pgemm(d, p, e ? atoi(e) : 256)) return ARTN_E_UNSUPPORTED;
+  if (!artn::make_pgemm(d, p, e ? atoi(e) : 256, true)) return ARTN_E_UNSUPPORTED;
   if (info) *info = p.info;
   run_pgemm(p.pack, (const cf *)A, (const cf *)B, (cf *)C);
   return 0;
