@@ -239,8 +239,11 @@ struct Tuning {
   int fuse3_run = 4;
   int fuse3 = 1;           // three consecutive steps on one tensor in one pass where they fit a 2^12 tile (artn_k_bits3): ARTN_FUSE3
   int pgemm16 = 1;         // reduced-precision packed GEMM: 0 v_mfma_f32_32x32x16_bf16, 1 16x16x32 (three chunk buffers), 2 16x16x32 on a ring of six half-chunk slots: ARTN_PGEMM16
-  int packed_min_k = 8;    // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used (measured, tools/ab_packk.sh:
-                           // 10 -> 8 gains 1 % on n53 m20 and the D = 4 network, 7 nothing more: below 2^10 the packing passes cost what they save) ...
+  int packed_min_k = 11;   // complex64 arithmetic: contracted bits from which the packed-operand GEMM is used.  8 in round 3 (tools/ab_packk.sh:
+                           // +1 % on n53 m20 and the D = 4 network then); since artn_k_gemm reads its operands two chunks ahead it wins up
+                           // to 2^10 contracted values -- the D = 4 network's 2^10-deep step 4.21 -> 3.93 ms, the leg 107.7 -> 114.0
+                           // TFLOP/s, n53 m20 91.5 -> 92.2 (A/B in one session) -- and the packed form keeps the 2^15-deep step of the
+                           // big-batch slice (180 against 131 TFLOP/s)
   int packed_min_ai = 160; // ... and the FLOP per byte of the step it needs (64 until round 4: the 2^20 x 2^8 x 2^8 step of an n53 m14 slice --
                            // 128 FLOP per byte, a quarter of its time in the packing passes -- takes 4.65 ms packed and 4.25 on
                            // artn_k_gemm; the 2^8- and 2^10-deep steps of the D = 4 random network (204-205) stay packed: 1.00 against 1.08 ms)
@@ -1307,7 +1310,7 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, bool
   const int k = (int)K.size(), m = (int)M.size(), n = (int)N.size();
   // worth two packing passes: 2^9+ contracted values (fp32, whose MFMAs are 16 times slower per FLOP and whose packed copy
   // saves no bytes: 2^10+), and enough tiles for every CU
-  if (k < (bf ? 9 : tuning().packed_min_k) || m < ARTN_PG_MT || n < ARTN_PG_NT) { p.why_generic = "packed GEMM: too few contracted or free bits"; return false; }
+  if (k < (bf ? 9 : (any_intensity ? 8 : tuning().packed_min_k)) || m < ARTN_PG_MT || n < ARTN_PG_NT) { p.why_generic = "packed GEMM: too few contracted or free bits"; return false; }
   if (!bf && !any_intensity) { // the packing passes move every operand element twice more: only where the GEMM itself is far from memory-bound
     const double flops = 8.0 * (double)(int64_t(1) << (m + n)) * (double)(int64_t(1) << k);
     const double bytes = 8.0 * ((double)(int64_t(1) << (m + k)) + (double)(int64_t(1) << (n + k)) + (double)(int64_t(1) << (m + n)));

@@ -66,7 +66,7 @@ typedef struct ArtnStepDesc {
 #define ARTN_KERNEL_GENERIC 0 /* one thread per output element, strided loops       */
 #define ARTN_KERNEL_BITS_MFMA 1 /* LDS-tiled bit-permuted complex GEMM on fp32 MFMA */
 #define ARTN_KERNEL_GEMM_MFMA 2 /* two-operand LDS GEMM on fp32 MFMA, contracted bits looped in-kernel */
-#define ARTN_KERNEL_PGEMM 4     /* big x big steps (2^8+ contracted values, arithmetic intensity >= 64): both operands packed in
+#define ARTN_KERNEL_PGEMM 4     /* big x big steps (complex64: 2^11+ contracted values, 160+ FLOP per byte; bf16 operands: 2^9+): both operands packed in
                                  * tile order into a workspace, then an LDS-DMA GEMM.  ARTN_C64: fp32 images, 3M arithmetic
                                  * (artn_k_pgemm3m; workspace 8 B x (2^(m+k) + 2^(n+k))); ARTN_C64_BF16: bfloat16 images
                                  * (artn_k_pgemm; half of that) */
