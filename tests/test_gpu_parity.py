@@ -1196,6 +1196,45 @@ def test_accumulate_in_the_store_phase():
         assert torch.equal(acc, acc0 + plain), n
         singles += 1
     assert singles >= 2, singles
+    # random pairs of 2^24-element states (2^12 tiles: enough for the non-temporal instantiations too): wherever the entry point
+    # accepts, the result equals the separate add; it must never accept a launch whose instantiation has no add (that traps)
+    rng = np.random.default_rng(77)
+    accepted = 0
+    for trial in range(24):
+        k1, k2 = int(rng.integers(2, 7)), int(rng.integers(2, 7))
+        ra = 24
+        la_ = [chr(65 + x) for x in range(ra)]
+        kl1 = list(rng.choice(la_[:16], size=k1, replace=False))
+        nl1 = [chr(97 + x) for x in range(k1)]
+        lb1 = kl1 + nl1
+        rng.shuffle(lb1)
+        lo1 = [x for x in la_ if x not in kl1]
+        for x in nl1:
+            lo1.insert(int(rng.integers(0, len(lo1) + 1)), x)
+        kl2 = list(rng.choice(lo1[:16], size=k2, replace=False))
+        nl2 = [chr(110 + x) for x in range(k2)]
+        lb2 = kl2 + nl2
+        rng.shuffle(lb2)
+        lo2 = [x for x in lo1 if x not in kl2]
+        for x in nl2:
+            lo2.insert(int(rng.integers(0, len(lo2) + 1)), x)
+        e1 = "".join(la_) + "," + "".join(lb1) + "->" + "".join(lo1)
+        e2 = "".join(lo1) + "," + "".join(lb2) + "->" + "".join(lo2)
+        a, b1, b2 = gpu(crandn(rng, (2,) * ra)), gpu(crandn(rng, (2,) * (2 * k1))), gpu(crandn(rng, (2,) * (2 * k2)))
+        plain = contract2(e1, a, b1, e2, b2)
+        if plain is None:
+            continue
+        acc0 = gpu(crandn(rng, tuple(plain.shape)))
+        acc = acc0.clone()
+        d1, d2, _ = _pair_descriptors(e1, a, b1, e2, b2)
+        rc = lib.artn_contract2_acc(ctypes.byref(d1), ctypes.byref(d2), a.data_ptr(), b1.data_ptr(), b2.data_ptr(), acc.data_ptr(), stream)
+        if rc == -2:
+            continue
+        assert rc == 0, lib.artn_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(acc, acc0 + plain), (e1, e2)
+        accepted += 1
+    assert accepted >= 6, accepted
     # a scheme whose last launch cannot add (a tiny step: strided kernel) falls back to the separate add
     a, b = gpu(crandn(np.random.default_rng(5), (2, 2, 2))), gpu(crandn(np.random.default_rng(6), (2, 2)))
     acc0 = gpu(crandn(np.random.default_rng(7), (2, 2, 2)))
