@@ -1229,6 +1229,8 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1
   r.run();
 }
 
+#include "artn_wide_kernel.h"
+
 // KB2 == 0: single stage.  BIGK: 7 or 8 contracted bits (KB1 = 6 of them in the chain).
 // NP: 0 = fp32 MFMA chains; 3 / 1 = split-bf16 chains (stages with >= 3 contracted bits).
 // GATHER: row indices on one outer axis (artn_contract_gather; single stage, fp32 chains).
@@ -1236,7 +1238,10 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1
 // M3: every stage with 5 contracted bits runs the 3M arithmetic (StageRun::run3; fp32 chains only).
 // FULL: input and output tiles are 2^12 elements (every big launch): the copy loops and their predicates are
 // compile-time constants -- a third of the scalar instructions and most of the branches of the tile loop go.
-template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false, bool NT = false, bool M3 = false, bool FULL = false>
+// N3: single step with 5-6 contracted bits and at most 4 result bits in the tile (ArtnBitsPlan::narrow3): the stage of
+// artn_k_wide on this kernel's four waves -- 16 x 16 x 4 blocks, three products -- instead of four-product 32 x 32 chains
+// of which at most 16 rows are results.
+template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false, bool NT = false, bool M3 = false, bool FULL = false, bool N3 = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(const float2 *__restrict__ A,
                                                                   const float2 *__restrict__ B1,
                                                                   const float2 *__restrict__ B2,
@@ -1293,6 +1298,11 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     L1.ksplit_scratch = (regions_end + (8u << (P.st[0].m_bits - 5)) + (512u * 8u + 32u * 32u) + 15u) & ~15u;
   }
   const StageConst<KB2e> L2 = stage_const<KB2e, M3>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2_a, R1, R0, SP2 ? 2 : 0);
+  static_assert(!N3 || (KB2 == 0 && (KB1 == 5 || KB1 == 6) && !BIGK && NP == 0 && !GATHER && !M3 && !FULL), "narrow 3M: single 5-6 bit steps");
+  constexpr int KBN = N3 ? KB1 : 2, NSTN = 1 << (KBN - 2);
+  WideConst<KBN> LN;
+  if constexpr (N3) LN = wide_const<KBN, 4>(P.st[0], nullptr, lane, wave, tab1_a);
+  float WN0[NSTN], WN1[NSTN], WN2[NSTN];
   // copy-out reads the last stage's (swizzled) output region
   const ArtnStage *zout = &P.st[KB2 > 0 ? 1 : 0];
   const unsigned tid16_out = swz(tid16, zout);
@@ -1372,7 +1382,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
         for (int b = 0; b < 2; ++b)
           if ((L1.ksplit_wave >> b) & 1) kb0 += L1.kb_hi[b];
       }
-      if constexpr (SP1 && BIGK) load_w_plane<KB1>(WS1[0], Bb + kb0, L1, ro);
+      if constexpr (N3) wide_load_w<KBN>(WN0, WN1, WN2, Bb, LN);
+      else if constexpr (SP1 && BIGK) load_w_plane<KB1>(WS1[0], Bb + kb0, L1, ro);
       else if constexpr (SP1) load_w_split<KB1, (SP1 ? NP : 1)>(WS1, Bb, L1, ro);
       else if constexpr (C31) load_w3<KB1>(W10, W11, W12, Bb, L1);
       else if constexpr (M3 && KB1 >= 2 && KB1 <= 4 && !BIGK && NP == 0) load_w4m3<KB1>(W10, W11, Bb, L1);
@@ -1407,7 +1418,13 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
     if (stage_prio) __builtin_amdgcn_s_setprio(2);
-    run_stage<KB1, BIGK, NP, M3>(L1, W10, W11, W12, h, lane, WH0, WH1, WS1);
+    if constexpr (N3) {
+      WideStage<KBN> sn{LN, WN0, WN1, WN2, R0, R1, -1, 0, 0};
+      WideNoFill nf;
+      sn.run(nf);
+    } else {
+      run_stage<KB1, BIGK, NP, M3>(L1, W10, W11, W12, h, lane, WH0, WH1, WS1);
+    }
     if (stage_prio && KB2 == 0) __builtin_amdgcn_s_setprio(0);
     PHASE_MARK(1);
     STAMP(5);
@@ -1752,10 +1769,8 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 #if defined(ARTN_TU_BITS) || defined(ARTN_TU_B128) || defined(ARTN_TU_BITS3) || defined(ARTN_TU_WIDE)
 #define ARTN_TU_PART 1
 #endif
-// (-DARTN_TU_WIDE: only artn_k_wide<*, *> behind artn_launch_wide())
-#if defined(ARTN_TU_WIDE) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
-#include "artn_wide_kernel.h"
-#endif
+// (-DARTN_TU_WIDE: only artn_k_wide<*, *> behind artn_launch_wide(); artn_wide_kernel.h itself is included above artn_k_bits,
+//  which borrows its stage)
 // (-DARTN_TU_BITS3=K: only artn_k_bits3<K, *, *> behind artn_launch_bits3_kK())
 #if defined(ARTN_TU_BITS3) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
 #include "artn_bits3_kernel.h"
@@ -2430,6 +2445,20 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
       }
 #undef ARTN_ALT_CASE
 #undef ARTN_ALT_GO
+    }
+  }
+  if constexpr (KB1 == 5 || KB1 == 6) { // single steps that keep at most 4 result bits in the tile: 16 x 16 x 4 blocks, three products
+    if (p.bits.narrow3 && k2 == 0 && split == 0 && p.bits.gather_dim < 0 && p.bits.st[0].k <= 6 && !full) {
+      if (p.bits.nt_loads) {
+        auto kern = artn_k_bits<KB1, 0, false, 0, false, true, false, false, true>;
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, 0, false, 0, false, true, false, false, true>>(lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
+      } else {
+        auto kern = artn_k_bits<KB1, 0, false, 0, false, false, false, false, true>;
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, 0, false, 0, false, false, false, false, true>>(lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
+      }
+      return hipGetLastError();
     }
   }
   if (p.bits.gather_dim >= 0) { // fused row gather: single stage, fp32 chains

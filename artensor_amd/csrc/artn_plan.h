@@ -85,6 +85,9 @@ struct ArtnBitsPlan {
                               // accumulate = 1: C += result (artn_contract_acc / artn_contract2_acc: the store phase reads the
                               // accumulator's chunk and adds -- every result element belongs to exactly one lane of one tile; set
                               // by the entry point on plans for which bits_can_accumulate() holds
+  int32_t narrow3;            // 1: single step with 5 or 6 contracted bits and at most 4 result bits in the tile: three products on
+  int32_t pad9_;              //    16 x 16 x 4 blocks (ArtnStage::m3 = 2; artn_k_bits<..., N3>) instead of four on 32 x 32 blocks of
+                              //    which at most 16 rows are results
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
   ArtnStage st[3];
@@ -247,6 +250,7 @@ struct Tuning {
   int packed_min_ai = 160; // ... and the FLOP per byte of the step it needs (64 until round 4: the 2^20 x 2^8 x 2^8 step of an n53 m14 slice --
                            // 128 FLOP per byte, a quarter of its time in the packing passes -- takes 4.65 ms packed and 4.25 on
                            // artn_k_gemm; the 2^8- and 2^10-deep steps of the D = 4 random network (204-205) stay packed: 1.00 against 1.08 ms)
+  int narrow3 = 1;    // single steps with 5-6 contracted bits and <= 4 result bits in the tile on 16 x 16 x 4 blocks, 3M (ArtnBitsPlan::narrow3)
   int wide = 2;       // fused pairs of 2^12-element tiles on artn_k_wide (ArtnBitsPlan::wide8): 0 never; 1 all of them (loses:
                       // 56.5 ms on n30 against 53.5); 2 (default) the pairs with 11+ contracted bits -- 5+6, 6+5, 6+6 -- whose
                       // fragments artn_k_bits cannot hold next to three accumulators (it runs them as four-product chains, or not
@@ -290,6 +294,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_PACKED")) x.packed = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_ALT")) x.alt = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_WIDE")) x.wide = std::min(2, std::max(0, atoi(e)));
+    if (const char *e = getenv("ARTN_NARROW3")) x.narrow3 = atoi(e);
     if (const char *e = getenv("ARTN_WIDE_MIN_TILES")) x.wide_min_tiles = atoi(e);
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
@@ -705,6 +710,16 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     if (b.m3)
       for (int q = 0; q < b.n_stages; ++q)
         if (b.st[q].k >= 2 && b.st[q].k <= 4) b.st[q].m3 = 2;
+    // a single step with 5-6 contracted bits that brings at most 4 result bits into the tile (the steps that SHRINK their
+    // tensor): on 32 x 32 blocks at most 16 of 32 rows are results and the stage runs four products; the 16 x 16 x 4 form
+    // (the stage of artn_k_wide on four waves) halves the rows and runs three -- n53's 2^30 -> 2^27 step is MFMA-bound on
+    // the wasted rows otherwise
+    if (!fused && use_3m && tuning().narrow3 && gather_label < 0 && (b.st[0].k == 5 || b.st[0].k == 6) && (int)K1.size() <= 6 &&
+        b.st[0].nt <= 4 && !b.st[0].m3) {
+      b.narrow3 = 1;
+      b.st[0].m3 = 2;
+      b.st[0].wn_log2 = 0;
+    }
   }
 
   // ---- outer axes: N-outer fastest (tiles sharing an A tile run together), then M-outer by A

@@ -72,7 +72,8 @@ struct WideConst {
 // lane (jj = l & 15, g = l >> 4): reads x[kc = 4 s + g][m = 16 half + jj], holds w[kc = 4 s + g][n = jj], accumulates
 // results n = 4 g + r of column m = jj (v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
 // D[i = 4 (l >> 4) + r][j = l & 15]); blocks of 16 results are dealt to the waves first, 32-column sub-tiles after
-template <int KB>
+// (NW: waves of the workgroup -- 8 in artn_k_wide, 4 where artn_k_bits borrows the stage: the narrow single steps, ArtnBitsPlan::narrow3)
+template <int KB, int NW = 8>
 __device__ __forceinline__ WideConst<KB> wide_const(const ArtnStage &st, const ArtnStage *zin, int lane, int wave, unsigned tab) {
   WideConst<KB> L;
   const int jj = lane & 15, g = lane >> 4;
@@ -80,7 +81,7 @@ __device__ __forceinline__ WideConst<KB> wide_const(const ArtnStage &st, const A
   const int wn = wave & ((1 << wn_log2) - 1);
   L.g = g;
   L.wm = wave >> wn_log2;
-  L.wm_count = 8 >> wn_log2;
+  L.wm_count = NW >> wn_log2;
   L.msubs = 1 << (st.m_bits - 5);
   L.nt_eff = st.nt < 4 ? st.nt : 4;
   L.msub_tab = tab;
@@ -302,6 +303,11 @@ struct WideStage {
       li[1] = li_n[1];
     }
   }
+};
+
+struct WideNoFill { // (a stage with nothing to interleave)
+  static constexpr int N = 0;
+  __device__ __forceinline__ void operator()(int) const {}
 };
 
 // LDS-DMA: 64 lanes x 16 bytes land at lds_dst + lane * 16 (wave-uniform destination in M0, per-lane source)

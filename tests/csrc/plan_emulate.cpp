@@ -37,7 +37,7 @@ static void run_stage(const ArtnStage &st, const ArtnStage *zin, const cf *in, c
         for (int half = 0; half < 2; ++half) {
           float t1[64][4] = {}, t2[64][4] = {}, t3[64][4] = {};
           int lane_out4[64];
-          for (int s = 0; s < (1 << (KB - 2)); ++s) { // chain steps of 4 contracted values (KB = 2..4)
+          for (int s = 0; s < (1 << (KB - 2)); ++s) { // chain steps of 4 contracted values (KB = 2..4; 5..6: ArtnBitsPlan::narrow3)
             float wre[64], wim[64], ax[64], ay[64];
             for (int lane = 0; lane < 64; ++lane) {
               const int jj = lane & 15, g = lane >> 4;

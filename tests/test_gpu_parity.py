@@ -1245,6 +1245,28 @@ def test_accumulate_in_the_store_phase():
         A.tensor_contraction({0: a.clone(), 1: b}, [((0, 1), "abc,cd->abd")], accumulate_into=acc[:1])
 
 
+@pytest.mark.parametrize("k,nt,ra,seed", [(5, 2, 22, 0), (5, 4, 22, 1), (6, 3, 22, 2), (6, 1, 21, 3), (5, 0, 21, 4), (6, 4, 23, 5), (5, 3, 20, 6)])
+def test_shrinking_single_steps_on_narrow_three_product_blocks(k, nt, ra, seed):
+    """ArtnBitsPlan::narrow3 on the GPU (artn_k_bits<KB1, 0, ..., N3>: the 16 x 16 x 4 three-product stage of artn_k_wide on four
+    waves, for single steps with 5-6 contracted bits that keep at most 4 result bits in the tile -- n53's 2^30 -> 2^27 step):
+    scattered bit positions, tiles of 2^12 and 2^13 elements, against the oracle."""
+    rng = np.random.default_rng(950 + seed)
+    la = [chr(65 + x) for x in range(ra)]
+    kl = list(rng.choice(la, size=k, replace=False))
+    nl = [chr(97 + x) for x in range(nt)]
+    lb = kl + nl
+    rng.shuffle(lb)
+    lo = [x for x in la if x not in kl]
+    for x in nl:
+        lo.insert(int(rng.integers(0, len(lo) + 1)), x)
+    eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
+    info = A.step_info(eq, (2,) * ra, (2,) * len(lb))
+    a, b = crandn(rng, (2,) * ra), crandn(rng, (2,) * len(lb))
+    got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
+    want = oracle.einsum_pair(eq, a, b)
+    assert rel(got, want) < STEP_TOL, (eq, info)
+
+
 def test_wide_kernel_pairs():
     """artn_k_wide (ARTN_WIDE=1: one 8-wave workgroup per CU on one tile, LDS-DMA ring, every stage 3M on 16 x 16 x 4 blocks --
     the default only for pairs with 11+ contracted bits) on EVERY pair shape against the oracle, in a process of its own because the planner reads its

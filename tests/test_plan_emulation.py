@@ -761,3 +761,29 @@ def test_wide_kernel_is_planned_for_pairs_with_11_or_more_contracted_bits():
             "i = pair_info(*_synthetic_pair(5, 6)); print('56', i['lds_bytes'] < 4 * 32768)\n") % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ARTN_WIDE="0"), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "66 True" in out.stdout and "56 True" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("k,nt,seed", [(5, 2, 0), (5, 4, 1), (6, 3, 2), (6, 1, 3), (5, 0, 4)])
+def test_shrinking_single_steps_on_narrow_three_product_blocks(k, nt, seed):
+    """ArtnBitsPlan::narrow3: a single step with 5 or 6 contracted bits that keeps at most 4 result bits in the tile (the steps
+    that shrink their tensor; reference loop contraction.py:66-70) runs three products on 16 x 16 x 4 blocks -- the stage of
+    artn_k_wide on four waves -- instead of four on 32 x 32 blocks of which at most 16 rows are results.  Planned that way
+    (arithmetic 1 = 3M, state-streaming kernel) and replayed lane by lane against the oracle, scattered bit positions."""
+    rng = np.random.default_rng(900 + seed)
+    ra = 18
+    la = [chr(65 + x) for x in range(ra)]
+    kl = list(rng.choice(la, size=k, replace=False))
+    nl = [chr(97 + x) for x in range(nt)]
+    lb = kl + nl
+    rng.shuffle(lb)
+    lo = [x for x in la if x not in kl]
+    for x in nl:
+        lo.insert(int(rng.integers(0, len(lo) + 1)), x)
+    eq = "".join(la) + "," + "".join(lb) + "->" + "".join(lo)
+    info = step_info(eq, (2,) * ra, (2,) * len(lb))
+    a, b = crandn(rng, (2,) * ra), crandn(rng, (2,) * len(lb))
+    got, used = emulate(eq, a, b)
+    want = oracle.einsum_pair(eq, a, b)
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), eq
+    if info["kernel"] == 1 and used == 1:   # (the state-streaming kernel took it: then as a three-product stage)
+        assert info["arith"] == 1 and abs(info["mfma_flops"] - 0.75 * info["flops"]) < 1.0, info
