@@ -1241,7 +1241,8 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1
 // N3: single step with 5-6 contracted bits and at most 4 result bits in the tile (ArtnBitsPlan::narrow3): the stage of
 // artn_k_wide on this kernel's four waves -- 16 x 16 x 4 blocks, three products -- instead of four-product 32 x 32 chains
 // of which at most 16 rows are results.
-template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false, bool NT = false, bool M3 = false, bool FULL = false, bool N3 = false>
+// (N3 = 2: the second stage of a fused pair instead -- a pair that shrinks its tensor; an M3 instantiation)
+template <int KB1, int KB2, bool BIGK, int NP = 0, bool GATHER = false, bool NT = false, bool M3 = false, bool FULL = false, int N3 = 0>
 __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(const float2 *__restrict__ A,
                                                                   const float2 *__restrict__ B1,
                                                                   const float2 *__restrict__ B2,
@@ -1298,10 +1299,12 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     L1.ksplit_scratch = (regions_end + (8u << (P.st[0].m_bits - 5)) + (512u * 8u + 32u * 32u) + 15u) & ~15u;
   }
   const StageConst<KB2e> L2 = stage_const<KB2e, M3>(P.st[KB2 > 0 ? 1 : 0], &P.st[0], j, h, wave, tab2_a, R1, R0, SP2 ? 2 : 0);
-  static_assert(!N3 || (KB2 == 0 && (KB1 == 5 || KB1 == 6) && !BIGK && NP == 0 && !GATHER && !M3 && !FULL), "narrow 3M: single 5-6 bit steps");
-  constexpr int KBN = N3 ? KB1 : 2, NSTN = 1 << (KBN - 2);
+  static_assert(N3 != 1 || (KB2 == 0 && (KB1 == 5 || KB1 == 6) && !BIGK && NP == 0 && !GATHER && !M3 && !FULL), "narrow 3M: single 5-6 bit steps");
+  static_assert(N3 != 2 || ((KB2 == 5 || KB2 == 6) && M3 && !BIGK && NP == 0 && !GATHER && !FULL), "narrow 3M: second stage of a 3M pair");
+  constexpr int KBN = N3 == 1 ? KB1 : (N3 == 2 ? KB2e : 2), NSTN = 1 << (KBN - 2);
   WideConst<KBN> LN;
-  if constexpr (N3) LN = wide_const<KBN, 4>(P.st[0], nullptr, lane, wave, tab1_a);
+  if constexpr (N3 == 1) LN = wide_const<KBN, 4>(P.st[0], nullptr, lane, wave, tab1_a);
+  if constexpr (N3 == 2) LN = wide_const<KBN, 4>(P.st[1], &P.st[0], lane, wave, tab2_a);
   float WN0[NSTN], WN1[NSTN], WN2[NSTN];
   // copy-out reads the last stage's (swizzled) output region
   const ArtnStage *zout = &P.st[KB2 > 0 ? 1 : 0];
@@ -1382,7 +1385,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
         for (int b = 0; b < 2; ++b)
           if ((L1.ksplit_wave >> b) & 1) kb0 += L1.kb_hi[b];
       }
-      if constexpr (N3) wide_load_w<KBN>(WN0, WN1, WN2, Bb, LN);
+      if constexpr (N3 == 1) wide_load_w<KBN>(WN0, WN1, WN2, Bb, LN);
       else if constexpr (SP1 && BIGK) load_w_plane<KB1>(WS1[0], Bb + kb0, L1, ro);
       else if constexpr (SP1) load_w_split<KB1, (SP1 ? NP : 1)>(WS1, Bb, L1, ro);
       else if constexpr (C31) load_w3<KB1>(W10, W11, W12, Bb, L1);
@@ -1405,7 +1408,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     }
     if (KB2 > 0 && off.b2 != prev_b2) {
       prev_b2 = off.b2;
-      if constexpr (SP2) load_w_split<KB2e, (SP2 ? NP : 1)>(WS2, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
+      if constexpr (N3 == 2) wide_load_w<KBN>(WN0, WN1, WN2, reinterpret_cast<const char *>(B2 + off.b2), LN);
+      else if constexpr (SP2) load_w_split<KB2e, (SP2 ? NP : 1)>(WS2, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
       else if constexpr (C32) load_w3<KB2e>(W20, W21, W22, reinterpret_cast<const char *>(B2 + off.b2), L2);
       else if constexpr (M3 && KB2 >= 2 && KB2 <= 4 && NP == 0) load_w4m3<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + off.b2), L2);
       else load_w<KB2e>(W20, W21, reinterpret_cast<const char *>(B2 + off.b2), L2, ro);
@@ -1418,7 +1422,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
     if (stage_prio) __builtin_amdgcn_s_setprio(2);
-    if constexpr (N3) {
+    if constexpr (N3 == 1) {
       WideStage<KBN> sn{LN, WN0, WN1, WN2, R0, R1, -1, 0, 0};
       WideNoFill nf;
       sn.run(nf);
@@ -1437,7 +1441,13 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     unsigned outr = R1;
     if (KB2 > 0) {
       STAMP(6);
-      run_stage<KB2e, false, NP, M3>(L2, W20, W21, W22, h, lane, WD0, WD1, WS2);
+      if constexpr (N3 == 2) {
+        WideStage<KBN> sn{LN, WN0, WN1, WN2, R1, R0, -1, 0, 0};
+        WideNoFill nf;
+        sn.run(nf);
+      } else {
+        run_stage<KB2e, false, NP, M3>(L2, W20, W21, W22, h, lane, WD0, WD1, WS2);
+      }
       if (stage_prio) __builtin_amdgcn_s_setprio(0);
       STAMP(5);
       __syncthreads();
@@ -2448,17 +2458,31 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
     }
   }
   if constexpr (KB1 == 5 || KB1 == 6) { // single steps that keep at most 4 result bits in the tile: 16 x 16 x 4 blocks, three products
-    if (p.bits.narrow3 && k2 == 0 && split == 0 && p.bits.gather_dim < 0 && p.bits.st[0].k <= 6 && !full) {
+    if (p.bits.narrow3 == 1 && k2 == 0 && split == 0 && p.bits.gather_dim < 0 && p.bits.st[0].k <= 6 && !full) {
       if (p.bits.nt_loads) {
-        auto kern = artn_k_bits<KB1, 0, false, 0, false, true, false, false, true>;
-        if (hipError_t e = ensure_lds<artn_k_bits<KB1, 0, false, 0, false, true, false, false, true>>(lds); e != hipSuccess) return e;
+        auto kern = artn_k_bits<KB1, 0, false, 0, false, true, false, false, 1>;
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, 0, false, 0, false, true, false, false, 1>>(lds); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
       } else {
-        auto kern = artn_k_bits<KB1, 0, false, 0, false, false, false, false, true>;
-        if (hipError_t e = ensure_lds<artn_k_bits<KB1, 0, false, 0, false, false, false, false, true>>(lds); e != hipSuccess) return e;
+        auto kern = artn_k_bits<KB1, 0, false, 0, false, false, false, false, 1>;
+        if (hipError_t e = ensure_lds<artn_k_bits<KB1, 0, false, 0, false, false, false, false, 1>>(lds); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
       }
       return hipGetLastError();
+    }
+  }
+  if constexpr (KB1 >= 2) { // 3M pairs whose SECOND stage keeps at most 4 result bits in the tile (ArtnBitsPlan::narrow3 = 2)
+    if (p.bits.narrow3 == 2 && p.bits.m3 && (k2 == 5 || k2 == 6) && split == 0 && p.bits.gather_dim < 0 && p.bits.st[0].k <= 6 && !full) {
+#define ARTN_N3_GO(K2, NTV)                                                                               \
+  {                                                                                                       \
+    auto kern = artn_k_bits<KB1, K2, false, 0, false, NTV, true, false, 2>;                               \
+    if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, 0, false, NTV, true, false, 2>>(lds); e != hipSuccess) return e; \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                                 \
+    return hipGetLastError();                                                                             \
+  }
+      if (k2 == 5) { if (p.bits.nt_loads) ARTN_N3_GO(5, true) else ARTN_N3_GO(5, false) }
+      else { if (p.bits.nt_loads) ARTN_N3_GO(6, true) else ARTN_N3_GO(6, false) }
+#undef ARTN_N3_GO
     }
   }
   if (p.bits.gather_dim >= 0) { // fused row gather: single stage, fp32 chains

@@ -87,7 +87,7 @@ struct ArtnBitsPlan {
                               // by the entry point on plans for which bits_can_accumulate() holds
   int32_t narrow3;            // 1: single step with 5 or 6 contracted bits and at most 4 result bits in the tile: three products on
   int32_t pad9_;              //    16 x 16 x 4 blocks (ArtnStage::m3 = 2; artn_k_bits<..., N3>) instead of four on 32 x 32 blocks of
-                              //    which at most 16 rows are results
+                              //    which at most 16 rows are results; 2: the second stage of a fused pair, likewise
   int64_t in_stride[ARTN_TILE_BITS_MAX];  // tile-local input bit  -> A element stride
   int64_t out_stride[ARTN_TILE_BITS_MAX]; // tile-local output bit -> C element stride
   ArtnStage st[3];
@@ -692,10 +692,15 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   {
     bool any = false, all = true;
     int frag = 0;
+    // (the SECOND stage of a pair that keeps at most 4 of its result bits in the tile -- a pair that shrinks its tensor -- counts as
+    //  three-product capable: it runs on 16 x 16 x 4 blocks, ArtnBitsPlan::narrow3 = 2, below)
+    const bool narrow2 = fused && use_3m && tuning().narrow3 && gather_label < 0 && (b.st[1].k == 5 || b.st[1].k == 6) && b.st[1].nt <= 4 &&
+                         b.st[0].k >= 2 && b.st[0].k <= 6 && (int)K1.size() <= 6 && !(b.T_in == 12 && b.T_out == 12);
     for (int q = 0; q < b.n_stages; ++q) {
       const bool wide = b.st[q].k == 5 || b.st[q].k == 6;
-      if (wide) { any = any || b.st[q].m3; all = all && b.st[q].m3; }
-      frag += 2 << (std::min(b.st[q].k, 6) - 1);
+      const bool ok3 = b.st[q].m3 || (q == 1 && narrow2);
+      if (wide) { any = any || ok3; all = all && ok3; }
+      frag += (q == 1 && narrow2) ? 3 << (b.st[q].k - 2) : 2 << (std::min(b.st[q].k, 6) - 1);
     }
     if (frag > tuning().m3_frag) all = false; // fragments of both stages next to three accumulators: 6+4 (80) fits, 6+5 (96) spills 24-36 registers
     // (a fused pair with a 6-bit 3M stage compiles with 8 spilled registers and still wins: 6+4 pairs of n30
@@ -710,6 +715,11 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     if (b.m3)
       for (int q = 0; q < b.n_stages; ++q)
         if (b.st[q].k >= 2 && b.st[q].k <= 4) b.st[q].m3 = 2;
+    if (b.m3 && narrow2) { // (artn_k_bits<KB1, KB2, ..., M3, ..., N3 = 2>)
+      b.narrow3 = 2;
+      b.st[1].m3 = 2;
+      b.st[1].wn_log2 = 0;
+    }
     // a single step with 5-6 contracted bits that brings at most 4 result bits into the tile (the steps that SHRINK their
     // tensor): on 32 x 32 blocks at most 16 of 32 rows are results and the stage runs four products; the 16 x 16 x 4 form
     // (the stage of artn_k_wide on four waves) halves the rows and runs three -- n53's 2^30 -> 2^27 step is MFMA-bound on
