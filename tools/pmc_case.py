@@ -2,7 +2,7 @@
 """Per-kernel PMC summary of tools/pmc_case.sh (launches longer than 1 ms, averaged per instantiation)."""
 import collections, csv, glob, os, sys
 out = sys.argv[1]
-for sub in ("a", "b"):
+for sub in ("a", "b", "c"):
     files = glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True)
     if not files:
         print(sub, "no counters:", open(os.path.join(out, sub + ".log")).read()[-600:])
@@ -18,6 +18,11 @@ for sub in ("a", "b"):
         a["n"] += 1
         for k, v in d.items():
             if k != "name": a[k] += v
+    if os.environ.get("PER_DISPATCH"):   # every launch longer than 1 ms on its own line (same instantiation, different plans)
+        for d in sorted(per.values(), key=lambda d: -d["t"]):
+            if d["t"] >= 1e6:
+                print(f"  {d['name'][:44]:44s} ms={d['t']/1e6:.2f} " + " ".join(f"{k}={v:.3g}" for k, v in d.items() if k not in ("name", "t")))
+        continue
     for name, a in agg.items():
         n = a["n"]
         print(f"{name[:60]:60s} n={n} ms={a['t']/n/1e6:.2f} " + " ".join(f"{k}={v/n:.3g}" for k, v in a.items() if k not in ("n", "t")))
