@@ -135,3 +135,20 @@ def test_precision_is_thread_local_and_caches_are_bounded():
         assert len(b) <= 3
     assert b[9] == 9
     assert isinstance(C._desc_cache, C._Bounded) and isinstance(C._plan_cache, C._Bounded)
+
+
+def test_single_row_index_lists_follow_the_reference_indexing():
+    """`t[idx]` with ONE index (reference contraction.py:177-179): the sparse executor takes the row as a view -- negative indices
+    count from the end, out of range raises (the reference dies with IndexError, contraction.py:192-195), several rows or rows of
+    8 bytes (not 16-byte aligned views) keep the gather path."""
+    from artensor_amd import contraction as C
+    t = torch.zeros(3, 4, dtype=torch.complex64)
+    assert C._single_row(torch.tensor([2]), t) == 2
+    assert C._single_row(torch.tensor([-1]), t) == 2 and C._single_row(torch.tensor([-3]), t) == 0
+    assert C._single_row(torch.tensor([0, 1]), t) is None
+    assert C._single_row(torch.tensor([0]), torch.zeros(3, 1, dtype=torch.complex64)) is None
+    assert C._single_row(torch.tensor([0]), torch.zeros((), dtype=torch.complex64)) is None
+    with pytest.raises(RuntimeError, match="row index out of range"):
+        C._single_row(torch.tensor([3]), t)
+    with pytest.raises(RuntimeError, match="row index out of range"):
+        C._single_row(torch.tensor([-4]), t)
