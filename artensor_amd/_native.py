@@ -15,7 +15,7 @@ ABI_VERSION = 6
 ARTN_MAX_LABELS = 96
 ARTN_PROGRAM_MAX_EXT = 256
 ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
-KERNEL_GENERIC, KERNEL_BITS_MFMA, KERNEL_GEMM_MFMA, KERNEL_PGEMM = 0, 1, 2, 4
+KERNEL_GENERIC, KERNEL_BITS_MFMA, KERNEL_GEMM_MFMA, KERNEL_PGEMM, KERNEL_XGEMM = 0, 1, 2, 4, 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARTN_LIB") or os.path.join(_HERE, "libartn_hip.so")  # ARTN_LIB: diagnostic builds

@@ -241,7 +241,7 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None
     for _, x in ka:
         e = a_shape[la.index(x)]
         if e & (e - 1):
-            return None
+            return _big_k_outer_extents(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype, ka)
         bits += e.bit_length() - 1
     if bits <= MAX_TILE_K_BITS:
         return None
@@ -269,6 +269,34 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None
         outer.append(x)
         bits -= a_shape[la.index(x)].bit_length() - 1
     return outer
+
+
+def _big_k_outer_extents(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype, ka):
+    """_big_k_outer for contracted labels whose extents are not powers of two (the extent-based GEMM, artn_k_xgemm, walks
+    every contracted value inside one workgroup): when the result has too few 128 x 96 tiles to fill the chip -- the
+    closing steps of a bond-dimension-3 network contract 3^11 values into a 3^7 x 3^5 result: 36 tiles -- the
+    slowest-varying contracted labels of A become a temporary batch label until SPLIT_K_MIN_TILES workgroups have
+    work, as long as a few hundred contracted values stay inside."""
+    if b_shape is None or dtype != torch.complex64:
+        return None
+    d, _ = _descriptor(tuple(la), tuple(lb), tuple(lo), tuple(a_shape), tuple(a_stride), tuple(b_shape),
+                       tuple(b_stride if b_stride is not None else _dense_strides(tuple(b_shape))), dtype)
+    info = _step_info_cached(d)
+    if info["kernel"] != N.KERNEL_XGEMM:
+        return None
+    tiles = max(1, info["n_tiles"])
+    k_total = 1
+    for _, x in ka:
+        k_total *= a_shape[la.index(x)]
+    outer = []
+    for _, x in sorted(ka, reverse=True):   # highest A stride first
+        e = a_shape[la.index(x)]
+        if tiles >= SPLIT_K_MIN_TILES or k_total // e < 256:
+            break
+        outer.append(x)
+        tiles *= e
+        k_total //= e
+    return outer or None
 
 
 def sum_leading(part, n_rows, out=None):

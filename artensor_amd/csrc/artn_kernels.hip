@@ -1792,6 +1792,7 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 #include "artn_gemm_kernel.h"
 #include "artn_gemm128_kernel.h"
 #include "artn_pgemm_kernel.h"
+#include "artn_xgemm_kernel.h"
 
 // ----------------------------------------------------------------------------------------
 // strided fallback: one thread per C element
@@ -2734,6 +2735,31 @@ static hipError_t launch_pgemm(const ArtnPlan &p, const void *A, const void *B, 
   return hipGetLastError();
 }
 
+static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, void *C, hipStream_t st) {
+  const ArtnXGemmPlan &g = p.xg;
+  const float2 *a = (const float2 *)(g.swapped ? B : A), *b = (const float2 *)(g.swapped ? A : B);
+  float2 *c = (float2 *)C;
+  dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
+  const size_t lds = (size_t)p.info.lds_bytes;
+#define ARTN_XGEMM_LAUNCH(NBV, TRV)                                                                  \
+  {                                                                                                  \
+    auto kern = artn_k_xgemm<NBV, TRV>;                                                              \
+    if (hipError_t e = ensure_lds<artn_k_xgemm<NBV, TRV>>(lds); e != hipSuccess) return e;           \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
+    return hipGetLastError();                                                                        \
+  }
+  switch (g.nb * 2 + (g.trans ? 1 : 0)) {
+    case 2: ARTN_XGEMM_LAUNCH(1, false)
+    case 3: ARTN_XGEMM_LAUNCH(1, true)
+    case 4: ARTN_XGEMM_LAUNCH(2, false)
+    case 5: ARTN_XGEMM_LAUNCH(2, true)
+    case 6: ARTN_XGEMM_LAUNCH(3, false)
+    case 7: ARTN_XGEMM_LAUNCH(3, true)
+  }
+#undef ARTN_XGEMM_LAUNCH
+  return hipErrorInvalidValue;
+}
+
 static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, void *C, hipStream_t st) {
   const ArtnGemmPlan &g = p.gemm;
   const float2 *a = (const float2 *)(g.swapped ? B : A), *b = (const float2 *)(g.swapped ? A : B);
@@ -3036,6 +3062,10 @@ int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, 
   }
   if (p.kernel == ARTN_KERNEL_GEMM_MFMA) {
     HIP_TRY(launch_gemm(p, A, B, C, st));
+    return ARTN_OK;
+  }
+  if (p.kernel == ARTN_KERNEL_XGEMM) {
+    HIP_TRY(launch_xgemm(p, A, B, C, st));
     return ARTN_OK;
   }
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);

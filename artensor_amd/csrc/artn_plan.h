@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "artn.h"
+#include "artn_xgemm_plan.h"
 
 #define ARTN_MAX_OUTER 36
 #define ARTN_TILE_BITS_MAX 13 /* 2^13 complex64 = 64 KiB per LDS region */
@@ -204,6 +205,7 @@ struct ArtnPlan {
   int n_cu;   // compute units the plan was made for
   ArtnBitsPlan bits;
   ArtnGemmPlan gemm;
+  ArtnXGemmPlan xg;
   ArtnGenericPlan gen;
   ArtnStepInfo info;
   int64_t stage1_repeats = 1; // fused pairs: visits of one input tile = values of the second step's result bits outside the tile
@@ -250,6 +252,7 @@ struct Tuning {
   int packed_min_ai = 160; // ... and the FLOP per byte of the step it needs (64 until round 4: the 2^20 x 2^8 x 2^8 step of an n53 m14 slice --
                            // 128 FLOP per byte, a quarter of its time in the packing passes -- takes 4.65 ms packed and 4.25 on
                            // artn_k_gemm; the 2^8- and 2^10-deep steps of the D = 4 random network (204-205) stay packed: 1.00 against 1.08 ms)
+  int xgemm = 1;      // steps with a label whose extent is not a power of two on the extent-based GEMM (artn_k_xgemm); 0: strided kernel (ARTN_XGEMM)
   int narrow3 = 1;    // single steps with 5-6 contracted bits and <= 4 result bits in the tile on 16 x 16 x 4 blocks, 3M (ArtnBitsPlan::narrow3)
   int wide = 2;       // fused pairs of 2^12-element tiles on artn_k_wide (ArtnBitsPlan::wide8): 0 never; 1 all of them (loses:
                       // 56.5 ms on n30 against 53.5); 2 (default) the pairs with 11+ contracted bits -- 5+6, 6+5, 6+6 -- whose
@@ -295,6 +298,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_ALT")) x.alt = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_WIDE")) x.wide = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_NARROW3")) x.narrow3 = atoi(e);
+    if (const char *e = getenv("ARTN_XGEMM")) x.xgemm = atoi(e) != 0;
     if (const char *e = getenv("ARTN_WIDE_MIN_TILES")) x.wide_min_tiles = atoi(e);
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
@@ -1422,6 +1426,132 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, bool
   return true;
 }
 
+// ----------------------------------------------------------------------------------------
+// extent-based GEMM planner (artn_k_xgemm, artn_xgemm_plan.h): complex64, any extents and strides.
+// Takes what the bit planners decline because a label's extent is not a power of two -- networks of bond
+// dimension 3, 5, 6 ... (reference tensor_network.py:4-30 accepts any bond_dims; the einsum at contraction.py:70
+// has no such restriction).
+// ----------------------------------------------------------------------------------------
+static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles) {
+  if (d->dtype != ARTN_C64 && d->dtype != ARTN_C64_BF16) { p.why_generic = "extent GEMM: dtype is not complex64"; return false; }
+  ArtnXGemmPlan &x = p.xg;
+  memset(&x, 0, sizeof(x));
+  struct Lab { int64_t e, sA, sB, sC; };
+  std::vector<Lab> M, N, K, H;
+  int64_t spanA = 1, spanB = 1, spanC = 1;
+  double work = 8.0;
+  for (int l = 0; l < d->n_labels; ++l) {
+    const int64_t e = d->extent[l];
+    if (e == 1) continue;
+    const bool a = d->stride_a[l] >= 0, b = d->stride_b[l] >= 0, c = d->stride_c[l] >= 0;
+    Lab L = {e, a ? d->stride_a[l] : 0, b ? d->stride_b[l] : 0, c ? d->stride_c[l] : 0};
+    if (a) spanA += (e - 1) * L.sA;
+    if (b) spanB += (e - 1) * L.sB;
+    if (c) spanC += (e - 1) * L.sC;
+    work *= (double)e;
+    if (a && b && !c) K.push_back(L);
+    else if (a && !b && c) M.push_back(L);
+    else if (!a && b && c) N.push_back(L);
+    else if (a && b && c) H.push_back(L);
+    else { p.why_generic = "extent GEMM: label summed out of a single operand"; return false; }
+    if (e >= (int64_t(1) << 31)) { p.why_generic = "extent GEMM: extent beyond 2^31"; return false; }
+  }
+  const int64_t lim = int64_t(1) << 31; // element offsets are 32-bit in the kernel
+  if (spanA >= lim || spanB >= lim || spanC >= lim) { p.why_generic = "extent GEMM: a tensor of 2^31 elements or more"; return false; }
+  auto prod = [](const std::vector<Lab> &v) { int64_t t = 1; for (auto &l : v) t *= l.e; return t; };
+  if (min_tiles > 1 && work < (double)(int64_t(1) << 24)) { p.why_generic = "extent GEMM: too little work for a tiled launch"; return false; }
+  // the first operand supplies the 128-row tiles: it is the one with more free values
+  x.swapped = prod(N) > prod(M) ? 1 : 0;
+  if (x.swapped) {
+    std::swap(M, N);
+    for (auto *v : {&M, &N, &K, &H})
+      for (auto &l : *v) std::swap(l.sA, l.sB);
+  }
+  if ((int)M.size() > ARTN_XG_MAXL || (int)N.size() > ARTN_XG_MAXL || (int)K.size() > ARTN_XG_MAXL || (int)H.size() > ARTN_XG_MAXH) {
+    p.why_generic = "extent GEMM: too many labels on one side";
+    return false;
+  }
+  // which label is the fastest of each tensor decides how its copy lanes run
+  auto fastest_is = [&](const std::vector<Lab> &cand, int which) { // which: 0 A, 1 B, 2 C
+    int64_t best = -1;
+    for (auto *v : {&M, &N, &K, &H})
+      for (auto &l : *v) {
+        const bool has = which == 0 ? (v != &N) : which == 1 ? (v != &M) : (v != &K);
+        const int64_t s = which == 0 ? l.sA : which == 1 ? l.sB : l.sC;
+        if (has && (best < 0 || s < best)) best = s;
+      }
+    for (auto &l : cand) {
+      const int64_t s = which == 0 ? l.sA : which == 1 ? l.sB : l.sC;
+      if (s == best) return true;
+    }
+    return false;
+  };
+  x.amode = fastest_is(K, 0) ? 1 : 0;
+  x.bmode = fastest_is(K, 1) ? 1 : 0;
+  x.trans = fastest_is(N, 2) ? 1 : 0;
+  // label order inside each flattened index (innermost first): that of the tensor whose copy lanes run along it
+  if (x.amode == 0) std::sort(M.begin(), M.end(), [](const Lab &u, const Lab &v) { return u.sA < v.sA; });
+  else std::sort(M.begin(), M.end(), [](const Lab &u, const Lab &v) { return u.sC < v.sC; });
+  if (x.bmode == 0) std::sort(N.begin(), N.end(), [](const Lab &u, const Lab &v) { return u.sB < v.sB; });
+  else std::sort(N.begin(), N.end(), [](const Lab &u, const Lab &v) { return u.sC < v.sC; });
+  if (x.amode == 0 && x.bmode == 1) std::sort(K.begin(), K.end(), [](const Lab &u, const Lab &v) { return u.sB < v.sB; });
+  else std::sort(K.begin(), K.end(), [](const Lab &u, const Lab &v) { return u.sA < v.sA; });
+  auto fill = [&](ArtnXSide &S, const std::vector<Lab> &v, int kind) { // kind 0: m (A, C), 1: n (B, C), 2: k (A, B)
+    S.n_lab = (int32_t)v.size();
+    S.total = 1;
+    for (int i = 0; i < S.n_lab; ++i) {
+      S.ext[i] = (int32_t)v[i].e;
+      S.s0[i] = kind == 1 ? v[i].sB : v[i].sA;
+      S.s1[i] = kind == 2 ? v[i].sB : v[i].sC;
+      S.total *= v[i].e;
+    }
+    S.L0 = S.L1 = 1;
+    S.n0 = S.n1 = 0;
+    while (S.n0 < S.n_lab && (int64_t)S.L0 * S.ext[S.n0] <= ARTN_XG_LEVEL) S.L0 *= S.ext[S.n0++];
+    if (kind != 2)
+      while (S.n0 + S.n1 < S.n_lab && (int64_t)S.L1 * S.ext[S.n0 + S.n1] <= ARTN_XG_LEVEL) S.L1 *= S.ext[S.n0 + S.n1++];
+  };
+  fill(x.m, M, 0);
+  fill(x.n, N, 1);
+  fill(x.k, K, 2);
+  if (x.k.n_lab > 0 && x.k.n0 == 0) { p.why_generic = "extent GEMM: innermost contracted label longer than a level table"; return false; }
+  if (x.m.total >= lim || x.n.total >= lim || x.k.total >= lim) { p.why_generic = "extent GEMM: a flattened index beyond 2^31"; return false; }
+  x.n_h = (int32_t)H.size();
+  int64_t hprod = 1;
+  for (int i = 0; i < x.n_h; ++i) {
+    x.h_ext[i] = (int32_t)H[i].e;
+    x.h_sA[i] = H[i].sA; x.h_sB[i] = H[i].sB; x.h_sC[i] = H[i].sC;
+    hprod *= H[i].e;
+  }
+  // 32-column blocks per tile: the count that wastes the fewest columns (ties: the wider tile)
+  double best = -1;
+  for (int nb = 3; nb >= 1; --nb) {
+    const int64_t tn = 32 * nb, tiles = (x.n.total + tn - 1) / tn;
+    const double eff = (double)x.n.total / (double)(tiles * tn);
+    if (eff > best + 1e-9) { best = eff; x.nb = nb; }
+  }
+  x.cpg = (x.k.L0 + ARTN_XG_KC - 1) / ARTN_XG_KC;
+  x.k_groups = x.k.total / x.k.L0;
+  const int64_t chunks = x.k_groups * x.cpg;
+  if (chunks >= lim) { p.why_generic = "extent GEMM: too many chunks per tile"; return false; }
+  x.flush_chunks = chunks > ARTN_XG_FLUSH / ARTN_XG_KC ? ARTN_XG_FLUSH / ARTN_XG_KC : 0;
+  x.tiles_m = (x.m.total + ARTN_XG_TM - 1) / ARTN_XG_TM;
+  x.tiles_n = (x.n.total + 32 * x.nb - 1) / (32 * x.nb);
+  x.n_tiles = x.tiles_m * x.tiles_n * hprod;
+  if (x.n_tiles >= lim) { p.why_generic = "extent GEMM: too many tiles"; return false; }
+  p.kernel = ARTN_KERNEL_XGEMM;
+  ArtnStepInfo &I = p.info;
+  I.kernel = ARTN_KERNEL_XGEMM;
+  I.m_tile_bits = 7;
+  I.n_tile_bits = 5;
+  I.k_bits = 4;
+  I.lds_bytes = artn_xg_lds_bytes(x.nb);
+  I.n_tiles = x.n_tiles;
+  I.grid = (int32_t)std::min<int64_t>(x.n_tiles, (int64_t)n_cu * 2);
+  I.a_rereads = x.tiles_n;
+  return true;
+}
+
 static inline void step_cost(const ArtnStepDesc *d, double &flops, double &na, double &nb, double &nc) {
   double prod = 1;
   na = nb = nc = 1;
@@ -1438,7 +1568,7 @@ static inline void step_cost(const ArtnStepDesc *d, double &flops, double &na, d
 // workgroups cannot fill 256 CUs; such steps are launch-latency bound either way).
 static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err, int n_cu = 256,
                             bool allow_bits = true, int64_t min_tiles = 32, int gather_label = -1, bool allow_gemm = true,
-                            bool allow_packed = false) {
+                            bool allow_packed = false, bool allow_xgemm = true) {
   int rc = validate(d, err);
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
@@ -1491,6 +1621,12 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
     if (!ok) p.why_generic = why + "; GEMM kernel: " + p.why_generic;
   }
   if (!ok && gather_label >= 0) { err = "row gather needs the tiled kernel: " + p.why_generic; return ARTN_E_UNSUPPORTED; }
+  // what every bit planner declined (in practice: a label whose extent is not a power of two): the extent-based GEMM
+  if (!ok && allow_bits && allow_xgemm && tuning().xgemm && d->dtype != ARTN_C128) {
+    const std::string why = p.why_generic;
+    ok = make_xgemm(d, p, n_cu, min_tiles);
+    if (!ok) p.why_generic = why + "; " + p.why_generic;
+  }
   if (!ok && !make_generic(d, p, err)) return ARTN_E_UNSUPPORTED;
   double na, nb, nc;
   step_cost(d, p.info.flops, na, nb, nc);
@@ -1506,6 +1642,9 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   } else if (p.kernel == ARTN_KERNEL_GEMM_MFMA) {
     p.info.arith = d->dtype == ARTN_C128 ? 3 : (p.gemm.split == 1 ? 2 : (p.gemm.m3 ? 1 : 0));
     p.info.mfma_flops = p.info.flops * (p.gemm.m3 ? 0.75 : 1.0);
+  } else if (p.kernel == ARTN_KERNEL_XGEMM) {
+    p.info.arith = 1; // three real products per complex product
+    p.info.mfma_flops = p.info.flops * 0.75;
   } else {
     p.info.arith = -1;
     p.info.mfma_flops = 0.0;

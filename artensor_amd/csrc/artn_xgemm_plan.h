@@ -1,0 +1,83 @@
+// artn_xgemm_plan.h -- launch plan of the EXTENT-based two-operand GEMM (artn_k_xgemm, artn_xgemm_kernel.h).
+//
+// The reference contracts tensor networks of any bond dimension: torch.einsum at
+// /root/reference/artensor/contraction.py:70 takes whatever `bond_dims` the AbstractTensorNetwork was built with
+// (/root/reference/artensor/tensor_network.py:4-30; the toy networks of /root/reference/tests/test_core.py:11,24).
+// The bit planners of artn_plan.h need power-of-two extents (a label of extent 2^p is p address bits); a label of
+// extent 3, 5, 6 ... used to send its step to the strided kernel.  Here a step is a GEMM over three FLATTENED mixed-radix
+// indices,
+//     C[h, m, n] = sum_k A[h, m, k] B[h, k, n]        m = free labels of A, n = free labels of B, k = contracted, h = batch,
+// whose element offsets are separable: off_A(m, k) = offAm(m) + offAk(k), and so on for B and C.  A tile is 128 consecutive
+// values of m x 32 nb consecutive values of n (no padding except in the last tile of a row / column: extents need not
+// divide anything), the contracted index is walked in chunks of 16 values, zero-padded to an even count only at the end of
+// a group.  Offsets come from small per-level tables built in LDS once per workgroup (levels 0 and 1: the innermost labels,
+// at most 256 combinations each) and a mixed-radix decode of what is left (once per tile and row).
+//
+// Pure C++ (no HIP): included by artn_plan.h, compiled into libartn_hip.so and into the CPU plan emulator.
+#ifndef ARTN_XGEMM_PLAN_H
+#define ARTN_XGEMM_PLAN_H
+
+#define ARTN_XG_MAXL 20   /* labels per flattened index */
+#define ARTN_XG_MAXH 8    /* batch labels */
+#define ARTN_XG_TM 128    /* rows (values of m) per tile: 4 waves x 32 */
+#define ARTN_XG_KC 16     /* contracted values per LDS chunk */
+#define ARTN_XG_LEVEL 256 /* entries of one level table */
+#define ARTN_XG_FLUSH 4096 /* contracted values per fp32 partial sum (as ARTN_GEMM_FLUSH_LOG2) */
+
+// One flattened index: labels innermost first, each with its extent and its element stride in the two tensors that
+// carry it (m: A and C; n: B and C; k: A and B).
+struct ArtnXSide {
+  int32_t n_lab;
+  int32_t n0, n1;  // labels of level 0 / level 1 (prefixes whose extents multiply to at most ARTN_XG_LEVEL)
+  int32_t L0, L1;  // product of the extents of level 0 / level 1
+  int32_t pad_;
+  int64_t total;   // product of all extents
+  int32_t ext[ARTN_XG_MAXL];
+  int64_t s0[ARTN_XG_MAXL], s1[ARTN_XG_MAXL];
+};
+
+struct ArtnXGemmPlan {
+  ArtnXSide m, n, k;
+  int32_t n_h;                 // batch labels (carried by A, B and C): one tile belongs to one value of them
+  int32_t h_ext[ARTN_XG_MAXH];
+  int64_t h_sA[ARTN_XG_MAXH], h_sB[ARTN_XG_MAXH], h_sC[ARTN_XG_MAXH];
+  int32_t nb;                  // 32-column MFMA blocks per tile (1..3): the tile is 128 x 32 nb
+  int32_t trans;               // 1: C's fastest label is a label of n -- the MFMA roles of the operands are swapped so that the lanes
+                               //    of a store run along n (accumulator register <-> row of m); 0: lanes run along m
+  int32_t amode, bmode;        // copy lanes of an operand run along its free index (0) or along k (1): whichever its fastest label is
+  int32_t swapped;             // 1: the kernel's first operand is the caller's B
+  int32_t cpg;                 // chunks per group of k.L0 contracted values: ceil(k.L0 / 16)
+  int32_t flush_chunks;        // partial sums leave the registers every this many chunks (read-add-write of C); 0: never
+  int32_t pad_;
+  int64_t k_groups;            // k.total / k.L0
+  int64_t tiles_m, tiles_n, n_tiles; // n_tiles = tiles_m * tiles_n * prod(h_ext); tile index = (h, tile of m, tile of n), n fastest
+};
+
+// LDS layout shared by the kernel, the launcher and the emulator (byte offsets).
+static inline int artn_xg_pitch_a() { return ARTN_XG_TM + 2; }          // elements between two contracted values of the A image
+static inline int artn_xg_pitch_b(int nb) { return 32 * nb + 2; }       // ... of the B image
+static inline int artn_xg_stage_bytes(int nb) { return ARTN_XG_KC * (artn_xg_pitch_a() + artn_xg_pitch_b(nb)) * 8; }
+static inline int artn_xg_level_bytes() { return 10 * ARTN_XG_LEVEL * 4; } // mA0 mC0 mA1 mC1 nB0 nC0 nB1 nC1 kA kB
+static inline int artn_xg_tiletab_bytes() { return 4 * ARTN_XG_TM * 4; }   // rowA rowC colB colC of one tile
+static inline int artn_xg_lds_bytes(int nb) { return 2 * artn_xg_stage_bytes(nb) + artn_xg_level_bytes() + 2 * artn_xg_tiletab_bytes(); }
+
+// Mixed-radix decode of `idx` over labels [first, first + count) of a side: the two element offsets.
+#if defined(__HIPCC__)
+#define ARTN_XG_HD __host__ __device__ __forceinline__
+#else
+#define ARTN_XG_HD static inline
+#endif
+ARTN_XG_HD void artn_xg_decode(const ArtnXSide &S, int first, int count, uint32_t idx, uint32_t &o0, uint32_t &o1) {
+  uint32_t a = 0, b = 0;
+  for (int i = first; i < first + count; ++i) {
+    const uint32_t e = (uint32_t)S.ext[i];
+    const uint32_t q = idx / e, d = idx - q * e;
+    a += d * (uint32_t)S.s0[i];
+    b += d * (uint32_t)S.s1[i];
+    idx = q;
+  }
+  o0 = a;
+  o1 = b;
+}
+
+#endif

@@ -70,6 +70,8 @@ typedef struct ArtnStepDesc {
                                  * tile order into a workspace, then an LDS-DMA GEMM.  ARTN_C64: fp32 images, 3M arithmetic
                                  * (artn_k_pgemm3m; workspace 8 B x (2^(m+k) + 2^(n+k))); ARTN_C64_BF16: bfloat16 images
                                  * (artn_k_pgemm; half of that) */
+#define ARTN_KERNEL_XGEMM 5     /* extent-based two-operand GEMM on fp32 MFMA (3M): any extents -- bond dimensions 3, 5, 6 ... --
+                                 * flattened mixed-radix indices, offset tables in LDS (artn_k_xgemm) */
 typedef struct ArtnStepInfo {
   int32_t kernel;       /* ARTN_KERNEL_*                                        */
   int32_t k_bits;       /* contracted bits handled inside a tile                */

@@ -779,6 +779,135 @@ static void run_pgemm(const ArtnPackPlan &P, const cf *A0, const cf *B0, cf *C) 
   }
 }
 
+// ---- artn_k_xgemm (artn_xgemm_kernel.h), replayed thread by thread from the same ArtnXGemmPlan -----------------------
+// Level tables, the per-tile row / column tables (indices past the end clamped), the copy slots of both modes with the
+// zero padding of a group's last chunk, the k walk (groups of k.L0 values x the outer contracted labels), the MFMA lane
+// and accumulator maps of both operand roles (TRANS), the partial-sum flush and the predicated stores.
+static void run_xgemm(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
+  const cf *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
+  const int NB = P.nb, TM = ARTN_XG_TM, TN = 32 * NB, KC = ARTN_XG_KC, PA = artn_xg_pitch_a(), PB = artn_xg_pitch_b(NB);
+  // level tables
+  std::vector<uint32_t> mA0(256), mC0(256), mA1(256), mC1(256), nB0(256), nC0(256), nB1(256), nC1(256), kA(256), kB(256);
+  auto level = [&](const ArtnXSide &S, std::vector<uint32_t> &a0, std::vector<uint32_t> &c0, std::vector<uint32_t> *a1, std::vector<uint32_t> *c1) {
+    for (int i = 0; i < S.L0; ++i) artn_xg_decode(S, 0, S.n0, (uint32_t)i, a0[i], c0[i]);
+    if (a1) for (int i = 0; i < S.L1; ++i) artn_xg_decode(S, S.n0, S.n1, (uint32_t)i, (*a1)[i], (*c1)[i]);
+  };
+  level(P.m, mA0, mC0, &mA1, &mC1);
+  level(P.n, nB0, nC0, &nB1, &nC1);
+  level(P.k, kA, kB, nullptr, nullptr);
+  const uint32_t K0 = (uint32_t)P.k.L0, Mtot = (uint32_t)P.m.total, Ntot = (uint32_t)P.n.total;
+  const int64_t n_chunks = P.k_groups * P.cpg;
+  std::vector<cf> imgA((size_t)KC * PA), imgB((size_t)KC * PB);
+  std::vector<uint32_t> rowA(TM), rowC(TM), colB(TM), colC(TM);
+  for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
+    const uint32_t tu = (uint32_t)tile, r = tu / (uint32_t)P.tiles_n, tn = tu - r * (uint32_t)P.tiles_n;
+    uint32_t hh = r / (uint32_t)P.tiles_m;
+    const uint32_t tm = r - hh * (uint32_t)P.tiles_m, m0 = tm * TM, n0 = tn * TN;
+    uint32_t hA = 0, hB = 0, hC = 0;
+    for (int i = 0; i < P.n_h; ++i) {
+      const uint32_t e = (uint32_t)P.h_ext[i], q = hh / e, d = hh - q * e;
+      hA += d * (uint32_t)P.h_sA[i]; hB += d * (uint32_t)P.h_sB[i]; hC += d * (uint32_t)P.h_sC[i];
+      hh = q;
+    }
+    auto side = [&](const ArtnXSide &S, uint32_t first, int count, const std::vector<uint32_t> &t0a, const std::vector<uint32_t> &t0c,
+                    const std::vector<uint32_t> &t1a, const std::vector<uint32_t> &t1c, std::vector<uint32_t> &oa, std::vector<uint32_t> &oc) {
+      for (int loc = 0; loc < count; ++loc) {
+        uint32_t idx = first + (uint32_t)loc;
+        if (idx >= (uint32_t)S.total) idx = (uint32_t)S.total - 1;
+        const uint32_t q0 = idx / (uint32_t)S.L0, i0 = idx - q0 * (uint32_t)S.L0, q1 = q0 / (uint32_t)S.L1, i1 = q0 - q1 * (uint32_t)S.L1;
+        uint32_t o0, o1;
+        artn_xg_decode(S, S.n0 + S.n1, S.n_lab - S.n0 - S.n1, q1, o0, o1);
+        oa[loc] = o0 + t0a[i0] + t1a[i1];
+        oc[loc] = o1 + t0c[i0] + t1c[i1];
+      }
+    };
+    side(P.m, m0, TM, mA0, mC0, mA1, mC1, rowA, rowC);
+    side(P.n, n0, TN, nB0, nC0, nB1, nC1, colB, colC);
+    // accumulators of every (wave, block, product, lane, register)
+    std::vector<float> acc((size_t)4 * NB * 3 * 64 * 16, 0.f);
+    auto ACC = [&](int wave, int b, int t, int lane, int rr) -> float & { return acc[((((size_t)wave * NB + b) * 3 + t) * 64 + lane) * 16 + rr]; };
+    bool flushed_before = false;
+    int since_flush = 0;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+      const uint32_t ig = (uint32_t)(c / P.cpg), iq = (uint32_t)(c % P.cpg);
+      uint32_t gA, gB;
+      artn_xg_decode(P.k, P.k.n0, P.k.n_lab - P.k.n0, ig, gA, gB);
+      const uint32_t kbase = iq * KC;
+      const int kvalid = (int)std::min<uint32_t>(K0 - kbase, KC);
+      for (auto &x : imgA) x = cf(-777.f, -777.f);
+      for (auto &x : imgB) x = cf(-777.f, -777.f);
+      for (int tid = 0; tid < 256; ++tid) {
+        for (int u = 0; u < TM * KC / 256; ++u) {
+          int row, kk;
+          if (P.amode) { kk = tid & 15; row = (tid >> 4) + 16 * u; } else { row = tid & (TM - 1); kk = (tid >> 7) + 2 * u; }
+          uint32_t kc = kbase + (uint32_t)kk;
+          if (kc >= K0) kc = K0 - 1;
+          const cf v = A[(uint32_t)(hA + gA + rowA[row] + kA[kc])];
+          imgA[(size_t)kk * PA + row] = kk >= kvalid ? cf(0.f, 0.f) : v;
+        }
+        for (int u = 0; u < TN * KC / 256; ++u) {
+          int col, kk;
+          if (P.bmode) { kk = tid & 15; col = (tid >> 4) + 16 * u; } else { const int e = tid + 256 * u; kk = e / TN; col = e - kk * TN; }
+          uint32_t kc = kbase + (uint32_t)kk;
+          if (kc >= K0) kc = K0 - 1;
+          const cf v = B[(uint32_t)(hB + gB + colB[col] + kB[kc])];
+          imgB[(size_t)kk * PB + col] = kk >= kvalid ? cf(0.f, 0.f) : v;
+        }
+      }
+      const int trips = (kvalid + 3) >> 2;
+      for (int wave = 0; wave < 4; ++wave)
+        for (int s = 0; s < 2 * trips; ++s)
+          for (int b = 0; b < NB; ++b)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int rr = 0; rr < 16; ++rr) {
+                const int i = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5), jj = lane & 31;
+                // srcA lane l: [row i = l & 31][kk = l >> 5]; srcB lane l: [kk = l >> 5][column j = l & 31]
+                const int xi = P.trans ? i : jj, wi = P.trans ? jj : i; // index into the A image (rows of m) / the B image (columns of n)
+                for (int kk = 0; kk < 2; ++kk) {
+                  const cf xv = imgA[(size_t)(2 * s + kk) * PA + 32 * wave + xi];
+                  const cf wv = imgB[(size_t)(2 * s + kk) * PB + 32 * b + wi];
+                  ACC(wave, b, 0, lane, rr) += wv.real() * xv.real();
+                  ACC(wave, b, 1, lane, rr) += wv.imag() * xv.imag();
+                  ACC(wave, b, 2, lane, rr) += (wv.real() + wv.imag()) * (xv.real() + xv.imag());
+                }
+              }
+      ++since_flush;
+      const bool last = c + 1 == n_chunks;
+      if (last || (P.flush_chunks > 0 && since_flush == P.flush_chunks)) {
+        for (int wave = 0; wave < 4; ++wave)
+          for (int b = 0; b < NB; ++b)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int rr = 0; rr < 16; ++rr) {
+                const int i = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5), jj = lane & 31;
+                const uint32_t m_loc = 32 * wave + (P.trans ? i : jj), n_loc = 32 * b + (P.trans ? jj : i);
+                if (m0 + m_loc >= Mtot || n0 + n_loc >= Ntot) continue;
+                const float t1 = ACC(wave, b, 0, lane, rr), t2 = ACC(wave, b, 1, lane, rr), t3 = ACC(wave, b, 2, lane, rr);
+                cf &dst = C[(uint32_t)(hC + rowC[m_loc] + colC[n_loc])];
+                const cf val(t1 - t2, t3 - t1 - t2);
+                dst = flushed_before ? dst + val : val;
+              }
+        flushed_before = true;
+        since_flush = 0;
+        std::fill(acc.begin(), acc.end(), 0.f);
+      }
+    }
+  }
+}
+
+// Force the extent-based GEMM plan; ARTN_E_UNSUPPORTED if make_xgemm declines.
+extern "C" int artn_emulate_xgemm(const ArtnStepDesc *d, const void *A, const void *B, void *C, ArtnStepInfo *info, int32_t *modes) {
+  ArtnPlan p;
+  std::string err;
+  int rc = artn::validate(d, err);
+  if (rc) return rc;
+  memset(&p.info, 0, sizeof(p.info));
+  if (!artn::make_xgemm(d, p, 256, 1)) return ARTN_E_UNSUPPORTED;
+  if (info) *info = p.info;
+  if (modes) { modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; }
+  run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
+  return 0;
+}
+
 extern "C" int artn_emulate_pgemm(const ArtnStepDesc *d, const void *A, const void *B, void *C, ArtnStepInfo *info) {
   ArtnPlan p;
   std::string err;
@@ -808,6 +937,7 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
   if (d->dtype != ARTN_C64 && !(d->dtype == ARTN_C64_BF16 && p.kernel == ARTN_KERNEL_GEMM_MFMA)) return ARTN_E_UNSUPPORTED;
   if (p.kernel == ARTN_KERNEL_BITS_MFMA) run_bits(p.bits, (const cf *)A, (const cf *)B, nullptr, (cf *)C);
   else if (p.kernel == ARTN_KERNEL_GEMM_MFMA) run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);
+  else if (p.kernel == ARTN_KERNEL_XGEMM) run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
   else run_generic(p.gen, (const cf *)A, (const cf *)B, (cf *)C);
   return 0;
 }

@@ -681,6 +681,39 @@ def case_random_bench():
               "slice0", res.reshape(-1), f"{dt:.0f} s", flush=True)
 
 
+def case_random_bench_nonpow2():
+    """Benchmark-scale random 3-regular networks whose bond dimension is NOT a power of two (round 5: the class of
+    inputs that used to run on the strided kernel).  Same recipe as case_random_bench (networkx.random_regular_graph(3,
+    nv, seed=0), leaves complex(randn, randn) / D^1.5, find_order trials 4, iters 5), sc_target 32 so that the planner
+    does not slice (the reference's slice loop enumerates 2**len(bonds) slices: bond dimension 2 only):
+      * D = 3, 112 vertices: largest intermediate 3^18 elements (3.1 GB), 10^11.2 complex multiply-adds;
+      * D = 6 = 2 x 3, 64 vertices: a composite extent.
+    The reference executor's own complex64 value pins each fixture; a complex128 run of the same executor is stored
+    beside it (`exact128`: the truth the 1e-5 contract is checked against)."""
+    for nv, D, name in [(112, 3, "rand_D3_nv112"), (64, 6, "rand_D6_nv64")]:
+        tensors, tensor_bonds, bond_dims = _rand_tn(nv, D, 0, 0)
+        order, slicing_bonds, ctree = find_order(
+            deepcopy(tensor_bonds), deepcopy(bond_dims), [], 0, 1, sc_target=32,
+            trials=4, iters=5, betas=np.linspace(3.0, 21.0, 61), start_seed=0, slicing_repeat=1)
+        assert len(slicing_bonds) == 0, (name, slicing_bonds)
+        scheme, output_bonds = contraction_scheme(deepcopy(ctree))
+        assert list(output_bonds) == []
+        tc, sc = ctree.tree_complexity()[:2]
+        t0 = time.time()
+        res = tensor_contraction(dict(tensors), scheme)
+        dt = time.time() - t0
+        t0 = time.time()
+        res128 = tensor_contraction({i: t.to(torch.complex128) for i, t in tensors.items()}, scheme)
+        dt128 = time.time() - t0
+        meta = dict(D=D, nv=nv, n_open=0, sc_target=32, log10_tc=float(tc), sc=float(sc), bond_dim=D,
+                    output_bonds=[], n_slicing=0, reference_cpu_seconds=dt, reference_cpu_seconds_c128=dt128,
+                    graph="networkx.random_regular_graph(3, nv, seed=0)")
+        save_case(os.path.join(HERE, name + ".npz"), tensors, scheme, meta,
+                  arrays=dict(final=res.reshape(-1).numpy().copy(), exact128=res128.reshape(-1).numpy().copy()))
+        print(name, "steps", len(scheme), "log10 tc", float(tc), "sc", float(sc), "value", res.reshape(-1), "c128",
+              res128.reshape(-1), f"{dt:.0f} s / {dt128:.0f} s", flush=True)
+
+
 def case_gates():
     """Gate lists (array + bond labels per gate, in circuit order) of the n12 and n30 circuits as
     the reference's TensorNetworkCircuit builds them (circuit.py:100-130): the input of
@@ -697,6 +730,7 @@ def case_gates():
 CASES = {
     "gates": case_gates,
     "random_bench": case_random_bench,
+    "random_bench_nonpow2": case_random_bench_nonpow2,
     "n53_plan": case_n53_plan,
     "n53_slice0": case_n53_slice0,
     "n53m20_plan": lambda: case_n53_plan("m20"),

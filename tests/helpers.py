@@ -69,7 +69,9 @@ def emulator():
     deps = [src, os.path.join(ROOT, "artensor_amd", "csrc", "artn_plan.h"), os.path.join(ROOT, "include", "artn.h"),
             os.path.join(ROOT, "artensor_amd", "csrc", "artn_gemm_kernel.h"),
             os.path.join(ROOT, "artensor_amd", "csrc", "artn_gemm128_kernel.h"),
-            os.path.join(ROOT, "artensor_amd", "csrc", "artn_pgemm_kernel.h")]
+            os.path.join(ROOT, "artensor_amd", "csrc", "artn_pgemm_kernel.h"),
+            os.path.join(ROOT, "artensor_amd", "csrc", "artn_xgemm_plan.h"),
+            os.path.join(ROOT, "artensor_amd", "csrc", "artn_xgemm_kernel.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "artensor_amd", "csrc"), src, "-o", so])
@@ -399,3 +401,29 @@ def emulate_program(prog, leaves):
             stats["in_lds"] += int(recs[s]["lds_c"] >= 0)
             stats["to_ws"] += int(recs[s]["to_ws"] != 0)
     return ws, stats
+
+
+def emulate_xgemm(eq, a, b):
+    """One step through the CPU replay of the extent-based GEMM (artn_k_xgemm; plan forced); returns (result, planner
+    info, modes) -- modes = dict(amode, bmode, trans, swapped, nb, flush_chunks) -- or (None, None, None) when
+    make_xgemm declines.  `eq`: an einsum string or a triple of label tuples; a / b may be strided views."""
+    import torch
+    from artensor_amd import contraction as C
+    from artensor_amd import _native as N
+    la, lb, lo = C._labels(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    d, out_shape = C._descriptor(la, lb, lo, tuple(ta.shape), tuple(ta.stride()), tuple(tb.shape), tuple(tb.stride()),
+                                 torch.complex64)
+    out = np.full(out_shape, np.nan + 0j, dtype=np.complex64)
+    info = N.ArtnStepInfo()
+    modes = (ctypes.c_int32 * 6)()
+    emu = emulator()
+    emu.artn_emulate_xgemm.restype = ctypes.c_int
+    # (strided views: the emulator takes the base pointer of the view, like the kernel)
+    rc = emu.artn_emulate_xgemm(ctypes.byref(d), ctypes.c_void_p(ta.data_ptr()), ctypes.c_void_p(tb.data_ptr()),
+                                out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info), modes)
+    if rc == -2:
+        return None, None, None
+    assert rc == 0, rc
+    names = ("amode", "bmode", "trans", "swapped", "nb", "flush_chunks")
+    return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}, dict(zip(names, modes))

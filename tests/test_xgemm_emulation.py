@@ -1,0 +1,133 @@
+"""CPU checks of the extent-based GEMM (artn_k_xgemm, artensor_amd/csrc/artn_xgemm_plan.h / artn_xgemm_kernel.h): steps whose
+labels have extents that are not powers of two -- the reference contracts any bond_dims
+(/root/reference/artensor/tensor_network.py:4-30, the einsum at contraction.py:70) -- planned by make_xgemm and replayed
+thread by thread by tests/csrc/plan_emulate.cpp::run_xgemm, against the oracle."""
+import numpy as np
+import pytest
+
+from artensor_amd import step_info
+from oracle import oracle
+from helpers import crandn, emulate, emulate_xgemm
+
+KERNEL_XGEMM = 5
+
+
+def random_step(rng, ext_choices, n_m, n_n, n_k, n_h=0):
+    """Random label orders in A, B and C; extents drawn per label."""
+    M = [f"m{i}" for i in range(n_m)]
+    Nn = [f"n{i}" for i in range(n_n)]
+    K = [f"k{i}" for i in range(n_k)]
+    H = [f"h{i}" for i in range(n_h)]
+    ext = {x: int(rng.choice(ext_choices)) for x in M + Nn + K + H}
+    la, lb, lo = M + K + H, Nn + K + H, M + Nn + H
+    for lst in (la, lb, lo):
+        rng.shuffle(lst)
+    return (tuple(la), tuple(lb), tuple(lo)), tuple(ext[x] for x in la), tuple(ext[x] for x in lb)
+
+
+def einsum_labels(eq, a, b):
+    la, lb, lo = eq
+    sym = {}
+    for x in la + lb + lo:
+        sym.setdefault(x, chr(65 + len(sym)) if len(sym) < 26 else chr(97 + len(sym) - 26))
+    s = "".join(sym[x] for x in la) + "," + "".join(sym[x] for x in lb) + "->" + "".join(sym[x] for x in lo)
+    return np.einsum(s, a.astype(np.complex128), b.astype(np.complex128))
+
+
+def check(eq, a, b, tol=2e-6):
+    got, info, modes = emulate_xgemm(eq, a, b)
+    assert got is not None, "make_xgemm declined"
+    want = einsum_labels(eq, a, b)
+    assert got.shape == want.shape
+    assert not np.isnan(got).any(), "an output element was never stored"
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err < tol, (eq, err, modes)
+    assert info["kernel"] == KERNEL_XGEMM
+    return info, modes
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_bond_dimension_3_steps(seed):
+    rng = np.random.default_rng(seed)
+    n_m, n_n, n_k = int(rng.integers(3, 8)), int(rng.integers(1, 5)), int(rng.integers(0, 5))
+    eq, sa, sb = random_step(rng, [3], n_m, n_n, n_k)
+    check(eq, crandn(rng, sa), crandn(rng, sb))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_mixed_extents(seed):
+    """Extents 2..7 mixed (D = 6 = 2 x 3 networks, D = 5), batch labels, every copy mode and both operand roles."""
+    rng = np.random.default_rng(1000 + seed)
+    n_m, n_n, n_k, n_h = int(rng.integers(2, 6)), int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(0, 2))
+    eq, sa, sb = random_step(rng, [2, 3, 5, 6, 7], n_m, n_n, n_k, n_h)
+    check(eq, crandn(rng, sa), crandn(rng, sb))
+
+
+def test_all_modes_are_covered():
+    """amode / bmode / trans / swapped each take both values over a set of steps (otherwise a copy mode could rot)."""
+    seen = {name: set() for name in ("amode", "bmode", "trans", "swapped", "nb")}
+    for seed in range(40):
+        rng = np.random.default_rng(5000 + seed)
+        eq, sa, sb = random_step(rng, [3], int(rng.integers(3, 7)), int(rng.integers(1, 5)), int(rng.integers(1, 4)))
+        _, modes = check(eq, crandn(rng, sa), crandn(rng, sb))
+        for name in seen:
+            seen[name].add(modes[name])
+    rng = np.random.default_rng(6000)   # 60 columns: two blocks of 32
+    _, modes = check((("m", "k"), ("k", "p", "q"), ("q", "m", "p")), crandn(rng, (200, 11)), crandn(rng, (11, 5, 12)))
+    seen["nb"].add(modes["nb"])
+    assert seen["amode"] == {0, 1} and seen["bmode"] == {0, 1} and seen["trans"] == {0, 1} and seen["swapped"] == {0, 1}
+    assert seen["nb"] == {1, 2, 3}
+
+
+def test_long_contraction_flushes_partial_sums():
+    """More than 4096 contracted values: the partial sums go through C (read-add-write); one group is not a multiple of 16."""
+    rng = np.random.default_rng(7)
+    eq = (("m0", "k0", "k1", "k2", "m1"), ("k2", "n0", "k0", "k1"), ("m0", "n0", "m1"))
+    a, b = crandn(rng, (5, 3, 81, 21, 7)), crandn(rng, (21, 6, 3, 81))   # K = 5103: levels of 243 x 21 groups
+    info, modes = check(eq, a, b, tol=5e-6)
+    assert modes["flush_chunks"] == 256
+
+
+def test_outer_product_and_single_contracted_value():
+    rng = np.random.default_rng(8)
+    check((("a", "b"), ("c", "d"), ("a", "c", "b", "d")), crandn(rng, (9, 27)), crandn(rng, (5, 7)))       # nothing contracted
+    check((("a", "k", "b"), ("k", "c"), ("c", "a", "b")), crandn(rng, (30, 1, 11)), crandn(rng, (1, 13)))  # extent-1 label
+
+
+def test_strided_views_as_operands():
+    """A and B may be arbitrary non-overlapping strided views (include/artn.h): a slice of a bigger tensor."""
+    rng = np.random.default_rng(9)
+    big_a, big_b = crandn(rng, (7, 9, 5, 6)), crandn(rng, (6, 4, 9))
+    a, b = big_a[1:6, :, ::2, :], big_b[:, 1:4, :]
+    check((("m", "k", "p", "q"), ("q", "n", "k"), ("p", "n", "m")), a, b)
+
+
+def test_levels_beyond_the_tables():
+    """More rows than two level tables hold (3^12 > 256^2): the outer labels are decoded per row."""
+    rng = np.random.default_rng(10)
+    la = tuple(f"m{i}" for i in range(12)) + ("k",)
+    eq = (la, ("k", "n"), tuple(reversed(la[:12])) + ("n",))
+    check(eq, crandn(rng, (3,) * 12 + (2,)), crandn(rng, (2, 3)))
+
+
+def test_planner_sends_non_power_of_two_steps_to_the_extent_gemm():
+    # D = 3: rank 12 x rank 6 over 3 bonds (a benchmark-size step would be rank 17 x rank 9)
+    info = step_info("ABCDEFGHIJKL,DHKxyz->ABCEFGIJLxyz", (3,) * 12, (3,) * 6)
+    assert info["kernel"] == KERNEL_XGEMM, info
+    assert info["arith"] == 1 and abs(info["mfma_flops"] - 0.75 * info["flops"]) < 1
+    # D = 6 = 2 x 3
+    assert step_info("ABCDEFG,CFxy->ABDEGxy", (6,) * 7, (6,) * 4)["kernel"] == KERNEL_XGEMM
+    # powers of two stay where they were; tiny steps stay on the strided kernel
+    assert step_info("ABCDEFGHIJKLMNOPQRST,DHKOwxyz->ABCEFGIJLMNPQRSTwxyz", (2,) * 20, (2,) * 8)["kernel"] == 1
+    assert step_info("ABC,Cxy->ABxy", (3,) * 3, (3,) * 3)["kernel"] == 0
+
+
+def test_default_plan_of_the_emulator_entry_point():
+    """artn_emulate (the default planner) routes a D = 3 step through run_xgemm."""
+    rng = np.random.default_rng(11)
+    a, b = crandn(rng, (3,) * 9), crandn(rng, (3,) * 5)
+    eq = "ABCDEFGHI,CFHxy->yABDEGIx"
+    got, used = emulate(eq, a, b)
+    assert used == KERNEL_XGEMM
+    want = oracle.einsum_pair(eq, a, b)
+    assert np.abs(got - want).max() / np.abs(want).max() < 2e-6
