@@ -9,7 +9,8 @@ all: $(LIB)
 # eight objects from ONE source (see "Translation units" in artn_kernels.hip): `make -j8` builds in about a
 # minute and a half instead of four
 SRCS := $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_pgemm_kernel.h \
-        $(CSRC)/artn_bits128_kernel.h $(CSRC)/artn_bits3_kernel.h $(CSRC)/artn_wide_kernel.h $(CSRC)/artn_plan.h include/artn.h
+        $(CSRC)/artn_bits128_kernel.h $(CSRC)/artn_bits3_kernel.h $(CSRC)/artn_wide_kernel.h $(CSRC)/artn_plan.h \
+        $(CSRC)/artn_xgemm_plan.h $(CSRC)/artn_xgemm_kernel.h include/artn.h
 OBJDIR := build/obj
 OBJS := $(OBJDIR)/main.o $(OBJDIR)/b128.o $(OBJDIR)/wide.o $(foreach k,1 2 3 4 5 6,$(OBJDIR)/bits_k$(k).o) $(foreach k,3 4 5,$(OBJDIR)/bits3_k$(k).o)
 FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -I$(CSRC)

@@ -207,6 +207,7 @@ SPLIT_K_MIN_TILES = 512   # the GEMM kernel loops over any number of contracted 
                           # contracted labels are turned into a batch label only to get this many tiles
 
 
+XGEMM_SPLIT_TILES = 4096  # the extent GEMM's persistent grid is 512 workgroups: eight rounds keep the last one's idle share under 6 %
 _ONE = object()  # operand id of the scalar 1 in a compiled sum-out op
 _ones = {}
 
@@ -232,7 +233,7 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None
     numel = 1
     for e in a_shape:
         numel *= e
-    if numel < (1 << 20):
+    if numel < (1 << 16):
         return None
     if a_stride is None:
         a_stride = _dense_strides(tuple(a_shape))
@@ -243,6 +244,8 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None
         if e & (e - 1):
             return _big_k_outer_extents(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype, ka)
         bits += e.bit_length() - 1
+    if numel < (1 << 20):
+        return None
     if bits <= MAX_TILE_K_BITS:
         return None
     keep = MAX_TILE_K_BITS
@@ -291,7 +294,7 @@ def _big_k_outer_extents(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype
     outer = []
     for _, x in sorted(ka, reverse=True):   # highest A stride first
         e = a_shape[la.index(x)]
-        if tiles >= SPLIT_K_MIN_TILES or k_total // e < 256:
+        if tiles >= XGEMM_SPLIT_TILES or k_total // e < 256:
             break
         outer.append(x)
         tiles *= e
@@ -302,14 +305,13 @@ def _big_k_outer_extents(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype
 def sum_leading(part, n_rows, out=None):
     """out[c] = sum_r part.reshape(n_rows, -1)[r, c] through artn_sum_axis_c64, as a two-pass tree
     when there are many rows (the first pass keeps every CU busy, the order of additions is
-    fixed).  `part` must be a contiguous complex64 GPU tensor with an even number of columns, or a
-    complex128 one (artn_sum_axis_c128)."""
+    fixed).  `part` must be a contiguous complex64 (artn_sum_axis_c64) or complex128 (artn_sum_axis_c128) GPU tensor."""
     n_cols = part.numel() // n_rows
     lib = N.lib()
     sum_axis = lib.artn_sum_axis_c64 if part.dtype == torch.complex64 else lib.artn_sum_axis_c128
     per16 = 2 if part.dtype == torch.complex64 else 1   # elements per 16-byte lane
     dst = out
-    if out is None or not out.is_contiguous() or out.data_ptr() % 16 or out.numel() != n_cols:
+    if out is None or not out.is_contiguous() or out.data_ptr() % 16 or out.numel() != n_cols:   # (tmp rows of an odd n_cols are 8-byte aligned: fine)
         out = torch.empty(n_cols, dtype=part.dtype, device=part.device)
     with torch.cuda.device(part.device):
         stream = N.current_stream_ptr(part.device)
@@ -332,7 +334,7 @@ def sum_leading(part, n_rows, out=None):
 def _sum_leading_ok(t, n_rows):
     if not (t.is_contiguous() and n_rows > 1 and t.numel() % n_rows == 0 and t.data_ptr() % 16 == 0):
         return False
-    return t.dtype == torch.complex128 or (t.dtype == torch.complex64 and (t.numel() // n_rows) % 2 == 0)
+    return t.dtype in (torch.complex128, torch.complex64)   # (complex64: an odd column count moves one element per lane)
 
 
 def _split_big_k(la, lb, lo, a, b):
@@ -1025,6 +1027,7 @@ def _compile_dense(scheme, shapes, dtype):
     if prog is not None:
         for t, (off, shape) in prog.outputs.items():
             shapes[t] = shape
+    scheme = _own_layouts(scheme, main_idx, shapes, dtype)
 
     def emit(n, i, j, la, lb, lo, sa, sb, warn=True):
         op = _Op()
@@ -1147,6 +1150,60 @@ def _compile_dense(scheme, shapes, dtype):
         shapes[i] = out_shape
         ops.append(op)
     return prog, ops
+
+
+def _own_layouts(scheme, main_idx, shapes, dtype):
+    """Label order of the INTERMEDIATES of a dense scheme whose labels have extents that are not powers of two.
+
+    The reference's compiler orders every result's labels as `list(set)` left them (contraction.py:49): for the bit
+    kernels that is a permutation of address bits inside a tile, but with odd extents nothing is aligned and every
+    label that separates two neighbours of the flattened row index costs a factor of its extent in run length.
+    tensor_contraction only promises the label order of the scheme's RESULT (fused pairs never materialise their
+    intermediate either), so the steps that run as launches get
+        result labels = batch labels, then the free labels of the operand with fewer free values (in that operand's
+                        order), then the free labels of the other operand (in its order, fastest)
+    -- consecutive rows of the extent GEMM's 128-row tiles are then consecutive in the first operand's free labels
+    AND in the result (1 KiB contiguous per tile column), whatever the planner's `list(set)` said.  The last step
+    keeps the scheme's order.  Returns the scheme itself or a rewritten copy (label-tuple equations)."""
+    if dtype != torch.complex64 or not main_idx or _os_environ.get("ARTN_OWN_LAYOUTS", "1") in ("0",):
+        return scheme
+    if all(e & (e - 1) == 0 for sh in shapes.values() for e in sh):
+        return scheme
+    perm = {}      # tensor id -> current dim order of the tensor as positions of the scheme's order
+    out = list(scheme)
+    shapes = dict(shapes)
+    last = len(scheme) - 1
+    for n in main_idx:
+        step = scheme[n]
+        if not _is_plain_step(step):
+            return scheme
+        (i, j), eq = step[0], step[1]
+        la, lb, lo = _labels(eq)
+        pa, pb = perm.get(i), perm.get(j)
+        la_act = tuple(la[p] for p in pa) if pa else tuple(la)
+        lb_act = tuple(lb[p] for p in pb) if pb else tuple(lb)
+        ext = {}
+        if i in shapes:
+            ext.update(zip(la_act, shapes[i]))
+        if j in shapes:
+            ext.update(zip(lb_act, shapes[j]))
+        if n == last or len(set(lo)) != len(lo):
+            lo_act = tuple(lo)
+        else:
+            in_a, in_b = set(la), set(lb)
+            h = [x for x in la_act if x in in_b and x in lo]
+            m = [x for x in la_act if x not in in_b and x in lo]
+            nn = [x for x in lb_act if x not in in_a and x in lo]
+            rest = [x for x in lo if x not in h and x not in m and x not in nn]
+            size = lambda v: __import__("math").prod(ext.get(x, 1) for x in v)
+            small, big = (nn, m) if size(m) >= size(nn) else (m, nn)
+            lo_act = tuple(rest + h + small + big)
+        if any(x not in ext for x in lo_act):
+            return scheme   # (shapes unknown: leave the scheme alone)
+        perm[i] = tuple(lo.index(x) for x in lo_act) if lo_act != tuple(lo) else None
+        out[n] = ((i, j), (la_act, lb_act, lo_act))
+        shapes[i] = tuple(ext[x] for x in lo_act)
+    return out
 
 
 _scheme_ids = _Bounded(256)   # id(scheme) -> (scheme, ids it reads, first-use order)

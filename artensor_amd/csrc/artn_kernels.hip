@@ -3600,8 +3600,16 @@ int artn_sum_axis_c64(const void *in, void *out, int64_t n_groups, int64_t n_row
   if (n_groups < 0 || n_rows < 1 || n_cols < 0) return fail(ARTN_E_INVALID, "bad extent");
   if (n_groups == 0 || n_cols == 0) return ARTN_OK;
   if (!in || !out) return fail(ARTN_E_INVALID, "null pointer");
-  if ((n_cols & 1) || ((((uintptr_t)in | (uintptr_t)out) & 15) != 0))
-    return fail(ARTN_E_UNSUPPORTED, "artn_sum_axis_c64 needs an even column count and 16-byte aligned buffers");
+  if ((((uintptr_t)in | (uintptr_t)out) & 7) != 0) return fail(ARTN_E_UNSUPPORTED, "artn_sum_axis_c64 needs 8-byte aligned buffers");
+  if ((n_cols & 1) || ((((uintptr_t)in | (uintptr_t)out) & 15) != 0)) {
+    // an odd column count (3^12 amplitudes of a bond-dimension-3 network) or buffers that are only 8-byte aligned: one element per lane
+    const long col_tiles = (n_cols + 63) / 64;
+    if (n_groups * col_tiles > (1L << 30)) return fail(ARTN_E_UNSUPPORTED, "too many workgroups");
+    hipLaunchKernelGGL(artn_k_sum_axis<v2f_t>, dim3((unsigned)(n_groups * col_tiles)), dim3(ARTN_WG_THREADS), 0, (hipStream_t)stream,
+                       (const v2f_t *)in, (v2f_t *)out, (long)n_rows, (long)n_cols, col_tiles);
+    HIP_TRY(hipGetLastError());
+    return ARTN_OK;
+  }
   const long n4 = n_cols / 2, col_tiles = (n4 + 63) / 64;
   if (n_groups * col_tiles > (1L << 30)) return fail(ARTN_E_UNSUPPORTED, "too many workgroups");
   hipLaunchKernelGGL(artn_k_sum_axis<f32x4>, dim3((unsigned)(n_groups * col_tiles)), dim3(ARTN_WG_THREADS), 0, (hipStream_t)stream,

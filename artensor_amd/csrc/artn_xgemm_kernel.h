@@ -27,12 +27,11 @@ struct XgTile {
   unsigned hA, hB, hC;   // element offsets of the tile's batch value
 };
 
-__device__ __forceinline__ XgTile xg_tile(const ArtnXGemmPlan &P, long t) {
+__device__ __forceinline__ XgTile xg_tile(const ArtnXGemmPlan &P, unsigned hm, unsigned tn) { // hm = batch value x tiles_m + tile of m
   XgTile T;
-  const unsigned tu = (unsigned)t, tsn = (unsigned)P.tiles_n, tsm = (unsigned)P.tiles_m; // (n_tiles < 2^31)
-  const unsigned r = tu / tsn, tn = tu - r * tsn;
-  unsigned hh = r / tsm;
-  const unsigned tm = r - hh * tsm;
+  const unsigned tsm = (unsigned)P.tiles_m;
+  unsigned hh = hm / tsm;
+  const unsigned tm = hm - hh * tsm;
   T.m0 = tm * ARTN_XG_TM;
   T.n0 = tn * 32u * (unsigned)P.nb;
   unsigned a = 0, b = 0, c = 0;
@@ -90,16 +89,25 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
   level_tables(P.n, T_NB0, T_NB1, true);
   level_tables(P.k, T_KA, 0u, false);
   // ---- per-tile tables: element offsets of the tile's rows in A and C, of its columns in B and C (set `s`)
+  // Rows (columns) of a tile are consecutive values of the flattened index: index = ((q1 L1) + i1) L0 + i0.  The tile's first
+  // value is split by two uniform divisions; a row adds its position to i0 and carries.  What lies above the two table
+  // levels (q1) is decoded label by label -- but a workgroup walks CONSECUTIVE tiles, so q1 changes once in L0 L1 / 128
+  // tiles and every thread keeps the decode of the q1 it met last.
+  unsigned c_q1 = 0xffffffffu, c_o0 = 0, c_o1 = 0;
   auto build_side = [&](const ArtnXSide &S, unsigned first, int loc, unsigned t0, unsigned t1, unsigned dst) {
-    unsigned idx = first + (unsigned)loc;
-    const unsigned tot = (unsigned)S.total;
-    if (idx >= tot) idx = tot - 1; // rows / columns past the end read valid memory and are never stored
-    const unsigned L0 = (unsigned)S.L0, L1 = (unsigned)S.L1;
-    const unsigned q0 = idx / L0, i0 = idx - q0 * L0, q1 = q0 / L1, i1 = q0 - q1 * L1;
-    unsigned o0, o1;
-    artn_xg_decode(S, S.n0 + S.n1, S.n_lab - S.n0 - S.n1, q1, o0, o1);
-    o0 += lds_read4(t0 + 4u * i0) + lds_read4(t1 + 4u * i1);
-    o1 += lds_read4(t0 + 1024u + 4u * i0) + lds_read4(t1 + 1024u + 4u * i1);
+    const unsigned tot = (unsigned)S.total, L0 = (unsigned)S.L0, L1 = (unsigned)S.L1;
+    unsigned pos = (unsigned)loc;
+    if (first + pos >= tot) pos = tot - 1 - first; // rows / columns past the end read valid memory and are never stored
+    const unsigned q0b = first / L0, i0b = first - q0b * L0, q1b = q0b / L1, i1b = q0b - q1b * L1;
+    unsigned i0 = i0b + pos, i1 = i1b, q1 = q1b;
+    while (i0 >= L0) { i0 -= L0; ++i1; }
+    while (i1 >= L1) { i1 -= L1; ++q1; }
+    if (q1 != c_q1) {
+      c_q1 = q1;
+      artn_xg_decode(S, S.n0 + S.n1, S.n_lab - S.n0 - S.n1, q1, c_o0, c_o1);
+    }
+    const unsigned o0 = c_o0 + lds_read4(t0 + 4u * i0) + lds_read4(t1 + 4u * i1);
+    const unsigned o1 = c_o1 + lds_read4(t0 + 1024u + 4u * i0) + lds_read4(t1 + 1024u + 4u * i1);
     lds_write4(dst + 4u * loc, o0);        // rowA / colB
     lds_write4(dst + 512u + 4u * loc, o1); // rowC / colC
   };
@@ -191,12 +199,22 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
     }
   };
 
-  long t0 = blockIdx.x;
-  const long G = gridDim.x, n_tiles = P.n_tiles;
-  if ((G & 7) == 0) t0 = (long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3); // XCD-contiguous tile ranges
+  // Tile order.  A RUN is `run` consecutive row tiles (same batch value or the next) of ONE column tile: the workgroup that
+  // walks it keeps its column tables and, most of the time, the decode cache above.  Runs are numbered column tile fastest
+  // and dealt round-robin: the workgroups that run side by side hold the tiles_n column tiles of the same rows (their
+  // reads of those rows meet in L2 instead of following each other through HBM) and neighbouring rows.  Measured on a
+  const unsigned G = gridDim.x, tiles_n = (unsigned)P.tiles_n;
+  const unsigned total_hm = (unsigned)(P.n_tiles / P.tiles_n);
+  unsigned run = (unsigned)(P.n_tiles / ((long)G * 4));
+  run = run < 1 ? 1 : (run > 16 ? 16 : run);
+  const unsigned n_super = (total_hm + run - 1) / run, n_runs = n_super * tiles_n; // (< 2^31: n_tiles is)
   __syncthreads(); // level tables are in LDS
-  if (t0 >= n_tiles) return;
-  XgTile T = xg_tile(P, t0), Tn = T;
+  // (consecutive runs on the SAME XCD -- workgroup b runs on XCD b mod 8 -- so that those shared rows meet in ONE L2)
+  const unsigned wg = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  unsigned R = wg, pos = 0; // current run, position inside it
+  if (R >= n_runs) return;
+  unsigned r_tn = R % tiles_n, r_hm0 = (R / tiles_n) * run;
+  XgTile T = xg_tile(P, r_hm0, r_tn), Tn = T;
   unsigned set = 0;
   build_tile(T, 0u);
   __syncthreads();
@@ -209,9 +227,17 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
   const unsigned lane_w = A_BYTES + (unsigned)(h * PB + j) * 8u;
   const int flush_chunks = P.flush_chunks;
 
-  for (long tile = t0; tile < n_tiles; tile += G) {
-    const bool more_tiles = tile + G < n_tiles;
-    if (more_tiles) Tn = xg_tile(P, tile + G);
+  for (;;) {
+    // the successor of this tile in the workgroup's sequence
+    bool more_tiles = true;
+    if (pos + 1 < run && r_hm0 + pos + 1 < total_hm) ++pos;
+    else {
+      R += G;
+      pos = 0;
+      more_tiles = R < n_runs;
+      if (more_tiles) { r_tn = R % tiles_n; r_hm0 = (R / tiles_n) * run; }
+    }
+    if (more_tiles) Tn = xg_tile(P, r_hm0 + pos, r_tn);
     f32x16 acc[NB * 3];
 #pragma unroll
     for (int b = 0; b < NB * 3; ++b)
@@ -338,6 +364,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
       __syncthreads();
       cur ^= 1u;
     }
+    if (!more_tiles) break;
     T = Tn;
     set ^= 1u;
   }

@@ -45,7 +45,8 @@ import torch  # noqa: E402
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (spec, ~2.5 PF)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak (spec)
-KERNEL_NAMES = {0: "artn_k_generic", 1: "artn_k_bits", 2: "artn_k_gemm", 3: "artn_k_program", 4: "artn_k_pgemm / artn_k_pgemm3m (+ packing passes)"}
+KERNEL_NAMES = {0: "artn_k_generic", 1: "artn_k_bits", 2: "artn_k_gemm", 3: "artn_k_program", 4: "artn_k_pgemm / artn_k_pgemm3m (+ packing passes)",
+                5: "artn_k_xgemm"}
 LOOSE_TOL = 1e-5              # |got - want| <= tol * max(|want|, rms(want)) for every amplitude
 STRICT_FACTOR = 2.0           # relative error per amplitude over |truth| >= 1e-3 rms, against the complex128 truth
 #                               of the same leaves and scheme (tests/golden/c128_truth_gpu.npz, pinned to an independent torch-CPU
@@ -60,7 +61,7 @@ def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
     for name in ("artn_kernels.hip", "artn_gemm_kernel.h", "artn_gemm128_kernel.h", "artn_bits128_kernel.h", "artn_bits3_kernel.h",
-                 "artn_wide_kernel.h", "artn_pgemm_kernel.h", "artn_plan.h"):
+                 "artn_wide_kernel.h", "artn_pgemm_kernel.h", "artn_plan.h", "artn_xgemm_kernel.h", "artn_xgemm_plan.h"):
         with open(os.path.join(ROOT, "artensor_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -275,6 +276,10 @@ SLICED_WORKLOADS = {
               "random 3-regular tensor network, bond dimension 2, 260 tensors, closed, 12 sliced bonds (sc 30)"),
     "rand4": ("rand_D4_nv100.npz", False,
               "random 3-regular tensor network, bond dimension 4, 100 tensors, closed, no slicing (sc 28)"),
+    "rand3": ("rand_D3_nv112.npz", False,
+              "random 3-regular tensor network, bond dimension 3, 112 tensors, closed, no slicing (largest intermediate 3^18 elements)"),
+    "rand6": ("rand_D6_nv64.npz", False,
+              "random 3-regular tensor network, bond dimension 6 = 2 x 3, 64 tensors, closed, no slicing (largest intermediate 6^11 elements)"),
 }
 
 
@@ -346,12 +351,15 @@ def run_sliced(A, name, dev, world, rank, dist, steps, warmup, per_step, precisi
         C.profiler = None
         kernel_times = (prof.summarize(), e0.elapsed_time(e1))
     truth = truth_value(fixture[:-4] + "_slice0")
+    truth_is = "complex128 on the GPU (tests/golden/c128_truth_gpu.npz)"
+    if truth is None and "exact128" in case.arrays:   # (round-5 fixtures carry the REFERENCE executor's own complex128 value)
+        truth, truth_is = case.arrays["exact128"].reshape(-1), f"the reference's executor in complex128 on the CPU (tests/golden/{fixture}: exact128)"
     vs_truth = None
     if truth is not None:
         tl, ts, _ = error_figures(got, truth)
         rl, rs, _ = error_figures(want, truth)
         vs_truth = {"hip_loose": tl, "hip_strict": ts, "reference_c64_loose": rl, "reference_c64_strict": rs,
-                    "truth": "complex128 on the GPU (tests/golden/c128_truth_gpu.npz)"}
+                    "truth": truth_is}
         if precision != "bf16":   # the contract: 1e-5 of the truth, or no farther from it than 2 x the reference's own complex64 run
             ok = ok and (tl <= LOOSE_TOL or tl <= 2 * rl)
     return {
@@ -522,6 +530,8 @@ LEGS = [
     ("n53m20", "the bundled n53 m20 circuit, one bitstring", "n53m20", "fp32", 2),
     ("rand2", "north_star: random tensor network, bond dimension 2", "rand2", "fp32", 4),
     ("rand4", "north_star: random tensor network, bond dimension 4", "rand4", "fp32", 4),
+    ("rand3", "north_star: random tensor network, bond dimension 3 (extents that are not powers of two)", "rand3", "fp32", 2),
+    ("rand6", "north_star: random tensor network, bond dimension 6 = 2 x 3", "rand6", "fp32", 2),
     ("n30_c128", "configs[1] in complex128 (reference simulation.py:90: any dtype)", "c128", "fp32", 1),
     ("n30_sliced3", "configs[1] split over 3 inner bonds: the N > 1 alternative to output partitioning, on one GPU", "n30s3", "fp32", 1),
 ]

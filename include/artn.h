@@ -221,8 +221,8 @@ int artn_axpy_c64(void *acc, const void *x, int64_t n, void *stream);
 /* the same for complex128 (the reference's slice loop takes any dtype, artensor/simulation.py:90, :101) */
 int artn_axpy_c128(void *acc, const void *x, int64_t n, void *stream);
 
-/* out[g][c] = sum_r in[g][r][c] for complex64 arrays in[n_groups][n_rows][n_cols] (n_cols even,
- * 16-byte aligned): sums out the leading label(s) of a dense tensor.  Closes a contraction whose
+/* out[g][c] = sum_r in[g][r][c] for complex64 arrays in[n_groups][n_rows][n_cols] (8-byte aligned; 16-byte
+ * lanes when n_cols is even and the buffers are 16-byte aligned): sums out the leading label(s) of a dense tensor.  Closes a contraction whose
  * contracted labels exceed one LDS tile: `torch.einsum` at artensor/contraction.py:70 contracts any
  * number of labels in one call; here the slowest ones become a batch label of artn_contract and are
  * summed afterwards.  Applied twice (n_rows = R * n_rows') it is a two-pass tree sum. */

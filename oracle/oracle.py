@@ -26,6 +26,8 @@ import numpy as np
 def parse_eq(eq):
     """'ab,bc->ac' -> (list a, list b, list out).  Labels are single characters
     (reference alphabet A-Y, a-y: contraction.py:9-10)."""
+    if not isinstance(eq, str):   # a triple of label tuples (any hashable labels)
+        return list(eq[0]), list(eq[1]), list(eq[2])
     lhs, out = eq.split("->")
     a, b = lhs.split(",")
     return list(a), list(b), list(out)

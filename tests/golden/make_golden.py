@@ -709,7 +709,7 @@ def case_random_bench_nonpow2():
                     output_bonds=[], n_slicing=0, reference_cpu_seconds=dt, reference_cpu_seconds_c128=dt128,
                     graph="networkx.random_regular_graph(3, nv, seed=0)")
         save_case(os.path.join(HERE, name + ".npz"), tensors, scheme, meta,
-                  arrays=dict(final=res.reshape(-1).numpy().copy(), exact128=res128.reshape(-1).numpy().copy()))
+                  arrays=dict(slice0=res.reshape(-1).numpy().copy(), exact128=res128.reshape(-1).numpy().copy()))
         print(name, "steps", len(scheme), "log10 tc", float(tc), "sc", float(sc), "value", res.reshape(-1), "c128",
               res128.reshape(-1), f"{dt:.0f} s / {dt128:.0f} s", flush=True)
 

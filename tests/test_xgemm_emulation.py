@@ -131,3 +131,42 @@ def test_default_plan_of_the_emulator_entry_point():
     assert used == KERNEL_XGEMM
     want = oracle.einsum_pair(eq, a, b)
     assert np.abs(got - want).max() / np.abs(want).max() < 2e-6
+
+
+def test_own_layouts_of_intermediates_keep_the_result():
+    """_own_layouts reorders the labels of intermediates of a bond-dimension-3 scheme (the free labels of the bigger operand
+    fastest, in that operand's order); the rewritten scheme, run by the oracle, gives the scheme's own result, and the
+    last step keeps the scheme's label order."""
+    import os
+    import torch
+    from artensor_amd import contraction as C
+    from artensor_amd.fixtures import load_case
+    from helpers import GOLDEN
+    case = load_case(os.path.join(GOLDEN, "rand_D3_open.npz"))
+    shapes = {i: tuple(t.shape) for i, t in case.tensors.items()}
+    main = list(range(len(case.scheme)))
+    new = C._own_layouts(case.scheme, main, shapes, torch.complex64)
+    assert new is not case.scheme and len(new) == len(case.scheme)
+    assert any(tuple(C._labels(a[1])[2]) != tuple(C._labels(b[1])[2]) for a, b in zip(new, case.scheme))
+    assert tuple(C._labels(new[-1][1])[2]) == tuple(C._labels(case.scheme[-1][1])[2])
+    want = oracle.tensor_contraction({i: t.numpy().copy() for i, t in case.tensors.items()}, case.scheme)
+    got = oracle.tensor_contraction({i: t.numpy().copy() for i, t in case.tensors.items()}, new)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    # a tail of the scheme only (the steps a small-step program did not take), and power-of-two schemes are left alone
+    tail = C._own_layouts(case.scheme, main[3:], shapes_after(case, 3), torch.complex64)
+    got = oracle.tensor_contraction(run_prefix(case, 3), tail[3:])
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    case2 = load_case(os.path.join(GOLDEN, "rand_D2_closed.npz"))
+    assert C._own_layouts(case2.scheme, list(range(len(case2.scheme))), {i: tuple(t.shape) for i, t in case2.tensors.items()},
+                          torch.complex64) is case2.scheme
+
+
+def run_prefix(case, n):
+    tensors = {i: t.numpy().copy() for i, t in case.tensors.items()}
+    oracle.tensor_contraction(tensors, case.scheme[:n])
+    return tensors
+
+
+def shapes_after(case, n):
+    return {i: tuple(t.shape) for i, t in run_prefix(case, n).items()}

@@ -21,8 +21,8 @@ def q(d):
     cls = ["".join(c for c, st in zip("ABC", (d.stride_a[i], d.stride_b[i], d.stride_c[i])) if st >= 0) for i in range(d.n_labels)]
     import collections
     cnt = collections.Counter()
-    for e, c in zip(ext, cls): cnt[c] += e.bit_length() - 1
-    info["shape"] = dict(cnt)
+    for e, c in zip(ext, cls): cnt[c] += __import__('math').log2(e)
+    info["shape"] = {k: round(v, 1) for k, v in cnt.items()}
     return info
 C._query = q
 import contextlib
@@ -42,4 +42,4 @@ rows = sorted(((e0.elapsed_time(e1), info) for info, e0, e1 in p.rows), key=lamb
 tot = sum(r[0] for r in rows)
 print(f"{sys.argv[1]}: wall {dt*1e3:.1f} ms; launches {len(rows)}: {tot:.1f} ms in kernels")
 for ms, info in rows[:int(os.environ.get("TOP", "12"))]:
-    print(f"   {ms:7.2f} ms kernel={info['kernel']} k={info['k_bits']}+{info['k2_bits']} T={info['tile_in_bits']}/{info['tile_out_bits']} runs={info['run_in_bits']}/{info['run_out_bits']} arith={info.get('arith')} tiles={info['n_tiles']} rereads={info['a_rereads']} GF={info['flops']/1e9:.1f} -> {info['flops']/ms/1e9:.1f} TF/s bits{info.get('shape','')} {info.get('note','')}")
+    print(f"   {ms:7.2f} ms kernel={info['kernel']} k={info['k_bits']}+{info['k2_bits']} T={info['tile_in_bits']}/{info['tile_out_bits']} runs={info.get('run_in_bits')}/{info.get('run_out_bits')} arith={info.get('arith')} tiles={info['n_tiles']} rereads={info['a_rereads']} GF={info['flops']/1e9:.1f} -> {info['flops']/ms/1e9:.1f} TF/s bits{info.get('shape','')} {info.get('note','')}")
