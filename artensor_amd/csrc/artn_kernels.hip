@@ -2748,6 +2748,17 @@ static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, 
     hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
     return hipGetLastError();                                                                        \
   }
+  if (g.kc == 8) { // few contracted values, one block of columns: chunks of 8, four workgroups per CU
+    if (g.nb != 1) return hipErrorInvalidValue;
+    if (g.trans) {
+      auto kern = artn_k_xgemm<1, true, 8>;
+      hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);
+    } else {
+      auto kern = artn_k_xgemm<1, false, 8>;
+      hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);
+    }
+    return hipGetLastError();
+  }
   switch (g.nb * 2 + (g.trans ? 1 : 0)) {
     case 2: ARTN_XGEMM_LAUNCH(1, false)
     case 3: ARTN_XGEMM_LAUNCH(1, true)

@@ -1489,6 +1489,10 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   x.amode = fastest_is(K, 0) ? 1 : 0;
   x.bmode = fastest_is(K, 1) ? 1 : 0;
   x.trans = fastest_is(N, 2) ? 1 : 0;
+  if (const char *e = getenv("ARTN_XG_AMODE")) x.amode = atoi(e) != 0; // (development: A/B of the copy modes)
+  if (const char *e = getenv("ARTN_XG_BMODE")) x.bmode = atoi(e) != 0;
+  x.prio = 0; // (measured: 6.72 / 3.06 ms without, 6.87 / 3.14 ms with, on the two biggest steps of the bond-dimension-3 network)
+  if (const char *e = getenv("ARTN_XG_PRIO")) x.prio = atoi(e) != 0;
   // label order inside each flattened index (innermost first): that of the tensor whose copy lanes run along it
   if (x.amode == 0) std::sort(M.begin(), M.end(), [](const Lab &u, const Lab &v) { return u.sA < v.sA; });
   else std::sort(M.begin(), M.end(), [](const Lab &u, const Lab &v) { return u.sC < v.sC; });
@@ -1523,18 +1527,25 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
     x.h_sA[i] = H[i].sA; x.h_sB[i] = H[i].sB; x.h_sC[i] = H[i].sC;
     hprod *= H[i].e;
   }
-  // 32-column blocks per tile: the count that wastes the fewest columns (ties: the wider tile)
+  // 32-column blocks per tile: the count that wastes the fewest columns (ties: the wider tile), a single block weighted down --
+  // one block per wave is 3 MFMAs per pair of LDS reads and per barrier share: 73 against 108 TFLOP/s on long contractions
+  // (216 columns: 7 tiles of 32 waste 4 %, 4 tiles of 64 waste 16 % and are still faster)
   double best = -1;
   for (int nb = 3; nb >= 1; --nb) {
     const int64_t tn = 32 * nb, tiles = (x.n.total + tn - 1) / tn;
-    const double eff = (double)x.n.total / (double)(tiles * tn);
+    const double eff = (double)x.n.total / (double)(tiles * tn) * (nb == 1 ? 0.75 : 1.0);
     if (eff > best + 1e-9) { best = eff; x.nb = nb; }
   }
-  x.cpg = (x.k.L0 + ARTN_XG_KC - 1) / ARTN_XG_KC;
+  if (const char *e = getenv("ARTN_XG_NB")) { const int v = atoi(e); if (v >= 1 && v <= 3) x.nb = v; } // (development)
+  // chunks of 8 where a tile is a handful of contracted values x at most 32 columns: those steps are latency chains per tile,
+  // and the small chunk lets four workgroups share a CU (artn_k_xgemm<1, *, 8>)
+  x.kc = (x.nb == 1 && x.k.total <= 32) ? 8 : ARTN_XG_KC;
+  if (const char *e = getenv("ARTN_XG_KC")) { const int v = atoi(e); if ((v == 8 && x.nb == 1) || v == 16) x.kc = v; }
+  x.cpg = (x.k.L0 + x.kc - 1) / x.kc;
   x.k_groups = x.k.total / x.k.L0;
   const int64_t chunks = x.k_groups * x.cpg;
   if (chunks >= lim) { p.why_generic = "extent GEMM: too many chunks per tile"; return false; }
-  x.flush_chunks = chunks > ARTN_XG_FLUSH / ARTN_XG_KC ? ARTN_XG_FLUSH / ARTN_XG_KC : 0;
+  x.flush_chunks = chunks > ARTN_XG_FLUSH / x.kc ? ARTN_XG_FLUSH / x.kc : 0;
   x.tiles_m = (x.m.total + ARTN_XG_TM - 1) / ARTN_XG_TM;
   x.tiles_n = (x.n.total + 32 * x.nb - 1) / (32 * x.nb);
   x.n_tiles = x.tiles_m * x.tiles_n * hprod;
@@ -1545,9 +1556,9 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   I.m_tile_bits = 7;
   I.n_tile_bits = 5;
   I.k_bits = 4;
-  I.lds_bytes = artn_xg_lds_bytes(x.nb);
+  I.lds_bytes = artn_xg_lds_bytes(x.nb, x.kc);
   I.n_tiles = x.n_tiles;
-  I.grid = (int32_t)std::min<int64_t>(x.n_tiles, (int64_t)n_cu * 2);
+  I.grid = (int32_t)std::min<int64_t>(x.n_tiles, (int64_t)n_cu * (x.kc == 8 ? 4 : 2));
   I.a_rereads = x.tiles_n;
   return true;
 }

@@ -52,19 +52,37 @@ __device__ __forceinline__ XgTile xg_tile(const ArtnXGemmPlan &P, unsigned hm, u
 
 __device__ __forceinline__ unsigned lds_read4(unsigned a) { return *(__attribute__((address_space(3))) unsigned *)(unsigned long)a; }
 
-template <int NB, bool TRANS>
-__global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 *__restrict__ A, const float2 *__restrict__ B,
+#ifdef XG_STAMPS // (timing probe builds only: phase marks of workgroup 0, tiles 8 and 9)
+__device__ unsigned long long xg_stamp_buf[64];
+#define XG_MARK(k)                                                                             \
+  if (blockIdx.x == 0 && tid == 0 && tile_count >= 8 && tile_count < 10) {                      \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    xg_stamp_buf[(tile_count - 8) * 16 + (k)] = __builtin_amdgcn_s_memtime();                  \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  }
+#else
+#define XG_MARK(k)
+#endif
+
+// KC: contracted values per chunk.  16; 8 for steps of a few contracted values and at most 32 columns (KC = 8, NB = 1: 36 KiB of
+// LDS and under 128 registers, so FOUR workgroups per CU: those steps are chains of LDS and memory latencies per tile --
+// 10 000 cycles per tile of a 9 x 9 step for 1 150 cycles of MFMAs -- and only more waves hide them).
+template <int NB, bool TRANS, int KC = ARTN_XG_KC>
+__global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xgemm(const float2 *__restrict__ A, const float2 *__restrict__ B,
                                                                   float2 *__restrict__ C, const ArtnXGemmPlan P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if ((unsigned)(unsigned long)(lds_byte_t *)smem != 0) __builtin_trap(); // LDS is addressed by raw byte offsets
-  constexpr int TM = ARTN_XG_TM, TN = 32 * NB, KC = ARTN_XG_KC;
+  constexpr int TM = ARTN_XG_TM, TN = 32 * NB;
+  static_assert(KC == 16 || KC == 8, "chunks of 16 or 8 contracted values");
+  constexpr int KCL = KC == 16 ? 4 : 3, RSTEP = ARTN_WG_THREADS / KC; // log2 KC; rows between two slots of a thread in mode 1
   constexpr int PA = TM + 2, PB = TN + 2;
   constexpr unsigned A_BYTES = KC * PA * 8, B_BYTES = KC * PB * 8, STAGE = A_BYTES + B_BYTES;
-  constexpr unsigned LEV = 2 * STAGE;                       // level tables: 10 x 256 x 4 bytes
+  constexpr unsigned LEV = 2 * STAGE;                       // level tables: 8 x 256 x 4 bytes (m, n) + 2 x 272 x 4 (k)
   constexpr unsigned T_MA0 = LEV, T_MC0 = LEV + 1024, T_MA1 = LEV + 2048, T_MC1 = LEV + 3072, T_NB0 = LEV + 4096, T_NC0 = LEV + 5120,
-                     T_NB1 = LEV + 6144, T_NC1 = LEV + 7168, T_KA = LEV + 8192, T_KB = LEV + 9216;
-  constexpr unsigned TT = LEV + 10240;                      // tile tables: 2 sets x (rowA, rowC, colB, colC) x 128 x 4 bytes
-  constexpr int NA = TM * KC / ARTN_WG_THREADS, NBL = TN * KC / ARTN_WG_THREADS; // loads per thread and chunk: 8 and 2 NB
+                     T_NB1 = LEV + 6144, T_NC1 = LEV + 7168, T_KA = LEV + 8192, T_KB = T_KA + ARTN_XG_KTAB * 4;
+  // (the k tables carry 16 more entries, copies of the last one: a chunk reads kbase .. kbase + 15 without clamping)
+  constexpr unsigned TT = T_KB + ARTN_XG_KTAB * 4;          // tile tables: 2 sets x (rowA, rowC, colB, colC) x 128 x 4 bytes
+  constexpr int NA = TM * KC / ARTN_WG_THREADS, NBL = TN * KC / ARTN_WG_THREADS; // loads per thread and chunk: 8 and 2 NB (KC = 16)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,7 +94,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
       unsigned o0, o1;
       artn_xg_decode(S, 0, S.n0, (unsigned)tid, o0, o1);
       lds_write4(t0 + 4u * tid, o0);
-      lds_write4(t0 + 1024u + 4u * tid, o1);
+      lds_write4((two ? t0 + 1024u : T_KB) + 4u * tid, o1);
     }
     if (two && tid < S.L1) {
       unsigned o0, o1;
@@ -88,17 +106,37 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
   level_tables(P.m, T_MA0, T_MA1, true);
   level_tables(P.n, T_NB0, T_NB1, true);
   level_tables(P.k, T_KA, 0u, false);
+  if (tid < ARTN_XG_KC) { // (padding of the k tables)
+    unsigned o0, o1;
+    artn_xg_decode(P.k, 0, P.k.n0, (unsigned)P.k.L0 - 1u, o0, o1);
+    lds_write4(T_KA + 4u * (P.k.L0 + tid), o0);
+    lds_write4(T_KB + 4u * (P.k.L0 + tid), o1);
+  }
   // ---- per-tile tables: element offsets of the tile's rows in A and C, of its columns in B and C (set `s`)
   // Rows (columns) of a tile are consecutive values of the flattened index: index = ((q1 L1) + i1) L0 + i0.  The tile's first
   // value is split by two uniform divisions; a row adds its position to i0 and carries.  What lies above the two table
   // levels (q1) is decoded label by label -- but a workgroup walks CONSECUTIVE tiles, so q1 changes once in L0 L1 / 128
   // tiles and every thread keeps the decode of the q1 it met last.
+  // The two divisions themselves are skipped when the tile follows the one this thread built last (first + 128: a run of
+  // row tiles), and the column tables are rebuilt only when the column tile changes (once per run).
   unsigned c_q1 = 0xffffffffu, c_o0 = 0, c_o1 = 0;
+  unsigned s_first = 0xffffffffu, s_i0b = 0, s_i1b = 0, s_q1b = 0;
   auto build_side = [&](const ArtnXSide &S, unsigned first, int loc, unsigned t0, unsigned t1, unsigned dst) {
     const unsigned tot = (unsigned)S.total, L0 = (unsigned)S.L0, L1 = (unsigned)S.L1;
     unsigned pos = (unsigned)loc;
     if (first + pos >= tot) pos = tot - 1 - first; // rows / columns past the end read valid memory and are never stored
-    const unsigned q0b = first / L0, i0b = first - q0b * L0, q1b = q0b / L1, i1b = q0b - q1b * L1;
+    unsigned i0b, i1b, q1b;
+    if (first == s_first + ARTN_XG_TM && L0 >= 32u) {
+      i0b = s_i0b + ARTN_XG_TM; i1b = s_i1b; q1b = s_q1b;
+      while (i0b >= L0) { i0b -= L0; ++i1b; }
+      while (i1b >= L1) { i1b -= L1; ++q1b; }
+    } else {
+      const unsigned q0b = first / L0;
+      i0b = first - q0b * L0;
+      q1b = q0b / L1;
+      i1b = q0b - q1b * L1;
+    }
+    s_first = first; s_i0b = i0b; s_i1b = i1b; s_q1b = q1b;
     unsigned i0 = i0b + pos, i1 = i1b, q1 = q1b;
     while (i0 >= L0) { i0 -= L0; ++i1; }
     while (i1 >= L1) { i1 -= L1; ++q1; }
@@ -111,28 +149,20 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
     lds_write4(dst + 4u * loc, o0);        // rowA / colB
     lds_write4(dst + 512u + 4u * loc, o1); // rowC / colC
   };
-  auto build_tile = [&](const XgTile &T, unsigned set) { // waves 0, 1: the rows; waves 2, 3: the columns
-    if (wave < 2) build_side(P.m, T.m0, tid, T_MA0, T_MA1, TT + set * 2048u);
-    else if (tid - TM < TN) build_side(P.n, T.n0, tid - TM, T_NB0, T_NB1, TT + set * 2048u + 1024u);
+  // tile tables: rows (rowA, rowC) in set `rs` at TT + 1024 rs, columns (colB, colC) in set `cs` at TT + 2048 + 1024 cs
+  auto build_tile = [&](const XgTile &T, unsigned rs, unsigned cs, bool cols) { // waves 0, 1: the rows; waves 2, 3: the columns
+    if (wave < 2) build_side(P.m, T.m0, tid, T_MA0, T_MA1, TT + rs * 1024u);
+    else if (cols && tid - TM < TN) build_side(P.n, T.n0, tid - TM, T_NB0, T_NB1, TT + 2048u + cs * 1024u);
   };
 
-  // ---- copy slots: element (row, kk) of slot u of this thread
+  // ---- copy slots.  An operand's copy lanes run along its free index (mode 0) or along k (mode 1):
+  //   A, mode 0: row = t & 127,                 kk = (t >> 7) + 2 u     A, mode 1: kk = t & 15, row = (t >> 4) + 16 u    (u < 8)
+  //   B, mode 0: col = (t & 31) + 32 (u % NB),  kk = (t >> 5) + 8 (u / NB)   B, mode 1: kk = t & 15, col = (t >> 4) + 16 u  (u < 2 NB)
+  //   (chunks of 16; with chunks of 8 a thread has half the slots and mode 1 reads kk = t & 7, row / col = (t >> 3) + 32 u)
+  // so that per chunk a thread reads one or two table entries per load from LDS at compile-time offsets and its LDS
+  // destinations differ by compile-time offsets too: the copy costs a handful of vector instructions per load (the first
+  // version recomputed row, kk, clamps and addresses per slot: 7.5 VALU instructions per MFMA, MFMA busy 0.53).
   const int amode = P.amode, bmode = P.bmode;
-  // (the thread id is passed in, opaque per call: otherwise every slot's row, kk, LDS address and table address -- 100+
-  //  registers -- is hoisted out of the chunk loop and the accumulators spill; shifts and masks instead of branches)
-  const int a_rs = amode ? 4 : 0, a_rm = amode ? 15 : TM - 1, a_rstep = amode ? 16 : 0;
-  const int a_ks = amode ? 0 : 7, a_km = amode ? 15 : 1, a_kstep = amode ? 0 : 2;
-  auto a_slot = [&](int t, int u, int &row, int &kk) {
-    row = ((t >> a_rs) & a_rm) + a_rstep * u;
-    kk = ((t >> a_ks) & a_km) + a_kstep * u;
-  };
-  auto b_slot = [&](int t, int u, int &col, int &kk) {
-    const int e = t + ARTN_WG_THREADS * u, k0 = e / TN, c0 = e - k0 * TN;
-    const int k1 = t & 15, c1 = (t >> 4) + 16 * u;
-    kk = bmode ? k1 : k0;
-    col = bmode ? c1 : c0;
-  };
-
   const unsigned K0 = (unsigned)P.k.L0;
   const int cpg = P.cpg;
   const long n_chunks = (long)P.k_groups * cpg;
@@ -143,8 +173,17 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
   int kvalid_next = 0; // valid contracted values of the chunk in flight
   v2f_t va[NA], vb[NBL];
   const char *Ac = reinterpret_cast<const char *>(A), *Bc = reinterpret_cast<const char *>(B);
+  auto ld = [&](const char *base, unsigned off) {
+#ifdef XG_ABLATE_MEM // (timing-only probe builds, tools/probes/xgemm_probe.hip: never in the library)
+    v2f_t v;
+    asm volatile("" : "=v"(v) : "s"(base), "v"(off));
+    return v;
+#else
+    return *reinterpret_cast<const v2f_t *>(base + ((unsigned long)off << 3));
+#endif
+  };
 
-  auto issue = [&](const XgTile &T, unsigned set, bool first_of_tile) {
+  auto issue = [&](const XgTile &T, unsigned rs, unsigned cs, bool first_of_tile) {
     if (first_of_tile) { iq = 0; ig = 0; gA = 0; gB = 0; }
     else if (++iq == cpg) {
       iq = 0;
@@ -156,46 +195,69 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
     }
     const unsigned kbase = (unsigned)iq * KC;
     kvalid_next = (int)(K0 - kbase < (unsigned)KC ? K0 - kbase : (unsigned)KC);
-    const unsigned tt = TT + set * 2048u;
-    int t = tid;
-    OPAQUE_V(t);
+    const unsigned ttr = TT + rs * 1024u, ttc = TT + 2048u + cs * 1024u;
+    unsigned t = (unsigned)tid;
+    OPAQUE_V(t); // (nothing derived from the thread id is hoisted out of the chunk loop: the accumulators need the registers)
+    if (amode == 0) {
+      const unsigned base = T.hA + gA + lds_read4(ttr + 4u * (t & 127u));
+      const unsigned ka = T_KA + 4u * (kbase + (t >> 7));
 #pragma unroll
-    for (int u = 0; u < NA; ++u) {
-      int row, kk;
-      a_slot(t, u, row, kk);
-      unsigned kc = kbase + (unsigned)kk;
-      if (kc >= K0) kc = K0 - 1;
-      const unsigned off = T.hA + gA + lds_read4(tt + 4u * row) + lds_read4(T_KA + 4u * kc);
-      va[u] = *reinterpret_cast<const v2f_t *>(Ac + ((unsigned long)off << 3));
+      for (int u = 0; u < NA; ++u) va[u] = ld(Ac, base + lds_read4(ka + 8u * u));
+    } else {
+      const unsigned base = T.hA + gA + lds_read4(T_KA + 4u * (kbase + (t & (KC - 1u))));
+      const unsigned ra = ttr + 4u * (t >> KCL);
+#pragma unroll
+      for (int u = 0; u < NA; ++u) va[u] = ld(Ac, base + lds_read4(ra + 4u * RSTEP * u));
     }
+    if (bmode == 0) {
+      const unsigned kb = T_KB + 4u * (kbase + (t >> 5)), cb = ttc + 4u * (t & 31u);
+      const unsigned k0 = T.hB + gB + lds_read4(kb), k1 = KC == 16 ? T.hB + gB + lds_read4(kb + 32u) : 0u;
+      unsigned cv[NB];
 #pragma unroll
-    for (int u = 0; u < NBL; ++u) {
-      int col, kk;
-      b_slot(t, u, col, kk);
-      unsigned kc = kbase + (unsigned)kk;
-      if (kc >= K0) kc = K0 - 1;
-      const unsigned off = T.hB + gB + lds_read4(tt + 1024u + 4u * col) + lds_read4(T_KB + 4u * kc);
-      vb[u] = *reinterpret_cast<const v2f_t *>(Bc + ((unsigned long)off << 3));
+      for (int b = 0; b < NB; ++b) cv[b] = lds_read4(cb + 128u * b);
+#pragma unroll
+      for (int u = 0; u < NBL; ++u) vb[u] = ld(Bc, (u / NB ? k1 : k0) + cv[u % NB]);
+    } else {
+      const unsigned base = T.hB + gB + lds_read4(T_KB + 4u * (kbase + (t & (KC - 1u))));
+      const unsigned cb = ttc + 4u * (t >> KCL);
+#pragma unroll
+      for (int u = 0; u < NBL; ++u) vb[u] = ld(Bc, base + lds_read4(cb + 4u * RSTEP * u));
     }
   };
   auto fill = [&](unsigned buf) { // registers -> LDS images; contracted values past the end of a group are zeros
-    int t = tid;
+    unsigned t = (unsigned)tid;
     OPAQUE_V(t);
+    const bool part = kvalid_next < KC; // (uniform: the last chunk of a group)
+    const int kv = kvalid_next;
+    if (amode == 0) {
+      const unsigned d = buf + ((t >> 7) * PA + (t & 127u)) * 8u;
+      const int kh = (int)(t >> 7);
 #pragma unroll
-    for (int u = 0; u < NA; ++u) {
-      int row, kk;
-      a_slot(t, u, row, kk);
-      v2f_t v = va[u];
-      if (kk >= kvalid_next) v = v2f_t{0.f, 0.f};
-      lds_write8(buf + (unsigned)(kk * PA + row) * 8u, v);
+      for (int u = 0; u < NA; ++u) {
+        v2f_t v = va[u];
+        if (part && kh + 2 * u >= kv) v = v2f_t{0.f, 0.f};
+        lds_write8(d + (unsigned)u * (2u * PA * 8u), v);
+      }
+    } else {
+      const unsigned d = buf + ((t & (KC - 1u)) * PA + (t >> KCL)) * 8u;
+      const bool z = part && (int)(t & (KC - 1u)) >= kv;
+#pragma unroll
+      for (int u = 0; u < NA; ++u) lds_write8(d + 8u * RSTEP * u, z ? v2f_t{0.f, 0.f} : va[u]);
     }
+    if (bmode == 0) {
+      const unsigned d = buf + A_BYTES + ((t >> 5) * PB + (t & 31u)) * 8u;
+      const int kh = (int)(t >> 5);
 #pragma unroll
-    for (int u = 0; u < NBL; ++u) {
-      int col, kk;
-      b_slot(t, u, col, kk);
-      v2f_t v = vb[u];
-      if (kk >= kvalid_next) v = v2f_t{0.f, 0.f};
-      lds_write8(buf + A_BYTES + (unsigned)(kk * PB + col) * 8u, v);
+      for (int u = 0; u < NBL; ++u) {
+        v2f_t v = vb[u];
+        if (part && kh + 8 * (u / NB) >= kv) v = v2f_t{0.f, 0.f};
+        lds_write8(d + (unsigned)(u / NB) * (8u * PB * 8u) + (unsigned)(u % NB) * 256u, v);
+      }
+    } else {
+      const unsigned d = buf + A_BYTES + ((t & (KC - 1u)) * PB + (t >> KCL)) * 8u;
+      const bool z = part && (int)(t & (KC - 1u)) >= kv;
+#pragma unroll
+      for (int u = 0; u < NBL; ++u) lds_write8(d + 8u * RSTEP * u, z ? v2f_t{0.f, 0.f} : vb[u]);
     }
   };
 
@@ -215,10 +277,10 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
   if (R >= n_runs) return;
   unsigned r_tn = R % tiles_n, r_hm0 = (R / tiles_n) * run;
   XgTile T = xg_tile(P, r_hm0, r_tn), Tn = T;
-  unsigned set = 0;
-  build_tile(T, 0u);
+  unsigned set = 0, cset = 0; // table sets of the current tile: rows, columns
+  build_tile(T, 0u, 0u, true);
   __syncthreads();
-  issue(T, 0u, true);
+  issue(T, 0u, 0u, true);
   int kvalid = kvalid_next;
   fill(0u);
   __syncthreads();
@@ -226,8 +288,12 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
   const unsigned lane_x = (unsigned)(h * PA + 32 * wave + j) * 8u;
   const unsigned lane_w = A_BYTES + (unsigned)(h * PB + j) * 8u;
   const int flush_chunks = P.flush_chunks;
+  // one of the two workgroups of a CU runs its MFMA loops at raised priority: what breaks their lockstep in artn_k_bits
+  const bool prio = P.prio && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1); // HW_ID.wave_id bit 0
 
-  for (;;) {
+  int tile_count = 0;
+  for (;; ++tile_count) {
+    XG_MARK(0);
     // the successor of this tile in the workgroup's sequence
     bool more_tiles = true;
     if (pos + 1 < run && r_hm0 + pos + 1 < total_hm) ++pos;
@@ -238,31 +304,52 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
       if (more_tiles) { r_tn = R % tiles_n; r_hm0 = (R / tiles_n) * run; }
     }
     if (more_tiles) Tn = xg_tile(P, r_hm0 + pos, r_tn);
+    XG_MARK(1);
     f32x16 acc[NB * 3];
 #pragma unroll
     for (int b = 0; b < NB * 3; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
     int since_flush = 0;
-    bool flushed_before = false;
+    bool flushed_before = false, cols_change = false;
     for (long c = 0; c < n_chunks; ++c) {
       const bool last = c + 1 == n_chunks;
-      bool have_next = true;
+      bool have_next = true, new_cols = false;
+      // the first operands of this chunk are read while the next chunk's loads are being issued
+      v2f_t X0, X1, W0[NB], W1[NB];
+      unsigned xo = cur * STAGE + lane_x, wo = cur * STAGE + lane_w;
+      X0 = lds_read8(xo);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) W0[b] = lds_read8(wo + (unsigned)b * 256u);
+      XG_MARK(2);
       if (!last) {
-        issue(T, set, false);
+        issue(T, set, cset, false);
       } else {
         have_next = more_tiles;
-        if (have_next) { // (the other table set was last read in the previous tile's epilogue, a barrier ago)
-          build_tile(Tn, set ^ 1u);
+        if (have_next) { // (the other table sets were last read in an earlier tile's epilogue, at least a barrier ago)
+          new_cols = Tn.n0 != T.n0;
+          cols_change = new_cols;
+#ifndef XG_ABLATE_BUILD // (timing probe: every tile uses stale tables)
+          build_tile(Tn, set ^ 1u, cset ^ 1u, new_cols);
+#endif
+          XG_MARK(3);
           __syncthreads();
-          issue(Tn, set ^ 1u, true);
+          XG_MARK(4);
+          issue(Tn, set ^ 1u, new_cols ? cset ^ 1u : cset, true);
         }
       }
       // ---- multiply chunk `cur`: pairs of contracted values, two per trip (a group's last chunk is zero-padded in LDS, so a
-      //      trip may run one pair past ceil(kvalid / 2); the operands of pair s + 1 are read under the MFMAs of pair s)
+      //      trip may run one pair past ceil(kvalid / 2); the operands of pair s + 1 are read under the MFMAs of pair s).
+      //      The next chunk goes registers -> LDS in the MIDDLE of the loop: its loads were issued a thousand cycles ago,
+      //      and what is left between the last MFMA and the barrier is nothing (two workgroups of a CU fall into lockstep --
+      //      both in their MFMA loops, then both copying -- so whatever a wave does outside the loop, the pipe is idle for).
       {
-        const unsigned xa = cur * STAGE + lane_x, wa = cur * STAGE + lane_w;
         auto mac = [&](const v2f_t &x, const v2f_t (&w)[NB]) {
+#ifdef XG_ABLATE_MFMA
+#pragma unroll
+          for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(x), "v"(w[b]));
+          return;
+#endif
           const float xs = x.x + x.y;
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
@@ -284,10 +371,9 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
           for (int b = 0; b < NB; ++b) w[b] = lds_read8(wo + (unsigned)b * 256u);
         };
         constexpr unsigned XS = 2u * PA * 8u, WS = 2u * PB * 8u; // bytes between two pairs
-        const int trips = (kvalid + 3) >> 2;
-        v2f_t X0, X1, W0[NB], W1[NB];
-        unsigned xo = xa, wo = wa;
-        load_ops(xo, wo, X0, W0);
+        XG_MARK(5);
+        const int trips = (kvalid + 3) >> 2, fill_at = trips > 1 ? 1 : 0;
+        if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
         for (int q = 0; q < trips; ++q) {
           load_ops(xo + XS, wo + WS, X1, W1);
@@ -298,56 +384,61 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
           load_ops(xo, wo, X0, W0); // (after the last trip: a pair of the next region, read and dropped)
           __builtin_amdgcn_sched_barrier(0);
           mac(X1, W1);
+          if (q == fill_at && have_next) fill((cur ^ 1u) * STAGE);
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
       }
+      XG_MARK(6);
       ++since_flush;
       const bool flush = last || (flush_chunks > 0 && since_flush == flush_chunks);
+#ifdef XG_ABLATE_EPI
+      if (false) {
+#else
       if (flush) {
-        // ---- epilogue: accumulators -> C (a later partial sum of the tile is added to what the earlier ones left)
-        const unsigned tt = TT + set * 2048u;
+#endif
+        // ---- epilogue: accumulators -> C (a later partial sum of the tile is added to what the earlier ones left).
+        //      Four consecutive table entries per LDS read; groups of four registers that lie past the last row / column are
+        //      skipped as a whole (a 9-column step stores 2 of its 4 groups); no predicates inside full tiles.  (The first
+        //      version -- one table read, one 64-bit address and two compares per stored element -- was 0.8 of the 1.9 ms
+        //      of a 27 x 27 step and 1.3 of the 2.8 ms of a 9 x 9 step, WITHOUT its stores.)
+        const unsigned ttr = TT + set * 1024u + 512u, ttc = TT + 2048u + cset * 1024u + 512u; // rowC, colC
         const unsigned Mtot = (unsigned)P.m.total, Ntot = (unsigned)P.n.total;
-        char *Cc = reinterpret_cast<char *>(C);
+        const unsigned rows_left = Mtot - T.m0, cols_left = Ntot - T.n0; // (uniform; may exceed the tile)
+        const bool full = rows_left >= (unsigned)TM && cols_left >= (unsigned)TN;
+        char *Cc = reinterpret_cast<char *>(C) + ((unsigned long)T.hC << 3);
         unsigned jj = (unsigned)j, hh4 = 4u * (unsigned)h; // (opaque: no store address is computed before its turn)
         OPAQUE_V(jj);
         OPAQUE_V(hh4);
-        if constexpr (!TRANS) {
-          const unsigned m_loc = 32u * wave + jj;
-          const bool m_ok = T.m0 + m_loc < Mtot;
-          const unsigned rowc = T.hC + lds_read4(tt + 512u + 4u * m_loc);
+        // lanes run along `lane side` (rows if !TRANS, columns if TRANS), registers along the other (`reg side`)
+        const unsigned lane_left = TRANS ? cols_left : rows_left, reg_left = TRANS ? rows_left : cols_left;
+        const unsigned lane_tab = TRANS ? ttc : ttr, reg_tab = TRANS ? ttr : ttc;
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NB; ++b) {
+          // (TRANS: the lane's column depends on the block; !TRANS: its row does not)
+          const unsigned lane_loc = TRANS ? 32u * b + jj : 32u * wave + jj;
+          const bool lane_ok = full || lane_loc < lane_left;
+          char *lp = Cc + ((unsigned long)lds_read4(lane_tab + 4u * lane_loc) << 3);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const unsigned n_loc = 32u * b + (unsigned)((r & 3) + 8 * (r >> 2)) + hh4;
-              const unsigned off = rowc + lds_read4(tt + 1536u + 4u * n_loc);
+          for (int g = 0; g < 4; ++g) {
+            const unsigned reg0 = (TRANS ? 32u * wave : 32u * b) + 8u * g; // first row / column of this group of registers (+ 4 h)
+            if (!full && reg0 >= reg_left) continue; // (uniform)
+            const u32x4_t tab = *(__attribute__((address_space(3))) u32x4_t *)(unsigned long)(reg_tab + 4u * (reg0 + hh4));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = 4 * g + q;
               const float t1 = acc[3 * b][r], t2 = acc[3 * b + 1][r], t3 = acc[3 * b + 2][r];
               v2f_t val = {t1 - t2, t3 - t1 - t2};
-              if (m_ok && T.n0 + n_loc < Ntot) {
-                v2f_t *dst = reinterpret_cast<v2f_t *>(Cc + ((unsigned long)off << 3));
+              if (lane_ok && (full || reg0 + hh4 + (unsigned)q < reg_left)) {
+                v2f_t *dst = reinterpret_cast<v2f_t *>(lp + ((unsigned long)tab[q] << 3));
                 if (flushed_before) val += __builtin_nontemporal_load(dst); // (written by this lane at the previous flush: read past the L1)
+#ifdef XG_ABLATE_STORE
+                asm volatile("" ::"v"(val), "v"(dst));
+#else
                 *dst = val;
+#endif
               }
-              if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0); // (no more than four addresses alive at a time)
             }
-        } else {
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const unsigned n_loc = 32u * b + jj;
-            const bool n_ok = T.n0 + n_loc < Ntot;
-            const unsigned colc = T.hC + lds_read4(tt + 1536u + 4u * n_loc);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const unsigned m_loc = 32u * wave + (unsigned)((r & 3) + 8 * (r >> 2)) + hh4;
-              const unsigned off = colc + lds_read4(tt + 512u + 4u * m_loc);
-              const float t1 = acc[3 * b][r], t2 = acc[3 * b + 1][r], t3 = acc[3 * b + 2][r];
-              v2f_t val = {t1 - t2, t3 - t1 - t2};
-              if (n_ok && T.m0 + m_loc < Mtot) {
-                v2f_t *dst = reinterpret_cast<v2f_t *>(Cc + ((unsigned long)off << 3));
-                if (flushed_before) val += __builtin_nontemporal_load(dst); // (written by this lane at the previous flush: read past the L1)
-                *dst = val;
-              }
-              if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
+            __builtin_amdgcn_sched_barrier(0); // (no more than four addresses alive at a time)
           }
         }
         flushed_before = true;
@@ -359,13 +450,15 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_xgemm(const float2 
             for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
         }
       }
-      if (have_next) fill((cur ^ 1u) * STAGE);
+      XG_MARK(7);
       kvalid = kvalid_next;
       __syncthreads();
+      XG_MARK(8);
       cur ^= 1u;
     }
     if (!more_tiles) break;
     T = Tn;
     set ^= 1u;
+    if (cols_change) cset ^= 1u;
   }
 }

@@ -22,6 +22,7 @@
 #define ARTN_XG_TM 128    /* rows (values of m) per tile: 4 waves x 32 */
 #define ARTN_XG_KC 16     /* contracted values per LDS chunk */
 #define ARTN_XG_LEVEL 256 /* entries of one level table */
+#define ARTN_XG_KTAB (ARTN_XG_LEVEL + ARTN_XG_KC) /* the k tables are padded by one chunk: no clamping in the copy loop */
 #define ARTN_XG_FLUSH 4096 /* contracted values per fp32 partial sum (as ARTN_GEMM_FLUSH_LOG2) */
 
 // One flattened index: labels innermost first, each with its extent and its element stride in the two tensors that
@@ -46,8 +47,10 @@ struct ArtnXGemmPlan {
                                //    of a store run along n (accumulator register <-> row of m); 0: lanes run along m
   int32_t amode, bmode;        // copy lanes of an operand run along its free index (0) or along k (1): whichever its fastest label is
   int32_t swapped;             // 1: the kernel's first operand is the caller's B
-  int32_t cpg;                 // chunks per group of k.L0 contracted values: ceil(k.L0 / 16)
+  int32_t cpg;                 // chunks per group of k.L0 contracted values: ceil(k.L0 / kc)
   int32_t flush_chunks;        // partial sums leave the registers every this many chunks (read-add-write of C); 0: never
+  int32_t prio;                // 1: the workgroup in the odd wave slots runs its MFMA loops at s_setprio 1
+  int32_t kc;                  // contracted values per chunk: 16, or 8 (few contracted values, nb = 1: four workgroups per CU)
   int32_t pad_;
   int64_t k_groups;            // k.total / k.L0
   int64_t tiles_m, tiles_n, n_tiles; // n_tiles = tiles_m * tiles_n * prod(h_ext); tile index = (h, tile of m, tile of n), n fastest
@@ -56,10 +59,10 @@ struct ArtnXGemmPlan {
 // LDS layout shared by the kernel, the launcher and the emulator (byte offsets).
 static inline int artn_xg_pitch_a() { return ARTN_XG_TM + 2; }          // elements between two contracted values of the A image
 static inline int artn_xg_pitch_b(int nb) { return 32 * nb + 2; }       // ... of the B image
-static inline int artn_xg_stage_bytes(int nb) { return ARTN_XG_KC * (artn_xg_pitch_a() + artn_xg_pitch_b(nb)) * 8; }
-static inline int artn_xg_level_bytes() { return 10 * ARTN_XG_LEVEL * 4; } // mA0 mC0 mA1 mC1 nB0 nC0 nB1 nC1 kA kB
+static inline int artn_xg_stage_bytes(int nb, int kc) { return kc * (artn_xg_pitch_a() + artn_xg_pitch_b(nb)) * 8; }
+static inline int artn_xg_level_bytes() { return 8 * ARTN_XG_LEVEL * 4 + 2 * ARTN_XG_KTAB * 4; } // mA0 mC0 mA1 mC1 nB0 nC0 nB1 nC1, kA kB
 static inline int artn_xg_tiletab_bytes() { return 4 * ARTN_XG_TM * 4; }   // rowA rowC colB colC of one tile
-static inline int artn_xg_lds_bytes(int nb) { return 2 * artn_xg_stage_bytes(nb) + artn_xg_level_bytes() + 2 * artn_xg_tiletab_bytes(); }
+static inline int artn_xg_lds_bytes(int nb, int kc) { return 2 * artn_xg_stage_bytes(nb, kc) + artn_xg_level_bytes() + 2 * artn_xg_tiletab_bytes(); }
 
 // Mixed-radix decode of `idx` over labels [first, first + count) of a side: the two element offsets.
 #if defined(__HIPCC__)

@@ -785,7 +785,7 @@ static void run_pgemm(const ArtnPackPlan &P, const cf *A0, const cf *B0, cf *C) 
 // and accumulator maps of both operand roles (TRANS), the partial-sum flush and the predicated stores.
 static void run_xgemm(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C) {
   const cf *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
-  const int NB = P.nb, TM = ARTN_XG_TM, TN = 32 * NB, KC = ARTN_XG_KC, PA = artn_xg_pitch_a(), PB = artn_xg_pitch_b(NB);
+  const int NB = P.nb, TM = ARTN_XG_TM, TN = 32 * NB, KC = P.kc, KCL = KC == 16 ? 4 : 3, RSTEP = 256 / KC, PA = artn_xg_pitch_a(), PB = artn_xg_pitch_b(NB);
   // level tables
   std::vector<uint32_t> mA0(256), mC0(256), mA1(256), mC1(256), nB0(256), nC0(256), nB1(256), nC1(256), kA(256), kB(256);
   auto level = [&](const ArtnXSide &S, std::vector<uint32_t> &a0, std::vector<uint32_t> &c0, std::vector<uint32_t> *a1, std::vector<uint32_t> *c1) {
@@ -839,7 +839,7 @@ static void run_xgemm(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C)
       for (int tid = 0; tid < 256; ++tid) {
         for (int u = 0; u < TM * KC / 256; ++u) {
           int row, kk;
-          if (P.amode) { kk = tid & 15; row = (tid >> 4) + 16 * u; } else { row = tid & (TM - 1); kk = (tid >> 7) + 2 * u; }
+          if (P.amode) { kk = tid & (KC - 1); row = (tid >> KCL) + RSTEP * u; } else { row = tid & (TM - 1); kk = (tid >> 7) + 2 * u; }
           uint32_t kc = kbase + (uint32_t)kk;
           if (kc >= K0) kc = K0 - 1;
           const cf v = A[(uint32_t)(hA + gA + rowA[row] + kA[kc])];
@@ -847,7 +847,7 @@ static void run_xgemm(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C)
         }
         for (int u = 0; u < TN * KC / 256; ++u) {
           int col, kk;
-          if (P.bmode) { kk = tid & 15; col = (tid >> 4) + 16 * u; } else { const int e = tid + 256 * u; kk = e / TN; col = e - kk * TN; }
+          if (P.bmode) { kk = tid & (KC - 1); col = (tid >> KCL) + RSTEP * u; } else { col = (tid & 31) + 32 * (u % NB); kk = (tid >> 5) + 8 * (u / NB); }
           uint32_t kc = kbase + (uint32_t)kk;
           if (kc >= K0) kc = K0 - 1;
           const cf v = B[(uint32_t)(hB + gB + colB[col] + kB[kc])];
@@ -903,7 +903,7 @@ extern "C" int artn_emulate_xgemm(const ArtnStepDesc *d, const void *A, const vo
   memset(&p.info, 0, sizeof(p.info));
   if (!artn::make_xgemm(d, p, 256, 1)) return ARTN_E_UNSUPPORTED;
   if (info) *info = p.info;
-  if (modes) { modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; }
+  if (modes) { modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; modes[6] = p.xg.kc; }
   run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
   return 0;
 }

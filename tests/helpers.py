@@ -416,7 +416,7 @@ def emulate_xgemm(eq, a, b):
                                  torch.complex64)
     out = np.full(out_shape, np.nan + 0j, dtype=np.complex64)
     info = N.ArtnStepInfo()
-    modes = (ctypes.c_int32 * 6)()
+    modes = (ctypes.c_int32 * 7)()
     emu = emulator()
     emu.artn_emulate_xgemm.restype = ctypes.c_int
     # (strided views: the emulator takes the base pointer of the view, like the kernel)
@@ -425,5 +425,5 @@ def emulate_xgemm(eq, a, b):
     if rc == -2:
         return None, None, None
     assert rc == 0, rc
-    names = ("amode", "bmode", "trans", "swapped", "nb", "flush_chunks")
+    names = ("amode", "bmode", "trans", "swapped", "nb", "flush_chunks", "kc")
     return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}, dict(zip(names, modes))
