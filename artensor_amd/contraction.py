@@ -1235,7 +1235,9 @@ def tensor_contraction(tensors, scheme, accumulate_into=None):
     `collect_tensor`, reference simulation.py:114): the result is ADDED to it and it is returned.  When the last launch of
     the scheme is a state-streaming step or pair the add happens in that launch's store phase (artn_contract_acc /
     artn_contract2_acc: the slice's result never exists in memory); otherwise the scheme runs as usual and the result is
-    added with artn_axpy_c64.
+    added with artn_axpy_c64.  With accumulate_into the entry of `tensors` that the last step rebinds is NOT the slice's
+    result (none exists): it aliases the accumulator -- the running sum -- and must not be read as the reference's
+    `tensors[i]`.
 
     Behind the unchanged entry point the scheme is compiled once (per scheme object and leaf
     shapes) into a launch list; two consecutive steps on the same big tensor execute as ONE
@@ -1308,7 +1310,12 @@ def tensor_contraction(tensors, scheme, accumulate_into=None):
                 continue
             b = _one_scalar(dtype, device) if op.j is _ONE else tensors[op.j]
             fused_acc = False
-            if op is last_op and acc_ok and op.d3 is None and getattr(op, "acc", None) is not False:
+            if op is last_op and acc_ok and op.d3 is None and getattr(op, "acc", None) is None:
+                # (decided once per compiled op: a last step that would run packed -- it wants a workspace the accumulating
+                #  entry point does not take -- or has an empty result keeps the separate add)
+                kern = (op.info or _step_info_cached(op.d1))["kernel"] if op.d2 is None else N.KERNEL_BITS_MFMA
+                op.acc = kern == N.KERNEL_BITS_MFMA and accumulate_into.numel() > 0
+            if op is last_op and acc_ok and op.d3 is None and getattr(op, "acc", None) is True:
                 # the slice loop's `collect += result` in the store phase of the last launch
                 if profiler is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1443,13 +1450,25 @@ def check_gather_flag(what="gather"):
                            "(the reference raises IndexError, contraction.py:192-195)")
 
 
+_single_row_cache = _Bounded(4096)   # id(index tensor) -> (index tensor, its one entry)
+
+
 def _single_row(idx, t):
     """the row an index list of ONE entry selects from t (reference semantics: `t[idx]`, negative counts from the end,
     out of range raises as contraction.py:192-195 would die), or None when it selects several rows or t has no rows"""
-    if not isinstance(idx, torch.Tensor) or idx.numel() != 1 or t.dim() == 0:
+    # (a 0-d index would DROP the dimension in the reference's t[idx]: only 1-d index lists of one entry are row selects)
+    if not isinstance(idx, torch.Tensor) or idx.dim() != 1 or idx.numel() != 1 or t.dim() == 0:
         return None
     rows = t.shape[0]
-    v = int(idx.reshape(-1)[0])
+    # the value is read ONCE per index tensor (a device-resident index would cost a host synchronisation per step and per
+    # slice here, and int() of it is illegal during HIP-graph capture): cached like _is_identity / _device_index
+    key = id(idx)
+    hit = _single_row_cache.get(key)
+    if hit is not None and hit[0] is idx:
+        v = hit[1]
+    else:
+        v = int(idx.reshape(-1)[0])
+        _single_row_cache[key] = (idx, v)
     if v < -rows or v >= rows:
         raise RuntimeError(f"row index out of range: {v} for {rows} rows")
     # (a row of one element would be an 8-byte view: the tiled kernels want 16-byte aligned operands)
@@ -1926,6 +1945,46 @@ def _merge_bits(bits_i, bits_j, loc_i, loc_j):
     return "".join(bits_i[loc_i.index(k)] if k in loc_i else bits_j[loc_j.index(k)] for k in range(n))
 
 
+class _BitTable:
+    """The bitstrings as a 0/1 matrix: `packed(cols)` = the integers whose binary digits are the chosen columns, first
+    column most significant -- int(''.join(b[k] for k in cols), 2) for every bitstring at once.  (The reference selects
+    and compares substrings bitstring by bitstring, contraction.py:249-283: quadratic in the batch; 2^16 bitstrings of
+    n53 m20 take hours there and seconds here, with the same tuples.)"""
+
+    def __init__(self, bitstrings):
+        self.n = len(bitstrings)
+        self.width = len(bitstrings[0]) if self.n else 0
+        self.ok = self.n > 0 and self.width <= 62 and all(len(b) == self.width for b in bitstrings)
+        if self.ok:
+            raw = np.frombuffer("".join(bitstrings).encode("ascii"), dtype=np.uint8).reshape(self.n, self.width)
+            self.ok = bool(np.all((raw == 48) | (raw == 49)))
+            self.bits = (raw - 48).astype(np.int64)
+
+    def packed(self, cols):
+        out = np.zeros(self.n, dtype=np.int64)
+        for k in cols:
+            out = (out << 1) | self.bits[:, k]
+        return out
+
+
+def _sub_bits(values, width, cols):
+    """For integers of `width` binary digits: the integer made of digits `cols` (0 = most significant), in that order."""
+    out = np.zeros(len(values), dtype=np.int64)
+    for k in cols:
+        out = (out << 1) | ((values >> (width - 1 - k)) & 1)
+    return out
+
+
+def _first_index(haystack, needles):
+    """np.argwhere(haystack == v)[0][0] for every v of `needles` (IndexError when one is absent, like the reference)."""
+    order = np.argsort(haystack, kind="stable")
+    srt = haystack[order]
+    pos = np.searchsorted(srt, needles, side="left")
+    if len(needles) and (pos.max(initial=0) >= len(srt) or np.any(srt[np.minimum(pos, len(srt) - 1)] != needles)):
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+    return order[pos]
+
+
 def contraction_scheme_sparse(ctree, bitstrings=None, sc_target=31, labels="einsum"):
     """Sparse-state scheme (reference contraction.py:208-341).
 
@@ -1951,6 +2010,7 @@ def contraction_scheme_sparse(ctree, bitstrings=None, sc_target=31, labels="eins
             info[tid] = ([], np.array([-1]))
     scheme = []
     out_bits = None
+    table = None   # _BitTable of the bitstrings, built when the first step with rows on both sides needs it
     for edge in order:
         i, j = edge
         bond_i, bond_j = tensor_bonds[i], tensor_bonds[j]
@@ -1989,26 +2049,54 @@ def contraction_scheme_sparse(ctree, bitstrings=None, sc_target=31, labels="eins
             loc_i = [fq.index(q) for q in fq_i]
             loc_j = [fq.index(q) for q in fq_j]
             bigger_left = int(len(rows_i) > len(rows_j))
-            wanted = np.unique(_select_bits(bitstrings, fq))
-            if len(wanted) == 2 ** len(fq) or len(fq) + len(new_i) <= sc_target:
+            if table is None:
+                table = _BitTable(bitstrings)
+            fast = table.ok and len(fq) <= 62
+            if fast:   # the same quantities as integers, whole batch at a time (sorted integers = sorted equal-length strings)
+                wanted_v = np.unique(table.packed(fq))
+                n_wanted = len(wanted_v)
+            else:
+                wanted = np.unique(_select_bits(bitstrings, fq))
+                n_wanted = len(wanted)
+            if n_wanted == 2 ** len(fq) or len(fq) + len(new_i) <= sc_target:
                 # outer product of the two row sets, optionally followed by a row select
-                rows = np.array([
-                    int(_merge_bits(np.binary_repr(x, len(fq_i)), np.binary_repr(y, len(fq_j)), loc_i, loc_j), 2)
-                    for x in rows_i for y in rows_j])
-                if len(wanted) != len(rows):
-                    sel = np.sort(np.array([np.argwhere(rows == int(s, 2))[0][0] for s in wanted]))
-                    rows = np.array([rows[k] for k in sel])
+                if fast:
+                    w = len(fq)
+                    ri, rj = np.asarray(rows_i, dtype=np.int64), np.asarray(rows_j, dtype=np.int64)
+                    rows = np.zeros((len(ri), len(rj)), dtype=np.int64)
+                    for n_, k in enumerate(loc_i):   # digit n_ of a left row lands at position k of the merged string
+                        rows |= (((ri >> (len(fq_i) - 1 - n_)) & 1) << (w - 1 - k))[:, None]
+                    for n_, k in enumerate(loc_j):
+                        rows |= (((rj >> (len(fq_j) - 1 - n_)) & 1) << (w - 1 - k))[None, :]
+                    rows = rows.reshape(-1)
+                else:
+                    rows = np.array([
+                        int(_merge_bits(np.binary_repr(x, len(fq_i)), np.binary_repr(y, len(fq_j)), loc_i, loc_j), 2)
+                        for x in rows_i for y in rows_j])
+                if n_wanted != len(rows):
+                    if fast:
+                        sel = np.sort(_first_index(rows, wanted_v))
+                        rows = rows[sel]
+                    else:
+                        sel = np.sort(np.array([np.argwhere(rows == int(s, 2))[0][0] for s in wanted]))
+                        rows = np.array([rows[k] for k in sel])
                     batch_seq = [[torch.tensor(sel)], []]
                 else:
                     batch_seq = [[], []]
             else:
                 # too big for an outer product: gather matching row pairs, in chunks
-                part = np.stack([
-                    np.array([int(s, 2) for s in _select_bits(wanted, loc_i)]),
-                    np.array([int(s, 2) for s in _select_bits(wanted, loc_j)])])
-                rows = np.array([int(s, 2) if len(s) > 0 else -1 for s in wanted])
-                pairs = np.array([[np.argwhere(rows_i == bi)[0][0], np.argwhere(rows_j == bj)[0][0]]
-                                  for bi, bj in zip(part[0], part[1])])
+                if fast:
+                    part = np.stack([_sub_bits(wanted_v, len(fq), loc_i), _sub_bits(wanted_v, len(fq), loc_j)])
+                    rows = wanted_v.copy()
+                    pairs = np.stack([_first_index(np.asarray(rows_i, dtype=np.int64), part[0]),
+                                      _first_index(np.asarray(rows_j, dtype=np.int64), part[1])], axis=1)
+                else:
+                    part = np.stack([
+                        np.array([int(s, 2) for s in _select_bits(wanted, loc_i)]),
+                        np.array([int(s, 2) for s in _select_bits(wanted, loc_j)])])
+                    rows = np.array([int(s, 2) if len(s) > 0 else -1 for s in wanted])
+                    pairs = np.array([[np.argwhere(rows_i == bi)[0][0], np.argwhere(rows_j == bj)[0][0]]
+                                      for bi, bj in zip(part[0], part[1])])
                 perm = np.argsort(pairs[:, 1 - bigger_left])
                 pairs = pairs[perm].T.reshape(2, -1)
                 batch_seq = [[torch.from_numpy(pairs[0])], [torch.from_numpy(pairs[1])]]
@@ -2024,7 +2112,7 @@ def contraction_scheme_sparse(ctree, bitstrings=None, sc_target=31, labels="eins
                         [batch_seq[1][0][c * length:(c + 1) * length] for c in range(n_chunks)]]
                 chunked = True
                 rows = rows[perm]
-            assert len(rows) == len(wanted)
+            assert len(rows) == n_wanted
 
         iy = []
         if len(fq_j):

@@ -41,6 +41,20 @@ def rank_slices(n_slices, rank, world_size, gray=False):
     return [rank + world_size * g for g in (t ^ (t >> 1) for t in range(span)) if g < count]
 
 
+def boundary_source_sha16():
+    """sha256 (first 16 hex digits) of the two files that ARE the drop-in boundary -- contraction.py (compilers,
+    executors) and simulation.py (slice loop, entry points).  tests/golden/check_boundary.py stamps its record with it;
+    tests/test_boundary_record.py fails when the record was made for other sources."""
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("contraction.py", "simulation.py"):
+        with open(os.path.join(here, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def apply_slice(tensors, slicing_indices, config):
     """Leaf tensors with the sliced bonds fixed to `config` (one bit per bond, in the
     mapping's order).  `slicing_indices[bond] = [(tensor_id, dim_index), ...]` with
@@ -412,10 +426,28 @@ def _checkpoint_path(prefix, rank, world):
     return f"{prefix}.rank{rank}of{world}.pt"
 
 
-def load_checkpoint(path, fingerprint, my_slices):
-    """(slices done, partial sum as a CPU tensor) of a checkpoint written for THIS plan and THIS shard, or (0, None).
-    A file of another plan (fingerprint) or another shard (slice list) is refused: resuming it would sum slices of a
-    different network, or the same slices twice."""
+def run_digest(runner, my_slices):
+    """What a checkpoint must match besides the plan: the VALUES of the leaves (same circuit structure, other gate
+    parameters: same plan fingerprint, different sums), their dtype, the accumulator's shape and dtype, and the whole
+    slice list of this shard (sha256; the leaves of a circuit are a few KB each)."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(runner.leaves, key=repr):
+        t = runner.leaves[k]
+        h.update(repr(k).encode())
+        if isinstance(t, torch.Tensor):
+            h.update(repr((str(t.dtype), tuple(t.shape))).encode())
+            h.update(np.ascontiguousarray(torch.view_as_real(t).cpu().numpy() if t.is_complex() else t.cpu().numpy()).tobytes())
+    h.update(repr((str(runner.collect.dtype), tuple(runner.collect.shape))).encode())
+    h.update(np.asarray([int(x) for x in my_slices], dtype=np.int64).tobytes())
+    return h.hexdigest()
+
+
+def load_checkpoint(path, fingerprint, my_slices, digest=None, collect=None):
+    """(slices done, partial sum as a CPU tensor) of a checkpoint written for THIS plan, THESE leaf values and THIS shard, or
+    (0, None).  A file of another plan (fingerprint), of other leaves / dtype / output shape / slice list (digest) is refused:
+    resuming it would sum slices of a different network, or the same slices twice -- and a FINISHED file of another run
+    would be returned as this run's result without contracting anything.  The prefix must be unique per run."""
     import os
     if not os.path.exists(path):
         return 0, None
@@ -425,16 +457,36 @@ def load_checkpoint(path, fingerprint, my_slices):
     done = int(ck["done"])
     if ck.get("n_slices") != len(my_slices) or ck.get("head") != [int(x) for x in my_slices[:done][-8:]]:
         raise RuntimeError(f"{path} was written for another shard of the slices: not resumed")
-    return done, ck["partial"]
+    if digest is not None and ck.get("digest") != digest:
+        raise RuntimeError(f"{path} was written for other leaf tensors, another dtype, output shape or slice list: not resumed")
+    partial = ck["partial"]
+    if collect is not None and (partial.dtype != collect.dtype or tuple(partial.shape) != tuple(collect.shape)):
+        raise RuntimeError(f"{path} holds a {partial.dtype} partial sum of shape {tuple(partial.shape)}, this run accumulates "
+                           f"{collect.dtype} {tuple(collect.shape)}: not resumed")
+    return done, partial
 
 
-def save_checkpoint(path, fingerprint, my_slices, done, collect):
+def save_checkpoint(path, fingerprint, my_slices, done, collect, digest=None):
     """Atomic: the previous checkpoint stays valid until the new one is complete on disk."""
     import os
     tmp = path + ".tmp"
-    torch.save({"fingerprint": fingerprint, "n_slices": len(my_slices), "done": int(done),
+    torch.save({"fingerprint": fingerprint, "n_slices": len(my_slices), "done": int(done), "digest": digest,
                 "head": [int(x) for x in my_slices[:done][-8:]], "partial": collect.detach().cpu()}, tmp)
     os.replace(tmp, path)
+
+
+def _all_ranks_ok(err, group, what):
+    """A failure on ONE rank (a foreign checkpoint, a slice that raised) must not leave the others waiting in the
+    collective that follows: every rank reports, every rank raises."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    all_ = [None] * world
+    dist.all_gather_object(all_, None if err is None else f"{type(err).__name__}: {err}", group=group)
+    bad = [(r, e) for r, e in enumerate(all_) if e is not None]
+    if bad:
+        if err is not None:
+            raise err
+        raise RuntimeError(f"{what} failed on rank {bad[0][0]}: {bad[0][1]}")
 
 
 def plan_fingerprint(scheme, slicing_indices, permute_dims=None):
@@ -492,14 +544,30 @@ def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce
         slices = [int(x) for x in slices]
         fp = plan_fingerprint(runner.scheme, runner.slicing_indices, permute_dims)
         path = _checkpoint_path(checkpoint, rank, world)
-        done, partial = load_checkpoint(path, fp, slices)
+        err, done, partial, dg = None, 0, None, None
+        try:
+            dg = run_digest(runner, slices)
+            done, partial = load_checkpoint(path, fp, slices, dg, runner.collect)
+        except Exception as e:   # (reported to every rank below: nobody enters the reduction alone)
+            err = e
+        if distributed and reduce is not None:
+            _all_ranks_ok(err, group, "loading the checkpoint")
+        elif err is not None:
+            raise err
         if partial is not None:
-            runner.collect.copy_(partial.to(runner.collect.device).reshape(runner.collect.shape))
+            runner.collect.copy_(partial.to(runner.collect.device))
         every = max(1, int(checkpoint_every))
-        while done < len(slices):
-            runner.run(slices[done:done + every])
-            done = min(done + every, len(slices))
-            save_checkpoint(path, fp, slices, done, runner.collect)
+        try:
+            while done < len(slices):
+                runner.run(slices[done:done + every])
+                done = min(done + every, len(slices))
+                save_checkpoint(path, fp, slices, done, runner.collect, dg)
+        except Exception as e:
+            err = e
+        if distributed and reduce is not None:
+            _all_ranks_ok(err, group, "the slice loop")
+        elif err is not None:
+            raise err
         collect = runner.collect
     if distributed and reduce is not None:
         buf = torch.view_as_real(collect)

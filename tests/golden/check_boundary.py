@@ -102,6 +102,20 @@ for sc in (30, 8, 6):
           same_sparse_scheme(m[0], r[0]) and list(m[1]) == list(r[1]) and list(m[2]) == list(r[2]),
           steps=len(r[0]), five_tuples=sum(len(s) == 5 for s in r[0]), chunked=sum(len(s[2][0]) > 1 for s in r[0]))
 
+# a big batch on the same tree: 1 500 random bitstrings, every branch of the compiler (outer products with and without a
+# row select, chunked gathers of several sizes) -- the vectorised compiler against the reference's bitstring-by-bitstring loops
+rng = np.random.RandomState(11)
+bits_many = sorted({np.binary_repr(x, 12) for x in rng.randint(0, 4096, size=2200)})[:1500]
+big = plan(bits_many, 30)
+for sc in (30, 12, 9):
+    m = A.contraction_scheme_sparse(deepcopy(big.ctree), bits_many, sc_target=sc)
+    r = R.contraction_scheme_sparse(deepcopy(big.ctree), bits_many, sc_target=sc)
+    check(f"contraction_scheme_sparse(1 500 bitstrings, sc_target={sc}) == reference",
+          same_sparse_scheme(m[0], r[0]) and list(m[1]) == list(r[1]) and list(m[2]) == list(r[2]),
+          steps=len(r[0]), five_tuples=sum(len(s) == 5 for s in r[0]), chunked=sum(len(s[2][0]) > 1 for s in r[0]),
+          selects=sum(len(s) == 5 and len(s[2][0]) == 1 and len(s[2][1]) == 0 for s in r[0]))
+
+
 def slicing_ok(sim):
     """True when the reference's slice loop is well defined for this plan: no tensor
     carries two sliced bonds in ascending dim order, and no sliced bond sits on a leaf whose leading
@@ -211,6 +225,8 @@ err = float(np.abs(got.reshape(-1).numpy() - want.reshape(-1).numpy()).max() / n
 check("quantum_circuit_simulation(n12, full amplitude) == reference", err < 1e-5, rel_err=err)
 
 record["all_passed"] = all(c["passed"] for c in record["checks"])
+# the sources this record vouches for (tests/test_boundary_record.py refuses a record older than they are)
+record["source_sha16"] = S.boundary_source_sha16()
 with open(os.path.join(HERE, "boundary_check.json"), "w") as f:
     json.dump(record, f, indent=1)
 print(f"{len(record['checks'])} boundary checks passed -> tests/golden/boundary_check.json")

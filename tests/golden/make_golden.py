@@ -618,6 +618,60 @@ def case_n53m20_batch_slice0():
               slicing_indices=case.slicing_indices)
 
 
+def case_n53m20_bigbatch(n_open=17, count=65536):
+    """configs[4] at a batch that deserves the name (round 5): the bundled n53 m20 circuit with 2^16 correlated
+    bitstrings -- a random HALF of the 2^17 product over 17 open qubits, so the sparse compiler emits row selects and
+    gathered steps with index lists of tens of thousands of rows.  The reference's own compiler compares substrings
+    bitstring by bitstring (contraction.py:249-283: quadratic in the batch, hours here), so the scheme is compiled by
+    artensor_amd.contraction_scheme_sparse -- its vectorised restatement, byte-identical to the reference's output on
+    every branch for the batches the reference can compile (tests/golden/check_boundary.py, 1 500 bitstrings) --
+    from the REFERENCE's tree; planning and the executor that produces the expected slice are the reference's."""
+    import artensor.simulation as RS
+    import artensor_amd
+    from artensor_amd.simulation import apply_slice, slice_assignments
+    bits, open_pos = n53_batch_bitstrings(n_open=n_open, count=count, seed=53)
+    ref_compiler = RS.contraction_scheme_sparse
+    RS.contraction_scheme_sparse = artensor_amd.contraction_scheme_sparse
+    try:
+        t0 = time.time()
+        sim, meta = plan(N53_M20, bits, 30)
+        meta["plan_and_compile_seconds"] = time.time() - t0
+    finally:
+        RS.contraction_scheme_sparse = ref_compiler
+    kinds = dict(A=0, B=0, C=0, C_select=0, D=0)
+    for st in sim.scheme:
+        if len(st[2][0]) > 1:
+            kinds["A"] += 1
+        elif len(st) > 3 and len(st[2][0]) == len(st[2][1]) == 1:
+            kinds["B"] += 1
+        elif len(st) > 3:
+            kinds["C"] += 1
+            kinds["C_select"] += len(st[2][0]) == 1
+        else:
+            kinds["D"] += 1
+    meta["branches"] = kinds
+    meta["open_qubits"] = open_pos
+    meta["n_slicing"] = len(sim.slicing_indices)
+    meta["scheme_compiled_by"] = "artensor_amd.contraction_scheme_sparse (vectorised restatement) on the reference's tree"
+    meta["derivation"] = f"circuit_n53_m20_s0_e0_pABCDCDAB.qsim as bundled; {count} bitstrings over {n_open} open qubits"
+    tensors = {i: sim.tensors[i].to(torch.complex64) for i in sim.tensors}
+    fixed = {}
+    for bond, lst in sim.slicing_indices.items():
+        fixed[bond] = [(tid, ind + tensors[tid].dim() - len(sim.tensor_bonds[tid])) for tid, ind in lst]
+    print("n53_m20_bigbatch plan:", len(sim.scheme), "steps,", len(sim.slicing_indices), "sliced bonds, log10 tc/slice",
+          meta["log10_tc"], "sc", meta["sc"], "branches", kinds, f"{meta['plan_and_compile_seconds']:.0f} s", flush=True)
+    cfg = slice_assignments(len(fixed), 0)
+    sliced = apply_slice({i: t.clone() for i, t in tensors.items()}, fixed, cfg)
+    t0 = time.time()
+    res = tensor_contraction_sparse(sliced, sim.scheme)   # the REFERENCE's executor
+    dt = time.time() - t0
+    meta["reference_cpu_seconds_per_slice"] = dt
+    meta["reference_cpu_threads"] = torch.get_num_threads()
+    save_case(os.path.join(HERE, "n53_m20_bigbatch.npz"), tensors, sim.scheme, meta,
+              arrays=dict(slice0=res.reshape(-1).numpy().copy()), slicing_indices=fixed)
+    print("n53 m20 bigbatch slice 0:", tuple(res.shape), f"{dt:.0f} s", flush=True)
+
+
 def case_c128_spread():
     """The reference's own complex64-vs-complex128 spread (its executors run in both dtypes on the same
     leaf tensors and schemes): the yardstick for the strict per-amplitude tolerance of SURVEY 8c
@@ -738,6 +792,7 @@ CASES = {
     "c128_spread": case_c128_spread,
     "n53m20_batch_plan": case_n53m20_batch_plan,
     "n53m20_batch_slice0": case_n53m20_batch_slice0,
+    "n53m20_bigbatch": case_n53m20_bigbatch,
     "trees": case_trees,
     "n12_dense": case_n12_dense,
     "n12_sparse5": case_n12_sparse5,

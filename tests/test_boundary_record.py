@@ -17,6 +17,7 @@ EXPECTED = [
     "contraction_scheme(live ContractionTree) == reference",
     "contraction_scheme_sparse(live tree, sc_target=30) == reference",
     "contraction_scheme_sparse(live tree, sc_target=8) == reference",
+    "contraction_scheme_sparse(1 500 bitstrings, sc_target=12) == reference",
     "contraction_scheme_sparse(sliced live tree) == reference scheme held by the planned object",
     "from_planned(dense)", "from_planned(sparse)", "from_planned(sliced)",
     "signature of contraction_scheme", "signature of tensor_contraction", "signature of contraction_scheme_sparse",
@@ -41,8 +42,18 @@ def test_boundary_record_is_complete_and_green():
     by = {c["name"]: c for c in rec["checks"]}
     assert by["contraction_scheme_sparse(live tree, sc_target=8) == reference"]["chunked"] >= 1
     assert by["a sliced sparse plan exists"]["sliced_bonds"] >= 2
+    assert by["contraction_scheme_sparse(1 500 bitstrings, sc_target=9) == reference"]["chunked"] >= 1
+    assert by["contraction_scheme_sparse(1 500 bitstrings, sc_target=30) == reference"]["selects"] >= 1
     errs = [c["rel_err"] for c in rec["checks"] if "rel_err" in c]
     assert len(errs) >= 5 and max(errs) < 1e-5
+
+
+def test_boundary_record_was_made_for_these_sources():
+    """The record is evidence about contraction.py and simulation.py AS THEY ARE: it carries their hash, and a record
+    made before the last edit of either file fails here (re-run tests/golden/check_boundary.py in the build container)."""
+    from artensor_amd.simulation import boundary_source_sha16
+    rec = json.load(open(RECORD))
+    assert rec.get("source_sha16") == boundary_source_sha16(), "boundary_check.json is stale: re-run tests/golden/check_boundary.py"
 
 
 @pytest.mark.skipif(not (os.path.isdir("/root/reference/artensor") and os.environ.get("ARTN_CHECK_BOUNDARY") == "1"),

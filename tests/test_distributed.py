@@ -242,11 +242,11 @@ def test_checkpoint_and_resume_of_the_slice_loop(tmp_path, monkeypatch):
     saves = []
     orig = S.save_checkpoint
 
-    def dying(path, fp, sl, done, collect):
+    def dying(path, fp, sl, done, collect, digest=None):
         if len(saves) == 3:
             raise KeyboardInterrupt
         saves.append(done)
-        orig(path, fp, sl, done, collect)
+        orig(path, fp, sl, done, collect, digest)
     monkeypatch.setattr(S, "save_checkpoint", dying)
     with pytest.raises(KeyboardInterrupt):
         S._shard_and_reduce(runner(), reduce=None, checkpoint=prefix, checkpoint_every=10)
@@ -273,3 +273,19 @@ def test_checkpoint_and_resume_of_the_slice_loop(tmp_path, monkeypatch):
                                    torch.complex64, "cpu", _oracle_execute(False), _cpu_add)
     with pytest.raises(RuntimeError, match="another plan"):
         S._shard_and_reduce(r2, reduce=None, checkpoint=prefix, checkpoint_every=10)
+    # the SAME plan with other leaf values (same circuit structure, other gate parameters), another dtype: refused --
+    # a finished file would otherwise be returned as the new run's result without contracting anything
+    scaled = {k: t * 2 for k, t in case.tensors.items()}
+    r3 = S.SliceRunner._with_seams(scaled, case.scheme, case.slicing_indices, want.shape, False, torch.complex64, "cpu",
+                                   _oracle_execute(False), _cpu_add)
+    with pytest.raises(RuntimeError, match="other leaf tensors"):
+        S._shard_and_reduce(r3, reduce=None, checkpoint=prefix, checkpoint_every=10)
+    r4 = S.SliceRunner._with_seams(case.tensors, case.scheme, case.slicing_indices, want.shape, False, torch.complex128, "cpu",
+                                   _oracle_execute(False), _cpu_add)
+    with pytest.raises(RuntimeError, match="other leaf tensors|partial sum"):
+        S._shard_and_reduce(r4, reduce=None, checkpoint=prefix, checkpoint_every=10)
+    # same length, same tail, other slices: the whole list is hashed
+    perm = list(range(64))
+    perm[0], perm[1] = perm[1], perm[0]
+    with pytest.raises(RuntimeError, match="slice list"):
+        S._shard_and_reduce(runner(), reduce=None, slices=perm, checkpoint=prefix, checkpoint_every=10)

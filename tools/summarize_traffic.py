@@ -22,6 +22,8 @@ def family(name):
         return "bits"          # (artn_k_bits128 too: the complex128 leg's planner id 1)
     if "artn_k_pgemm" in name or "artn_k_pack" in name:
         return "pgemm"         # packing passes + the packed GEMM: one artn_contract_ws call
+    if "artn_k_xgemm" in name:
+        return "xgemm"         # the extent-based GEMM (non power-of-two extents)
     if "artn_k_gemm" in name:
         return "gemm"          # artn_k_gemm, artn_k_gemm_deep, artn_k_gemm128
     if "artn_k_program" in name:
