@@ -12,8 +12,19 @@ SRCS := $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128
         $(CSRC)/artn_bits128_kernel.h $(CSRC)/artn_bits3_kernel.h $(CSRC)/artn_wide_kernel.h $(CSRC)/artn_plan.h \
         $(CSRC)/artn_xgemm_plan.h $(CSRC)/artn_xgemm_kernel.h include/artn.h
 OBJDIR := build/obj
-OBJS := $(OBJDIR)/main.o $(OBJDIR)/b128.o $(OBJDIR)/wide.o $(foreach k,1 2 3 4 5 6,$(OBJDIR)/bits_k$(k).o) $(foreach k,3 4 5,$(OBJDIR)/bits3_k$(k).o)
-FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -I$(CSRC)
+# The product library carries what the default planner can select.  `make dev` (DEV=1) adds the development-only pieces:
+# every ARTN_* planner switch of the A/B measurements in DESIGN.md (-DARTN_DEV_SWITCHES), three-step fusion (artn_k_bits3 /
+# artn_contract3: -DARTN_DEV_BITS3, three more translation units) and the split-bf16 instantiations (-DARTN_DEV_SPLIT3).
+DEV ?= 0
+ifeq ($(DEV),1)
+DEVFLAGS := -DARTN_DEV_SWITCHES -DARTN_DEV_BITS3 -DARTN_DEV_SPLIT3
+DEVOBJS := $(foreach k,3 4 5,$(OBJDIR)/bits3_k$(k).o)
+else
+DEVFLAGS :=
+DEVOBJS :=
+endif
+OBJS := $(OBJDIR)/main.o $(OBJDIR)/b128.o $(OBJDIR)/wide.o $(foreach k,1 2 3 4 5 6,$(OBJDIR)/bits_k$(k).o) $(DEVOBJS)
+FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -I$(CSRC) $(DEVFLAGS)
 
 $(OBJDIR)/main.o: $(SRCS)
 	@mkdir -p $(OBJDIR)
@@ -39,10 +50,10 @@ single: $(SRCS)
 
 # diagnostic build with in-kernel phase stamps (never loaded by the product; tools/stamps.py)
 stamps: $(SRCS)
-	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_STAMPS -Iinclude -I$(CSRC) $< -o tools/libartn_hip_stamps.so
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_STAMPS -DARTN_DEV_SWITCHES -Iinclude -I$(CSRC) $< -o tools/libartn_hip_stamps.so
 
 phases: $(SRCS)
-	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_PHASES -Iinclude -I$(CSRC) $< -o tools/libartn_hip_phases.so
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_PHASES -DARTN_DEV_SWITCHES -Iinclude -I$(CSRC) $< -o tools/libartn_hip_phases.so
 
 # timing-only ablations (wrong results by construction; never loaded by the product)
 ablate: $(SRCS)
@@ -82,7 +93,11 @@ asan: $(SRCS) tests/csrc/plan_emulate.cpp
 	  ARTN_LIB=$(ASAN_DIR)/libartn_host_asan.so python3 tools/stress_planner.py 3000 0 2>&1 ) | tee $(ASAN_LOG)
 	@! grep -E "ERROR: AddressSanitizer|runtime error:" $(ASAN_LOG)
 
+# development build (the tools/ab_*.sh scripts and the switch sweeps need it); `make clean` before switching flavours
+dev:
+	$(MAKE) DEV=1 all
+
 clean:
 	rm -f $(LIB)
 	rm -rf $(OBJDIR)
-.PHONY: all clean probes stamps phases ablate single asan
+.PHONY: all clean probes stamps phases ablate single asan dev

@@ -11,7 +11,7 @@ import threading
 
 import torch
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 ARTN_MAX_LABELS = 96
 ARTN_PROGRAM_MAX_EXT = 256
 ARTN_C64, ARTN_C128, ARTN_C64_BF16 = 0, 1, 2
@@ -88,9 +88,6 @@ _EXPORTS = {
     "artn_program_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int64]),
-    "artn_contract3_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "artn_contract3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_program_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                         ctypes.c_void_p, ctypes.c_void_p]),
     "artn_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
@@ -107,6 +104,23 @@ _EXPORTS = {
     "artn_absmax_normalize_c128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                   ctypes.c_void_p]),
 }
+
+
+# entry points of DEVELOPMENT builds only (make dev): bound when the loaded library has them
+_DEV_EXPORTS = {
+    "artn_contract3_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "artn_contract3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+
+def has(name):
+    """True when the loaded library exports `name` (the development-only entry points)."""
+    try:
+        getattr(lib(), name)
+        return True
+    except AttributeError:
+        return False
 
 
 def exported_symbols():
@@ -135,6 +149,11 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in _DEV_EXPORTS.items():
+            if hasattr(handle, name):
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
         if handle.artn_abi_version() != ABI_VERSION:
             raise RuntimeError("libartn_hip.so ABI version mismatch")
         _lib = handle

@@ -478,6 +478,8 @@ def contract3(eq1, a, b1, eq2, b2, eq3, b3):
     """einsum(eq3, einsum(eq2, einsum(eq1, a, b1), b2), b3) in ONE pass over HBM through artn_contract3: neither
     intermediate leaves LDS (three consecutive steps of reference contraction.py:66-70 on the state tensor).  Returns None
     when the planner declines the triple (the caller falls back to a pair and a single step)."""
+    if not N.has("artn_contract3"):
+        raise RuntimeError("three-step fusion (artn_contract3) is compiled into development builds only: make dev")
     for t in (a, b1, b2, b3):
         N.require_gpu(t, "contract3")
     if not (a.dtype == b1.dtype == b2.dtype == b3.dtype == torch.complex64) or not a.is_contiguous() or precision.current() not in (None, "fp32"):
@@ -520,6 +522,8 @@ def triple_info(eq1, a_shape, b1_shape, eq2, b2_shape, eq3, b3_shape):
 
         def stride(self):
             return self._st
+    if not N.has("artn_contract3_query"):
+        return None   # (the product library has no triples: development builds only, make dev)
     d1, d2, d3, out_shape = _triple_descriptors(eq1, _S(a_shape), _S(b1_shape), eq2, _S(b2_shape), eq3, _S(b3_shape))
     info = N.ArtnStepInfo()
     rc = N.lib().artn_contract3_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), ctypes.byref(info))
@@ -630,9 +634,6 @@ def fusion_schedule(scheme):
     order, done = [], set()
     n_steps = len(scheme)
     unpaired = set()
-    shift = _os_environ.get("ARTN_PAIR_SHIFT")   # experiment: leave step <n> single, so that the pairs after it shift by one
-    if shift:
-        unpaired = {int(x) for x in shift.split(",")}
     for n in range(n_steps):
         if n in done:
             continue
@@ -739,7 +740,7 @@ def _cut_chain(scheme, members, shapes, dtype, skip):
             r *= e
         return r
     fuse_ok = dtype in _DTYPES
-    fuse3_ok = dtype == torch.complex64 and precision.current() in (None, "fp32") and N.lib().artn_contract3_query is not None
+    fuse3_ok = dtype == torch.complex64 and precision.current() in (None, "fp32") and N.has("artn_contract3_query")
     L = len(members)
     cand = {}   # (p, g) -> (info, descriptors, out_shape)
 
@@ -968,8 +969,6 @@ def _build_program(scheme, small, recs, needed=None):
     if image_bytes < 0:
         return None
     image = torch.zeros(image_bytes, dtype=torch.uint8)
-    if __import__("os").environ.get("ARTN_PROG_KEEP_ALL"):   # diagnostics: every result also goes to the workspace
-        keep = [1] * len(keep)
     rc = lib.artn_program_build(len(descs), arr, i64(la_), i64(lb_), i64(lc_), (ctypes.c_uint8 * len(keep))(*keep), n_groups,
                                 (ctypes.c_int32 * len(group_start))(*group_start), image.data_ptr(), image_bytes)
     if rc != 0:   # no program: every step runs as its own launch (what a scheme did before programs existed)
@@ -1064,7 +1063,8 @@ def _compile_dense(scheme, shapes, dtype):
     # no committed workload); everywhere else the pairing of rounds 1-3 -- fusion_schedule, pairs from the left -- is kept
     # exactly: re-pairing alone cost the random D = 2 network 8 % (pairs the old schedule never formed).
     use_chains = False
-    if dtype == torch.complex64 and precision.current() in (None, "fp32") and not _os_environ.get("ARTN_NO_FUSE"):
+    if (dtype == torch.complex64 and precision.current() in (None, "fp32") and not _os_environ.get("ARTN_NO_FUSE")
+            and N.has("artn_contract3_query")):   # (development builds only: the product library has no triples)
         probe = dict(shapes)
         for entry in chain_schedule(scheme):
             if entry[0] == "chain":

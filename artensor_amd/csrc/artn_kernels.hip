@@ -1782,7 +1782,7 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 // (-DARTN_TU_WIDE: only artn_k_wide<*, *> behind artn_launch_wide(); artn_wide_kernel.h itself is included above artn_k_bits,
 //  which borrows its stage)
 // (-DARTN_TU_BITS3=K: only artn_k_bits3<K, *, *> behind artn_launch_bits3_kK())
-#if defined(ARTN_TU_BITS3) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
+#if defined(ARTN_TU_BITS3) || (defined(ARTN_DEV_BITS3) && !defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
 #include "artn_bits3_kernel.h"
 #endif
 #if defined(ARTN_TU_B128) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
@@ -2360,11 +2360,18 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
     if (hipError_t e = ensure_lds<artn_k_bits<KB1, K2, false, NPV>>(lds); e != hipSuccess) return e;      \
     hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);                                 \
   }
-  // split-bf16 instantiations exist only where a stage has the >= 3 contracted bits they need
+  // split-bf16 instantiations exist only where a stage has the >= 3 contracted bits they need -- and only in development
+  // builds (-DARTN_DEV_SPLIT3): fp32-grade results from three bfloat16 pieces, parity-green, no faster on any workload
+  // (DESIGN.md 4.1); the product never plans split = 3
+#ifdef ARTN_DEV_SPLIT3
+#define ARTN_SPLIT3_CASE(K2) if (split == 3) { ARTN_LAUNCH_NP(K2, 3) break; }
+#else
+#define ARTN_SPLIT3_CASE(K2) if (split == 3) return hipErrorInvalidValue;
+#endif
 #define ARTN_LAUNCH(K2)                                                                                   \
   case K2: {                                                                                              \
     if constexpr (KB1 >= 3 || K2 >= 3) {                                                                  \
-      if (split == 3) { ARTN_LAUNCH_NP(K2, 3) break; }                                                    \
+      ARTN_SPLIT3_CASE(K2)                                                                                \
       if constexpr (KB1 >= 3 && (K2 == 0 || K2 >= 3)) {                                                   \
         if (split == 1 && p.bits.nt_loads) { /* bf16 operands: every big launch is HBM-bound */           \
           auto kern = artn_k_bits<KB1, K2, false, 1, false, true>;                                        \
@@ -2651,6 +2658,9 @@ hipError_t artn_launch_bits_k4(const ArtnPlan &, const float2 *, const float2 *,
 hipError_t artn_launch_bits_k5(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
 hipError_t artn_launch_bits_k6(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
 #endif
+// Three-step fusion (artn_k_bits3 / artn_contract3, round 4) was built, is parity-green and shortens no committed workload
+// (DESIGN.md 4.1c): it is compiled only into development builds (make dev: -DARTN_DEV_BITS3).
+#if defined(ARTN_DEV_BITS3)
 #ifdef ARTN_TU_MAIN
 hipError_t artn_launch_bits3_k3(const ArtnPlan &, const float2 *, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
 hipError_t artn_launch_bits3_k4(const ArtnPlan &, const float2 *, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
@@ -2672,6 +2682,7 @@ static hipError_t launch_bits3(const ArtnPlan &p, const void *A, const void *B1,
   }
   return hipErrorInvalidValue;
 }
+#endif // ARTN_DEV_BITS3
 
 static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C,
                               hipStream_t st) {
@@ -3211,6 +3222,7 @@ int artn_contract_acc(const ArtnStepDesc *d, const void *A, const void *B, void 
   return ARTN_OK;
 }
 
+#if defined(ARTN_DEV_BITS3)
 int artn_contract3_query(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const ArtnStepDesc *d3, ArtnStepInfo *info) {
   if (!info || !d1 || !d2 || !d3) return fail(ARTN_E_INVALID, "null argument");
   if (env_flag("ARTN_NO_FUSE")) return fail(ARTN_E_UNSUPPORTED, "not fusable: ARTN_NO_FUSE is set");
@@ -3235,6 +3247,7 @@ int artn_contract3(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const ArtnSte
   HIP_TRY(launch_bits3(p, A, B1, B2, B3, C, (hipStream_t)stream));
   return ARTN_OK;
 }
+#endif // ARTN_DEV_BITS3
 
 #if defined(ARTN_STAMPS) || defined(ARTN_PHASES)
 // diagnostic builds only

@@ -268,9 +268,17 @@ struct Tuning {
   int bits_3m = 2;    // state-streaming kernel, fp32 stages with 5/6 contracted bits and 32+ columns: the same
                       // (1: not in fused pairs that hold a 6-bit stage, 0: never)
 };
+// Product builds read THREE planner switches from the environment -- ARTN_WIDE, ARTN_WIDE_MIN_TILES (the tests force
+// artn_k_wide onto every fused pair through them) and ARTN_XGEMM (0: steps with odd extents back on the strided kernel,
+// the A/B of the round-5 tests).  Everything else is the switch of one concluded A/B measurement (DESIGN.md sections 4-7)
+// and exists only in development builds (`make dev`: -DARTN_DEV_SWITCHES), where tools/ab_env.sh can flip it.
 static inline Tuning &tuning() {
   static Tuning t = [] {
     Tuning x;
+    if (const char *e = getenv("ARTN_WIDE")) x.wide = std::min(2, std::max(0, atoi(e)));
+    if (const char *e = getenv("ARTN_WIDE_MIN_TILES")) x.wide_min_tiles = atoi(e);
+    if (const char *e = getenv("ARTN_XGEMM")) x.xgemm = atoi(e) != 0;
+#ifdef ARTN_DEV_SWITCHES
     if (const char *e = getenv("ARTN_WG_PER_CU")) x.wg_per_cu = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_TILE_TARGET")) x.tile_target = std::min(ARTN_TILE_BITS_MAX, std::max(9, atoi(e)));
     if (const char *e = getenv("ARTN_RUN_MAX")) x.run_max = std::min(6, std::max(1, atoi(e)));
@@ -296,12 +304,12 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_PACKED_MIN_AI")) x.packed_min_ai = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_PACKED")) x.packed = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_ALT")) x.alt = std::min(2, std::max(0, atoi(e)));
-    if (const char *e = getenv("ARTN_WIDE")) x.wide = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_NARROW3")) x.narrow3 = atoi(e);
-    if (const char *e = getenv("ARTN_XGEMM")) x.xgemm = atoi(e) != 0;
-    if (const char *e = getenv("ARTN_WIDE_MIN_TILES")) x.wide_min_tiles = atoi(e);
     if (const char *e = getenv("ARTN_BITS_3M")) x.bits_3m = std::min(2, std::max(0, atoi(e)));
+#ifdef ARTN_DEV_SPLIT3
     if (const char *e = getenv("ARTN_SPLIT")) { int v = atoi(e); x.split = (v == 3 || v == 1) ? v : 0; }
+#endif
+#endif
     return x;
   }();
   return t;
@@ -1489,10 +1497,12 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   x.amode = fastest_is(K, 0) ? 1 : 0;
   x.bmode = fastest_is(K, 1) ? 1 : 0;
   x.trans = fastest_is(N, 2) ? 1 : 0;
-  if (const char *e = getenv("ARTN_XG_AMODE")) x.amode = atoi(e) != 0; // (development: A/B of the copy modes)
-  if (const char *e = getenv("ARTN_XG_BMODE")) x.bmode = atoi(e) != 0;
   x.prio = 0; // (measured: 6.72 / 3.06 ms without, 6.87 / 3.14 ms with, on the two biggest steps of the bond-dimension-3 network)
+#ifdef ARTN_DEV_SWITCHES // (A/B of the copy modes: no difference on any measured layout, tools/xgemm_modes.py)
+  if (const char *e = getenv("ARTN_XG_AMODE")) x.amode = atoi(e) != 0;
+  if (const char *e = getenv("ARTN_XG_BMODE")) x.bmode = atoi(e) != 0;
   if (const char *e = getenv("ARTN_XG_PRIO")) x.prio = atoi(e) != 0;
+#endif
   // label order inside each flattened index (innermost first): that of the tensor whose copy lanes run along it
   if (x.amode == 0) std::sort(M.begin(), M.end(), [](const Lab &u, const Lab &v) { return u.sA < v.sA; });
   else std::sort(M.begin(), M.end(), [](const Lab &u, const Lab &v) { return u.sC < v.sC; });
@@ -1536,11 +1546,15 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
     const double eff = (double)x.n.total / (double)(tiles * tn) * (nb == 1 ? 0.75 : 1.0);
     if (eff > best + 1e-9) { best = eff; x.nb = nb; }
   }
-  if (const char *e = getenv("ARTN_XG_NB")) { const int v = atoi(e); if (v >= 1 && v <= 3) x.nb = v; } // (development)
+#ifdef ARTN_DEV_SWITCHES
+  if (const char *e = getenv("ARTN_XG_NB")) { const int v = atoi(e); if (v >= 1 && v <= 3) x.nb = v; }
+#endif
   // chunks of 8 where a tile is a handful of contracted values x at most 32 columns: those steps are latency chains per tile,
   // and the small chunk lets four workgroups share a CU (artn_k_xgemm<1, *, 8>)
   x.kc = (x.nb == 1 && x.k.total <= 32) ? 8 : ARTN_XG_KC;
+#ifdef ARTN_DEV_SWITCHES
   if (const char *e = getenv("ARTN_XG_KC")) { const int v = atoi(e); if ((v == 8 && x.nb == 1) || v == 16) x.kc = v; }
+#endif
   x.cpg = (x.k.L0 + x.kc - 1) / x.kc;
   x.k_groups = x.k.total / x.k.L0;
   const int64_t chunks = x.k_groups * x.cpg;

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ARTN_ABI_VERSION 6
+#define ARTN_ABI_VERSION 7
 #define ARTN_MAX_LABELS 96
 
 /* error codes */
@@ -94,7 +94,7 @@ typedef struct ArtnStepInfo {
   double mfma_flops;    /* real FLOP the matrix pipe executes: `flops` with 6 instead of 8 per complex
                            multiply-add in every 3M stage (0 for the strided kernel)     */
   int64_t workspace_bytes; /* scratch the step wants from artn_contract_ws (0: none; artn_contract never needs any) */
-  int32_t k3_bits;      /* fused triple (artn_contract3): contracted bits of the third step (else 0) */
+  int32_t k3_bits;      /* fused triple (development builds only: artn_contract3): contracted bits of the third step (else 0) */
   int32_t reserved_;
 } ArtnStepInfo;
 
@@ -165,15 +165,14 @@ int artn_contract_acc(const ArtnStepDesc *d, const void *A, const void *B, void 
 int artn_contract2_acc(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const void *A, const void *B1,
                        const void *B2, void *C, void *stream);
 
-/* THREE consecutive steps on the same first operand in one pass (round 4): C = step3(step2(step1(A, B1), B2), B3), neither
- * intermediate leaves LDS -- the loop body of artensor/contraction.py:66-70 three times on one tensors[i].  d2 / d3
- * describe their first operand as the dense result of the step before.  ARTN_E_UNSUPPORTED (-2) with "not fusable: ..."
- * when the triple does not fit (complex64, power-of-two extents, no batch label, 3..5 contracted bits per step, every
- * step brings as many bits as it contracts, all contracted old bits + the 128-byte runs inside one 2^12-element tile):
- * the caller then runs a pair and a single step. */
+/* (ABI 7: artn_contract3 / artn_contract3_query -- three steps in one pass, round 4 -- left the product library: built,
+ * parity-green, and shorter on no committed workload.  Development builds (make dev, -DARTN_DEV_BITS3)
+ * still export them with the ABI-6 signatures, declared here for those builds only.) */
+#ifdef ARTN_DEV_BITS3
 int artn_contract3_query(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const ArtnStepDesc *d3, ArtnStepInfo *info);
 int artn_contract3(const ArtnStepDesc *d1, const ArtnStepDesc *d2, const ArtnStepDesc *d3, const void *A, const void *B1,
                    const void *B2, const void *B3, void *C, void *stream);
+#endif
 
 /*
  * dst[r, :] = src[idx[r], :] for r < nrows, rows of `row_bytes` bytes (multiple of 8).

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "artn.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef ARTN_DEV_\w+.*?#endif", "", text, flags=re.S)   # (development-only entry points: not the product ABI)
     return sorted(set(re.findall(r"\b(artn_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -30,6 +31,25 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.artn_abi_version() == N.ABI_VERSION
     assert lib.artn_device_count() >= 0
+
+
+def test_product_library_carries_no_development_entry_points_or_switches():
+    """ABI 7 (round 5): the experiments that lost their A/B measurements -- three-step fusion, the split-bf16 arithmetic,
+    some thirty planner switches -- are compiled into development builds only (make dev); the product library exports the
+    header's entry points and reads a handful of switches from the environment."""
+    lib = N.lib()
+    dev = os.path.basename(N.LIB_PATH) != "libartn_hip.so" or os.environ.get("ARTN_LIB")
+    if not dev and not hasattr(lib, "artn_contract3"):
+        assert not N.has("artn_contract3_query")
+        assert A.contraction.triple_info("ABCDEFGHIJKLMNOPQRSTUVWX,ABCab->DEFGHIJKLMNOPQRSTUVWXab", (2,) * 24, (2,) * 5,
+                             "DEFGHIJKLMNOPQRSTUVWXab,DEFcd->GHIJKLMNOPQRSTUVWXabcd", (2,) * 5,
+                             "GHIJKLMNOPQRSTUVWXabcd,GHIef->JKLMNOPQRSTUVWXabcdef", (2,) * 5) is None
+    blob = open(N.LIB_PATH, "rb").read()
+    switches = set(re.findall(rb"ARTN_[A-Z][A-Z0-9_]{2,}", blob))
+    env_like = {s.decode() for s in switches}
+    # names that are not environment switches (error text, macros that ended up in strings) are few; the bound is on all of them
+    if not hasattr(lib, "artn_contract3"):
+        assert len(env_like) < 15, sorted(env_like)
 
 
 def test_struct_layouts_match_header():
@@ -61,7 +81,8 @@ def test_no_cpu_fallback_anywhere():
     assert N.lib().artn_contract2(ctypes.byref(d), ctypes.byref(d), p, p, p, p, None) == -4
     assert N.lib().artn_contract2_acc(ctypes.byref(d), ctypes.byref(d), p, p, p, p, None) == -4
     assert N.lib().artn_contract_acc(ctypes.byref(d), p, p, p, None) == -4
-    assert N.lib().artn_contract3(ctypes.byref(d), ctypes.byref(d), ctypes.byref(d), p, p, p, p, p, None) == -4
+    if N.has("artn_contract3"):   # (development builds)
+        assert N.lib().artn_contract3(ctypes.byref(d), ctypes.byref(d), ctypes.byref(d), p, p, p, p, p, None) == -4
     assert N.lib().artn_absmax_normalize_c128(p, 4, p, None) == -4
     assert N.lib().artn_gather_rows(p, p, p, 1, 8, 1, None, None) == -4
     assert N.lib().artn_absmax_normalize_c64(p, 4, p, None) == -4

@@ -1215,6 +1215,7 @@ def test_c128_truth_against_torch_einsum_on_the_gpu(key):
     assert np.abs(got - t).max() <= 1e-11 * rms, (key, float(np.abs(got - t).max() / rms))
 
 
+@pytest.mark.skipif(not N.has("artn_contract3"), reason="three-step fusion is compiled into development builds only (make dev)")
 def test_fused_triples_on_the_gpu(monkeypatch):
     """artn_contract3 (artn_k_bits3: three steps of reference contraction.py:66-70 on one tensor in ONE pass; region 0 -> 1
     -> 0 -> 1) against three oracle steps: the two triples of the n30 scheme that fit a 2^12 tile with 128-byte runs, on

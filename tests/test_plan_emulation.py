@@ -701,14 +701,16 @@ def test_n30_triples_planned_and_emulated():
     three-step fusion does not shorten THIS scheme: 26 chain members = 2 triples + 10 pairs would need the triples to
     sit at even distances; tools/fusion_depth.py)."""
     from helpers import emulate3, shrink_triple
-    from artensor_amd.contraction import triple_info
+    import torch
     case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
     steps = dense_scheme_shapes(case)
     big = [n for n, (eq, sa, sb) in enumerate(steps) if len(sa) == 30]
     fit = []
     for p in range(len(big) - 2):
         (e1, sa, sb1), (e2, _, sb2), (e3, _, sb3) = (steps[n] for n in big[p:p + 3])
-        if triple_info(e1, sa, sb1, e2, sb2, e3, sb3) is not None:
+        # (plan only, at full size, through the CPU emulator's copy of the planner: the product library carries no triples)
+        meta = lambda sh: torch.empty(sh, dtype=torch.complex64, device="meta")
+        if emulate3(e1, meta(sa), meta(sb1), e2, meta(sb2), e3, meta(sb3), run=False)[0] is not None:
             fit.append(tuple(big[p:p + 3]))
     assert fit == [(125, 128, 131), (149, 155, 159)], fit
     rng = np.random.default_rng(3)
