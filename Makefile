@@ -6,7 +6,7 @@ LIB := artensor_amd/libartn_hip.so
 
 all: $(LIB)
 
-# eight objects from ONE source (see "Translation units" in artn_kernels.hip): `make -j8` builds in about a
+# thirteen objects from ONE source (see "Translation units" in artn_kernels.hip): `make -j8` builds in about a
 # minute and a half instead of four
 SRCS := $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_pgemm_kernel.h \
         $(CSRC)/artn_bits128_kernel.h $(CSRC)/artn_bits3_kernel.h $(CSRC)/artn_wide_kernel.h $(CSRC)/artn_plan.h \
@@ -23,7 +23,8 @@ else
 DEVFLAGS :=
 DEVOBJS :=
 endif
-OBJS := $(OBJDIR)/main.o $(OBJDIR)/b128.o $(OBJDIR)/wide.o $(foreach k,1 2 3 4 5 6,$(OBJDIR)/bits_k$(k).o) $(DEVOBJS)
+OBJS := $(OBJDIR)/main.o $(OBJDIR)/b128.o $(OBJDIR)/wide.o $(foreach k,1 2 3 4,$(OBJDIR)/bits_k$(k).o) \
+        $(foreach k,5 6,$(OBJDIR)/bits_k$(k)h0.o $(OBJDIR)/bits_k$(k)h1.o) $(DEVOBJS)
 FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -I$(CSRC) $(DEVFLAGS)
 
 $(OBJDIR)/main.o: $(SRCS)
@@ -38,6 +39,13 @@ $(OBJDIR)/wide.o: $(SRCS)
 $(OBJDIR)/bits3_k%.o: $(SRCS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -DARTN_TU_BITS3=$* -c $< -o $@
+# (the families of 5 and 6 contracted bits in two halves each: second-stage counts 0..3 / 4..6)
+$(OBJDIR)/bits_k%h0.o: $(SRCS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FLAGS) -DARTN_TU_BITS=$* -DARTN_TU_HALF=0 -c $< -o $@
+$(OBJDIR)/bits_k%h1.o: $(SRCS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FLAGS) -DARTN_TU_BITS=$* -DARTN_TU_HALF=1 -c $< -o $@
 $(OBJDIR)/bits_k%.o: $(SRCS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -DARTN_TU_BITS=$* -c $< -o $@

@@ -1834,6 +1834,57 @@ __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_generic(const T2 *__re
 }
 
 
+// The same with ONE WORKGROUP per output element: closing steps contract thousands of values into a handful of results (the
+// last step of a closed network is a dot product: one output, 1 296 terms on the bond-dimension-6 network -- 1.06 ms on a
+// single thread of the kernel above, a sixth of that network's contraction).  The 256 threads stride over the terms; their
+// partial sums are added in a fixed order (a tree over LDS), so the result does not depend on scheduling.
+template <typename T2, typename T>
+__global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_generic_red(const T2 *__restrict__ A, const T2 *__restrict__ B, T2 *__restrict__ C,
+                                                                     const ArtnGenericPlan G) {
+  __shared__ T part_re[ARTN_WG_THREADS], part_im[ARTN_WG_THREADS];
+  for (long idx = blockIdx.x; idx < G.out_numel; idx += gridDim.x) {
+    long r = idx, oa = 0, ob = 0;
+    for (int d = 0; d < G.n_out; ++d) {
+      const long e = G.out_ext[d];
+      const long x = r % e;
+      r /= e;
+      oa += x * G.out_sA[d];
+      ob += x * G.out_sB[d];
+    }
+    T re = 0, im = 0;
+    for (long q = threadIdx.x; q < G.red_numel; q += ARTN_WG_THREADS) {
+      long rr = q, ka = 0, kbo = 0;
+      for (int d = 0; d < G.n_red; ++d) {
+        const long e = G.red_ext[d];
+        const long x = rr % e;
+        rr /= e;
+        ka += x * G.red_sA[d];
+        kbo += x * G.red_sB[d];
+      }
+      const T2 a = A[oa + ka], b = B[ob + kbo];
+      re += a.x * b.x - a.y * b.y;
+      im += a.x * b.y + a.y * b.x;
+    }
+    part_re[threadIdx.x] = re;
+    part_im[threadIdx.x] = im;
+    __syncthreads();
+    for (int s = ARTN_WG_THREADS / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) {
+        part_re[threadIdx.x] += part_re[threadIdx.x + s];
+        part_im[threadIdx.x] += part_im[threadIdx.x + s];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      T2 o;
+      o.x = part_re[0];
+      o.y = part_im[0];
+      C[idx] = o;
+    }
+    __syncthreads();
+  }
+}
+
 // ----------------------------------------------------------------------------------------
 // small-step programs: the launch-latency tail of a scheme in one launch
 // ----------------------------------------------------------------------------------------
@@ -2346,6 +2397,13 @@ static hipError_t ensure_lds(size_t lds) {
   return e;
 }
 
+// (-DARTN_TU_HALF=0 / 1 with -DARTN_TU_BITS=K: only the second-stage counts 0..3 / 4..6 of that family -- the families of 5 and
+//  6 contracted bits took a minute each to compile and were the long pole of `make -j8`)
+#ifndef ARTN_TU_HALF
+#define ARTN_TU_HALF -1
+#endif
+#define ARTN_K2_LO (ARTN_TU_HALF != 1)
+#define ARTN_K2_HI (ARTN_TU_HALF != 0)
 template <int KB1>
 static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, float2 *C,
                                  hipStream_t st) {
@@ -2454,17 +2512,22 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
     break;                                                                                                \
   }
       switch (k2) {
+#if ARTN_K2_LO
         ARTN_ALT_CASE(0)
         ARTN_ALT_CASE(3)
+#endif
+#if ARTN_K2_HI
         ARTN_ALT_CASE(4)
         ARTN_ALT_CASE(5)
         ARTN_ALT_CASE(6)
+#endif
         default: break;
       }
 #undef ARTN_ALT_CASE
 #undef ARTN_ALT_GO
     }
   }
+#if ARTN_K2_LO
   if constexpr (KB1 == 5 || KB1 == 6) { // single steps that keep at most 4 result bits in the tile: 16 x 16 x 4 blocks, three products
     if (p.bits.narrow3 == 1 && k2 == 0 && split == 0 && p.bits.gather_dim < 0 && p.bits.st[0].k <= 6 && !full) {
       if (p.bits.nt_loads) {
@@ -2479,6 +2542,8 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
       return hipGetLastError();
     }
   }
+#endif
+#if ARTN_K2_HI
   if constexpr (KB1 >= 2) { // 3M pairs whose SECOND stage keeps at most 4 result bits in the tile (ArtnBitsPlan::narrow3 = 2)
     if (p.bits.narrow3 == 2 && p.bits.m3 && (k2 == 5 || k2 == 6) && split == 0 && p.bits.gather_dim < 0 && p.bits.st[0].k <= 6 && !full) {
 #define ARTN_N3_GO(K2, NTV)                                                                               \
@@ -2493,6 +2558,8 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
 #undef ARTN_N3_GO
     }
   }
+#endif
+#if ARTN_K2_LO
   if (p.bits.gather_dim >= 0) { // fused row gather: single stage, fp32 chains
     if (k2 != 0) return hipErrorInvalidValue;
     if (KB1 == 6 && p.bits.st[0].k > 6) {
@@ -2518,14 +2585,19 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
     hipLaunchKernelGGL(kern, grid, block, lds, st, A, B1, B2, C, p.bits);
     return hipGetLastError();
   }
+#endif
   switch (k2) {
+#if ARTN_K2_LO
     ARTN_LAUNCH(0)
     ARTN_LAUNCH(1)
     ARTN_LAUNCH(2)
     ARTN_LAUNCH(3)
+#endif
+#if ARTN_K2_HI
     ARTN_LAUNCH(4)
     ARTN_LAUNCH(5)
     ARTN_LAUNCH(6)
+#endif
     default: return hipErrorInvalidValue;
   }
 #undef ARTN_LAUNCH
@@ -2644,6 +2716,11 @@ hipError_t ARTN_CAT(artn_launch_bits3_k, ARTN_TU_BITS3)(const ArtnPlan &p, const
 #endif
 #if defined(ARTN_TU_B128) || defined(ARTN_TU_BITS3) || defined(ARTN_TU_WIDE)
 // (nothing else in this translation unit)
+#elif defined(ARTN_TU_BITS) && ARTN_TU_HALF >= 0
+hipError_t ARTN_CAT(ARTN_CAT(ARTN_CAT(artn_launch_bits_k, ARTN_TU_BITS), h), ARTN_TU_HALF)(const ArtnPlan &p, const float2 *A, const float2 *B1,
+                                                                                        const float2 *B2, float2 *C, hipStream_t st) {
+  return launch_bits_k2<ARTN_TU_BITS>(p, A, B1, B2, C, st);
+}
 #elif defined(ARTN_TU_BITS)
 hipError_t ARTN_CAT(artn_launch_bits_k, ARTN_TU_BITS)(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, float2 *C,
                                                      hipStream_t st) {
@@ -2655,8 +2732,10 @@ hipError_t artn_launch_bits_k1(const ArtnPlan &, const float2 *, const float2 *,
 hipError_t artn_launch_bits_k2(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
 hipError_t artn_launch_bits_k3(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
 hipError_t artn_launch_bits_k4(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
-hipError_t artn_launch_bits_k5(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
-hipError_t artn_launch_bits_k6(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits_k5h0(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits_k5h1(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits_k6h0(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
+hipError_t artn_launch_bits_k6h1(const ArtnPlan &, const float2 *, const float2 *, const float2 *, float2 *, hipStream_t);
 #endif
 // Three-step fusion (artn_k_bits3 / artn_contract3, round 4) was built, is parity-green and shortens no committed workload
 // (DESIGN.md 4.1c): it is compiled only into development builds (make dev: -DARTN_DEV_BITS3).
@@ -2700,8 +2779,8 @@ static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, 
     case 2: return artn_launch_bits_k2(p, a, b1, b2, c, st);
     case 3: return artn_launch_bits_k3(p, a, b1, b2, c, st);
     case 4: return artn_launch_bits_k4(p, a, b1, b2, c, st);
-    case 5: return artn_launch_bits_k5(p, a, b1, b2, c, st);
-    case 6: return artn_launch_bits_k6(p, a, b1, b2, c, st);
+    case 5: return ((p.bits.n_stages == 2 && p.bits.st[1].k >= 4) ? artn_launch_bits_k5h1 : artn_launch_bits_k5h0)(p, a, b1, b2, c, st);
+    case 6: return ((p.bits.n_stages == 2 && p.bits.st[1].k >= 4) ? artn_launch_bits_k6h1 : artn_launch_bits_k6h0)(p, a, b1, b2, c, st);
 #else
     case 1: return launch_bits_k2<1>(p, a, b1, b2, c, st);
     case 2: return launch_bits_k2<2>(p, a, b1, b2, c, st);
@@ -3092,6 +3171,15 @@ int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, 
   }
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
   if (p.gen.out_numel == 0) return ARTN_OK;
+  if (p.gen.out_numel <= 4096 && p.gen.red_numel >= 512) { // few results of long sums: a workgroup per result
+    dim3 rgrid((unsigned)p.gen.out_numel);
+    if (d->dtype != ARTN_C128)
+      hipLaunchKernelGGL((artn_k_generic_red<float2, float>), rgrid, block, 0, st, (const float2 *)A, (const float2 *)B, (float2 *)C, p.gen);
+    else
+      hipLaunchKernelGGL((artn_k_generic_red<double2, double>), rgrid, block, 0, st, (const double2 *)A, (const double2 *)B, (double2 *)C, p.gen);
+    HIP_TRY(hipGetLastError());
+    return ARTN_OK;
+  }
   if (d->dtype != ARTN_C128) // (small steps of the reduced-precision mode run in fp32: they are launch-bound)
     hipLaunchKernelGGL((artn_k_generic<float2, float>), grid, block, 0, st, (const float2 *)A,
                        (const float2 *)B, (float2 *)C, p.gen);

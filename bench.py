@@ -288,6 +288,9 @@ SLICED_WORKLOADS = {
     "n53m20b": ("n53_m20_batch.npz", True,
                 "Sycamore n53 m20 big-batch sampling (BASELINE configs[4]): 1 024 correlated bitstrings over 16 open "
                 "qubits, 40 sliced bonds"),
+    "n53m20bb": ("n53_m20_bigbatch.npz", True,
+                 "Sycamore n53 m20 big-batch sampling at 2^16 bitstrings (half of the 2^17 product over 17 open qubits), "
+                 "41 sliced bonds; scheme from the vectorised sparse compiler"),
     "rand2": ("rand_D2_nv260_sliced.npz", False,
               "random 3-regular tensor network, bond dimension 2, 260 tensors, closed, 12 sliced bonds (sc 30)"),
     "rand4": ("rand_D4_nv100.npz", False,
@@ -543,6 +546,8 @@ LEGS = [
     ("n53", "configs[3] (one rank's share: slices are independent)", "n53", "fp32", 4),
     ("n53m20b", "configs[4], complex64 arithmetic", "n53m20b", "fp32", 1),
     ("n53m20b_bf16", "configs[4] as written: bf16-complex MFMA path", "n53m20b", "bf16", 1),
+    ("n53m20bb", "configs[4] at 65 536 bitstrings, complex64 arithmetic", "n53m20bb", "fp32", 1),
+    ("n53m20bb_bf16", "configs[4] at 65 536 bitstrings: bf16-complex MFMA path", "n53m20bb", "bf16", 1),
     ("n53m20", "the bundled n53 m20 circuit, one bitstring", "n53m20", "fp32", 2),
     ("rand2", "north_star: random tensor network, bond dimension 2", "rand2", "fp32", 4),
     ("rand4", "north_star: random tensor network, bond dimension 4", "rand4", "fp32", 4),

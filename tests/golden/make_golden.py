@@ -408,6 +408,72 @@ def case_n30_sliced(k=3):
     print("n30_sliced", k, "bonds", chosen, "log10 tc/slice", tc)
 
 
+def case_n30_dense_parts():
+    """The unsliced n30 m14 contraction over N = 2, 4, 8 ranks WITHOUT a collective: rank r computes the slab of 2^30 / N
+    amplitudes whose log2 N chosen output qubits spell r.  Round 4 fixed those qubits at the leaves of the ONE tree
+    planned for the full network (artensor_amd.partition_output: 1.36 / 2.13 / 3.78 x the unsliced FLOP at N = 2 / 4 /
+    8); here the REDUCED network -- those output bonds removed from their leaves -- goes back to the reference's planner
+    (order_finder.py:174-198, same budget as the full plan), one plan per N (the slabs of one N differ in leaf VALUES
+    only).  Several choices of qubits are planned and the cheapest kept.  Expected values: the full fixture's amplitudes
+    at Google's bitstrings, which the reference computed (n30_dense.npz)."""
+    from artensor_amd.fixtures import load_case
+    full = load_case(os.path.join(HERE, "n30_dense.npz"))
+    tc_full = full.meta["log10_tc"]
+    sim0 = TensorNetworkSimulation.from_circuit_file(n30_qsim(), [])
+    fq = sorted(sim0.final_qubits) if isinstance(sim0.final_qubits, (set, frozenset)) else list(sim0.final_qubits)
+    assert len(fq) == 30
+    count = {}
+    for tid, bonds in sim0.tensor_bonds.items():
+        for b in bonds:
+            count[b] = count.get(b, 0) + 1
+    dangling = {}
+    for q, tid in enumerate(fq):
+        mine = [b for b in sim0.tensor_bonds[tid] if count[b] == 1]
+        assert len(mine) == 1, (tid, mine)
+        dangling[q] = mine[0]
+    for k in (1, 2, 3):
+        N = 2 ** k
+        # every run of k neighbouring qubits (in the reference's final-qubit order) + one spread choice: the planner's result
+        # depends strongly on WHICH qubits are fixed (N = 8: 0.97 x for qubits 27-29, 11 x for 14-16), and a plan is 12 s
+        cands = [tuple(range(q, q + k)) for q in range(0, 31 - k)] + [tuple(int(round(x)) for x in np.linspace(0, 29, k + 2)[1:-1])]
+        best = None
+        for cand in dict.fromkeys(cands):
+            tb = {t: list(b) for t, b in sim0.tensor_bonds.items()}
+            fixed = []
+            for q in cand:
+                tid = fq[q]
+                dim = tb[tid].index(dangling[q])
+                fixed.append((int(tid), int(dim), int(q)))
+            for tid, dim, q in sorted(fixed, key=lambda x: -x[1]):
+                tb[tid].pop(dim)
+            fq2 = [t for q, t in enumerate(fq) if q not in cand]
+            bd = {b: 2.0 for b in set().union(*tb.values())}
+            t0 = time.time()
+            order, slicing_bonds, ctree = find_order(
+                deepcopy(tb), deepcopy(bd), set(fq2), 0, 1, sc_target=30, betas=np.linspace(3.0, 21.0, 61), start_seed=0, **PLAN)
+            tc, sc = ctree.tree_complexity()[:2]
+            print(f"N={N} fixed qubits {cand}: log10 tc {tc:.3f} sc {sc:.1f} sliced {len(slicing_bonds)} overhead "
+                  f"{N * 10 ** (tc - tc_full):.2f} x  ({time.time() - t0:.0f} s)", flush=True)
+            if len(slicing_bonds) == 0 and (best is None or tc < best[0]):
+                best = (float(tc), float(sc), cand, fixed, fq2, ctree)
+        tc, sc, cand, fixed, fq2, ctree = best
+        scheme, output_bonds = contraction_scheme(deepcopy(ctree))
+        # raw result dim x <-> the qubit (0 = first final qubit, most significant in the reference's final order)
+        out_qubits = []
+        for b in output_bonds:
+            q = [q for q in range(30) if dangling[q] == b]
+            assert len(q) == 1
+            out_qubits.append(int(q[0]))
+        tensors = {i: sim0.tensors[i].to(torch.complex64) for i in sim0.tensors}
+        meta = dict(n_slabs=N, fixed=[list(x) for x in fixed], fixed_qubits=[int(q) for q in cand], out_qubits=out_qubits,
+                    log10_tc=tc, sc=sc, log10_tc_full=float(tc_full), executed_flop_over_unsliced=float(N * 10 ** (tc - tc_full)),
+                    plan=PLAN, hashseed=0,
+                    note="slab r: fixed[j] = (leaf tensor id, dim, qubit) takes bit j of r (bit 0 = first entry); the scheme runs on "
+                         "the leaves after those selects; raw result dim x holds qubit out_qubits[x]")
+        save_case(os.path.join(HERE, f"n30_dense_part{N}.npz"), tensors, scheme, meta)
+        print(f"n30_dense_part{N}: qubits {cand}, {len(scheme)} steps, overhead {meta['executed_flop_over_unsliced']:.2f} x", flush=True)
+
+
 def _dump_tree(ctree):
     """Planner products as plain data (what contraction.py:23-59 / :208-341 consume):
     vertices with their bond lists IN THE ITERATION ORDER the reference saw."""
@@ -804,6 +870,7 @@ CASES = {
     "n30_sparse100": lambda: case_n30_sparse(100),
     "n30_sparse10000": lambda: case_n30_sparse(10000),
     "n30_sliced3": lambda: case_n30_sliced(3),
+    "n30_dense_parts": case_n30_dense_parts,
 }
 
 if __name__ == "__main__":

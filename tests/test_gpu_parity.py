@@ -809,6 +809,15 @@ def test_non_power_of_two_extents_on_the_matrix_cores():
     got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
     want = _einsum128_labels(eq, a, b)
     assert np.abs(got - want).max() <= 5e-6 * np.abs(want).max()
+    # few results of long sums (the closing steps of a closed network end in a dot product): one workgroup per result
+    a, b = crandn(rng, (6, 6, 6, 6)), crandn(rng, (6, 6, 6, 6))
+    got = A.contract((("a", "b", "c", "d"), ("c", "a", "d", "b"), ()), gpu(a), gpu(b)).cpu().numpy()
+    want = np.einsum("abcd,cadb->", a.astype(np.complex128), b.astype(np.complex128))
+    assert abs(got - want) <= 3e-6 * np.sqrt(1296) * 2
+    a, b = crandn(rng, (3, 7, 5, 11, 9)), crandn(rng, (9, 2, 11, 7, 5))
+    got = A.contract((("m", "i", "j", "k", "l"), ("l", "n", "k", "i", "j"), ("n", "m")), gpu(a), gpu(b)).cpu().numpy()
+    want = np.einsum("mijkl,lnkij->nm", a.astype(np.complex128), b.astype(np.complex128))
+    assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max()
     # strided views of bigger tensors
     big_a, big_b = gpu(crandn(rng, (27, 9, 25, 6, 30))), gpu(crandn(rng, (6, 14, 9, 30)))
     va, vb = big_a[1:26, :, ::2, :, :], big_b[:, 1:12, :, :]
@@ -1569,6 +1578,39 @@ def test_n53_m20_big_batch_slice0():
     assert fidelity >= 0.9996, fidelity
     assert rms_err <= 2.2e-2, rms_err
     assert abs(np.mean(y - x)) / rms_amp <= 4 * rms_err / np.sqrt(len(x)), (np.mean(y - x), rms_err)   # no systematic offset
+
+
+def test_n53_m20_big_batch_of_65536_bitstrings_slice0():
+    """BASELINE configs[4] at a batch that deserves the name (round 5; tests/golden/n53_m20_bigbatch.npz): 2^16 correlated
+    bitstrings -- half of the 2^17 product over 17 open qubits -- on the bundled n53 m20 circuit, planned by the reference
+    (41 sliced bonds), compiled by the vectorised sparse compiler (same tuples as the reference's wherever that one
+    finishes: tests/golden/check_boundary.py), slice 0 from the REFERENCE's executor (200 s on 8 cores).  complex64 against
+    that value; then the bf16-complex MFMA path by state fidelity."""
+    case = load_case(os.path.join(GOLDEN, "n53_m20_bigbatch.npz"))
+    br = case.meta["branches"]
+    assert br["A"] >= 1 and br["B"] >= 1 and br["C_select"] >= 1
+    rows = len(case.meta["bitstrings_sorted"])
+    assert rows == 65536 and len(case.slicing_indices) == 41
+    # the scheme stored in the fixture IS what this package's compiler returns for that batch: index lists of 2^16 rows
+    assert max(int(x.numel()) for st in case.scheme if len(st) > 2 for side in st[2] for x in side) >= 32768
+    leaves = case.fresh_tensors(device=DEV)
+    runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (rows,), sparse=True, device=DEV)
+    got = runner.run([0]).reshape(-1).cpu().numpy().copy()
+    want = case.arrays["slice0"].reshape(-1)
+    # (no complex128 truth for this fixture: both runs are complex64 -- the reference's own distance from the truth is
+    #  2-4e-6 on the neighbouring fixtures -- so the bound is the contract plus that, and the rms error a tenth of it)
+    assert amp_rel(got, want) <= 1.5e-5, amp_rel(got, want)
+    rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+    assert float(np.sqrt(np.mean(np.abs(got - want) ** 2))) <= 1e-5 * rms
+    with A.precision("bf16"):
+        r16 = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (rows,), sparse=True, device=DEV)
+        got16 = r16.run([0]).reshape(-1).cpu().numpy().copy()
+    x, y = got.astype(np.complex128), got16.astype(np.complex128)
+    fidelity = abs(np.vdot(x, y)) ** 2 / (np.vdot(x, x).real * np.vdot(y, y).real)
+    rms_err = float(np.sqrt(np.mean(np.abs(y - x) ** 2))) / float(np.sqrt(np.mean(np.abs(x) ** 2)))
+    print(f"bf16 big-batch (65 536 bitstrings) slice 0: fidelity {fidelity:.6f}, rms error {rms_err:.3e} of the rms amplitude")
+    assert fidelity >= 0.999, fidelity
+    assert amp_rel(got16, got) > 1e-4   # and it is not the fp32 path
 
 
 def _bf16_round(x):
