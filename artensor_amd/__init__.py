@@ -31,6 +31,8 @@ from .simulation import (  # noqa: F401
     apply_slice,
     partition_output,
     partitioned_contraction,
+    plan_output_slabs,
+    slab_contraction,
     quantum_circuit_simulation,
     rank_slices,
     slice_assignments,

@@ -682,6 +682,72 @@ def partitioned_contraction(tensors, scheme, n_fix, part, device="cuda", dtype=t
     return tensor_contraction(leaves, new_scheme), fixed_dims, values
 
 
+def plan_output_slabs(tensor_bonds, bond_dims, final_qubits, n_slabs, candidates=None, planner=None, **plan_args):
+    """Re-plan an unsliced dense (full-amplitude) network for `n_slabs` = 2^k ranks WITHOUT a collective (round 5).
+
+    partition_output fixes k output labels at the leaves of the tree planned for the FULL network; here the REDUCED
+    network -- the dangling bonds of k chosen output qubits removed from their leaves -- goes back to the reference's
+    planner (order_finder.py:174-198), which is free to find a tree for it.  On Sycamore n30 m14 the slabs then cost
+    0.85 / 0.88 / 0.97 x the unsliced FLOP IN TOTAL at N = 2 / 4 / 8 (1.36 / 2.13 / 3.78 x with the one tree): the 8 ranks of
+    a node together execute what one GPU executes alone.  Which qubits are fixed matters (0.97 x ... 11 x at N = 8), a
+    plan of n30 takes 12 s: every run of k neighbouring final qubits is tried unless `candidates` (tuples of positions
+    in sorted(final_qubits)) says otherwise.  Returns dict(fixed=[(leaf id, dim, qubit)...], tensor_bonds, final_qubits,
+    ctree, log10_tc, candidates_tried).  Slab r: fixed[j] takes bit j of r."""
+    import copy
+    import math
+    R = _planner(planner)
+    k = int(round(math.log2(n_slabs)))
+    if (1 << k) != n_slabs or k < 1:
+        raise RuntimeError("n_slabs must be a power of two >= 2")
+    fq = sorted(final_qubits)
+    count = {}
+    for tid, bonds in tensor_bonds.items():
+        for b in bonds:
+            count[b] = count.get(b, 0) + 1
+    dangling = {}
+    for q, tid in enumerate(fq):
+        mine = [b for b in tensor_bonds[tid] if count[b] == 1]
+        if len(mine) != 1:
+            raise RuntimeError(f"final qubit {q} (tensor {tid}) has {len(mine)} dangling bonds: not a full-amplitude network")
+        dangling[q] = mine[0]
+    if candidates is None:
+        candidates = [tuple(range(q, q + k)) for q in range(0, len(fq) - k + 1)]
+    best, tried = None, []
+    for cand in candidates:
+        tb = {t: list(b) for t, b in tensor_bonds.items()}
+        fixed = [(tid, tb[tid].index(dangling[q]), q) for q, tid in ((q, fq[q]) for q in cand)]
+        for tid, dim, q in sorted(fixed, key=lambda x: -x[1]):
+            tb[tid].pop(dim)
+        fq2 = [t for q, t in enumerate(fq) if q not in cand]
+        bd = {b: bond_dims[b] for b in set().union(*tb.values())}
+        order, slicing_bonds, ctree = R.find_order(copy.deepcopy(tb), copy.deepcopy(bd), set(fq2), 0, 1, **plan_args)
+        tc = float(ctree.tree_complexity()[0])
+        tried.append((tuple(cand), tc, len(slicing_bonds)))
+        if len(slicing_bonds) == 0 and (best is None or tc < best["log10_tc"]):
+            best = dict(fixed=fixed, tensor_bonds=tb, final_qubits=fq2, ctree=ctree, log10_tc=tc, dangling=dangling)
+    if best is None:
+        raise RuntimeError("the planner sliced every reduced network: raise sc_target")
+    best["candidates_tried"] = tried
+    return best
+
+
+def slab_contraction(tensors, scheme, fixed, part, device="cuda", dtype=torch.complex64):
+    """Slab `part` of a full-amplitude contraction planned by plan_output_slabs (or loaded from a committed plan such as
+    tests/golden/n30_dense_part8.npz): the leaves with fixed[j] = (leaf id, dim, qubit) set to bit j of `part`, contracted
+    by `scheme` (the reduced network's own scheme).  Returns the raw slab (dims in the scheme's output order)."""
+    items = list(tensors.items()) if isinstance(tensors, dict) else list(enumerate(tensors))
+    per_leaf = {}
+    for j, (leaf, dim, _q) in enumerate(fixed):
+        per_leaf.setdefault(leaf, {})[int(dim)] = (int(part) >> j) & 1
+    leaves = {}
+    for k, t in items:
+        t = t.to(dtype).to(device)
+        if k in per_leaf:
+            t = t[tuple(per_leaf[k].get(d, slice(None)) for d in range(t.dim()))].contiguous()
+        leaves[k] = t
+    return tensor_contraction(leaves, scheme)
+
+
 def _planner(planner=None):
     """The planning front end (circuit parser, simplifier, order finder, contraction tree): the
     reference package itself -- `north_star` keeps it untouched -- or any module with the same names."""

@@ -874,6 +874,41 @@ def test_random_networks_whose_bond_dimension_is_not_a_power_of_two(name):
     assert amp_rel(plain, got) <= 1e-5
 
 
+@pytest.mark.parametrize("n_slabs", [2, 4, 8])
+def test_n30_slabs_of_the_replanned_reduced_network(n_slabs):
+    """The unsliced n30 m14 contraction over N ranks without a collective (round 5): log2 N output qubits fixed at the leaves
+    and the REDUCED network re-planned by the reference's order finder (tests/golden/make_golden.py::case_n30_dense_parts;
+    0.85 / 0.88 / 0.97 x the unsliced plan's FLOP in total at N = 2 / 4 / 8, against 1.36 / 2.13 / 3.78 x for the one tree
+    of round 4).  Slabs 0 and N - 1 against the matching amplitudes of the FULL result as the reference computed it
+    (n30_dense.npz: Google's 10 000 bitstrings)."""
+    full = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    part = load_case(os.path.join(GOLDEN, f"n30_dense_part{n_slabs}.npz"))
+    k = int(np.log2(n_slabs))
+    assert len(part.meta["fixed"]) == k and len(part.meta["out_qubits"]) == 30 - k
+    assert part.meta["executed_flop_over_unsliced"] <= 1.0
+    fpos = np.array([int(b, 2) for b in full.meta["google_bitstrings"]], dtype=np.int64)
+    want_all = full.arrays["amps_at_google"]
+    rms = float(np.sqrt(np.mean(np.abs(want_all) ** 2)))
+    leaves = part.fresh_tensors(device=DEV)
+    seen = 0
+    for r in (0, n_slabs - 1):
+        raw = A.slab_contraction(leaves, part.scheme, part.meta["fixed"], r, device=DEV)
+        assert raw.numel() == 2 ** (30 - k)
+        sel = np.ones(len(fpos), dtype=bool)
+        for j, (_leaf, _dim, q) in enumerate(part.meta["fixed"]):
+            sel &= ((fpos >> (29 - q)) & 1) == ((r >> j) & 1)
+        oq = part.meta["out_qubits"]
+        local = np.zeros(int(sel.sum()), dtype=np.int64)
+        for x, q in enumerate(oq):
+            local |= ((fpos[sel] >> (29 - q)) & 1) << (len(oq) - 1 - x)
+        got = raw.reshape(-1)[torch.from_numpy(local).to(DEV)].cpu().numpy()
+        assert sel.sum() > 10000 // n_slabs // 2
+        assert amp_rel(got, want_all[sel], rms) <= 1e-5, (n_slabs, r, amp_rel(got, want_all[sel], rms))
+        seen += int(sel.sum())
+        del raw
+    assert seen > 0
+
+
 def test_state_vec_n12_and_n30():
     """circuit.py:155-175 on the device.  n12: the reference's own state vector.  n30: the state
     vector (1 270 gate applications on 2^30 amplitudes) against the tensor-network amplitudes the
