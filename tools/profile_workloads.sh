@@ -6,7 +6,7 @@ R=${1:-r01}
 OUT=gpurun_out/profw_$R
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-for w in n53 n53m20 rand2 rand4; do
+for w in n53 n53m20 rand2 rand4 rand3 rand6 n53m20bb; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w -- python3 bench.py --workload $w --slices 4 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$w.log 2>&1
   grep -h '^{' $OUT/$w.log | tail -1 > $OUT/$w.json
 done

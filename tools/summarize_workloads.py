@@ -8,7 +8,7 @@ md = [f"# rocprofv3 kernel statistics of the secondary workloads, round {R}", ""
       f"`tools/profile_workloads.sh {R}` on one MI355X: `rocprofv3 --kernel-trace --stats` around",
       "`bench.py --workload W --slices 4 --steps 2 --warmup 1` (13 slices incl. warm-up and check) and around",
       "`tools/trace_sparse.py` (3 runs of the n30 sparse fixtures) and `tools/trace_c128.py` (3 runs of the n30 dense fixture in complex128).", ""]
-for w in ("n53", "n53m20", "n53m20b", "n53m20b_bf16", "rand2", "rand4", "n30_sparse10000", "n30_sparse100", "n30_c128"):
+for w in ("n53", "n53m20", "n53m20b", "n53m20b_bf16", "n53m20bb", "rand2", "rand4", "rand3", "rand6", "n30_sparse10000", "n30_sparse100", "n30_c128"):
     fs = sorted(glob.glob(f"{root}/{w}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
     if not fs:
         continue

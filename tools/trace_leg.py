@@ -3,7 +3,7 @@
 traffic of every kernel family per unit of work -- tools/profile_traffic.sh).
 
     python3 tools/trace_leg.py LEG UNITS      LEG: n30 | n30_sparse10000 | n30_c128 | n30_sliced3 | n53 | n53m20 | n53m20b |
-                                                   n53m20b_bf16 | rand2 | rand4
+                                                   n53m20b_bf16 | rand2 | rand4 | rand3 | rand6 | n53m20bb | n53m20bb_bf16
 A unit is one whole contraction (n30*, rand4) or one slice (the sliced fixtures, Gray order from slice 0).  Prints
 "units N" on the last line."""
 import os
@@ -16,7 +16,9 @@ import artensor_amd as A  # noqa: E402
 from artensor_amd.fixtures import load_case  # noqa: E402
 
 SLICED = {"n53": ("n53_m14_sliced.npz", True), "n53m20": ("n53_m20_sliced.npz", True), "n53m20b": ("n53_m20_batch.npz", True),
-          "n53m20b_bf16": ("n53_m20_batch.npz", True), "rand2": ("rand_D2_nv260_sliced.npz", False), "rand4": ("rand_D4_nv100.npz", False)}
+          "n53m20b_bf16": ("n53_m20_batch.npz", True), "rand2": ("rand_D2_nv260_sliced.npz", False), "rand4": ("rand_D4_nv100.npz", False),
+          "rand3": ("rand_D3_nv112.npz", False), "rand6": ("rand_D6_nv64.npz", False),
+          "n53m20bb": ("n53_m20_bigbatch.npz", True), "n53m20bb_bf16": ("n53_m20_bigbatch.npz", True)}
 leg, units = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2
 G = os.path.join(ROOT, "tests", "golden")
 dev = "cuda:0"
