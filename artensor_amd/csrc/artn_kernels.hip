@@ -1793,6 +1793,9 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 #include "artn_gemm128_kernel.h"
 #include "artn_pgemm_kernel.h"
 #include "artn_xgemm_kernel.h"
+#ifdef ARTN_DEV_XGPC
+#include "artn_xgemm_pc_kernel.h"
+#endif
 
 // ----------------------------------------------------------------------------------------
 // strided fallback: one thread per C element
@@ -2838,6 +2841,30 @@ static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, 
     hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
     return hipGetLastError();                                                                        \
   }
+#ifdef ARTN_DEV_XGPC
+  if (g.pc) { // one 8-wave workgroup per CU: four consumer waves (MFMAs, epilogue), four producer waves (tables, loads, LDS fills)
+    dim3 pblock(ARTN_XGPC_THREADS);
+#define ARTN_XGPC_LAUNCH(NBV, TRV)                                                                   \
+  {                                                                                                  \
+    auto kern = artn_k_xgemm_pc<NBV, TRV>;                                                           \
+    if (hipError_t e = ensure_lds<artn_k_xgemm_pc<NBV, TRV>>(lds); e != hipSuccess) return e;        \
+    hipLaunchKernelGGL(kern, grid, pblock, lds, st, a, b, c, g);                                     \
+    return hipGetLastError();                                                                        \
+  }
+    switch (g.nb * 2 + (g.trans ? 1 : 0)) {
+      case 2: ARTN_XGPC_LAUNCH(1, false)
+      case 3: ARTN_XGPC_LAUNCH(1, true)
+      case 4: ARTN_XGPC_LAUNCH(2, false)
+      case 5: ARTN_XGPC_LAUNCH(2, true)
+      case 6: ARTN_XGPC_LAUNCH(3, false)
+      case 7: ARTN_XGPC_LAUNCH(3, true)
+    }
+#undef ARTN_XGPC_LAUNCH
+    return hipErrorInvalidValue;
+  }
+#else
+  if (g.pc) return hipErrorInvalidValue; // (development builds only)
+#endif
   if (g.kc == 8) { // few contracted values, one block of columns: chunks of 8, four workgroups per CU
     if (g.nb != 1) return hipErrorInvalidValue;
     if (g.trans) {

@@ -1555,6 +1555,11 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
 #ifdef ARTN_DEV_SWITCHES
   if (const char *e = getenv("ARTN_XG_KC")) { const int v = atoi(e); if ((v == 8 && x.nb == 1) || v == 16) x.kc = v; }
 #endif
+  x.pc = 0; // (artn_k_xgemm_pc, the producer / consumer form: correct, measured slower -- 7.5 against 6.7 ms on the biggest step of the
+            //  bond-dimension-3 network -- and compiled into development builds only)
+#if defined(ARTN_DEV_SWITCHES) && defined(ARTN_DEV_XGPC)
+  if (const char *e = getenv("ARTN_XG_PC")) x.pc = (atoi(e) != 0 && x.kc == ARTN_XG_KC) ? 1 : 0;
+#endif
   x.cpg = (x.k.L0 + x.kc - 1) / x.kc;
   x.k_groups = x.k.total / x.k.L0;
   const int64_t chunks = x.k_groups * x.cpg;
@@ -1570,9 +1575,9 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   I.m_tile_bits = 7;
   I.n_tile_bits = 5;
   I.k_bits = 4;
-  I.lds_bytes = artn_xg_lds_bytes(x.nb, x.kc);
+  I.lds_bytes = x.pc ? artn_xg_pc_lds_bytes(x.nb) : artn_xg_lds_bytes(x.nb, x.kc);
   I.n_tiles = x.n_tiles;
-  I.grid = (int32_t)std::min<int64_t>(x.n_tiles, (int64_t)n_cu * (x.kc == 8 ? 4 : 2));
+  I.grid = (int32_t)std::min<int64_t>(x.n_tiles, (int64_t)n_cu * (x.pc ? 1 : (x.kc == 8 ? 4 : 2)));
   I.a_rereads = x.tiles_n;
   return true;
 }

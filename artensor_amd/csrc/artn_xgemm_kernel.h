@@ -288,9 +288,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
   const unsigned lane_x = (unsigned)(h * PA + 32 * wave + j) * 8u;
   const unsigned lane_w = A_BYTES + (unsigned)(h * PB + j) * 8u;
   const int flush_chunks = P.flush_chunks;
-  // one of the two workgroups of a CU runs its MFMA loops at raised priority: what breaks their lockstep in artn_k_bits
-  const bool prio = P.prio && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1); // HW_ID.wave_id bit 0
-
+  const int fill_sel = P.prio; // (development: the trip after which the next chunk goes to LDS; 0: after the second)
   int tile_count = 0;
   for (;; ++tile_count) {
     XG_MARK(0);
@@ -372,8 +370,8 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
         };
         constexpr unsigned XS = 2u * PA * 8u, WS = 2u * PB * 8u; // bytes between two pairs
         XG_MARK(5);
-        const int trips = (kvalid + 3) >> 2, fill_at = trips > 1 ? 1 : 0;
-        if (prio) __builtin_amdgcn_s_setprio(1);
+        const int trips = (kvalid + 3) >> 2;
+        const int fill_at = fill_sel == 0 ? (trips > 1 ? 1 : 0) : (fill_sel < trips ? fill_sel : trips - 1);
 #pragma unroll 1
         for (int q = 0; q < trips; ++q) {
           load_ops(xo + XS, wo + WS, X1, W1);
@@ -386,7 +384,6 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
           mac(X1, W1);
           if (q == fill_at && have_next) fill((cur ^ 1u) * STAGE);
         }
-        if (prio) __builtin_amdgcn_s_setprio(0);
       }
       XG_MARK(6);
       ++since_flush;

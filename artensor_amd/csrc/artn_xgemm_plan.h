@@ -51,7 +51,7 @@ struct ArtnXGemmPlan {
   int32_t flush_chunks;        // partial sums leave the registers every this many chunks (read-add-write of C); 0: never
   int32_t prio;                // 1: the workgroup in the odd wave slots runs its MFMA loops at s_setprio 1
   int32_t kc;                  // contracted values per chunk: 16, or 8 (few contracted values, nb = 1: four workgroups per CU)
-  int32_t pad_;
+  int32_t pc;                  // 1: artn_k_xgemm_pc -- one 8-wave workgroup per CU, four consumer and four producer waves (kc = 16)
   int64_t k_groups;            // k.total / k.L0
   int64_t tiles_m, tiles_n, n_tiles; // n_tiles = tiles_m * tiles_n * prod(h_ext); tile index = (h, tile of m, tile of n), n fastest
 };
@@ -63,6 +63,7 @@ static inline int artn_xg_stage_bytes(int nb, int kc) { return kc * (artn_xg_pit
 static inline int artn_xg_level_bytes() { return 8 * ARTN_XG_LEVEL * 4 + 2 * ARTN_XG_KTAB * 4; } // mA0 mC0 mA1 mC1 nB0 nC0 nB1 nC1, kA kB
 static inline int artn_xg_tiletab_bytes() { return 4 * ARTN_XG_TM * 4; }   // rowA rowC colB colC of one tile
 static inline int artn_xg_lds_bytes(int nb, int kc) { return 2 * artn_xg_stage_bytes(nb, kc) + artn_xg_level_bytes() + 2 * artn_xg_tiletab_bytes(); }
+static inline int artn_xg_pc_lds_bytes(int nb) { return 2 * artn_xg_stage_bytes(nb, ARTN_XG_KC) + artn_xg_level_bytes() + 8 * 1024; } // four row + four column table sets
 
 // Mixed-radix decode of `idx` over labels [first, first + count) of a side: the two element offsets.
 #if defined(__HIPCC__)

@@ -1,6 +1,6 @@
 // Stand-alone timing harness of artn_k_xgemm (diagnostics only; never part of the product): builds the plan of one step whose
 // label layout is given low -> high stride per operand (letters K, M, N, H), launches the kernel a few times and prints ms.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Iartensor_amd/csrc [-DXG_ABLATE_MFMA] [-DXG_ABLATE_MEM] [-DXG_ABLATE_STORE]
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DARTN_DEV_SWITCHES -DARTN_DEV_XGPC -Iinclude -Iartensor_amd/csrc [-DXG_ABLATE_MFMA] [-DXG_ABLATE_MEM] [-DXG_ABLATE_STORE]
 //         tools/probes/xgemm_probe.hip -o tools/probes/xgemm_probe
 //   tools/probes/xgemm_probe KMMMMMMMMKMMMKMMK KNNKNKKNN 3
 #include <hip/hip_runtime.h>
@@ -19,8 +19,32 @@ __device__ __forceinline__ v2f_t lds_read8(unsigned a) { return *(lds_v2f_t *)(u
 __device__ __forceinline__ void lds_write8(unsigned a, v2f_t v) { *(lds_v2f_t *)(unsigned long)a = v; }
 __device__ __forceinline__ void lds_write4(unsigned a, unsigned v) { *(__attribute__((address_space(3))) unsigned *)(unsigned long)a = v; }
 #include "artn_xgemm_kernel.h"
+#include "artn_xgemm_pc_kernel.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <int NB, bool TR>
+static int run_pc(const ArtnPlan &p, const float2 *a, const float2 *b, float2 *c, int reps) {
+  auto kern = artn_k_xgemm_pc<NB, TR>;
+  CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.info.lds_bytes));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kern, dim3(p.info.grid), dim3(512), p.info.lds_bytes, 0, a, b, c, p.xg);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(p.info.grid), dim3(512), p.info.lds_bytes, 0, a, b, c, p.xg);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const ArtnXGemmPlan &x = p.xg;
+  const double flops = 8.0 * (double)x.m.total * (double)x.n.total * (double)x.k.total;
+  printf("PC  M %ld N %ld K %ld nb %d tiles %ld grid %d: %.3f ms  %.1f TFLOP/s\n", (long)x.m.total, (long)x.n.total, (long)x.k.total, x.nb,
+         (long)x.n_tiles, p.info.grid, ms, flops / ms / 1e9);
+  return 0;
+}
 
 template <int NB, bool TR, int KC = 16>
 static int run(const ArtnPlan &p, const float2 *a, const float2 *b, float2 *c, int reps) {
@@ -97,6 +121,16 @@ int main(int argc, char **argv) {
   CK(hipMemset(b, 0x3c, sb * 8));
   const ArtnXGemmPlan &x = p.xg;
   const float2 *pa = x.swapped ? b : a, *pb = x.swapped ? a : b;
+  if (x.pc) {
+    switch (x.nb * 2 + (x.trans ? 1 : 0)) {
+      case 2: return run_pc<1, false>(p, pa, pb, c, reps);
+      case 3: return run_pc<1, true>(p, pa, pb, c, reps);
+      case 4: return run_pc<2, false>(p, pa, pb, c, reps);
+      case 5: return run_pc<2, true>(p, pa, pb, c, reps);
+      case 6: return run_pc<3, false>(p, pa, pb, c, reps);
+      case 7: return run_pc<3, true>(p, pa, pb, c, reps);
+    }
+  }
   if (x.kc == 8) return x.trans ? run<1, true, 8>(p, pa, pb, c, reps) : run<1, false, 8>(p, pa, pb, c, reps);
   switch (x.nb * 2 + (x.trans ? 1 : 0)) {
     case 2: return run<1, false>(p, pa, pb, c, reps);
