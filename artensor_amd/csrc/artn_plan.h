@@ -1501,7 +1501,7 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
 #ifdef ARTN_DEV_SWITCHES // (A/B of the copy modes: no difference on any measured layout, tools/xgemm_modes.py)
   if (const char *e = getenv("ARTN_XG_AMODE")) x.amode = atoi(e) != 0;
   if (const char *e = getenv("ARTN_XG_BMODE")) x.bmode = atoi(e) != 0;
-  if (const char *e = getenv("ARTN_XG_PRIO")) x.prio = atoi(e) != 0;
+  if (const char *e = getenv("ARTN_XG_PRIO")) x.prio = atoi(e);
 #endif
   // label order inside each flattened index (innermost first): that of the tensor whose copy lanes run along it
   if (x.amode == 0) std::sort(M.begin(), M.end(), [](const Lab &u, const Lab &v) { return u.sA < v.sA; });
