@@ -661,28 +661,31 @@ def fusion_schedule(scheme):
     return order
 
 
-def chain_schedule(scheme):
+def chain_schedule(scheme, _steps=None):
     """Execution order with CHAINS: maximal runs s0 < s1 < ... of steps on the same first operand such that no step in
     between reads or writes that tensor or any of the chain's second operands (the steps in between only build later small
     operands from other tensors and are moved in front of the chain: they do not depend on it).  Returns a list of
     ("one", n) / ("chain", [s0, s1, ...]) entries (chains have two or more members) covering every step exactly once.
-    A chain is what one, two or three stages per pass over HBM are cut from (_compile_dense)."""
+    A chain is what one, two or three stages per pass over HBM are cut from (_compile_dense, _plan_chain).  The steps
+    moved in front of a chain are scheduled the same way among themselves (a circuit scheme's first tensor is touched by
+    its first two steps and by its last one: everything in between is "moved" and holds every other chain)."""
+    steps = list(range(len(scheme))) if _steps is None else _steps
     order, done = [], set()
-    n_steps = len(scheme)
-    for n in range(n_steps):
+    for pos, n in enumerate(steps):
         if n in done:
             continue
         i, j = scheme[n][0]
         chain, js, moved = [n], {j}, []
-        last = n
+        last = pos
         while True:
             partner, between = None, []
-            for m in range(last + 1, n_steps):
+            for q in range(last + 1, len(steps)):
+                m = steps[q]
                 if m in done:
                     continue
                 i2, j2 = scheme[m][0]
                 if i2 == i:
-                    partner = m
+                    partner = q
                     break
                 if j2 == i or i2 in js or j2 in js:
                     break
@@ -691,11 +694,11 @@ def chain_schedule(scheme):
                 break
             moved += between
             done.update(between)
-            chain.append(partner)
-            js.add(scheme[partner][0][1])
+            chain.append(steps[partner])
+            js.add(scheme[steps[partner]][0][1])
             last = partner
-        for m in moved:
-            order.append(("one", m))
+        if moved:
+            order += chain_schedule(scheme, moved)
         if len(chain) == 1:
             order.append(("one", n))
         else:
@@ -1456,10 +1459,15 @@ _single_row_cache = _Bounded(4096)   # id(index tensor) -> (index tensor, its on
 def _single_row(idx, t):
     """the row an index list of ONE entry selects from t (reference semantics: `t[idx]`, negative counts from the end,
     out of range raises as contraction.py:192-195 would die), or None when it selects several rows or t has no rows"""
+    return _single_row_of_shape(idx, tuple(t.shape), t.element_size())
+
+
+def _single_row_of_shape(idx, shape, itemsize):
+    """_single_row for a tensor known by its shape only (the chain planner of the sparse executor)"""
     # (a 0-d index would DROP the dimension in the reference's t[idx]: only 1-d index lists of one entry are row selects)
-    if not isinstance(idx, torch.Tensor) or idx.dim() != 1 or idx.numel() != 1 or t.dim() == 0:
+    if not isinstance(idx, torch.Tensor) or idx.dim() != 1 or idx.numel() != 1 or len(shape) == 0:
         return None
-    rows = t.shape[0]
+    rows = shape[0]
     # the value is read ONCE per index tensor (a device-resident index would cost a host synchronisation per step and per
     # slice here, and int() of it is illegal during HIP-graph capture): cached like _is_identity / _device_index
     key = id(idx)
@@ -1472,7 +1480,10 @@ def _single_row(idx, t):
     if v < -rows or v >= rows:
         raise RuntimeError(f"row index out of range: {v} for {rows} rows")
     # (a row of one element would be an 8-byte view: the tiled kernels want 16-byte aligned operands)
-    if t[0].numel() * t.element_size() % 16 != 0:
+    row_numel = 1
+    for e in shape[1:]:
+        row_numel *= e
+    if rows == 0 or row_numel * itemsize % 16 != 0:
         return None
     return v % rows
 
@@ -1778,7 +1789,7 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
     key = id(scheme)
     hit = _schedule_cache.get(key)
     if hit is None or hit[0] is not scheme or not _same_steps(hit[2], scheme):
-        hit = _schedule_cache[key] = (scheme, fusion_schedule(scheme), tuple(scheme))
+        hit = _schedule_cache[key] = (scheme, chain_schedule(scheme) if _chain_plan_on() else fusion_schedule(scheme), tuple(scheme))
     factor = None
     last = scheme[-1][0][0]
 
@@ -1826,12 +1837,238 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
     return tensors[last]
 
 
+def _chain_plan_on():
+    return _os_environ.get("ARTN_CHAIN_PLAN", "1") not in ("0",)
+
+
+class _ShapeOnly:
+    """shape / stride / dtype carrier for host-only planner queries"""
+    __slots__ = ("shape", "_st", "dtype")
+
+    def __init__(self, shape, dtype):
+        self.shape, self._st, self.dtype = tuple(shape), _dense_strides(tuple(shape)), dtype
+
+    def stride(self):
+        return self._st
+
+
+def _plain_form(step, a_shape, b_shape, itemsize):
+    """How an un-chunked step of the sparse executor runs as ONE plain contraction on (views of) its operands:
+    (row of the first operand or None = all of it, row of the second or None, shape the result is viewed in or None,
+    row select after it or None, shape of tensors[i] afterwards); None for the chunk loop (A) and for gathers of
+    several rows (B with real index lists): those steps are never part of a fused pair."""
+    bi, bj = step[2]
+    if len(bi) > 1:
+        return None
+    la, lb, lo = _labels(step[1])
+    ra = rb = view = select = None
+    if len(step) > 3 and len(bi) == 1 and len(bj) == 1:   # (B): identities and single rows are views
+        if len(a_shape) == 0 or len(b_shape) == 0:
+            return None
+        if not _is_identity(bi[0], a_shape[0]):
+            ra = _single_row_of_shape(bi[0], a_shape, itemsize)
+            if ra is None:
+                return None
+            a_shape = (1,) + tuple(a_shape[1:])
+        if not _is_identity(bj[0], b_shape[0]):
+            rb = _single_row_of_shape(bj[0], b_shape, itemsize)
+            if rb is None:
+                return None
+            b_shape = (1,) + tuple(b_shape[1:])
+    if len(la) != len(a_shape) or len(lb) != len(b_shape):
+        return None
+    ext = dict(zip(la, a_shape))
+    for x, e in zip(lb, b_shape):
+        if ext.setdefault(x, e) != e:
+            return None
+    after = tuple(ext[x] for x in lo)
+    if len(step) > 3 and not (len(bi) == 1 and len(bj) == 1):   # (C): free reshape, optional row select
+        n = 1
+        for e in after:
+            n *= e
+        try:
+            after = _resolve_reshape(n, step[3])
+        except RuntimeError:
+            return None
+        view = step[3]
+        view_rows = after[0] if len(after) else 0
+        if len(bi) == 1:
+            select = bi[0]
+            after = (len(select),) + tuple(after[1:])
+        return ra, rb, view, select, tuple(a_shape), tuple(b_shape), after, view_rows
+    return ra, rb, view, select, tuple(a_shape), tuple(b_shape), after, 0
+
+
+_chain_cache = _Bounded(1024)   # (id(scheme), first member, shape of the chain's tensor, ...) -> (scheme, groups)
+CHAIN_BW, CHAIN_FLOPS = 5.0e12, 120e12   # what a tile-structured pass / the fp32 matrix pipe sustain (DESIGN 4.1): the cost model
+CHAIN_PAIR_BYTES = 1.35
+CHAIN_MIN_GAIN = 0.97                    # the pairs-from-the-left cut stays unless another one is estimated 3 % faster
+
+
+def _plan_chain(tensors, scheme, members):
+    """Cut the head of a chain (steps on the same first operand, chain_schedule) into single steps and fused pairs.
+
+    Pairs from the left -- what fusion_schedule forms -- leave a declined pair as two single steps even when the second
+    of them fuses with ITS successor, and never look at what a pair saves: an n53 m14 slice ran 2^29 -> 2^30 -> 2^27
+    (6 contracted bits, then 5) as two launches, 17 GB through HBM for an intermediate that fits the tile.  Here every
+    adjacent pair the planner accepts is a candidate, a launch is priced at max(bytes / 5 TB/s, FLOP / 120 TFLOP/s)
+    (pairs: 1.35 x the bytes, re-run first stages paid for, spilling instantiations x 4), and a dynamic programme picks the cut; the
+    left-to-right cut is kept unless the estimate improves by 3 %.  Returns groups (tuples of one or two members)
+    covering a prefix of `members`: planning stops at the first step that is not a plain contraction."""
+    first = scheme[members[0]]
+    a = tensors[first[0][0]]
+    if not isinstance(a, torch.Tensor) or not a.is_cuda or a.dtype not in _DTYPES:
+        return [(members[0],)]
+    key = (id(scheme), members[0], len(members), tuple(a.shape), a.dtype, precision.current())
+    hit = _chain_cache.get(key)
+    if hit is not None and hit[0] is scheme:
+        return hit[1]
+    b_shapes = [tuple(tensors[scheme[n][0][1]].shape) if hasattr(tensors[scheme[n][0][1]], "shape") else None for n in members]
+    groups = _cut_sparse_chain(scheme, members, tuple(a.shape), b_shapes, a.dtype)
+    _chain_cache[key] = (scheme, groups)
+    return groups
+
+
+def _cut_sparse_chain(scheme, members, a_shape, b_shapes, dtype):
+    """_plan_chain on shapes alone (host only): a_shape = the chain's tensor before members[0], b_shapes[q] = the second
+    operand of members[q] (None: not a tensor)."""
+    itemsize = 8 if dtype == torch.complex64 else 16
+    a = _ShapeOnly(a_shape, dtype)
+    forms, shape = [], tuple(a_shape)
+    for n, sb in zip(members, b_shapes):
+        f = _plain_form(scheme[n], shape, sb, itemsize) if sb is not None else None
+        if f is None:
+            break
+        forms.append(f)
+        shape = f[6]
+    L = len(forms)
+    if L == 0:
+        return [(members[0],)]
+
+    def numel(sh):
+        r = 1
+        for e in sh:
+            r *= e
+        return r
+
+    single, pair, flops1 = [0.0] * L, {}, [0.0] * L
+    for p in range(L):
+        ra, rb, view, select, sa, sb, after, view_rows = forms[p]
+        la, lb, lo = _labels(scheme[members[p]][1])
+        d, _ = _descriptor(la, lb, lo, sa, _dense_strides(sa), sb, _dense_strides(sb), a.dtype)
+        info = _step_info_cached(d)
+        single[p], flops1[p] = max(info["bytes"] / CHAIN_BW, info["flops"] / CHAIN_FLOPS), info["flops"]
+        if p + 1 >= L or numel(sa) < FUSE_MIN_NUMEL:
+            continue
+        # between the two contractions the first step may only reshape (free) or select every row in order (the
+        # identity): anything else needs the intermediate in memory; the second step reads ALL of it
+        ra2, sb2 = forms[p + 1][0], forms[p + 1][5]
+        if ra2 is not None or (select is not None and not _is_identity(select, view_rows)):
+            continue
+        out1 = numel(after)
+        if out1 * FUSE_MIN_MID < numel(sa):
+            continue
+        try:
+            d1, d2, _ = _pair_descriptors(scheme[members[p]][1], _ShapeOnly(sa, a.dtype), _ShapeOnly(sb, a.dtype),
+                                          scheme[members[p + 1]][1], _ShapeOnly(sb2, a.dtype), view)
+        except RuntimeError:
+            continue
+        q = N.ArtnStepInfo()
+        rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
+        if rc == -2:
+            continue
+        N.check(rc)
+        # a pair's pass costs more per byte than a single step's (two stages per tile between its copy phases: the
+        # measured pairs of the n53 slices sit at 1.3-1.4 x bytes / 5 TB/s); a first stage that is re-run for every
+        # value of an outer result bit re-reads its input and repeats its FLOP; and the four-wave kernel's instantiations
+        # for 11+ contracted bits spill (6+5 with a shrinking second stage: 228 bytes of scratch, 2.05 ms for a pass
+        # that two launches do in 0.72)
+        rr = max(1, int(q.a_rereads))
+        t = max(CHAIN_PAIR_BYTES * (q.bytes + (rr - 1) * float(itemsize) * numel(sa)) / CHAIN_BW,
+                (q.flops + (rr - 1) * flops1[p]) / CHAIN_FLOPS)
+        if q.k_bits + q.k2_bits >= 11 and q.grid > 256:
+            t *= 4.0
+        pair[p] = t
+    best, take = [0.0] * (L + 2), [1] * L
+    for p in range(L - 1, -1, -1):
+        best[p], take[p] = single[p] + best[p + 1], 1
+        if p in pair and pair[p] + best[p + 2] <= best[p]:
+            best[p], take[p] = pair[p] + best[p + 2], 2
+    left, cost_left, p = [], 0.0, 0
+    while p < L:
+        g = 2 if p in pair else 1
+        left.append(g)
+        cost_left += pair[p] if g == 2 else single[p]
+        p += g
+    groups, p = [], 0
+    use_dp = best[0] < CHAIN_MIN_GAIN * cost_left
+    while p < L:
+        g = take[p] if use_dp else left[len(groups)]
+        groups.append(tuple(members[p:p + g]))
+        p += g
+    return groups
+
+
+def _run_sparse_pair(tensors, scheme, n, m):
+    """Steps n and m (a group of _plan_chain) as one pass through artn_contract2; False when the pair does not run
+    after all (the caller then runs the two steps one after the other)."""
+    s1, s2 = scheme[n], scheme[m]
+    (i, j1), j2 = s1[0], s2[0][1]
+    for t in (j1, j2):   # (second operands are never read through a deferred select)
+        if isinstance(tensors[t], _RowsOf):
+            tensors[t] = rows_of(tensors[t])
+    a, b1, b2 = tensors[i], tensors[j1], tensors[j2]
+    if not all(isinstance(t, torch.Tensor) for t in (a, b1, b2)) or not a.is_cuda:
+        return False
+    f1 = _plain_form(s1, tuple(a.shape), tuple(b1.shape), a.element_size())
+    if f1 is None or (f1[3] is not None and not _is_identity(f1[3], f1[7])):
+        return False
+    f2 = _plain_form(s2, f1[6], tuple(b2.shape), a.element_size())
+    if f2 is None or f2[0] is not None:
+        return False
+    if f1[0] is not None:
+        a = a[f1[0]:f1[0] + 1]
+    if f1[1] is not None:
+        b1 = b1[f1[1]:f1[1] + 1]
+    if f2[1] is not None:
+        b2 = b2[f2[1]:f2[1] + 1]
+    try:
+        fused = contract2(s1[1], a, b1, s2[1], b2, mid_view=f1[2])
+    except Exception as e:
+        raise RuntimeError(f"tensor_contraction_sparse failed at fused steps {n}+{m}: {e}") from e
+    if fused is None:
+        return False
+    if f2[2] is not None:   # branch (C) of the second step: free reshape, optional row select
+        fused = fused.reshape(f2[2])
+        if f2[3] is not None:
+            if (getattr(_lazy_state, "on", False) and fused.numel() >= LAZY_SELECT_MIN_NUMEL
+                    and not _is_identity(f2[3], fused.shape[0])):
+                _device_index(f2[3], fused.device, fused.shape[0])
+                fused = _RowsOf(fused, f2[3])
+            else:
+                fused = gather_rows(fused, f2[3])
+    tensors[i] = fused
+    tensors[j1] = []
+    tensors[j2] = []
+    return True
+
+
 def _run_sparse_main(tensors, scheme, schedule, hoisted, one):
     """The step loop of tensor_contraction_sparse after the small-step program: single steps and fused pairs."""
     for entry in schedule:
         if entry[0] == "one":
             if entry[1] not in hoisted:
                 one(entry[1])
+            continue
+        if entry[0] == "chain":
+            members = [n for n in entry[1] if n not in hoisted]
+            p = 0
+            while p < len(members):
+                for g in _plan_chain(tensors, scheme, members[p:]):
+                    if len(g) == 1 or not _run_sparse_pair(tensors, scheme, g[0], g[1]):
+                        for n in g:
+                            one(n)
+                    p += len(g)
             continue
         n, m = entry[1], entry[2]
         if n in hoisted or m in hoisted:

@@ -1800,34 +1800,71 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 // ----------------------------------------------------------------------------------------
 // strided fallback: one thread per C element
 // ----------------------------------------------------------------------------------------
+// (mixed-radix digits of a flat index -> element offsets in both operands.  The small closing steps of a circuit slice
+//  spend their time HERE, not in memory: 64-bit `%` and `/` per label and term were 1.6 us per term -- a 256-result step of
+//  256-term sums took 412 us, 2 % of an n53 m14 slice.  Indices below 2^31 are decoded in 32 bits, extents that are
+//  powers of two -- every label of a circuit -- with a mask and a shift.)
+template <typename I>
+__device__ __forceinline__ void gen_decode(I r, int n, const int64_t *ext, const int64_t *sA, const int64_t *sB, long &oa, long &ob) {
+  oa = ob = 0;
+  for (int d = 0; d < n; ++d) {
+    const I e = (I)ext[d];
+    I x;
+    if ((e & (e - 1)) == 0) {
+      x = r & (e - 1);
+      r >>= __builtin_ctzll((unsigned long long)e);
+    } else {
+      x = r % e;
+      r /= e;
+    }
+    oa += (long)x * sA[d];
+    ob += (long)x * sB[d];
+  }
+}
+template <typename T2, typename T, typename I>
+__device__ __forceinline__ void gen_terms(const T2 *__restrict__ A, const T2 *__restrict__ B, const ArtnGenericPlan &G, long oa, long ob,
+                                          I q0, I q1, I stride, T &re, T &im) {
+  // (four terms per trip: their loads are in flight together)
+  I q = q0;
+  for (; q + 3 * stride < q1; q += 4 * stride) {
+    T2 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      long ka, kb;
+      gen_decode<I>(q + (I)u * stride, G.n_red, G.red_ext, G.red_sA, G.red_sB, ka, kb);
+      a[u] = A[oa + ka];
+      b[u] = B[ob + kb];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      re += a[u].x * b[u].x - a[u].y * b[u].y;
+      im += a[u].x * b[u].y + a[u].y * b[u].x;
+    }
+  }
+  for (; q < q1; q += stride) {
+    long ka, kb;
+    gen_decode<I>(q, G.n_red, G.red_ext, G.red_sA, G.red_sB, ka, kb);
+    const T2 a = A[oa + ka], b = B[ob + kb];
+    re += a.x * b.x - a.y * b.y;
+    im += a.x * b.y + a.y * b.x;
+  }
+}
 template <typename T2, typename T>
 __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_generic(const T2 *__restrict__ A,
                                                                   const T2 *__restrict__ B,
                                                                   T2 *__restrict__ C,
                                                                   const ArtnGenericPlan G) {
+  const bool narrow = G.out_numel < (1l << 31) && G.red_numel < (1l << 29);
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < G.out_numel;
        idx += (long)gridDim.x * blockDim.x) {
-    long r = idx, oa = 0, ob = 0;
-    for (int d = 0; d < G.n_out; ++d) {
-      const long e = G.out_ext[d];
-      const long x = r % e;
-      r /= e;
-      oa += x * G.out_sA[d];
-      ob += x * G.out_sB[d];
-    }
+    long oa, ob;
     T re = 0, im = 0;
-    for (long q = 0; q < G.red_numel; ++q) {
-      long rr = q, ka = 0, kbo = 0;
-      for (int d = 0; d < G.n_red; ++d) {
-        const long e = G.red_ext[d];
-        const long x = rr % e;
-        rr /= e;
-        ka += x * G.red_sA[d];
-        kbo += x * G.red_sB[d];
-      }
-      const T2 a = A[oa + ka], b = B[ob + kbo];
-      re += a.x * b.x - a.y * b.y;
-      im += a.x * b.y + a.y * b.x;
+    if (narrow) {
+      gen_decode<unsigned>((unsigned)idx, G.n_out, G.out_ext, G.out_sA, G.out_sB, oa, ob);
+      gen_terms<T2, T, unsigned>(A, B, G, oa, ob, 0u, (unsigned)G.red_numel, 1u, re, im);
+    } else {
+      gen_decode<long>(idx, G.n_out, G.out_ext, G.out_sA, G.out_sB, oa, ob);
+      gen_terms<T2, T, long>(A, B, G, oa, ob, 0l, G.red_numel, 1l, re, im);
     }
     T2 o;
     o.x = re;
@@ -1845,28 +1882,16 @@ template <typename T2, typename T>
 __global__ __launch_bounds__(ARTN_WG_THREADS) void artn_k_generic_red(const T2 *__restrict__ A, const T2 *__restrict__ B, T2 *__restrict__ C,
                                                                      const ArtnGenericPlan G) {
   __shared__ T part_re[ARTN_WG_THREADS], part_im[ARTN_WG_THREADS];
+  const bool narrow = G.out_numel < (1l << 31) && G.red_numel < (1l << 29);
   for (long idx = blockIdx.x; idx < G.out_numel; idx += gridDim.x) {
-    long r = idx, oa = 0, ob = 0;
-    for (int d = 0; d < G.n_out; ++d) {
-      const long e = G.out_ext[d];
-      const long x = r % e;
-      r /= e;
-      oa += x * G.out_sA[d];
-      ob += x * G.out_sB[d];
-    }
+    long oa, ob;
     T re = 0, im = 0;
-    for (long q = threadIdx.x; q < G.red_numel; q += ARTN_WG_THREADS) {
-      long rr = q, ka = 0, kbo = 0;
-      for (int d = 0; d < G.n_red; ++d) {
-        const long e = G.red_ext[d];
-        const long x = rr % e;
-        rr /= e;
-        ka += x * G.red_sA[d];
-        kbo += x * G.red_sB[d];
-      }
-      const T2 a = A[oa + ka], b = B[ob + kbo];
-      re += a.x * b.x - a.y * b.y;
-      im += a.x * b.y + a.y * b.x;
+    if (narrow) {
+      gen_decode<unsigned>((unsigned)idx, G.n_out, G.out_ext, G.out_sA, G.out_sB, oa, ob);
+      gen_terms<T2, T, unsigned>(A, B, G, oa, ob, threadIdx.x, (unsigned)G.red_numel, (unsigned)ARTN_WG_THREADS, re, im);
+    } else {
+      gen_decode<long>(idx, G.n_out, G.out_ext, G.out_sA, G.out_sB, oa, ob);
+      gen_terms<T2, T, long>(A, B, G, oa, ob, (long)threadIdx.x, G.red_numel, (long)ARTN_WG_THREADS, re, im);
     }
     part_re[threadIdx.x] = re;
     part_im[threadIdx.x] = im;
@@ -3198,7 +3223,7 @@ int artn_contract(const ArtnStepDesc *d, const void *A, const void *B, void *C, 
   }
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
   if (p.gen.out_numel == 0) return ARTN_OK;
-  if (p.gen.out_numel <= 4096 && p.gen.red_numel >= 512) { // few results of long sums: a workgroup per result
+  if (p.gen.out_numel <= 4096 && p.gen.red_numel >= 64) { // few results of sums: a workgroup per result
     dim3 rgrid((unsigned)p.gen.out_numel);
     if (d->dtype != ARTN_C128)
       hipLaunchKernelGGL((artn_k_generic_red<float2, float>), rgrid, block, 0, st, (const float2 *)A, (const float2 *)B, (float2 *)C, p.gen);

@@ -697,6 +697,41 @@ def test_more_contracted_bits_than_a_tile_holds():
         assert rel(hip_step(eq, a, b), oracle.einsum_pair(eq, a.astype(np.complex128), b.astype(np.complex128))) < 1e-5, eq
 
 
+def test_n53_slice_with_the_chain_cut_and_with_pairs_from_the_left(monkeypatch):
+    """The sparse executor cuts every chain of steps on the state tensor into single steps and fused pairs by a priced
+    dynamic programme (contraction._plan_chain); ARTN_CHAIN_PLAN=0 restores the pairs-from-the-left schedule of rounds
+    1-4.  Same amplitudes either way (reference loop: contraction.py:140-191, one einsum per step), more fused pairs."""
+    from artensor_amd import contraction as C
+    case = load_case(os.path.join(GOLDEN, "n53_m14_sliced.npz"))
+    n_b = len(case.slicing_indices)
+    leaves = case.fresh_tensors(device=DEV)
+
+    class Count:
+        def __init__(self):
+            self.n = 0
+
+        def record(self, info, e0, e1):
+            self.n += 1 if info.get("k2_bits", 0) > 0 else 0   # fused pairs
+
+    def one(mode):
+        monkeypatch.setenv("ARTN_CHAIN_PLAN", mode)
+        C._schedule_cache.clear()
+        sliced = A.apply_slice(leaves, case.slicing_indices, A.slice_assignments(n_b, 0))
+        counter = Count()
+        monkeypatch.setattr(C, "profiler", counter)
+        out = A.tensor_contraction_sparse(sliced, case.scheme).reshape(-1).cpu().numpy()
+        monkeypatch.setattr(C, "profiler", None)
+        return out, counter.n
+
+    left, n_left = one("0")
+    cut, n_cut = one("1")
+    C._schedule_cache.clear()
+    assert np.abs(cut - left).max() <= 1e-5 * np.abs(left).max()
+    assert n_cut > n_left   # more of the big steps run as fused pairs
+    if "slice0" in case.arrays:
+        assert_contract(cut, case.arrays["slice0"], "n53_m14_sliced_slice0")
+
+
 def test_n53_slices(monkeypatch):
     """BASELINE config 4 (Sycamore n53 m14, derived from the bundled m20 circuit; one bitstring,
     14 sliced bonds): slice 0 against the reference executor's CPU result, and the slice loop
