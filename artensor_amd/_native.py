@@ -55,7 +55,7 @@ class ArtnStepInfo(ctypes.Structure):
         ("mfma_flops", ctypes.c_double),
         ("workspace_bytes", ctypes.c_int64),
         ("k3_bits", ctypes.c_int32),
-        ("reserved_", ctypes.c_int32),
+        ("stage1_reruns", ctypes.c_int32),
     ]
 
 

@@ -1062,6 +1062,41 @@ def _compile_dense(scheme, shapes, dtype):
         else:
             shapes[i] = emit(n, i, j, la, lb, lo, shapes[i], shapes[j])
 
+    def pair(n, m):
+        """steps n and m as one fused launch, if the planner takes them; False: nothing emitted"""
+        (i, j), eq1 = scheme[n][0], scheme[n][1]
+        (_, j2), eq2 = scheme[m][0], scheme[m][1]
+        numel = 1
+        for e in shapes[i]:
+            numel *= e
+        info = None
+        if fuse_ok and numel >= FUSE_MIN_NUMEL:
+            la1, lb1, lo1 = _labels(eq1)
+            la2, lb2, lo2 = _labels(eq2)
+            d1, mid = _descriptor(la1, lb1, lo1, shapes[i], _dense_strides(shapes[i]), shapes[j],
+                                  _dense_strides(shapes[j]), dtype)
+            mid_numel = 1
+            for e in mid:
+                mid_numel *= e
+            if len(la2) == len(mid) and mid_numel * FUSE_MIN_MID >= numel:
+                d2, out_shape = _descriptor(la2, lb2, lo2, mid, _dense_strides(mid), shapes[j2],
+                                            _dense_strides(shapes[j2]), dtype)
+                q = N.ArtnStepInfo()
+                rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
+                if rc == 0:
+                    info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
+                elif rc != -2:
+                    N.check(rc)
+        if info is None:
+            return False
+        op = _Op()
+        op.steps, op.i, op.j, op.j2, op.d1, op.d2, op.out_shape, op.info = (n, m), i, j, j2, d1, d2, out_shape, info
+        op.j3 = op.d3 = None
+        op.sum_rows = 0
+        shapes[i] = out_shape
+        ops.append(op)
+        return True
+
     # Three-step fusion (artn_contract3) changes the launch list only where a triple SAVES bytes (section 4.1c of DESIGN.md: on
     # no committed workload); everywhere else the pairing of rounds 1-3 -- fusion_schedule, pairs from the left -- is kept
     # exactly: re-pairing alone cost the random D = 2 network 8 % (pairs the old schedule never formed).
@@ -1108,10 +1143,36 @@ def _compile_dense(scheme, shapes, dtype):
         return prog, ops
     # (the pairing is decided on the whole scheme, as if there were no program: steps the program has
     #  taken are simply skipped -- they ran before everything else)
-    for entry in fusion_schedule(scheme):
+    if _chain_plan_on():
+        # every chain of steps on one tensor is cut into single steps and fused pairs by the priced dynamic programme of
+        # the sparse executor (_cut_sparse_chain); pairs from the left (fusion_schedule, below) with ARTN_CHAIN_PLAN=0
+        schedule = []
+        for entry in chain_schedule(scheme):
+            if entry[0] == "one":
+                schedule.append(entry)
+                continue
+            members = [n for n in entry[1] if n not in in_prog]
+            if len(members) < 2:
+                schedule += [("one", n) for n in members]
+                continue
+            schedule.append(("cut", members))
+    else:
+        schedule = fusion_schedule(scheme)
+    for entry in schedule:
         if entry[0] == "one":
             if entry[1] not in in_prog:
                 single(entry[1])
+            continue
+        if entry[0] == "cut":
+            members = entry[1]
+            ci = scheme[members[0]][0][0]
+            groups = _cut_sparse_chain(scheme, members, tuple(shapes[ci]), [tuple(shapes[scheme[n][0][1]]) for n in members], dtype)
+            covered = sum(len(g) for g in groups)
+            groups += [(n,) for n in members[covered:]]
+            for g in groups:
+                if len(g) == 1 or not pair(g[0], g[1]):
+                    for n in g:
+                        single(n)
             continue
         n, m = entry[1], entry[2]
         if n in in_prog or m in in_prog:
@@ -1119,39 +1180,9 @@ def _compile_dense(scheme, shapes, dtype):
                 if q not in in_prog:
                     single(q)
             continue
-        (i, j), eq1 = scheme[n][0], scheme[n][1]
-        (_, j2), eq2 = scheme[m][0], scheme[m][1]
-        numel = 1
-        for e in shapes[i]:
-            numel *= e
-        info = None
-        if fuse_ok and numel >= FUSE_MIN_NUMEL:
-            la1, lb1, lo1 = _labels(eq1)
-            la2, lb2, lo2 = _labels(eq2)
-            d1, mid = _descriptor(la1, lb1, lo1, shapes[i], _dense_strides(shapes[i]), shapes[j],
-                                  _dense_strides(shapes[j]), dtype)
-            mid_numel = 1
-            for e in mid:
-                mid_numel *= e
-            if len(la2) == len(mid) and mid_numel * FUSE_MIN_MID >= numel:
-                d2, out_shape = _descriptor(la2, lb2, lo2, mid, _dense_strides(mid), shapes[j2],
-                                            _dense_strides(shapes[j2]), dtype)
-                q = N.ArtnStepInfo()
-                rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
-                if rc == 0:
-                    info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
-                elif rc != -2:
-                    N.check(rc)
-        if info is None:
+        if not pair(n, m):
             single(n)
             single(m)
-            continue
-        op = _Op()
-        op.steps, op.i, op.j, op.j2, op.d1, op.d2, op.out_shape, op.info = (n, m), i, j, j2, d1, d2, out_shape, info
-        op.j3 = op.d3 = None
-        op.sum_rows = 0
-        shapes[i] = out_shape
-        ops.append(op)
     return prog, ops
 
 
@@ -1857,7 +1888,7 @@ def _plain_form(step, a_shape, b_shape, itemsize):
     (row of the first operand or None = all of it, row of the second or None, shape the result is viewed in or None,
     row select after it or None, shape of tensors[i] afterwards); None for the chunk loop (A) and for gathers of
     several rows (B with real index lists): those steps are never part of a fused pair."""
-    bi, bj = step[2]
+    bi, bj = step[2] if len(step) > 2 else ((), ())   # (dense steps are 2-tuples: plain contractions)
     if len(bi) > 1:
         return None
     la, lb, lo = _labels(step[1])
@@ -1899,6 +1930,7 @@ def _plain_form(step, a_shape, b_shape, itemsize):
     return ra, rb, view, select, tuple(a_shape), tuple(b_shape), after, 0
 
 
+_chain_trace = None             # optional hook: called with the prices and the cut of every planned chain
 _chain_cache = _Bounded(1024)   # (id(scheme), first member, shape of the chain's tensor, ...) -> (scheme, groups)
 CHAIN_BW, CHAIN_FLOPS = 5.0e12, 120e12   # what a tile-structured pass / the fp32 matrix pipe sustain: the cost model
 CHAIN_PAIR_BYTES = 1.35
@@ -1912,7 +1944,7 @@ def _plan_chain(tensors, scheme, members):
     of them fuses with ITS successor, and never look at what a pair saves: an n53 m14 slice ran 2^29 -> 2^30 -> 2^27
     (6 contracted bits, then 5) as two launches, 17 GB through HBM for an intermediate that fits the tile.  Here every
     adjacent pair the planner accepts is a candidate, a launch is priced at max(bytes / 5 TB/s, FLOP / 120 TFLOP/s)
-    (pairs: 1.35 x the bytes, re-run first stages paid for, spilling instantiations x 4), and a dynamic programme picks the cut; the
+    (pairs: 1.35 x the bytes, re-run first stages paid for, spilling instantiations x 2.5), and a dynamic programme picks the cut; the
     left-to-right cut is kept unless the estimate improves by 3 %.  Returns groups (tuples of one or two members)
     covering a prefix of `members`: planning stops at the first step that is not a plain contraction."""
     first = scheme[members[0]]
@@ -1927,6 +1959,17 @@ def _plan_chain(tensors, scheme, members):
     groups = _cut_sparse_chain(scheme, members, tuple(a.shape), b_shapes, a.dtype)
     _chain_cache[key] = (scheme, groups)
     return groups
+
+
+_left_cache = _Bounded(64)
+
+
+def _left_pairs(scheme):
+    """the candidate pairs of fusion_schedule (pairs from the left: the cut of rounds 1-4) as a set of (n, m)"""
+    hit = _left_cache.get(id(scheme))
+    if hit is None or hit[0] is not scheme or not _same_steps(hit[2], scheme):
+        hit = _left_cache[id(scheme)] = (scheme, frozenset((e[1], e[2]) for e in fusion_schedule(scheme) if e[0] == "pair"), tuple(scheme))
+    return hit[1]
 
 
 def _cut_sparse_chain(scheme, members, a_shape, b_shapes, dtype):
@@ -1951,7 +1994,7 @@ def _cut_sparse_chain(scheme, members, a_shape, b_shapes, dtype):
             r *= e
         return r
 
-    single, pair, flops1 = [0.0] * L, {}, [0.0] * L
+    single, pair, flops1, pair_q = [0.0] * L, {}, [0.0] * L, {}
     for p in range(L):
         ra, rb, view, select, sa, sb, after, view_rows = forms[p]
         la, lb, lo = _labels(scheme[members[p]][1])
@@ -1981,22 +2024,24 @@ def _cut_sparse_chain(scheme, members, a_shape, b_shapes, dtype):
         # a pair's pass costs more per byte than a single step's (two stages per tile between its copy phases: the
         # measured pairs of the n53 slices sit at 1.3-1.4 x bytes / 5 TB/s); a first stage that is re-run for every
         # value of an outer result bit re-reads its input and repeats its FLOP; and the four-wave kernel's instantiations
-        # for 11+ contracted bits spill (6+5 with a shrinking second stage: 228 bytes of scratch, 2.05 ms for a pass
-        # that two launches do in 0.72)
-        rr = max(1, int(q.a_rereads))
+        # for two 5- or 6-bit stages of which the second SHRINKS the tile spill (6+5: 228 bytes of scratch, 2.05 ms for a
+        # pass that two launches do in 0.72 on n53 m14; 5+5: 84 registers, 6.45 ms for 412 GFLOP on the random D = 2 network)
+        rr = max(1, int(q.stage1_reruns))
         t = max(CHAIN_PAIR_BYTES * (q.bytes + (rr - 1) * float(itemsize) * numel(sa)) / CHAIN_BW,
                 (q.flops + (rr - 1) * flops1[p]) / CHAIN_FLOPS)
-        if q.k_bits + q.k2_bits >= 11 and q.grid > 256:
-            t *= 4.0
+        if q.tile_out_bits < q.tile_mid_bits and q.k_bits >= 5 and q.k2_bits >= 5 and q.grid > 256:
+            t *= 2.5
         pair[p] = t
+        pair_q[members[p]] = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
     best, take = [0.0] * (L + 2), [1] * L
     for p in range(L - 1, -1, -1):
         best[p], take[p] = single[p] + best[p + 1], 1
         if p in pair and pair[p] + best[p + 2] <= best[p]:
             best[p], take[p] = pair[p] + best[p + 2], 2
+    left_pairs = _left_pairs(scheme)
     left, cost_left, p = [], 0.0, 0
     while p < L:
-        g = 2 if p in pair else 1
+        g = 2 if p in pair and (members[p], members[p + 1]) in left_pairs else 1
         left.append(g)
         cost_left += pair[p] if g == 2 else single[p]
         p += g
@@ -2006,6 +2051,10 @@ def _cut_sparse_chain(scheme, members, a_shape, b_shapes, dtype):
         g = take[p] if use_dp else left[len(groups)]
         groups.append(tuple(members[p:p + g]))
         p += g
+    if _chain_trace is not None:   # (tools/chain_plans.py)
+        _chain_trace({"members": list(members[:L]), "log2_numel": [numel(f[4]).bit_length() - 1 for f in forms], "single_ms": [x * 1e3 for x in single],
+                      "pair_ms": {members[q]: v * 1e3 for q, v in pair.items()}, "cut_ms": best[0] * 1e3, "left_ms": cost_left * 1e3,
+                      "groups": groups, "pair_info": pair_q})
     return groups
 
 

@@ -762,7 +762,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   b.rows_a = b.rows_b = nullptr;
   b.src_rows_a = b.src_rows_b = 0;
   b.gather_err = nullptr;
-  int64_t a_rereads = 1;
+  int64_t a_rereads = 1, stage1_reruns = 1;
   for (int i : outer) {
     const Axis &a = ax[i];
     ArtnOuterDim od;
@@ -775,6 +775,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
     od.pad_ = 0;
     b.n_tiles *= a.ext;
     if (a.sA < 0) a_rereads *= a.ext;
+    if (a.sA < 0 && a.sB1 < 0) stage1_reruns *= a.ext; // an outer result label of the SECOND step: stage 1 runs again per value
     if (b.n_outer > 0) { // merge with the previous dim when both are powers of two and contiguous everywhere
       ArtnOuterDim &pr = b.outer[b.n_outer - 1];
       auto okf = [&](int64_t ps, int64_t ns) { return (ps == 0 && ns == 0) || (ps != 0 && ns == ps * pr.ext); };
@@ -848,6 +849,7 @@ static inline bool make_bits(const ArtnStepDesc *d1, const ArtnStepDesc *d2, Art
   }
   f.n_tiles = b.n_tiles;
   f.a_rereads = a_rereads;
+  f.stage1_reruns = fused ? (int32_t)std::min<int64_t>(stage1_reruns, INT32_MAX) : 1;
   f.k2_bits = k2; f.n2_tile_bits = nt2; f.tile_mid_bits = b.T_mid;
   int wg_per_cu = std::max(1, std::min(tuning().wg_per_cu, (160 * 1024) / f.lds_bytes));
   f.grid = (int32_t)std::min<int64_t>(b.n_tiles, (int64_t)n_cu * wg_per_cu);

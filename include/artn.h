@@ -95,7 +95,8 @@ typedef struct ArtnStepInfo {
                            multiply-add in every 3M stage (0 for the strided kernel)     */
   int64_t workspace_bytes; /* scratch the step wants from artn_contract_ws (0: none; artn_contract never needs any) */
   int32_t k3_bits;      /* fused triple (development builds only: artn_contract3): contracted bits of the third step (else 0) */
-  int32_t reserved_;
+  int32_t stage1_reruns;/* fused pair: how often the first stage of a tile runs (the product of the outer result labels that only the
+                           second step brings: each value repeats stage 1 and its reads); 0 or 1 otherwise */
 } ArtnStepInfo;
 
 int artn_abi_version(void);

@@ -55,7 +55,7 @@ def test_product_library_carries_no_development_entry_points_or_switches():
 def test_struct_layouts_match_header():
     # sizes the C side was compiled with (ArtnStepDesc: 2 int32 + 4 arrays of 96 int64)
     assert ctypes.sizeof(N.ArtnStepDesc) == 8 + 4 * 96 * 8
-    assert ctypes.sizeof(N.ArtnStepInfo) == 10 * 4 + 2 * 8 + 2 * 8 + 4 * 4 + 8 + 8 + 2 * 4   # (+ k3_bits, reserved_: ABI version 5)
+    assert ctypes.sizeof(N.ArtnStepInfo) == 10 * 4 + 2 * 8 + 2 * 8 + 4 * 4 + 8 + 8 + 2 * 4   # (+ k3_bits, stage1_reruns: ABI versions 5, 7)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the CPU-only refusal")
