@@ -89,7 +89,7 @@ _EXPORTS = {
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int64]),
     "artn_program_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
-                                        ctypes.c_void_p, ctypes.c_void_p]),
+                                        ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "artn_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "artn_axpy_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),

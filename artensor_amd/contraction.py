@@ -835,7 +835,8 @@ class _Program:
     """Compiled small steps of a dense scheme: device image per device, workspace layout, which tensor
     ids it reads from the caller (`ext_ids`, in kernel-argument order) and which results it leaves
     (`outputs`: id -> (workspace byte offset, shape))."""
-    __slots__ = ("host_image", "host_groups", "n_groups", "n_steps", "ext_ids", "ws_bytes", "outputs", "step_out", "dev", "flops", "ext_array")
+    __slots__ = ("host_image", "host_groups", "n_groups", "n_steps", "ext_ids", "ws_bytes", "outputs", "step_out", "dev", "flops", "ext_array",
+                 "dtype")
 
     def device_copy(self, device):
         hit = self.dev.get(device)
@@ -850,7 +851,7 @@ def _plan_small_program(scheme, shapes, dtype):
     remaining steps).  Sequential semantics are kept: a step joins the program only if neither operand
     was produced by a remaining step and its target is not still to be read by an earlier remaining step."""
     every = list(range(len(scheme)))
-    if dtype != torch.complex64 or len(scheme) < PROGRAM_MIN_STEPS or __import__("os").environ.get("ARTN_NO_PROGRAM", "0") not in ("", "0"):
+    if dtype not in _DTYPES or len(scheme) < PROGRAM_MIN_STEPS or __import__("os").environ.get("ARTN_NO_PROGRAM", "0") not in ("", "0"):
         return None, every
     cur = dict(shapes)
     tainted, main_reads, small, main = set(), set(), [], []
@@ -888,18 +889,20 @@ def _plan_small_program(scheme, shapes, dtype):
     for n in main:
         needed.update(scheme[n][0])
     needed.add(scheme[-1][0][0])
-    prog = _build_program(scheme, small, recs, needed)
+    prog = _build_program(scheme, small, recs, needed, dtype)
     if prog is None:
         return None, every
     return prog, main
 
 
-def _build_program(scheme, small, recs, needed=None):
+def _build_program(scheme, small, recs, needed=None, dtype=torch.complex64):
     """Compile the steps `small` (indices into `scheme`, in execution order; recs[n] = (la, lb, lo, shape_i, shape_j,
     out_shape)) into a one-launch program image.  needed: tensor ids whose LAST version must be in the workspace after
     the launch (everything else may live and die in LDS); None: the result of EVERY step is kept (prog.step_out[n] =
     (workspace byte offset, shape)) -- what the slice loop needs, which keeps each step's result for later slices.
+    dtype: complex64 (small matrix-core steps included) or complex128 (artn_k_program<double>: vector ALU only).
     Returns a _Program or None (the caller then runs the steps one by one)."""
+    esz = 16 if dtype == torch.complex128 else 8
     def numel(sh):
         n = 1
         for e in sh:
@@ -940,7 +943,7 @@ def _build_program(scheme, small, recs, needed=None):
             if t not in loc:
                 loc[t] = -(len(ext_ids) + 1)
                 ext_ids.append(t)
-        d, _ = _descriptor(la, lb, lo, sa, _dense_strides(sa), sb, _dense_strides(sb), torch.complex64)
+        d, _ = _descriptor(la, lb, lo, sa, _dense_strides(sa), sb, _dense_strides(sb), dtype)
         descs.append(d)
         la_.append(loc[i])
         lb_.append(loc[j])
@@ -948,7 +951,7 @@ def _build_program(scheme, small, recs, needed=None):
         loc[i] = ws
         where[i] = (ws, so)
         step_out[n] = (ws, so)
-        ws += (numel(so) * 8 + 15) // 16 * 16
+        ws += (numel(so) * esz + 15) // 16 * 16
         f = 8.0
         for x in dict.fromkeys(la + lb):
             f *= dict(zip(la, sa)).get(x) or dict(zip(lb, sb))[x]
@@ -982,6 +985,7 @@ def _build_program(scheme, small, recs, needed=None):
     prog.outputs = {t: v for t, v in where.items() if needed is None or t in needed}
     prog.step_out = step_out
     prog.dev, prog.flops, prog.ext_array = {}, flops, None
+    prog.dtype = dtype
     return prog
 
 
@@ -994,21 +998,21 @@ def _run_program(prog, tensors, dtype, device, stream):
     if profiler is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    N.check(N.lib().artn_program_run(image.data_ptr(), prog.n_groups, ext, len(prog.ext_ids), ws.data_ptr(), stream))
+    N.check(N.lib().artn_program_run(image.data_ptr(), prog.n_groups, ext, len(prog.ext_ids), ws.data_ptr(), _DTYPES[prog.dtype], stream))
     if profiler is not None:
         e1.record()
         profiler.record({"kernel": KERNEL_PROGRAM, "flops": prog.flops, "bytes": 0.0, "k_bits": 0, "k2_bits": 0, "m_tile_bits": 0,
                          "n_tile_bits": 0, "tile_in_bits": 0, "tile_out_bits": 0, "n_tiles": prog.n_steps, "a_rereads": 1}, e0, e1)
     for t, (off, shape) in prog.outputs.items():
-        tensors[t] = _ws_view(ws, off, shape)
+        tensors[t] = _ws_view(ws, off, shape, prog.dtype)
     return ws
 
 
-def _ws_view(ws, off, shape):
-    n = 8
+def _ws_view(ws, off, shape, dtype=torch.complex64):
+    n = 16 if dtype == torch.complex128 else 8
     for e in shape:
         n *= e
-    return ws[off:off + n].view(torch.complex64).reshape(shape)
+    return ws[off:off + n].view(dtype).reshape(shape)
 
 
 def _is_plain_step(step):
@@ -1787,7 +1791,7 @@ def _sparse_program(scheme, tensors):
             shapes[k] = tuple(t.shape)
             dtype = dtype or t.dtype
             on_gpu = on_gpu and t.is_cuda and t.is_contiguous()
-    if dtype != torch.complex64 or not on_gpu:
+    if dtype not in _DTYPES or not on_gpu:
         return None, _NO_HOIST
     sig = tuple(shapes.items())
     hit = _sparse_prog_cache.get(id(scheme))

@@ -1971,34 +1971,59 @@ struct ArtnExtPtrs {
 // A[oa[e] + ka] * B[ob[e] + kb].  AL / BL: the operand sits in the LDS arena (byte address a_lds / b_lds, read with
 // ds_read_b64) or behind a global pointer.  Eight terms per trip: their table entries, then their 16 * NE operand
 // loads, are in flight together -- the loop is a chain of load latencies, not of arithmetic.
-template <bool AL, bool BL, int NE>
-__device__ __forceinline__ void prog_reduce(const float2 *__restrict__ Ag, unsigned a_lds, const float2 *__restrict__ Bg, unsigned b_lds,
-                                            const int (&oa)[NE], const int (&ob)[NE], unsigned red_addr, int red_numel, float (&re)[NE],
-                                            float (&im)[NE]) {
-  auto ldA = [&](int i) -> v2f_t {
-    if constexpr (AL) return lds_read8(a_lds + 8u * (unsigned)i);
-    else { const float2 v = Ag[i]; return v2f_t{v.x, v.y}; }
+// (element type of a program: complex64 -- the general path below plus the matrix-core steps -- or complex128, general path
+//  only, 16-byte elements through ds_read_b128 / ds_write_b128, four terms in flight instead of eight: 128 registers per lane)
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2d_t lds_v2d_t;
+template <typename T> struct ProgElem;
+template <> struct ProgElem<float> {
+  typedef v2f_t V2;
+  typedef float2 G2;
+  static constexpr unsigned ESZ = 8u;
+  static constexpr int U = 8;
+  static __device__ __forceinline__ V2 ldsr(unsigned a) { return lds_read8(a); }
+  static __device__ __forceinline__ void ldsw(unsigned a, V2 v) { lds_write8(a, v); }
+};
+template <> struct ProgElem<double> {
+  typedef v2d_t V2;
+  typedef double2 G2;
+  static constexpr unsigned ESZ = 16u;
+  static constexpr int U = 4;
+  static __device__ __forceinline__ V2 ldsr(unsigned a) { return *(lds_v2d_t *)(unsigned long)a; }
+  static __device__ __forceinline__ void ldsw(unsigned a, V2 v) { *(lds_v2d_t *)(unsigned long)a = v; }
+};
+template <bool AL, bool BL, int NE, typename T>
+__device__ __forceinline__ void prog_reduce(const typename ProgElem<T>::G2 *__restrict__ Ag, unsigned a_lds,
+                                            const typename ProgElem<T>::G2 *__restrict__ Bg, unsigned b_lds,
+                                            const int (&oa)[NE], const int (&ob)[NE], unsigned red_addr, int red_numel, T (&re)[NE],
+                                            T (&im)[NE]) {
+  typedef ProgElem<T> E;
+  typedef typename E::V2 V2;
+  constexpr int U = E::U;
+  auto ldA = [&](int i) -> V2 {
+    if constexpr (AL) return E::ldsr(a_lds + E::ESZ * (unsigned)i);
+    else { const typename E::G2 v = Ag[i]; return V2{v.x, v.y}; }
   };
-  auto ldB = [&](int i) -> v2f_t {
-    if constexpr (BL) return lds_read8(b_lds + 8u * (unsigned)i);
-    else { const float2 v = Bg[i]; return v2f_t{v.x, v.y}; }
+  auto ldB = [&](int i) -> V2 {
+    if constexpr (BL) return E::ldsr(b_lds + E::ESZ * (unsigned)i);
+    else { const typename E::G2 v = Bg[i]; return V2{v.x, v.y}; }
   };
 #pragma unroll
-  for (int e = 0; e < NE; ++e) re[e] = im[e] = 0.f;
+  for (int e = 0; e < NE; ++e) re[e] = im[e] = (T)0;
   int q = 0;
-  for (; q + 8 <= red_numel; q += 8) {
-    u2_t t[8];
-    v2f_t a[NE][8], b[NE][8];
+  for (; q + U <= red_numel; q += U) {
+    u2_t t[U];
+    V2 a[NE][U], b[NE][U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = lds_read_u2(red_addr + 8u * (unsigned)(q + u));
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { a[e][u] = ldA(oa[e] + (int)t[u].x); b[e][u] = ldB(ob[e] + (int)t[u].y); }
+    for (int u = 0; u < U; ++u) t[u] = lds_read_u2(red_addr + 8u * (unsigned)(q + u));
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < U; ++u) { a[e][u] = ldA(oa[e] + (int)t[u].x); b[e][u] = ldB(ob[e] + (int)t[u].y); }
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
         re[e] += a[e][u].x * b[e][u].x - a[e][u].y * b[e][u].y;
         im[e] += a[e][u].x * b[e][u].y + a[e][u].y * b[e][u].x;
       }
@@ -2007,7 +2032,7 @@ __device__ __forceinline__ void prog_reduce(const float2 *__restrict__ Ag, unsig
     const u2_t t = lds_read_u2(red_addr + 8u * (unsigned)q);
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-      const v2f_t a = ldA(oa[e] + (int)t.x), b = ldB(ob[e] + (int)t.y);
+      const V2 a = ldA(oa[e] + (int)t.x), b = ldB(ob[e] + (int)t.y);
       re[e] += a.x * b.x - a.y * b.y;
       im[e] += a.x * b.y + a.y * b.x;
     }
@@ -2123,7 +2148,10 @@ __device__ __forceinline__ void prog_mfma_task(int n_mbits, int n_nbits, int tas
       }
     }
 }
+template <typename T>
 __global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ image, const ArtnExtPtrs ext, char *__restrict__ ws) {
+  typedef ProgElem<T> E;
+  typedef typename E::G2 G2;
   extern __shared__ __attribute__((aligned(16))) unsigned char prog_smem[];
   int2 *red_all = reinterpret_cast<int2 *>(prog_smem);
   unsigned char *arena = prog_smem + ARTN_PROG_RED_ENTRIES * 8 + ARTN_PROG_BITS_BYTES;
@@ -2170,13 +2198,13 @@ __global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ 
     if (R.fast && lane < 48) // (mbit_sA, mbit_sC, nbit_sB, nbit_sC are contiguous: 48 ints)
       bits_all[R.fast_index * 48 + lane] = (reinterpret_cast<const int *>(&R) + offsetof(ArtnProgStep, mbit_sA) / 4)[lane];
     if (R.pre_a) {
-      const float2 *src = reinterpret_cast<const float2 *>(ext.p[-(R.loc_a + 1)]);
-      float2 *dst = reinterpret_cast<float2 *>(arena + R.lds_a);
+      const G2 *src = reinterpret_cast<const G2 *>(ext.p[-(R.loc_a + 1)]);
+      G2 *dst = reinterpret_cast<G2 *>(arena + R.lds_a);
       for (int e = lane; e < R.a_numel; e += 64) dst[e] = src[e];
     }
     if (R.pre_b) {
-      const float2 *src = reinterpret_cast<const float2 *>(ext.p[-(R.loc_b + 1)]);
-      float2 *dst = reinterpret_cast<float2 *>(arena + R.lds_b);
+      const G2 *src = reinterpret_cast<const G2 *>(ext.p[-(R.loc_b + 1)]);
+      G2 *dst = reinterpret_cast<G2 *>(arena + R.lds_b);
       for (int e = lane; e < R.b_numel; e += 64) dst[e] = src[e];
     }
   }
@@ -2218,11 +2246,11 @@ __global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ 
       }
       if (t == t_begin) PROG_FINE(L - G.level_begin, 2, n_out + (int)loc_c);
       // (an operand is in the arena, in the workspace or behind an external pointer)
-      const float2 *A = nullptr, *B = nullptr;
-      if (lds_a < 0) A = reinterpret_cast<const float2 *>(loc_a >= 0 ? ws + loc_a : (const char *)ext.p[-(loc_a + 1)]);
-      if (lds_b < 0) B = reinterpret_cast<const float2 *>(loc_b >= 0 ? ws + loc_b : (const char *)ext.p[-(loc_b + 1)]);
+      const G2 *A = nullptr, *B = nullptr;
+      if (lds_a < 0) A = reinterpret_cast<const G2 *>(loc_a >= 0 ? ws + loc_a : (const char *)ext.p[-(loc_a + 1)]);
+      if (lds_b < 0) B = reinterpret_cast<const G2 *>(loc_b >= 0 ? ws + loc_b : (const char *)ext.p[-(loc_b + 1)]);
       const unsigned al = arena_lds + (unsigned)lds_a, bl = arena_lds + (unsigned)lds_b, rt = red_lds + 8u * (unsigned)red_base;
-      if (fast) {
+      if constexpr (std::is_same<T, float>::value) if (fast) {
         float2 *Cg = to_ws ? reinterpret_cast<float2 *>(ws + loc_c) : nullptr;
         const unsigned cl = arena_lds + (unsigned)lds_c, bits = bits_lds + 192u * (unsigned)fast_index;
         const int dbg = t == t_begin ? L - G.level_begin : 1000;
@@ -2267,16 +2295,21 @@ __global__ __launch_bounds__(1024) void artn_k_program(const char *__restrict__ 
           oc[e] += x * R.out_sC[d];
         }
       }
-      float re[NE], im[NE];
-      if (lds_a >= 0 && lds_b >= 0) prog_reduce<true, true, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
-      else if (lds_a >= 0) prog_reduce<true, false, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
-      else if (lds_b >= 0) prog_reduce<false, true, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
-      else prog_reduce<false, false, NE>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
+      T re[NE], im[NE];
+      if (lds_a >= 0 && lds_b >= 0) prog_reduce<true, true, NE, T>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
+      else if (lds_a >= 0) prog_reduce<true, false, NE, T>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
+      else if (lds_b >= 0) prog_reduce<false, true, NE, T>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
+      else prog_reduce<false, false, NE, T>(A, al, B, bl, oa, ob, rt, red_numel, re, im);
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         if (live[e]) {
-          if (lds_c >= 0) lds_write8(arena_lds + (unsigned)lds_c + 8u * (unsigned)oc[e], v2f_t{re[e], im[e]});
-          if (to_ws) reinterpret_cast<float2 *>(ws + loc_c)[oc[e]] = make_float2(re[e], im[e]);
+          if (lds_c >= 0) E::ldsw(arena_lds + (unsigned)lds_c + E::ESZ * (unsigned)oc[e], typename E::V2{re[e], im[e]});
+          if (to_ws) {
+            G2 o;
+            o.x = re[e];
+            o.y = im[e];
+            reinterpret_cast<G2 *>(ws + loc_c)[oc[e]] = o;
+          }
         }
       }
       W = Wn;
@@ -3441,12 +3474,14 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
     return fail(ARTN_E_INVALID, "null argument");
   if (group_start[0] != 0 || group_start[n_groups] != n_steps) return fail(ARTN_E_INVALID, "group_start must cover the steps");
   std::vector<ArtnProgStep> rec(n_steps);
+  const bool c128 = n_steps > 0 && descs[0]->dtype == ARTN_C128;
+  const int64_t esz = c128 ? 16 : 8; // bytes per element in the LDS arena (workspace offsets are the caller's)
   for (int s = 0; s < n_steps; ++s) {
     const ArtnStepDesc *d = descs[s];
     std::string err;
     int rc = artn::validate(d, err);
     if (rc) return fail(rc, err);
-    if (d->dtype != ARTN_C64 && d->dtype != ARTN_C64_BF16) return fail(ARTN_E_UNSUPPORTED, "small-step programs are complex64");
+    if ((d->dtype == ARTN_C128) != (descs[0]->dtype == ARTN_C128)) return fail(ARTN_E_INVALID, "the steps of a program share one element type");
     ArtnPlan p;
     if (!artn::make_generic(d, p, err)) return fail(ARTN_E_UNSUPPORTED, err);
     const ArtnGenericPlan &g = p.gen;
@@ -3540,7 +3575,7 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
         }
       }
     }
-    r.fast = (ok && mb >= 5) ? 1 : 0;
+    r.fast = (ok && mb >= 5 && !c128) ? 1 : 0; // (complex128: the general path only)
     r.n_mbits = r.fast ? mb : 0; r.n_nbits = r.fast ? nb : 0;
   }
   for (int s = 0; s < n_steps; ++s)
@@ -3617,7 +3652,7 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
         auto it = exts.find(loc);
         if (it == exts.end()) {
           Ext x = {-1, numel, level[s]};
-          if (numel <= ARTN_PROG_PRELOAD_MAX) x.lds = alloc(numel * 8);
+          if (numel <= ARTN_PROG_PRELOAD_MAX) x.lds = alloc(numel * (int)esz);
           if (x.lds >= 0) (which ? rec[s].pre_b : rec[s].pre_a) = 1;
           it = exts.insert({loc, x}).first;
         } else if (it->second.numel != numel) {
@@ -3637,7 +3672,7 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
         ArtnProgStep &r = rec[s];
         const bool read_inside = last_use[s] > 0; // (through the arena)
         r.to_ws = (!keep || keep[s] || !read_inside) ? 1 : 0;
-        if (read_inside) r.lds_c = alloc(r.out_numel * 8);
+        if (read_inside) r.lds_c = alloc(r.out_numel * (int)esz);
         if (r.lds_c < 0) r.to_ws = 1;
         if (r.fast) { // 32 x 16 blocks: first-operand sub-tile fastest
           const int n_tasks = (1 << (r.n_mbits - 5)) * (r.n_nbits > 4 ? 1 << (r.n_nbits - 4) : 1);
@@ -3656,11 +3691,11 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
           const int64_t loc = which ? loc_b[s] : loc_a[s];
           if (loc < 0) {
             Ext &x = exts[loc];
-            if (x.lds >= 0 && x.last == L) { release(x.lds, x.numel * 8); x.last = -1; }
+            if (x.lds >= 0 && x.last == L) { release(x.lds, x.numel * (int)esz); x.last = -1; }
           } else {
             const int p = producer[loc];
             (which ? rec[s].lds_b : rec[s].lds_a) = rec[p].lds_c;
-            if (rec[p].lds_c >= 0 && last_use[p] == L) { release(rec[p].lds_c, rec[p].out_numel * 8); last_use[p] = -1; }
+            if (rec[p].lds_c >= 0 && last_use[p] == L) { release(rec[p].lds_c, rec[p].out_numel * (int)esz); last_use[p] = -1; }
           }
         }
       }
@@ -3703,7 +3738,8 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
   return ARTN_OK;
 }
 
-int artn_program_run(const void *dev_image, int32_t n_groups, const void *const *ext, int32_t n_ext, void *workspace, void *stream) {
+int artn_program_run(const void *dev_image, int32_t n_groups, const void *const *ext, int32_t n_ext, void *workspace, int32_t dtype,
+                     void *stream) {
   if (artn_device_count() < 1) return fail(ARTN_E_NODEVICE, "no gfx950 device visible");
   if (n_groups < 0 || n_ext < 0 || n_ext > ARTN_PROGRAM_MAX_EXT) return fail(ARTN_E_INVALID, "bad group or pointer count");
   if (n_groups == 0) return ARTN_OK;
@@ -3711,9 +3747,17 @@ int artn_program_run(const void *dev_image, int32_t n_groups, const void *const 
   ArtnExtPtrs e;
   memset(&e, 0, sizeof(e));
   for (int i = 0; i < n_ext; ++i) e.p[i] = ext[i];
-  HIP_TRY(ensure_lds<artn_k_program>(ARTN_PROG_LDS_BYTES));
-  hipLaunchKernelGGL(artn_k_program, dim3(n_groups), dim3(1024), ARTN_PROG_LDS_BYTES, (hipStream_t)stream, (const char *)dev_image, e,
-                     (char *)workspace);
+  if (dtype == ARTN_C128) {
+    HIP_TRY(ensure_lds<artn_k_program<double>>(ARTN_PROG_LDS_BYTES));
+    hipLaunchKernelGGL(artn_k_program<double>, dim3(n_groups), dim3(1024), ARTN_PROG_LDS_BYTES, (hipStream_t)stream, (const char *)dev_image, e,
+                       (char *)workspace);
+  } else if (dtype == ARTN_C64 || dtype == ARTN_C64_BF16) {
+    HIP_TRY(ensure_lds<artn_k_program<float>>(ARTN_PROG_LDS_BYTES));
+    hipLaunchKernelGGL(artn_k_program<float>, dim3(n_groups), dim3(1024), ARTN_PROG_LDS_BYTES, (hipStream_t)stream, (const char *)dev_image, e,
+                       (char *)workspace);
+  } else {
+    return fail(ARTN_E_INVALID, "dtype must be ARTN_C64, ARTN_C64_BF16 or ARTN_C128");
+  }
   HIP_TRY(hipGetLastError());
   return ARTN_OK;
 }

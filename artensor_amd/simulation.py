@@ -242,7 +242,8 @@ class SliceRunner:
             # launch of the small-step program (artn_program_*): recs[n] = labels and shapes, the same for every slice
             self._recs, self._progs = {}, {}
             self.program_launches = 0
-            if dtype == torch.complex64 and __import__("os").environ.get("ARTN_NO_PROGRAM", "0") in ("", "0"):
+            self._dtype = dtype
+            if dtype in (torch.complex64, torch.complex128) and __import__("os").environ.get("ARTN_NO_PROGRAM", "0") in ("", "0"):
                 cur_shapes = dict(shapes)
                 numel = lambda sh: int(np.prod(sh, dtype=np.int64)) if len(sh) else 1
                 for n in small:
@@ -301,15 +302,15 @@ class SliceRunner:
                 if pk not in self._progs:
                     if len(self._progs) > 256:
                         self._progs.clear()
-                    self._progs[pk] = _C._build_program(self.scheme, list(batch), self._recs, None)
+                    self._progs[pk] = _C._build_program(self.scheme, list(batch), self._recs, None, self._dtype)
                 prog = self._progs[pk]
             if prog is not None:
                 with torch.cuda.device(self.device):
-                    ws = _C._run_program(prog, batch_ext, torch.complex64, self.device, N.current_stream_ptr(self.device))
+                    ws = _C._run_program(prog, batch_ext, self._dtype, self.device, N.current_stream_ptr(self.device))
                 self.program_launches += 1
                 for n in batch:
                     off, shape = prog.step_out[n]
-                    memo[n] = (tuple(cfg[x] for x in self._step_rel[n]), _C._ws_view(ws, off, shape))
+                    memo[n] = (tuple(cfg[x] for x in self._step_rel[n]), _C._ws_view(ws, off, shape, self._dtype))
             else:
                 src = dict(batch_ext)
                 for n in batch:

@@ -200,11 +200,14 @@ int artn_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t nro
  *   artn_program_build(...)        host only: fills `host_image` from the step descriptors; operand k of step s is
  *                                  the result written at workspace byte offset loc >= 0 by an earlier step, or
  *                                  external pointer number -(loc + 1) when loc < 0; keep[s] != 0 (or keep == NULL):
- *                                  the result of step s must be in the workspace after the launch.  Steps must be
- *                                  complex64 with dense operands; returns ARTN_E_UNSUPPORTED when a step does
- *                                  not fit a record (the caller then issues artn_contract per step).
+ *                                  the result of step s must be in the workspace after the launch.  Steps must
+ *                                  have dense operands and ONE element type (all complex64 -- small matrix-core
+ *                                  steps included -- or all complex128: 16-byte elements, vector ALU only);
+ *                                  returns ARTN_E_UNSUPPORTED when a step does not fit a record (the caller then
+ *                                  issues artn_contract per step).
  *   artn_program_run(...)          enqueue: `dev_image` is the device copy of the image, `ext` a HOST array of
- *                                  n_ext (<= 256) device pointers.
+ *                                  n_ext (<= 256) device pointers, `dtype` the element type the image was built for
+ *                                  (ARTN_C64 / ARTN_C64_BF16 / ARTN_C128).
  */
 #define ARTN_PROGRAM_MAX_EXT 256
 int64_t artn_program_record_bytes(void);
@@ -213,7 +216,7 @@ int artn_program_build(int32_t n_steps, const ArtnStepDesc *const *descs, const 
                        const int64_t *loc_c, const uint8_t *keep, int32_t n_groups, const int32_t *group_start,
                        void *host_image, int64_t image_bytes);
 int artn_program_run(const void *dev_image, int32_t n_groups, const void *const *ext, int32_t n_ext, void *workspace,
-                     void *stream);
+                     int32_t dtype, void *stream);
 
 /* acc[i] += x[i], i < n complex64 elements: the slice accumulation
  * `collect_tensor += ...` of artensor/simulation.py:114 and :210. */

@@ -533,6 +533,48 @@ def test_small_step_program(monkeypatch):
     C._plan_cache.clear()
 
 
+def test_small_step_program_in_complex128(monkeypatch):
+    """artn_k_program<double>: the same one-launch program for complex128 tensors (16-byte elements in the LDS arena, vector
+    ALU only).  n12 dense = 68 tiny steps in ONE launch; against the step-by-step executor (same sums: 1e-14) and against
+    numpy's complex128 einsums of the same scheme (reference loop contraction.py:66-70 run in complex128)."""
+    from artensor_amd import contraction as C
+    case = load_case(os.path.join(GOLDEN, "n12_dense.npz"))
+    shapes = {k: tuple(t.shape) for k, t in case.tensors.items()}
+    prog, main = C._plan_small_program(case.scheme, shapes, torch.complex128)
+    assert prog is not None and prog.n_steps == 68 and main == [] and prog.dtype == torch.complex128
+
+    class Count:
+        def __init__(self):
+            self.kernels = []
+
+        def record(self, info, e0, e1):
+            self.kernels.append(info["kernel"])
+
+    counter = Count()
+    monkeypatch.setattr(C, "profiler", counter)
+    a = A.tensor_contraction(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme).cpu().numpy()
+    monkeypatch.setattr(C, "profiler", None)
+    assert counter.kernels == [C.KERNEL_PROGRAM]
+    monkeypatch.setenv("ARTN_NO_PROGRAM", "1")
+    C._plan_cache.clear()
+    b = A.tensor_contraction(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme).cpu().numpy()
+    monkeypatch.delenv("ARTN_NO_PROGRAM")
+    C._plan_cache.clear()
+    assert a.dtype == np.complex128 and np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
+    want = oracle.tensor_contraction({k: v.numpy().astype(np.complex128) for k, v in case.tensors.items()}, case.scheme)
+    assert np.abs(a - want).max() <= 1e-12 * np.abs(want).max()
+    assert amp_rel(a.astype(np.complex64), case.arrays["raw"]) < 1e-5
+    # bond dimension 3 (divisions in the decode), a sparse-state scheme (hoisted program) and the slice loop's batches
+    case = load_case(os.path.join(GOLDEN, "rand_D3_open.npz"))
+    out = A.tensor_contraction(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme).cpu().numpy()
+    want = oracle.tensor_contraction({k: v.numpy().astype(np.complex128) for k, v in case.tensors.items()}, case.scheme)
+    assert np.abs(out - want).max() <= 1e-12 * np.abs(want).max()
+    case = load_case(os.path.join(GOLDEN, "n12_sparse_sliced.npz"))
+    got = A.sliced_contraction(case.tensors, case.scheme, case.slicing_indices, case.arrays["final"].shape, sparse=True,
+                               dtype=torch.complex128, device=DEV)
+    assert got.dtype == torch.complex128 and amp_rel(got.cpu().numpy().astype(np.complex64), case.arrays["final"]) < 1e-5
+
+
 def test_deferred_row_select(monkeypatch):
     """A branch-(C) row select of a big tensor (reference contraction.py:187) is deferred to its consumer: the chunk loop
     that follows it in the n30 x 10 000 scheme reads the un-selected tensor through composed indices (`base[idx][rows] ==

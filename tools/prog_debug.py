@@ -18,7 +18,7 @@ dev = {k: torch.from_numpy(v).cuda() for k, v in leaves.items()}
 image = prog.device_copy(torch.device("cuda:0"))
 ws = torch.zeros(prog.ws_bytes, dtype=torch.uint8, device="cuda")
 ext = (ctypes.c_void_p * len(prog.ext_ids))(*[dev[t].data_ptr() for t in prog.ext_ids])
-N.check(N.lib().artn_program_run(image.data_ptr(), prog.n_groups, ext, len(prog.ext_ids), ws.data_ptr(), None))
+N.check(N.lib().artn_program_run(image.data_ptr(), prog.n_groups, ext, len(prog.ext_ids), ws.data_ptr(), N.ARTN_C64, None))
 torch.cuda.synchronize()
 ws_gpu = ws.cpu().numpy().view(np.complex64)
 groups, levels, wtasks, recs = parse_program_image(prog.host_image.numpy())
