@@ -326,14 +326,18 @@ def parse_program_image(image):
 def emulate_program(prog, leaves):
     """Execute a compiled small-step program the way artn_k_program does -- per group: preloads, then level by
     level, wave task by wave task, results written in place into the arena / workspace as soon as they are
-    computed -- and return the workspace (complex64 view).  An arena block handed out while its previous
-    tenant was still to be read shows up as a wrong result."""
+    computed -- and return the workspace (viewed in the program's element type: complex64, or complex128 with 16-byte
+    elements).  An arena block handed out while its previous tenant was still to be read shows up as a wrong result."""
+    import torch
     groups, levels, wtasks, recs = parse_program_image(prog.host_image.numpy())
-    ws = np.zeros(prog.ws_bytes // 8 + 2, dtype=np.complex64)
-    ext = [np.ascontiguousarray(leaves[t]).reshape(-1).astype(np.complex64) for t in prog.ext_ids]
+    c128 = getattr(prog, "dtype", torch.complex64) == torch.complex128
+    esz, cdt = (16, np.complex128) if c128 else (8, np.complex64)
+    assert not (c128 and (recs["fast"] != 0).any())   # matrix-core steps are complex64 only
+    ws = np.zeros(prog.ws_bytes // esz + 2, dtype=cdt)
+    ext = [np.ascontiguousarray(leaves[t]).reshape(-1).astype(cdt) for t in prog.ext_ids]
     stats = {"levels": len(levels), "wtasks": len(wtasks), "in_lds": 0, "to_ws": 0, "fast": int((recs["fast"] != 0).sum())}
     for (sb, se, lb, le) in groups:
-        arena = np.full(PROG_ARENA_BYTES // 8, np.nan + 0j, dtype=np.complex64)
+        arena = np.full(PROG_ARENA_BYTES // esz, np.nan + 0j, dtype=cdt)
         red = {}
         for s in range(sb, se):
             R = recs[s]
@@ -353,8 +357,8 @@ def emulate_program(prog, leaves):
                 if R["pre_" + which]:
                     src = ext[-(int(R["loc_" + which]) + 1)]
                     n, off = int(R[which + "_numel"]), int(R["lds_" + which])
-                    assert off % 16 == 0 and off + 8 * n <= PROG_ARENA_BYTES and src.size == n
-                    arena[off // 8: off // 8 + n] = src
+                    assert off % 16 == 0 and off + esz * n <= PROG_ARENA_BYTES and src.size == n
+                    arena[off // esz: off // esz + n] = src
         for L in range(lb, le):
             wb, wc = levels[L]
             for (s, first) in wtasks[wb: wb + wc]:
@@ -362,9 +366,9 @@ def emulate_program(prog, leaves):
                 assert sb <= s < se
                 def operand(which):
                     if R["lds_" + which] >= 0:
-                        return arena[int(R["lds_" + which]) // 8:]
+                        return arena[int(R["lds_" + which]) // esz:]
                     loc = int(R["loc_" + which])
-                    return ws[loc // 8:] if loc >= 0 else ext[-(loc + 1)]
+                    return ws[loc // esz:] if loc >= 0 else ext[-(loc + 1)]
                 A, B = operand("a"), operand("b")
                 ka = np.array([t[0] for t in red[s]], dtype=np.int64); kb = np.array([t[1] for t in red[s]], dtype=np.int64)
                 if R["fast"]:
@@ -393,10 +397,10 @@ def emulate_program(prog, leaves):
                     acc = (A[oa[:, None] + ka[None, :]].astype(np.complex128) * B[ob[:, None] + kb[None, :]].astype(np.complex128)).sum(axis=1)
                 assert R["lds_c"] >= 0 or R["to_ws"]
                 if R["lds_c"] >= 0:
-                    assert int(R["lds_c"]) + 8 * int(R["out_numel"]) <= PROG_ARENA_BYTES
-                    arena[int(R["lds_c"]) // 8 + oc] = acc
+                    assert int(R["lds_c"]) % 16 == 0 and int(R["lds_c"]) + esz * int(R["out_numel"]) <= PROG_ARENA_BYTES
+                    arena[int(R["lds_c"]) // esz + oc] = acc
                 if R["to_ws"]:
-                    ws[int(R["loc_c"]) // 8 + oc] = acc
+                    ws[int(R["loc_c"]) // esz + oc] = acc
         for s in range(sb, se):
             stats["in_lds"] += int(recs[s]["lds_c"] >= 0)
             stats["to_ws"] += int(recs[s]["to_ws"] != 0)

@@ -180,6 +180,35 @@ def test_small_step_program_image_emulated(name, limit, monkeypatch):
         assert stats["levels"] == 19 and stats["fast"] >= 15 and stats["to_ws"] == 1
 
 
+@pytest.mark.parametrize("name,limit", [("n12_dense", 1 << 14), ("n12_dense", 256), ("n30_dense", 1 << 14), ("rand_D3_open", 1 << 12),
+                                        ("n30_sparse100", 1 << 14)])
+def test_small_step_program_image_in_complex128_emulated(name, limit, monkeypatch):
+    """The complex128 image (artn_k_program<double>): 16-byte elements in the arena and the workspace, no matrix-core steps;
+    replayed on the CPU it must leave what numpy's complex128 einsums of the small steps leave, to 1e-13."""
+    from artensor_amd import contraction as C
+    from helpers import emulate_program
+    monkeypatch.setattr(C, "PROGRAM_MAX_NUMEL", limit)
+    case = load_case(os.path.join(GOLDEN, name + ".npz"))
+    rng = np.random.default_rng(6)
+    leaves = {k: rng.standard_normal(tuple(t.shape)) + 1j * rng.standard_normal(tuple(t.shape)) for k, t in case.tensors.items()}
+    shapes = {k: v.shape for k, v in leaves.items()}
+    prog, main = C._plan_small_program(case.scheme, shapes, torch.complex128)
+    assert prog is not None and prog.dtype == torch.complex128
+    ws, stats = emulate_program(prog, leaves)
+    assert ws.dtype == np.complex128 and stats["fast"] == 0
+    small = [n for n in range(len(case.scheme)) if n not in set(main)]
+    cur = dict(leaves)
+    for n in small:
+        oracle.tensor_contraction(cur, [case.scheme[n]])
+    assert prog.outputs
+    for t, (off, shape) in prog.outputs.items():
+        want = np.asarray(cur[t]).reshape(-1)
+        assert off % 16 == 0
+        got = ws[off // 16: off // 16 + want.size]
+        assert np.abs(got - want).max() <= 1e-13 * max(np.abs(want).max(), 1e-300), (name, t)
+    assert stats["levels"] < prog.n_steps
+
+
 @pytest.mark.parametrize("mb,kb,extra", [(12, 2, 3), (9, 1, 3), (11, 3, 20), (12, 2, 60), (8, 3, 4)])
 def test_small_step_program_with_fully_contracted_second_operand(mb, kb, extra):
     """A matrix-core step whose second operand is contracted away entirely ('abcdefghijkl,kl->abcdefghij') is cut
