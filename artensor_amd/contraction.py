@@ -1315,7 +1315,7 @@ def tensor_contraction(tensors, scheme, accumulate_into=None):
         shape_key.append(t.shape)
     if first is None or dtype not in _DTYPES:
         raise RuntimeError("tensor_contraction needs complex64 or complex128 GPU tensors")
-    key = (id(scheme), dtype, precision.current(), tuple(shape_key), _HAS_PAIR_QUERY(), bool(_os_environ.get("ARTN_NO_FUSE")))
+    key = (id(scheme), dtype, precision.current(), tuple(shape_key), _HAS_PAIR_QUERY(), bool(_os_environ.get("ARTN_NO_FUSE")), _chain_plan_on())
     hit = _plan_cache.get(key)
     if hit is None or hit[0] is not scheme or hit[3] is not su[2]:   # (su[2]: the step snapshot just verified above)
         shapes = {k: tuple(tensors[k].shape) for k in su[1] if (k in tensors if is_dict else isinstance(k, int) and 0 <= k < n_list)}
@@ -1957,11 +1957,13 @@ def _plan_chain(tensors, scheme, members):
         return [(members[0],)]
     key = (id(scheme), members[0], len(members), tuple(a.shape), a.dtype, precision.current())
     hit = _chain_cache.get(key)
-    if hit is not None and hit[0] is scheme:
+    # (the entry holds the scheme, so its id cannot be reused, and the member steps as they were: a scheme list edited in
+    #  place between two calls must not replay a stale cut -- _same_steps)
+    if hit is not None and hit[0] is scheme and len(hit[2]) == len(members) and all(scheme[n] is st for n, st in zip(members, hit[2])):
         return hit[1]
     b_shapes = [tuple(tensors[scheme[n][0][1]].shape) if hasattr(tensors[scheme[n][0][1]], "shape") else None for n in members]
     groups = _cut_sparse_chain(scheme, members, tuple(a.shape), b_shapes, a.dtype)
-    _chain_cache[key] = (scheme, groups)
+    _chain_cache[key] = (scheme, groups, tuple(scheme[n] for n in members))
     return groups
 
 
