@@ -2738,7 +2738,7 @@ hipError_t artn_launch_wide(const ArtnPlan &p, const void *A, const void *B1, co
 #define ARTN_CAT(a, b) ARTN_CAT2(a, b)
 // fused triples (make_bits3): artn_k_bits3<KB1, KB2, KB3, M3>, 3..5 contracted bits per stage, fragments of at most 80 registers;
 // M3 exactly when a stage contracts 5 bits
-#if defined(ARTN_TU_BITS3) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
+#if defined(ARTN_TU_BITS3) || (defined(ARTN_DEV_BITS3) && !defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
 template <int KB1>
 static hipError_t launch_bits3_k(const ArtnPlan &p, const float2 *A, const float2 *B1, const float2 *B2, const float2 *B3, float2 *C,
                                  hipStream_t st) {
