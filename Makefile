@@ -83,7 +83,7 @@ tools/bw_probe2: tools/bw_probe2.hip
 ASAN_RT := $(firstword $(wildcard /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so))
 ASAN_DIR := build/asan
 ASAN_FLAGS := -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared-libsan -fPIC -Iinclude -I$(CSRC)
-ASAN_LOG ?= profiles/r04_asan.log
+ASAN_LOG ?= profiles/r05_asan.log
 asan: $(SRCS) tests/csrc/plan_emulate.cpp
 	@mkdir -p $(ASAN_DIR)
 	$(HIPCC) $(ASAN_FLAGS) --offload-host-only -c $(CSRC)/artn_kernels.hip -o $(ASAN_DIR)/host.o
@@ -96,7 +96,7 @@ asan: $(SRCS) tests/csrc/plan_emulate.cpp
 	  LD_PRELOAD=$(ASAN_RT) ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 	  ARTN_LIB=$(ASAN_DIR)/libartn_host_asan.so ARTN_EMU_LIB=$(ASAN_DIR)/libplan_emulate_asan.so \
 	  python3 -m pytest tests/test_abi_cpu.py tests/test_plan_emulation.py tests/test_slice_runner.py tests/test_scheme_compilers.py \
-	      tests/test_distributed.py -q -m "not gpu" -p no:cacheprovider 2>&1; \
+	      tests/test_distributed.py tests/test_xgemm_emulation.py tests/test_chain_plan.py -q -m "not gpu" -p no:cacheprovider 2>&1; \
 	  LD_PRELOAD=$(ASAN_RT) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 	  ARTN_LIB=$(ASAN_DIR)/libartn_host_asan.so python3 tools/stress_planner.py 3000 0 2>&1 ) | tee $(ASAN_LOG)
 	@! grep -E "ERROR: AddressSanitizer|runtime error:" $(ASAN_LOG)

@@ -10,8 +10,6 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_I
   --kernel-trace --output-format csv -d $OUT/a -- python3 tools/time_case.py $FIX > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS \
   --kernel-trace --output-format csv -d $OUT/b -- python3 tools/time_case.py $FIX > $OUT/b.log 2>&1
-# (FETCH_SIZE and WRITE_SIZE in one pass here: a diagnostic, not the traffic figure bench.py quotes; the TCC_EA_* request
-#  counters made this pass run for ten minutes on n53 and are left out)
-rocprofv3 --pmc FETCH_SIZE WRITE_SIZE \
-  --kernel-trace --output-format csv -d $OUT/c -- python3 tools/time_case.py $FIX > $OUT/c.log 2>&1
+# (FETCH_SIZE and WRITE_SIZE in ONE pass hang the box until the limit kills the call -- twice in round 5, 25 GPU-minutes each:
+#  the traffic figures come from tools/profile_traffic.sh, separate passes; nothing of that kind here any more)
 python3 tools/pmc_case.py $OUT
