@@ -114,3 +114,20 @@ def test_chain_schedule_is_a_reordering_that_changes_no_operand(name):
     for members in chains:
         assert members == sorted(members) and len({scheme[n][0][0] for n in members}) == 1
     assert max(len(m) for m in chains) >= 12
+
+
+def test_stage1_reruns_counts_only_the_outer_labels_of_the_second_step():
+    """ArtnStepInfo.stage1_reruns (ABI 7): result labels that only the SECOND step brings and that do not fit the tile
+    repeat the first stage per value -- the chain planner prices that; outer labels of the FIRST step (a growth step reads its
+    small input once per value: a_rereads) repeat nothing."""
+    def info(steps):
+        scheme, b = _chain(26, steps)
+        return C.pair_info(scheme[0][1], (2,) * 26, b[0], scheme[1][1], b[1])
+    plain = info([(3, 3), (3, 3)])
+    assert plain["stage1_reruns"] == 1 and plain["a_rereads"] == 1
+    two = info([(3, 3), (3, 5)])       # five new labels in the second step, four in the tile
+    assert two["n2_tile_bits"] == 4 and two["stage1_reruns"] == 2 and two["a_rereads"] == 2
+    four = info([(4, 4), (4, 6)])
+    assert four["stage1_reruns"] == 4
+    grow = info([(3, 7), (3, 3)])      # seven new labels in the FIRST step: re-reads of A, no repeated stage
+    assert grow["a_rereads"] == 8 and grow["stage1_reruns"] == 1
