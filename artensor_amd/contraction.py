@@ -1938,6 +1938,7 @@ _chain_trace = None             # optional hook: called with the prices and the 
 _chain_cache = _Bounded(1024)   # (id(scheme), first member, shape of the chain's tensor, ...) -> (scheme, groups)
 CHAIN_BW, CHAIN_FLOPS = 5.0e12, 120e12   # what a tile-structured pass / the fp32 matrix pipe sustain: the cost model
 CHAIN_PAIR_BYTES = 1.35
+CHAIN_SPILL_FACTOR = 2.5
 CHAIN_MIN_GAIN = 0.97                    # the pairs-from-the-left cut stays unless another one is estimated 3 % faster
 
 
@@ -2036,7 +2037,7 @@ def _cut_sparse_chain(scheme, members, a_shape, b_shapes, dtype):
         t = max(CHAIN_PAIR_BYTES * (q.bytes + (rr - 1) * float(itemsize) * numel(sa)) / CHAIN_BW,
                 (q.flops + (rr - 1) * flops1[p]) / CHAIN_FLOPS)
         if q.tile_out_bits < q.tile_mid_bits and q.k_bits >= 5 and q.k2_bits >= 5 and q.grid > 256:
-            t *= 2.5
+            t *= CHAIN_SPILL_FACTOR
         pair[p] = t
         pair_q[members[p]] = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
     best, take = [0.0] * (L + 2), [1] * L
