@@ -77,8 +77,10 @@ __device__ __forceinline__ long gaddr(long t, int c, int rs) {
   const long rows = 32768L >> rb;
   return (t >> (st - rb)) * (rows << st) + ((t & ((1L << (st - rb)) - 1)) << rb) + (long)(c >> (rb - 4)) * ((1L << st) + g_skew) + (c & ((1 << (rb - 4)) - 1)) * 16;
 }
+__device__ unsigned long long g_marks[1024 * 10];
+#define MARK(i) do { if (marks && iter == 20 && tid == 0) g_marks[blockIdx.x * 10 + (i)] = wall_clock64(); } while (0)
 template <int L1, int L2, int WPC, bool WLDS, bool MFMA, bool COPY>
-__global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char *__restrict__ C, long n_tiles, int rs_in, int rs_out) {
+__global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char *__restrict__ C, long n_tiles, int rs_in, int rs_out, int marks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // fragments (synthetic): in LDS, or in registers for the whole kernel
@@ -107,23 +109,30 @@ __global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char
       for (int i = 0; i < 8; ++i) v[i] = *(const f32x4 *)(A + gaddr(t + G, tid + 256 * i, rs_in));
   }
   __syncthreads();
-  for (; t < n_tiles; t += G) {
+  int iter = 0;
+  for (; t < n_tiles; t += G, ++iter) {
     float hold[32];
+    MARK(0);
     stage<L1, WLDS, MFMA>(a_lane, W1_OFF + w_lane, wreg1, hold);
+    MARK(1);
     __syncthreads();                       // every wave has read the tile: results go over it
 #pragma unroll
     for (int e = 0; e < 16; ++e) ldw8((sc_lane + (unsigned)e * 1024u) & (REGION - 1), v2f{hold[2 * e], hold[2 * e + 1]});
     __syncthreads();
+    MARK(2);
     stage<L2, WLDS, MFMA>(a_lane, W2_OFF + w_lane, wreg2, hold);
+    MARK(3);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 16; ++e) ldw8((sc_lane + (unsigned)e * 1024u) & (REGION - 1), v2f{hold[2 * e], hold[2 * e + 1]});
     __syncthreads();
+    MARK(4);
     if (COPY) {
       f32x4 x[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) x[i] = ldr16((unsigned)(tid + 256 * i) * 16u);
       __syncthreads();
+      MARK(5);
       if (t + G < n_tiles)
 #pragma unroll
         for (int i = 0; i < 8; ++i) ldw16((unsigned)(tid + 256 * i) * 16u, v[i]);
@@ -132,13 +141,17 @@ __global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char
       if (t + 2 * G < n_tiles)
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load((const f32x4 *)(A + gaddr(t + 2 * G, tid + 256 * i, rs_in)));
+      MARK(6);
     } else if (hold[0] == 12345.f) {
       C[tid] = 1;
     }
     __syncthreads();
+    MARK(7);
+    if (marks && iter == 21 && tid == 0) g_marks[blockIdx.x * 10 + 8] = wall_clock64();
   }
 }
 
+static int g_want_marks = 0;
 template <int L1, int L2>
 static void run_all(const char *a, char *c, long n_tiles, hipEvent_t e0, hipEvent_t e1, int rs_in, int rs_out) {
   auto timeit = [&](const char *name, auto kern, int wpc, unsigned lds) {
@@ -148,12 +161,28 @@ static void run_all(const char *a, char *c, long n_tiles, hipEvent_t e0, hipEven
     float best = 1e9;
     for (int r = 0; r < 4; ++r) {
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(kern, dim3(256 * wpc), dim3(256), lds, 0, a, c, n_tiles, rs_in, rs_out);
+      hipLaunchKernelGGL(kern, dim3(256 * wpc), dim3(256), lds, 0, a, c, n_tiles, rs_in, rs_out, g_want_marks);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms;
       CK(hipEventElapsedTime(&ms, e0, e1));
       if (r > 0 && ms < best) best = ms;
+    }
+    if (g_want_marks) {
+      static unsigned long long m[1024 * 10];
+      CK(hipMemcpyFromSymbol(m, HIP_SYMBOL(g_marks), sizeof(m)));
+      const int nb = 256 * wpc;
+      double seg[8] = {0};
+      for (int b = 0; b < nb; ++b) {
+        for (int i = 0; i < 7; ++i) seg[i] += (double)(m[b * 10 + i + 1] - m[b * 10 + i]);
+        seg[7] += (double)(m[b * 10 + 8] - m[b * 10 + 0]);   // (mark 8 is taken one iteration later, after the end barrier: a period + the tail)
+      }
+      const char *nm[7] = {"stage 1", "barrier scatter barrier", "stage 2", "barrier scatter barrier", "x reads + barrier", "refill stores loads", "end barrier"};
+      printf("      phases (ns, mean over workgroups, iteration 20):");
+      for (int i = 0; i < 7; ++i) printf(" %s %.0f |", nm[i], seg[i] / nb * 10);
+      printf("\n      raw marks of workgroup 0:");
+      for (int i = 0; i < 9; ++i) printf(" %llu", m[i] - m[0]);
+      printf("\n");
     }
     const double flop = 8.0 / 6.0 * 3.0 * (L1 + L2) * 4.0 * 32 * 32 * 2 * 2 * (double)n_tiles; // nominal (8 per complex MAC) of the 3M triples
     printf("  %-58s occ %d  %7.3f ms  %6.2f TB/s  %6.1f TFLOP/s nominal  %5.2f us per tile and workgroup\n", name, occ, best,
@@ -174,6 +203,7 @@ int main(int argc, char **argv) {
   const int rs_in = (rb_in ? (rb_in << 8) | st : 0) | (xcd << 16), rs_out = rb_out ? (rb_out << 8) | st : 0;
   const long n_tiles = 262144;
   const long skew = argc > 7 ? atol(argv[7]) : 0;
+  g_want_marks = argc > 8 ? atoi(argv[8]) : 0;
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_skew), &skew, sizeof(long)));
   printf("row stride skew %ld bytes\n", skew);
   char *a, *c;
