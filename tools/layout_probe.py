@@ -52,7 +52,7 @@ for q, op in enumerate(pairs[lo_:hi_], lo_):
     eq1n = "".join(new_la) + "," + "".join(lb1) + "->" + "".join(lo1)
     info1 = C.pair_info(eq1n, a_shape, b1.shape, eq2, b2.shape)
     t0 = timeit(lambda: C.contract2(eq1, a, b1, eq2, b2))
-    t1 = timeit(lambda: C.contract2(eq1n, a, b1, eq2, b2)) if info1 else float("nan")
+    t1 = timeit(lambda: C.contract2(eq1n, a, b1, eq2, b2)) if info1 and not os.environ.get("ONLY_SCHEME") else float("nan")
     f = lambda i: f"k={i['k_bits']}+{i['k2_bits']} runs {i['run_in_bits']}/{i['run_out_bits']} T {i['tile_in_bits']}/{i['tile_out_bits']} rr {i['a_rereads']}" if i else "declined"
     print(f"pair {q} steps {n}+{m}: scheme layout {t0:6.3f} ms ({f(info0)})   contiguous input tiles {t1:6.3f} ms ({f(info1)})", flush=True)
     del a, b1, b2
