@@ -774,6 +774,27 @@ def test_n53_slice_with_the_chain_cut_and_with_pairs_from_the_left(monkeypatch):
         assert_contract(cut, case.arrays["slice0"], "n53_m14_sliced_slice0")
 
 
+@pytest.mark.parametrize("name", ["n30_sparse100", "n12_sparse5", "n12_sparse_sliced"])
+def test_sparse_schemes_with_the_chain_cut_and_with_pairs_from_the_left(name, monkeypatch):
+    """Every committed sparse-state scheme under both schedules (contraction._plan_chain / fusion_schedule): the same
+    amplitudes to 1e-5 of the largest, and the reference's (fixture) either way."""
+    from artensor_amd import contraction as C
+    case = load_case(os.path.join(GOLDEN, name + ".npz"))
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ARTN_CHAIN_PLAN", mode)
+        C._schedule_cache.clear()
+        if case.slicing_indices:
+            out = A.sliced_contraction(case.tensors, case.scheme, case.slicing_indices, case.arrays["final"].shape, sparse=True,
+                                       device=DEV).cpu().numpy()
+        else:
+            out = A.tensor_contraction_sparse(case.fresh_tensors(device=DEV), case.scheme).cpu().numpy()
+        outs[mode] = out.reshape(-1)
+        assert amp_rel(outs[mode], case.arrays["final"].reshape(-1)) < 1e-5
+    C._schedule_cache.clear()
+    assert np.abs(outs["0"] - outs["1"]).max() <= 1e-5 * np.abs(outs["0"]).max()
+
+
 def test_n53_slices(monkeypatch):
     """BASELINE config 4 (Sycamore n53 m14, derived from the bundled m20 circuit; one bitstring,
     14 sliced bonds): slice 0 against the reference executor's CPU result, and the slice loop
