@@ -192,6 +192,9 @@ static void run_all(const char *a, char *c, long n_tiles, hipEvent_t e0, hipEven
   timeit("fragments in LDS, 3 workgroups per CU", tri<L1, L2, 3, true, true, true>, 3, LDS_MIN);
   timeit("fragments in LDS, 2 workgroups per CU (LDS padded)", tri<L1, L2, 3, true, true, true>, 2, 70 * 1024);
   timeit("fragments in registers, 2 per CU", tri<L1, L2, 2, false, true, true>, 2, LDS_MIN);
+  timeit("fragments in registers, ONE per CU (one wave per SIMD)", tri<L1, L2, 2, false, true, true>, 1, LDS_MIN);
+  timeit("fragments in registers, ONE per CU, no global traffic", tri<L1, L2, 2, false, true, false>, 1, LDS_MIN);
+  timeit("fragments in registers, 2 per CU, no global traffic", tri<L1, L2, 2, false, true, false>, 2, LDS_MIN);
   timeit("fragments in LDS, 3 per CU, no global traffic", tri<L1, L2, 3, true, true, false>, 3, LDS_MIN);
   timeit("fragments in LDS, 3 per CU, no MFMA", tri<L1, L2, 3, true, false, true>, 3, LDS_MIN);
 }
