@@ -23,8 +23,9 @@ else
 DEVFLAGS :=
 DEVOBJS :=
 endif
-OBJS := $(OBJDIR)/main.o $(OBJDIR)/b128.o $(OBJDIR)/wide.o $(foreach k,1 2 3 4,$(OBJDIR)/bits_k$(k).o) \
-        $(foreach k,5 6,$(OBJDIR)/bits_k$(k)h0.o $(OBJDIR)/bits_k$(k)h1.o) $(DEVOBJS)
+# (the longest translation units first: make -j starts its jobs in this order)
+OBJS := $(foreach k,6 5,$(OBJDIR)/bits_k$(k)h0.o $(OBJDIR)/bits_k$(k)h1.o) $(OBJDIR)/main.o $(OBJDIR)/bits_k4.o $(OBJDIR)/bits_k3.o \
+        $(OBJDIR)/b128.o $(OBJDIR)/b128a.o $(OBJDIR)/wide.o $(OBJDIR)/bits_k2.o $(OBJDIR)/bits_k1.o $(DEVOBJS)
 FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -I$(CSRC) $(DEVFLAGS)
 
 $(OBJDIR)/main.o: $(SRCS)
@@ -33,6 +34,9 @@ $(OBJDIR)/main.o: $(SRCS)
 $(OBJDIR)/b128.o: $(SRCS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -DARTN_TU_B128 -c $< -o $@
+$(OBJDIR)/b128a.o: $(SRCS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FLAGS) -DARTN_TU_B128A -c $< -o $@
 $(OBJDIR)/wide.o: $(SRCS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -DARTN_TU_WIDE -c $< -o $@

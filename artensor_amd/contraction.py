@@ -1338,7 +1338,7 @@ def tensor_contraction(tensors, scheme, accumulate_into=None):
             if not (isinstance(accumulate_into, torch.Tensor) and accumulate_into.is_cuda and accumulate_into.device == device
                     and accumulate_into.is_contiguous() and accumulate_into.dtype == dtype):
                 raise RuntimeError("accumulate_into must be a contiguous tensor of the scheme's dtype on its device")
-            acc_ok = (last_op is not None and dtype == torch.complex64 and precision.current() in (None, "fp32")
+            acc_ok = (last_op is not None and (dtype == torch.complex128 or (dtype == torch.complex64 and precision.current() in (None, "fp32")))
                       and last_op.steps and last_op.steps[-1] == len(scheme) - 1
                       and int(np.prod(last_op.out_shape, dtype=np.int64)) == accumulate_into.numel())
         for op in ops:

@@ -163,7 +163,15 @@ __device__ __forceinline__ void run_stage128(const Stage128<KB> &L, const double
   }
 }
 
-template <int KB1, int KB2>
+// ACC: C += result (ArtnBitsPlan::accumulate: the slice loop's `collect += ...`, reference simulation.py:114, in the store phase of
+// a complex128 slice's last launch): the accumulator's 16-byte chunks are read and added before the stores -- every result
+// element belongs to exactly one lane of one tile.  A separate set of instantiations (its own translation unit): behind a
+// run-time flag the conditional loads cost every launch of the complex64 kernel 40 %.
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 add_c128(f32x4 x, f32x4 c) {
+  return __builtin_bit_cast(f32x4, __builtin_bit_cast(f64x2_t, x) + __builtin_bit_cast(f64x2_t, c));
+}
+template <int KB1, int KB2, bool ACC = false>
 __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits128(const double2 *__restrict__ A, const double2 *__restrict__ B1,
                                                                     const double2 *__restrict__ B2, double2 *__restrict__ C,
                                                                     const ArtnBitsPlan P) {
@@ -284,6 +292,22 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits128(const doubl
         if (pf_half) store_lds<NV, NV / 2>(v, R0, t16);
         else store_lds(v, R0, t16);
       }
+      if constexpr (ACC) { // (into the registers the refill has just freed)
+        f32x4 c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (i < n_out_iters && out_active) {
+            long o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              if ((i >> b) & 1) o += out_hi[b];
+            c[i] = *reinterpret_cast<const f32x4 *>(Cbase + o + lo_out);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < n_out_iters && out_active) x[i] = add_c128(x[i], c[i]);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (i < n_out_iters && out_active) {
@@ -307,7 +331,9 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, 2) void artn_k_bits128(const doubl
 #pragma unroll
           for (int b = 0; b < 4; ++b)
             if ((i >> b) & 1) o += out_hi[b];
-          *reinterpret_cast<f32x4 *>(Cbase + o + lo_out) = lds_read16(outr + (t16o ^ out_i_swz[i]));
+          f32x4 xv = lds_read16(outr + (t16o ^ out_i_swz[i]));
+          if constexpr (ACC) xv = add_c128(xv, *reinterpret_cast<const f32x4 *>(Cbase + o + lo_out));
+          *reinterpret_cast<f32x4 *>(Cbase + o + lo_out) = xv;
         }
       }
       if (KB2 > 0) __syncthreads();

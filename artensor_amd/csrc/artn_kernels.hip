@@ -1776,6 +1776,9 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 // artn_launch_bits_kK(), -DARTN_TU_B128 only artn_k_bits128<*, *> behind artn_launch_bits128(), -DARTN_TU_MAIN
 // everything else and calls those; with none of the macros (diagnostic and development builds) the file is one
 // translation unit as before.
+#if defined(ARTN_TU_B128A) && !defined(ARTN_TU_B128)
+#define ARTN_TU_B128 1 /* (-DARTN_TU_B128A: the accumulating instantiations artn_k_bits128<*, *, true> behind artn_launch_bits128_acc()) */
+#endif
 #if defined(ARTN_TU_BITS) || defined(ARTN_TU_B128) || defined(ARTN_TU_BITS3) || defined(ARTN_TU_WIDE)
 #define ARTN_TU_PART 1
 #endif
@@ -2666,9 +2669,10 @@ static hipError_t launch_bits_k2(const ArtnPlan &p, const float2 *A, const float
   return hipGetLastError();
 }
 
-// complex128 plans of make_bits: artn_k_bits128<KB1, KB2>
+// complex128 plans of make_bits: artn_k_bits128<KB1, KB2, ACC> (ACC: ArtnBitsPlan::accumulate; its own translation unit)
 #if defined(ARTN_TU_B128) || (!defined(ARTN_TU_PART) && !defined(ARTN_TU_MAIN))
-hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st) {
+template <bool ACC>
+static hipError_t launch_bits128_t(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st) {
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
   const size_t lds = (size_t)p.info.lds_bytes;
   const int k1 = p.bits.st[0].k, k2 = p.bits.n_stages == 2 ? p.bits.st[1].k : 0;
@@ -2676,8 +2680,8 @@ hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1,
   double2 *c = (double2 *)C;
 #define ARTN_B128_GO(K1, K2)                                                                        \
   {                                                                                                 \
-    auto kern = artn_k_bits128<K1, K2>;                                                             \
-    if (hipError_t e = ensure_lds<artn_k_bits128<K1, K2>>(lds); e != hipSuccess) return e;          \
+    auto kern = artn_k_bits128<K1, K2, ACC>;                                                        \
+    if (hipError_t e = ensure_lds<artn_k_bits128<K1, K2, ACC>>(lds); e != hipSuccess) return e;     \
     hipLaunchKernelGGL(kern, grid, block, lds, st, a, b1, b2, c, p.bits);                           \
     return hipGetLastError();                                                                       \
   }
@@ -2705,8 +2709,19 @@ hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1,
 #undef ARTN_B128_K2
 #undef ARTN_B128_GO
 }
+#if !defined(ARTN_TU_B128A)
+hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st) {
+  return launch_bits128_t<false>(p, A, B1, B2, C, st);
+}
+#endif
+#if defined(ARTN_TU_B128A) || !defined(ARTN_TU_PART)
+hipError_t artn_launch_bits128_acc(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st) {
+  return launch_bits128_t<true>(p, A, B1, B2, C, st);
+}
+#endif
 #elif defined(ARTN_TU_MAIN)
 hipError_t artn_launch_bits128(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st);
+hipError_t artn_launch_bits128_acc(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C, hipStream_t st);
 #endif
 
 // fused pairs of 2^12-element tiles (ArtnBitsPlan::wide8): artn_k_wide<KB1, KB2>, 3..6 contracted bits per stage
@@ -2826,7 +2841,7 @@ static hipError_t launch_bits3(const ArtnPlan &p, const void *A, const void *B1,
 
 static hipError_t launch_bits(const ArtnPlan &p, const void *A, const void *B1, const void *B2, void *C,
                               hipStream_t st) {
-  if (p.bits.c128) return artn_launch_bits128(p, A, B1, B2, C, st);
+  if (p.bits.c128) return p.bits.accumulate ? artn_launch_bits128_acc(p, A, B1, B2, C, st) : artn_launch_bits128(p, A, B1, B2, C, st);
   if (p.bits.wide8) return artn_launch_wide(p, A, B1, B2, C, st);
   const float2 *a = (const float2 *)A, *b1 = (const float2 *)B1, *b2 = (const float2 *)B2;
   float2 *c = (float2 *)C;

@@ -1709,7 +1709,8 @@ static inline bool wide_eligible(const ArtnPlan &p) {
 static inline bool bits_can_accumulate(const ArtnPlan &p) {
   if (p.kernel != ARTN_KERNEL_BITS_MFMA) return false;
   const ArtnBitsPlan &b = p.bits;
-  if (b.c128 || b.wide8 || b.n_stages > 2 || b.gather_dim >= 0 || b.st[0].k > 6 || b.split != 0) return false;
+  if (b.wide8 || b.n_stages > 2 || b.gather_dim >= 0 || b.st[0].k > 6 || b.split != 0) return false;
+  if (b.c128) return true; // (artn_k_bits128<*, *, true>: every tile shape; its own instantiations)
   if (b.T_in != 12 || b.T_out != 12) return false;
   // ... and the launch must be one of the FULL instantiations (launch_bits_k2): 3M pairs / steps, or non-temporal loads with
   // 3+ contracted bits per stage

@@ -205,9 +205,9 @@ class SliceRunner:
         self.n_bonds = len(self.slicing_indices)
         self.collect = torch.zeros(tuple(out_shape), dtype=dtype, device=device)
         seams = _execute is not None or _accumulate is not None
-        # dense complex64 schemes: `collect += result` rides in the store phase of the slice's last launch where that launch is
+        # dense schemes (complex64, and complex128 on artn_k_bits128): `collect += result` rides in the store phase of the slice's last launch where that launch is
         # a state-streaming step or pair (tensor_contraction(accumulate_into=...)); ARTN_NO_ACC=1 keeps the separate add
-        self._fused_add = (not seams and not sparse and dtype == torch.complex64 and self.device.type == "cuda"
+        self._fused_add = (not seams and not sparse and dtype in (torch.complex64, torch.complex128) and self.device.type == "cuda"
                            and __import__("os").environ.get("ARTN_NO_ACC", "0") in ("", "0"))
         on_gpu = not seams and self.device.type == "cuda" and self.n_bonds > 0
         self.use_graph = graph is True and on_gpu

@@ -1386,6 +1386,56 @@ def test_fused_triples_on_the_gpu(monkeypatch):
         torch.cuda.empty_cache()
 
 
+def test_accumulate_in_the_store_phase_in_complex128(monkeypatch):
+    """The same for complex128 (artn_k_bits128<KB1, KB2, true>, round 5): the 13 fusable pairs of the n30 scheme on surrogates of
+    2^22 elements against accumulator + the plain launch (one f64 add per element either way: equal to the last bit), through
+    tensor_contraction(accumulate_into=...), and a sliced dense loop in complex128 with and without the fused add."""
+    from artensor_amd.contraction import fusion_schedule, contract2, _pair_descriptors
+    from helpers import shrink_pair
+    import ctypes
+    lib = N.lib()
+    case = load_case(os.path.join(GOLDEN, "n30_dense.npz"))
+    steps = dense_scheme_shapes(case)
+    pairs = [e for e in fusion_schedule(case.scheme) if e[0] == "pair" and np.prod(steps[e[1]][1]) >= 2 ** 22]
+    stream = N.current_stream_ptr(torch.device("cuda:0"))
+    c128 = lambda rng, shape: torch.from_numpy(rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).to(DEV)
+    fused = 0
+    for _, n, m in pairs:
+        eq1, sa, sb1 = steps[n]
+        eq2, _, sb2 = steps[m]
+        e1, a_s, b1_s, e2, b2_s = shrink_pair(eq1, sa, sb1, eq2, sb2, max_log2=22)
+        rng = np.random.default_rng(300 + n)
+        a, b1, b2 = c128(rng, a_s), c128(rng, b1_s), c128(rng, b2_s)
+        plain = contract2(e1, a, b1, e2, b2)
+        if plain is None:
+            continue
+        acc0 = c128(rng, tuple(plain.shape))
+        acc = acc0.clone()
+        d1, d2, _ = _pair_descriptors(e1, a, b1, e2, b2)
+        rc = lib.artn_contract2_acc(ctypes.byref(d1), ctypes.byref(d2), a.data_ptr(), b1.data_ptr(), b2.data_ptr(), acc.data_ptr(), stream)
+        if rc == -2:
+            continue
+        assert rc == 0, lib.artn_last_error()
+        assert torch.equal(acc, acc0 + plain), (n, m)
+        fused += 1
+        tensors = {0: a.clone(), 1: b1, 2: b2}
+        acc2 = acc0.clone()
+        got = A.tensor_contraction(tensors, [((0, 1), e1), ((0, 2), e2)], accumulate_into=acc2)
+        assert got is acc2 and torch.equal(acc2, acc0 + plain), (n, m)
+    assert fused >= 10, fused   # (every tile shape of artn_k_bits128 can add)
+    # the slice loop in complex128: `collect += slice` inside each slice's last launch against the separate artn_axpy_c128
+    case = load_case(os.path.join(GOLDEN, "n30_dense_sliced3.npz"))
+    shape = case.arrays["final"].shape if "final" in case.arrays else (2,) * 30
+    fused_sum = A.sliced_contraction(case.tensors, case.scheme, case.slicing_indices, shape, dtype=torch.complex128, device=DEV,
+                                     slices=[0, 1, 2])
+    monkeypatch.setenv("ARTN_NO_ACC", "1")
+    plain_sum = A.sliced_contraction(case.tensors, case.scheme, case.slicing_indices, shape, dtype=torch.complex128, device=DEV,
+                                     slices=[0, 1, 2])
+    monkeypatch.delenv("ARTN_NO_ACC")
+    assert fused_sum.dtype == torch.complex128
+    assert float((fused_sum - plain_sum).abs().max()) <= 1e-13 * float(plain_sum.abs().max())
+
+
 def test_accumulate_in_the_store_phase():
     """`collect_tensor += tensor_contraction(...)` (reference simulation.py:114) with the add in the store phase of the last
     launch (artn_contract2_acc / artn_contract_acc): the 13 fusable pairs of the n30 scheme and its big single steps on
