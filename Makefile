@@ -8,7 +8,7 @@ all: $(LIB)
 
 # thirteen objects from ONE source (see "Translation units" in artn_kernels.hip): `make -j8` builds in about a
 # minute and a half instead of four
-SRCS := $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_pgemm_kernel.h \
+SRCS := $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_pgemm_kernel.h $(CSRC)/artn_xgemm128_kernel.h \
         $(CSRC)/artn_bits128_kernel.h $(CSRC)/artn_bits3_kernel.h $(CSRC)/artn_wide_kernel.h $(CSRC)/artn_plan.h \
         $(CSRC)/artn_xgemm_plan.h $(CSRC)/artn_xgemm_kernel.h $(CSRC)/artn_xgemm_pc_kernel.h include/artn.h
 OBJDIR := build/obj

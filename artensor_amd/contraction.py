@@ -1203,7 +1203,7 @@ def _own_layouts(scheme, main_idx, shapes, dtype):
     -- consecutive rows of the extent GEMM's 128-row tiles are then consecutive in the first operand's free labels
     AND in the result (1 KiB contiguous per tile column), whatever the planner's `list(set)` said.  The last step
     keeps the scheme's order.  Returns the scheme itself or a rewritten copy (label-tuple equations)."""
-    if dtype != torch.complex64 or not main_idx or _os_environ.get("ARTN_OWN_LAYOUTS", "1") in ("0",):
+    if dtype not in _DTYPES or not main_idx or _os_environ.get("ARTN_OWN_LAYOUTS", "1") in ("0",):
         return scheme
     if all(e & (e - 1) == 0 for sh in shapes.values() for e in sh):
         return scheme

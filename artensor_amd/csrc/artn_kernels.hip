@@ -1796,6 +1796,7 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 #include "artn_gemm128_kernel.h"
 #include "artn_pgemm_kernel.h"
 #include "artn_xgemm_kernel.h"
+#include "artn_xgemm128_kernel.h"
 #ifdef ARTN_DEV_XGPC
 #include "artn_xgemm_pc_kernel.h"
 #endif
@@ -2901,8 +2902,23 @@ static hipError_t launch_pgemm(const ArtnPlan &p, const void *A, const void *B, 
   return hipGetLastError();
 }
 
+static hipError_t launch_xgemm128(const ArtnPlan &p, const void *A, const void *B, void *C, hipStream_t st) {
+  const ArtnXGemmPlan &g = p.xg;
+  const double2 *a = (const double2 *)(g.swapped ? B : A), *b = (const double2 *)(g.swapped ? A : B);
+  dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
+  const size_t lds = (size_t)p.info.lds_bytes;
+  if (g.kc != ARTN_XG128_KC || g.pc) return hipErrorInvalidValue;
+  if (g.nb == 1) {
+    if (hipError_t e = ensure_lds<artn_k_xgemm128<1>>(lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(artn_k_xgemm128<1>, grid, block, lds, st, a, b, (double2 *)C, g);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, void *C, hipStream_t st) {
   const ArtnXGemmPlan &g = p.xg;
+  if (g.c128) return launch_xgemm128(p, A, B, C, st);
   const float2 *a = (const float2 *)(g.swapped ? B : A), *b = (const float2 *)(g.swapped ? A : B);
   float2 *c = (float2 *)C;
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);

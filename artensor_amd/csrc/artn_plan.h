@@ -1443,7 +1443,7 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, bool
 // has no such restriction).
 // ----------------------------------------------------------------------------------------
 static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles) {
-  if (d->dtype != ARTN_C64 && d->dtype != ARTN_C64_BF16) { p.why_generic = "extent GEMM: dtype is not complex64"; return false; }
+  const bool c128 = d->dtype == ARTN_C128; // (artn_k_xgemm128: the same plan with 16-byte elements, chunks of 8, one or two column blocks)
   ArtnXGemmPlan &x = p.xg;
   memset(&x, 0, sizeof(x));
   struct Lab { int64_t e, sA, sB, sC; };
@@ -1543,7 +1543,7 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   // one block per wave is 3 MFMAs per pair of LDS reads and per barrier share: 73 against 108 TFLOP/s on long contractions
   // (216 columns: 7 tiles of 32 waste 4 %, 4 tiles of 64 waste 16 % and are still faster)
   double best = -1;
-  for (int nb = 3; nb >= 1; --nb) {
+  for (int nb = c128 ? 1 : 3; nb >= 1; --nb) { // (complex128: one block -- two need 128 accumulator registers and spill)
     const int64_t tn = 32 * nb, tiles = (x.n.total + tn - 1) / tn;
     const double eff = (double)x.n.total / (double)(tiles * tn) * (nb == 1 ? 0.75 : 1.0);
     if (eff > best + 1e-9) { best = eff; x.nb = nb; }
@@ -1557,10 +1557,12 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
 #ifdef ARTN_DEV_SWITCHES
   if (const char *e = getenv("ARTN_XG_KC")) { const int v = atoi(e); if ((v == 8 && x.nb == 1) || v == 16) x.kc = v; }
 #endif
+  x.c128 = c128 ? 1 : 0;
+  if (c128) { x.kc = 8; x.trans = 0; }
   x.pc = 0; // (artn_k_xgemm_pc, the producer / consumer form: correct, measured slower -- 7.5 against 6.7 ms on the biggest step of the
             //  bond-dimension-3 network -- and compiled into development builds only)
 #if defined(ARTN_DEV_SWITCHES) && defined(ARTN_DEV_XGPC)
-  if (const char *e = getenv("ARTN_XG_PC")) x.pc = (atoi(e) != 0 && x.kc == ARTN_XG_KC) ? 1 : 0;
+  if (const char *e = getenv("ARTN_XG_PC")) x.pc = (atoi(e) != 0 && x.kc == ARTN_XG_KC && !c128) ? 1 : 0;
 #endif
   x.cpg = (x.k.L0 + x.kc - 1) / x.kc;
   x.k_groups = x.k.total / x.k.L0;
@@ -1577,9 +1579,9 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   I.m_tile_bits = 7;
   I.n_tile_bits = 5;
   I.k_bits = 4;
-  I.lds_bytes = x.pc ? artn_xg_pc_lds_bytes(x.nb) : artn_xg_lds_bytes(x.nb, x.kc);
+  I.lds_bytes = c128 ? artn_xg128_lds_bytes(x.nb) : (x.pc ? artn_xg_pc_lds_bytes(x.nb) : artn_xg_lds_bytes(x.nb, x.kc));
   I.n_tiles = x.n_tiles;
-  I.grid = (int32_t)std::min<int64_t>(x.n_tiles, (int64_t)n_cu * (x.pc ? 1 : (x.kc == 8 ? 4 : 2)));
+  I.grid = (int32_t)std::min<int64_t>(x.n_tiles, (int64_t)n_cu * (c128 ? 2 : (x.pc ? 1 : (x.kc == 8 ? 4 : 2))));
   I.a_rereads = x.tiles_n;
   return true;
 }
@@ -1654,7 +1656,7 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
   }
   if (!ok && gather_label >= 0) { err = "row gather needs the tiled kernel: " + p.why_generic; return ARTN_E_UNSUPPORTED; }
   // what every bit planner declined (in practice: a label whose extent is not a power of two): the extent-based GEMM
-  if (!ok && allow_bits && allow_xgemm && tuning().xgemm && d->dtype != ARTN_C128) {
+  if (!ok && allow_bits && allow_xgemm && tuning().xgemm) { // (complex64: artn_k_xgemm; complex128: artn_k_xgemm128)
     const std::string why = p.why_generic;
     ok = make_xgemm(d, p, n_cu, min_tiles);
     if (!ok) p.why_generic = why + "; " + p.why_generic;
@@ -1675,8 +1677,8 @@ static inline int make_plan(const ArtnStepDesc *d, ArtnPlan &p, std::string &err
     p.info.arith = d->dtype == ARTN_C128 ? 3 : (p.gemm.split == 1 ? 2 : (p.gemm.m3 ? 1 : 0));
     p.info.mfma_flops = p.info.flops * (p.gemm.m3 ? 0.75 : 1.0);
   } else if (p.kernel == ARTN_KERNEL_XGEMM) {
-    p.info.arith = 1; // three real products per complex product
-    p.info.mfma_flops = p.info.flops * 0.75;
+    p.info.arith = d->dtype == ARTN_C128 ? 3 : 1; // complex64: three real products per complex product; complex128: four, on the f64 MFMA
+    p.info.mfma_flops = p.info.flops * (d->dtype == ARTN_C128 ? 1.0 : 0.75);
   } else {
     p.info.arith = -1;
     p.info.mfma_flops = 0.0;

@@ -52,6 +52,7 @@ struct ArtnXGemmPlan {
   int32_t prio;                // 1: the workgroup in the odd wave slots runs its MFMA loops at s_setprio 1
   int32_t kc;                  // contracted values per chunk: 16, or 8 (few contracted values, nb = 1: four workgroups per CU)
   int32_t pc;                  // 1: artn_k_xgemm_pc -- one 8-wave workgroup per CU, four consumer and four producer waves (kc = 16)
+  int32_t c128, pad_;          // 1: complex128 operands -- artn_k_xgemm128 (16-byte elements, kc = 8, nb = 1, f64 MFMA)
   int64_t k_groups;            // k.total / k.L0
   int64_t tiles_m, tiles_n, n_tiles; // n_tiles = tiles_m * tiles_n * prod(h_ext); tile index = (h, tile of m, tile of n), n fastest
 };
@@ -63,6 +64,8 @@ static inline int artn_xg_stage_bytes(int nb, int kc) { return kc * (artn_xg_pit
 static inline int artn_xg_level_bytes() { return 8 * ARTN_XG_LEVEL * 4 + 2 * ARTN_XG_KTAB * 4; } // mA0 mC0 mA1 mC1 nB0 nC0 nB1 nC1, kA kB
 static inline int artn_xg_tiletab_bytes() { return 4 * ARTN_XG_TM * 4; }   // rowA rowC colB colC of one tile
 static inline int artn_xg_lds_bytes(int nb, int kc) { return 2 * artn_xg_stage_bytes(nb, kc) + artn_xg_level_bytes() + 2 * artn_xg_tiletab_bytes(); }
+// complex128 (artn_k_xgemm128): 16-byte elements, chunks of 8 contracted values, nb = 1
+static inline int artn_xg128_lds_bytes(int nb) { return 2 * 8 * (artn_xg_pitch_a() + artn_xg_pitch_b(nb)) * 16 + artn_xg_level_bytes() + 2 * artn_xg_tiletab_bytes(); }
 static inline int artn_xg_pc_lds_bytes(int nb) { return 2 * artn_xg_stage_bytes(nb, ARTN_XG_KC) + artn_xg_level_bytes() + 8 * 1024; } // four row + four column table sets
 
 // Mixed-radix decode of `idx` over labels [first, first + count) of a side: the two element offsets.

@@ -894,6 +894,121 @@ static void run_xgemm(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C)
   }
 }
 
+// artn_k_xgemm128: the same walk with 16-byte elements, chunks of 8, and the lane / accumulator map of v_mfma_f64_16x16x4_f64
+// (wave w: rows 32 w + 16 a + j, a = 0, 1; blocks b of 8 complex columns; lane (j, g): W row 2 n_in + ro with j = 2 n_in + ro,
+// contracted value 2 s + (g >> 1), component p = g & 1; accumulator register r: component g & 1 of column (g >> 1) + 2 r).
+static void run_xgemm128(const ArtnXGemmPlan &P, const cd *A0, const cd *B0, cd *C) {
+  const cd *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
+  const int NB = P.nb, TM = ARTN_XG_TM, TN = 32 * NB, KC = P.kc, KCL = 3, RSTEP = 256 / KC, PA = artn_xg_pitch_a(), PB = artn_xg_pitch_b(NB);
+  if (KC != 8 || NB != 1) abort();
+  std::vector<uint32_t> mA0(256), mC0(256), mA1(256), mC1(256), nB0(256), nC0(256), nB1(256), nC1(256), kA(256), kB(256);
+  auto level = [&](const ArtnXSide &S, std::vector<uint32_t> &a0, std::vector<uint32_t> &c0, std::vector<uint32_t> *a1, std::vector<uint32_t> *c1) {
+    for (int i = 0; i < S.L0; ++i) artn_xg_decode(S, 0, S.n0, (uint32_t)i, a0[i], c0[i]);
+    if (a1) for (int i = 0; i < S.L1; ++i) artn_xg_decode(S, S.n0, S.n1, (uint32_t)i, (*a1)[i], (*c1)[i]);
+  };
+  level(P.m, mA0, mC0, &mA1, &mC1);
+  level(P.n, nB0, nC0, &nB1, &nC1);
+  level(P.k, kA, kB, nullptr, nullptr);
+  const uint32_t K0 = (uint32_t)P.k.L0, Mtot = (uint32_t)P.m.total, Ntot = (uint32_t)P.n.total;
+  const int64_t n_chunks = P.k_groups * P.cpg;
+  std::vector<cd> imgA((size_t)KC * PA), imgB((size_t)KC * PB);
+  std::vector<uint32_t> rowA(TM), rowC(TM), colB(TM), colC(TM);
+  for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
+    const uint32_t tu = (uint32_t)tile, r = tu / (uint32_t)P.tiles_n, tn = tu - r * (uint32_t)P.tiles_n;
+    uint32_t hh = r / (uint32_t)P.tiles_m;
+    const uint32_t tm = r - hh * (uint32_t)P.tiles_m, m0 = tm * TM, n0 = tn * TN;
+    uint32_t hA = 0, hB = 0, hC = 0;
+    for (int i = 0; i < P.n_h; ++i) {
+      const uint32_t e = (uint32_t)P.h_ext[i], q = hh / e, d = hh - q * e;
+      hA += d * (uint32_t)P.h_sA[i]; hB += d * (uint32_t)P.h_sB[i]; hC += d * (uint32_t)P.h_sC[i];
+      hh = q;
+    }
+    auto side = [&](const ArtnXSide &S, uint32_t first, int count, const std::vector<uint32_t> &t0a, const std::vector<uint32_t> &t0c,
+                    const std::vector<uint32_t> &t1a, const std::vector<uint32_t> &t1c, std::vector<uint32_t> &oa, std::vector<uint32_t> &oc) {
+      for (int loc = 0; loc < count; ++loc) {
+        uint32_t idx = first + (uint32_t)loc;
+        if (idx >= (uint32_t)S.total) idx = (uint32_t)S.total - 1;
+        const uint32_t q0 = idx / (uint32_t)S.L0, i0 = idx - q0 * (uint32_t)S.L0, q1 = q0 / (uint32_t)S.L1, i1 = q0 - q1 * (uint32_t)S.L1;
+        uint32_t o0, o1;
+        artn_xg_decode(S, S.n0 + S.n1, S.n_lab - S.n0 - S.n1, q1, o0, o1);
+        oa[loc] = o0 + t0a[i0] + t1a[i1];
+        oc[loc] = o1 + t0c[i0] + t1c[i1];
+      }
+    };
+    side(P.m, m0, TM, mA0, mC0, mA1, mC1, rowA, rowC);
+    side(P.n, n0, TN, nB0, nC0, nB1, nC1, colB, colC);
+    std::vector<double> acc((size_t)4 * 2 * 4 * NB * 64 * 4, 0.0); // wave, a, b, lane, register
+    auto ACC = [&](int wave, int a, int b, int lane, int rr) -> double & { return acc[((((size_t)wave * 2 + a) * 4 * NB + b) * 64 + lane) * 4 + rr]; };
+    bool flushed_before = false;
+    int since_flush = 0;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+      const uint32_t ig = (uint32_t)(c / P.cpg), iq = (uint32_t)(c % P.cpg);
+      uint32_t gA, gB;
+      artn_xg_decode(P.k, P.k.n0, P.k.n_lab - P.k.n0, ig, gA, gB);
+      const uint32_t kbase = iq * KC;
+      const int kvalid = (int)std::min<uint32_t>(K0 - kbase, KC);
+      for (auto &x : imgA) x = cd(-777., -777.);
+      for (auto &x : imgB) x = cd(-777., -777.);
+      for (int tid = 0; tid < 256; ++tid) {
+        for (int u = 0; u < TM * KC / 256; ++u) {
+          int row, kk;
+          if (P.amode) { kk = tid & (KC - 1); row = (tid >> KCL) + RSTEP * u; } else { row = tid & (TM - 1); kk = (tid >> 7) + 2 * u; }
+          uint32_t kc = kbase + (uint32_t)kk;
+          if (kc >= K0) kc = K0 - 1;
+          const cd v = A[(uint32_t)(hA + gA + rowA[row] + kA[kc])];
+          imgA[(size_t)kk * PA + row] = kk >= kvalid ? cd(0., 0.) : v;
+        }
+        for (int u = 0; u < TN * KC / 256; ++u) {
+          int col, kk;
+          if (P.bmode) { kk = tid & (KC - 1); col = (tid >> KCL) + RSTEP * u; } else { col = (tid & 31) + 32 * u; kk = tid >> 5; }
+          uint32_t kc = kbase + (uint32_t)kk;
+          if (kc >= K0) kc = K0 - 1;
+          const cd v = B[(uint32_t)(hB + gB + colB[col] + kB[kc])];
+          imgB[(size_t)kk * PB + col] = kk >= kvalid ? cd(0., 0.) : v;
+        }
+      }
+      const int pairs = (kvalid + 1) >> 1;
+      for (int wave = 0; wave < 4; ++wave)
+        for (int s = 0; s < pairs; ++s)
+          for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 4 * NB; ++b)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int rr = 0; rr < 4; ++rr) {
+                  // D[i][j] += sum over the four lane groups gg of Aop[i][gg] * Bop[gg][j]; this lane holds D[i = g + 4 rr][j]
+                  const int jj = lane & 15, g = lane >> 4, i = g + 4 * rr;
+                  const int n_in = i >> 1, ro = i & 1;
+                  for (int gg = 0; gg < 4; ++gg) {
+                    const int kk = 2 * s + (gg >> 1), pp = gg & 1;
+                    const cd xv = imgA[(size_t)kk * PA + 32 * wave + 16 * a + jj];
+                    const cd wv = imgB[(size_t)kk * PB + 8 * b + n_in];
+                    const double x = pp ? xv.imag() : xv.real();
+                    const double w = (ro ^ pp) ? wv.imag() : wv.real();
+                    ACC(wave, a, b, lane, rr) += ((ro == 0 && pp == 1) ? -w : w) * x;
+                  }
+                }
+      ++since_flush;
+      const bool last = c + 1 == n_chunks;
+      if (last || (P.flush_chunks > 0 && since_flush == P.flush_chunks)) {
+        for (int wave = 0; wave < 4; ++wave)
+          for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 4 * NB; ++b)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int rr = 0; rr < 4; ++rr) {
+                  const int jj = lane & 15, g = lane >> 4;
+                  const uint32_t m_loc = 32 * wave + 16 * a + jj, n_loc = 8 * b + (g >> 1) + 2 * rr;
+                  if (m0 + m_loc >= Mtot || n0 + n_loc >= Ntot) continue;
+                  double *dst = reinterpret_cast<double *>(&C[(uint32_t)(hC + rowC[m_loc] + colC[n_loc])]) + (g & 1);
+                  const double val = ACC(wave, a, b, lane, rr);
+                  *dst = flushed_before ? *dst + val : val;
+                }
+        flushed_before = true;
+        since_flush = 0;
+        std::fill(acc.begin(), acc.end(), 0.0);
+      }
+    }
+  }
+}
+
 // Force the extent-based GEMM plan; ARTN_E_UNSUPPORTED if make_xgemm declines.
 extern "C" int artn_emulate_xgemm(const ArtnStepDesc *d, const void *A, const void *B, void *C, ArtnStepInfo *info, int32_t *modes) {
   ArtnPlan p;
@@ -904,7 +1019,8 @@ extern "C" int artn_emulate_xgemm(const ArtnStepDesc *d, const void *A, const vo
   if (!artn::make_xgemm(d, p, 256, 1)) return ARTN_E_UNSUPPORTED;
   if (info) *info = p.info;
   if (modes) { modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; modes[6] = p.xg.kc; }
-  run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
+  if (p.xg.c128) run_xgemm128(p.xg, (const cd *)A, (const cd *)B, (cd *)C);
+  else run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
   return 0;
 }
 
@@ -930,6 +1046,7 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
   if (kernel_used) *kernel_used = p.kernel;
   if (d->dtype == ARTN_C128) {
     if (p.kernel == ARTN_KERNEL_BITS_MFMA) { run_bits128(p.bits, (const cd *)A, (const cd *)B, nullptr, (cd *)C); return 0; }
+    if (p.kernel == ARTN_KERNEL_XGEMM) { run_xgemm128(p.xg, (const cd *)A, (const cd *)B, (cd *)C); return 0; }
     if (p.kernel != ARTN_KERNEL_GEMM_MFMA) return ARTN_E_UNSUPPORTED;
     run_gemm128(p.gemm, (const cd *)A, (const cd *)B, (cd *)C);
     return 0;

@@ -416,9 +416,9 @@ def emulate_xgemm(eq, a, b):
     from artensor_amd import _native as N
     la, lb, lo = C._labels(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
     ta, tb = torch.from_numpy(a), torch.from_numpy(b)
-    d, out_shape = C._descriptor(la, lb, lo, tuple(ta.shape), tuple(ta.stride()), tuple(tb.shape), tuple(tb.stride()),
-                                 torch.complex64)
-    out = np.full(out_shape, np.nan + 0j, dtype=np.complex64)
+    # (complex128 operands: the replay of artn_k_xgemm128)
+    d, out_shape = C._descriptor(la, lb, lo, tuple(ta.shape), tuple(ta.stride()), tuple(tb.shape), tuple(tb.stride()), ta.dtype)
+    out = np.full(out_shape, np.nan + 0j, dtype=a.dtype)
     info = N.ArtnStepInfo()
     modes = (ctypes.c_int32 * 7)()
     emu = emulator()

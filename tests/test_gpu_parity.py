@@ -902,7 +902,7 @@ def test_non_power_of_two_extents_on_the_matrix_cores():
     rng = np.random.default_rng(100)
     # 5 103 contracted values: partial sums through C
     eq = (("m0", "k0", "k1", "k2", "m1"), ("k2", "n0", "k0", "k1"), ("m0", "n0", "m1"))
-    a, b = crandn(rng, (50, 3, 81, 21, 70)), crandn(rng, (21, 60, 3, 81))
+    a, b = crandn(rng, (20, 3, 81, 21, 14)), crandn(rng, (21, 12, 3, 81))   # (numpy's complex128 einsum of a bigger one takes minutes)
     assert A.step_info(eq, a.shape, b.shape)["kernel"] == KERNEL_XGEMM
     got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
     want = _einsum128_labels(eq, a, b)
@@ -923,6 +923,44 @@ def test_non_power_of_two_extents_on_the_matrix_cores():
     got = A.contract(eq, va, vb).cpu().numpy()
     want = _einsum128_labels(eq, va.cpu().numpy(), vb.cpu().numpy())
     assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max()
+
+
+def test_non_power_of_two_extents_in_complex128_on_the_f64_matrix_cores():
+    """artn_k_xgemm128 (round 5): the same steps with complex128 operands run on v_mfma_f64_16x16x4_f64 instead of the strided
+    kernel -- against numpy's complex128 einsum to 1e-12: copy modes, batch labels, partial tiles, a contraction long enough to
+    flush partial sums, strided views; and a whole bond-dimension-3 network in complex128 against the oracle."""
+    seen = set()
+    c128 = lambda rng, shape: rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    for seed in range(24):
+        rng = np.random.default_rng(700 + seed)
+        exts = [3] if seed % 2 == 0 else [2, 3, 5, 6, 7]
+        eq, sa, sb = _random_extent_step(rng, exts, int(rng.integers(4, 9)), int(rng.integers(1, 5)), int(rng.integers(1, 5)),
+                                         int(rng.integers(0, 2)) if seed % 2 else 0)
+        a, b = c128(rng, sa), c128(rng, sb)
+        info = A.step_info(eq, sa, sb, dtype=torch.complex128)
+        got = A.contract(eq, torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu().numpy()
+        want = _einsum128_labels(eq, a, b)
+        assert got.dtype == np.complex128 and np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), (seed, eq, info["kernel"])
+        seen.add(info["kernel"])
+    assert KERNEL_XGEMM in seen
+    rng = np.random.default_rng(800)
+    eq = (("m0", "k0", "k1", "k2", "m1"), ("k2", "n0", "k0", "k1"), ("m0", "n0", "m1"))
+    a, b = c128(rng, (20, 3, 81, 21, 14)), c128(rng, (21, 12, 3, 81))   # (5 103 contracted values: partial sums through C)
+    assert A.step_info(eq, a.shape, b.shape, dtype=torch.complex128)["kernel"] == KERNEL_XGEMM
+    got = A.contract(eq, torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu().numpy()
+    want = _einsum128_labels(eq, a, b)
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    big_a, big_b = torch.from_numpy(c128(rng, (27, 9, 25, 6, 30))).to(DEV), torch.from_numpy(c128(rng, (6, 14, 9, 30))).to(DEV)
+    va, vb = big_a[1:26, :, ::2, :, :], big_b[:, 1:12, :, :]
+    eq = (("m", "k", "p", "q", "r"), ("q", "n", "k", "r"), ("p", "n", "m"))
+    got = A.contract(eq, va, vb).cpu().numpy()
+    want = _einsum128_labels(eq, va.cpu().numpy(), vb.cpu().numpy())
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    # a whole network of bond dimension 3 (small-step program in complex128 + artn_k_xgemm128 for whatever is big enough)
+    case = load_case(os.path.join(GOLDEN, "rand_D3_open.npz"))
+    out = A.tensor_contraction(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme).cpu().numpy()
+    want = oracle.tensor_contraction({k: v.numpy().astype(np.complex128) for k, v in case.tensors.items()}, case.scheme)
+    assert np.abs(out - want).max() <= 1e-12 * np.abs(want).max()
 
 
 @pytest.mark.parametrize("name", ["rand_D3_nv112", "rand_D6_nv64"])

@@ -170,3 +170,39 @@ def run_prefix(case, n):
 
 def shapes_after(case, n):
     return {i: tuple(t.shape) for i, t in run_prefix(case, n).items()}
+
+
+def crandn128(rng, shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_complex128_steps_on_the_f64_matrix_cores(seed):
+    """artn_k_xgemm128 (round 5): the same plan with 16-byte elements, chunks of 8 and the lane map of v_mfma_f64_16x16x4_f64,
+    replayed by run_xgemm128 -- bond dimension 3 and mixed extents, batch labels, both copy modes, partial tiles and chunks --
+    against numpy's complex128 einsum to 1e-13."""
+    rng = np.random.default_rng(5000 + seed)
+    if seed < 5:
+        n_m, n_n, n_k = int(rng.integers(3, 8)), int(rng.integers(1, 5)), int(rng.integers(0, 5))
+        eq, sa, sb = random_step(rng, [3], n_m, n_n, n_k)
+    else:
+        n_m, n_n, n_k, n_h = int(rng.integers(2, 6)), int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(0, 2))
+        eq, sa, sb = random_step(rng, [2, 3, 5, 6, 7], n_m, n_n, n_k, n_h)
+    a, b = crandn128(rng, sa), crandn128(rng, sb)
+    info, modes = check(eq, a, b, tol=1e-13)
+    assert modes["kc"] == 8 and modes["nb"] == 1 and info["arith"] in (0, 3)   # (arith is filled in by make_plan: 3 there)
+
+
+def test_complex128_long_contraction_with_partial_sums():
+    """5 103 contracted values: partial sums leave the registers every 512 chunks of 8 (read-add-write of C)."""
+    rng = np.random.default_rng(77)
+    eq = (("m0", "k0", "k1", "k2"), ("k2", "n0", "k1", "k0"), ("n0", "m0"))
+    a, b = crandn128(rng, (5, 3, 243, 7)), crandn128(rng, (7, 4, 243, 3))
+    info, modes = check(eq, a, b, tol=1e-13)
+    assert modes["flush_chunks"] > 0
+
+
+def test_planner_gives_complex128_odd_extents_to_the_extent_gemm():
+    import torch
+    info = step_info("abcdefghijklmn,nmx->abcdefghijklx", (3,) * 14, (3, 3, 3), dtype=torch.complex128)
+    assert info["kernel"] == KERNEL_XGEMM and info["arith"] == 3 and info["mfma_flops"] == info["flops"]
