@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Brute force over the cuts of the big chain of a sliced DENSE fixture: every way to cut N of its members (from index I0) into single steps
+"""Brute force over the cuts of the big chain of a sliced fixture (dense or sparse-state): every way to cut N of its members (from index I0) into single steps
 and planner-accepted pairs, timed on the GPU (ms per slice) next to the chain planner's own cut -- calibration of
 contraction._cut_sparse_chain's cost model.   python3 tools/cut_search.py rand_D2_nv260_sliced.npz [N=9 [I0]]"""
 import itertools, os, sys
@@ -19,8 +19,11 @@ def spy(scheme, members, a_shape, b_shapes, dtype):
     seen[tuple(members)] = (g, a_shape, b_shapes)
     return g
 C._cut_sparse_chain = spy
+SPARSE = "bitstrings_sorted" in case.meta
+ROWS = len(case.meta["bitstrings_sorted"]) if SPARSE else 1
 def time_slices(n=6):
-    r = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (1,), sparse=False, device="cuda")
+    C._chain_cache.clear()
+    r = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (ROWS,), sparse=SPARSE, device="cuda")
     order = A.rank_slices(2 ** len(case.slicing_indices), 0, 8, gray=True)
     r.run(order[:2]); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
