@@ -35,10 +35,71 @@ def rank_slices(n_slices, rank, world_size, gray=False):
     count = len(range(rank, n_slices, world_size))
     if not gray:
         return range(rank, n_slices, world_size)
-    span = 1
-    while span < count:
-        span *= 2
-    return [rank + world_size * g for g in (t ^ (t >> 1) for t in range(span)) if g < count]
+    return _GraySlices(rank, world_size, count)
+
+
+class _GraySlices:
+    """rank + world_size * g for g = t ^ (t >> 1), t = 0, 1, ... (values g >= count skipped): the Gray-ordered shard of
+    rank_slices as a LAZY sequence -- a plan with 41 sliced bonds has 2^41 slices, and a list of a rank's share does not fit any
+    host (a diagnostic that built one took its machine down in round 5).  Iteration, len(), integer indices and slices
+    (a slice is a list: prefixes and the checkpoint loop's pieces are what callers take) cost what they touch."""
+    __slots__ = ("rank", "world", "count", "span")
+
+    def __init__(self, rank, world_size, count):
+        self.rank, self.world, self.count = int(rank), int(world_size), int(count)
+        span = 1
+        while span < self.count:
+            span *= 2
+        self.span = span
+
+    def __len__(self):
+        return self.count
+
+    def _from(self, start):
+        """the values from position `start` on"""
+        if self.count == self.span:       # a power of two: position p holds Gray(p)
+            for t in range(start, self.span):
+                yield self.rank + self.world * (t ^ (t >> 1))
+            return
+        seen = 0
+        for t in range(self.span):
+            g = t ^ (t >> 1)
+            if g < self.count:
+                if seen >= start:
+                    yield self.rank + self.world * g
+                seen += 1
+
+    def __iter__(self):
+        return self._from(0)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            start, stop, step = idx.indices(self.count)
+            if step <= 0:
+                raise ValueError("Gray-ordered shards are sliced forwards")
+            out, pos = [], start
+            for v in self._from(start):
+                if pos >= stop:
+                    break
+                if (pos - start) % step == 0:
+                    out.append(v)
+                pos += 1
+            return out
+        idx = int(idx)
+        if idx < 0:
+            idx += self.count
+        if not 0 <= idx < self.count:
+            raise IndexError("slice position out of range")
+        return next(self._from(idx))
+
+    def __eq__(self, other):
+        try:
+            return len(other) == self.count and all(a == b for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self):
+        return f"<Gray-ordered shard: {self.count} slices of rank {self.rank} / {self.world}>"
 
 
 def boundary_source_sha16():
@@ -542,6 +603,8 @@ def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce
     if checkpoint is None:
         collect = runner.run(slices)
     else:   # resumable: the shard in pieces of `checkpoint_every` slices, the partial sum saved after each
+        if len(slices) > (1 << 26):
+            raise RuntimeError(f"checkpointing keeps the shard's slice list ({len(slices)} slices): pass `slices=` pieces of at most 2^26")
         slices = [int(x) for x in slices]
         fp = plan_fingerprint(runner.scheme, runner.slicing_indices, permute_dims)
         path = _checkpoint_path(checkpoint, rank, world)

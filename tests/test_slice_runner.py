@@ -240,3 +240,19 @@ def test_small_step_program_with_fully_contracted_second_operand(mb, kb, extra):
     (off, shape), = [v for t, v in prog.outputs.items() if t == 0]
     got = ws[off // 8: off // 8 + want.size]
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
+def test_gray_ordered_shard_is_lazy():
+    """A plan with 41 sliced bonds (tests/golden/n53_m20_bigbatch.npz) has 2^41 slices: the Gray-ordered shard of rank_slices is
+    a sequence object that costs what is touched -- a list of a rank's 2^38 slices does not fit any host."""
+    g = A.rank_slices(2 ** 41, 3, 8, gray=True)
+    assert len(g) == 2 ** 38
+    assert g[:5] == [3 + 8 * x for x in (0, 1, 3, 2, 6)] and g[7] == 3 + 8 * 4 and g[2 ** 30] == 3 + 8 * (2 ** 30 ^ 2 ** 29)
+    it = iter(g)
+    assert [next(it) for _ in range(3)] == [3, 11, 27]
+    # counts that are not powers of two: the same set as the plain shard, each slice once, and the list API of before
+    h = A.rank_slices(16, 1, 3, gray=True)
+    assert sorted(h) == list(A.rank_slices(16, 1, 3)) and len(h) == 5 and h[1:3] == list(h)[1:3] and h[-1] == list(h)[-1]
+    assert h == list(h)
+    with pytest.raises(IndexError):
+        h[5]
