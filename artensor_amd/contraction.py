@@ -82,13 +82,42 @@ def _same_steps(snapshot, scheme, _is=__import__("operator").is_):
     return len(snapshot) == len(scheme) and all(map(_is, snapshot, scheme))
 
 
-_desc_cache = _Bounded(8192)   # key: labels + shapes + strides of one step
+_MISS = object()
+
+
+class _IdMemo(_Bounded):
+    """Memo keyed on the IDENTITY of objects -- scheme lists, descriptors, the index tensors of a scheme -- plus hashable
+    extras.  The reference re-reads its inputs on every call; what is cached here is derived from objects the caller keeps
+    (a scheme is reused for every slice), so the key is who they are, not what they hold.  The one rule, in one place: an
+    entry HOLDS the objects it was made for (their ids cannot be reused while it lives), is returned only when each of them
+    `is` the caller's, and -- for scheme lists, which callers may edit in place between two calls -- only when the list
+    still holds the same step objects (_same_steps).  (tensor_contraction's own two look-ups, _scheme_ids and _plan_cache,
+    stay hand-written: they share one snapshot check per call on the launch-latency path.)"""
+
+    def find(self, objs, extra=(), schemes=()):
+        hit = self.get(tuple(map(id, objs)) + tuple(extra))
+        if hit is None:
+            return _MISS
+        held, snaps, value = hit
+        for h, o in zip(held, objs):
+            if h is not o:
+                return _MISS
+        for snap, sch in zip(snaps, schemes):
+            if not _same_steps(snap, sch):
+                return _MISS
+        return value
+
+    def keep(self, objs, value, extra=(), schemes=()):
+        self[tuple(map(id, objs)) + tuple(extra)] = (tuple(objs), tuple(tuple(sch) for sch in schemes), value)
+        return value
+
+
+_desc_cache = _Bounded(8192)   # key: labels + shapes + strides of one step (values, not identities)
 
 # Optional per-launch timing hook (bench.py / profiling only): an object with
 # .record(info_dict, start_event, end_event); events are recorded on the launch stream.
 profiler = None
-_info_cache = _Bounded(8192)   # id(descriptor) -> (descriptor, planner answer); the descriptor is held
-                               # so that its id cannot be reused while the entry lives
+_info_cache = _IdMemo(8192)    # descriptor -> planner answer
 
 
 def _query(d):
@@ -98,10 +127,8 @@ def _query(d):
 
 
 def _step_info_cached(d):
-    hit = _info_cache.get(id(d))
-    if hit is None or hit[0] is not d:
-        hit = _info_cache[id(d)] = (d, _query(d))
-    return hit[1]
+    info = _info_cache.find((d,))
+    return _info_cache.keep((d,), _query(d)) if info is _MISS else info
 
 
 # A big step that the bit planner declines runs on the strided kernel (one thread per output
@@ -113,8 +140,7 @@ _warned_generic = set()
 def _warn_if_generic(d, numel, what):
     if numel < GENERIC_WARN_NUMEL:
         return
-    hit = _info_cache.get(id(d))
-    if hit is not None and hit[0] is d:
+    if _info_cache.find((d,)) is not _MISS:
         return                    # already looked at (and warned about, if need be)
     info = _step_info_cached(d)   # leaves the planner's reason in artn_last_plan_note()
     if info["kernel"] != N.KERNEL_GENERIC:
@@ -422,7 +448,7 @@ def _dense_strides(shape):
     return tuple(reversed(st))
 
 
-_pair_cache = _Bounded(4096)
+_pair_cache = _IdMemo(4096)     # (descriptor of step 1, of step 2) -> planner answer or False
 
 
 def _resolve_reshape(numel, shape):
@@ -471,7 +497,7 @@ def _triple_descriptors(eq1, a, b1, eq2, b2, eq3, b3):
     return d1, d2, d3, s3
 
 
-_triple_cache = _Bounded(4096)
+_triple_cache = _IdMemo(4096)
 
 
 def contract3(eq1, a, b1, eq2, b2, eq3, b3):
@@ -486,10 +512,8 @@ def contract3(eq1, a, b1, eq2, b2, eq3, b3):
         return None
     b1, b2, b3 = _as_operand(b1), _as_operand(b2), _as_operand(b3)
     d1, d2, d3, out_shape = _triple_descriptors(eq1, a, b1, eq2, b2, eq3, b3)
-    key = (id(d1), id(d2), id(d3))
-    hit = _triple_cache.get(key)
-    info = hit[3] if hit is not None and hit[0] is d1 and hit[1] is d2 and hit[2] is d3 else None
-    if info is None:
+    info = _triple_cache.find((d1, d2, d3))
+    if info is _MISS:
         q = N.ArtnStepInfo()
         rc = N.lib().artn_contract3_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), ctypes.byref(q))
         if rc == -2:
@@ -497,7 +521,7 @@ def contract3(eq1, a, b1, eq2, b2, eq3, b3):
         else:
             N.check(rc)
             info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
-        _triple_cache[key] = (d1, d2, d3, info)
+        _triple_cache.keep((d1, d2, d3), info)
     if info is False:
         return None
     out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
@@ -565,10 +589,8 @@ def contract2(eq1, a, b1, eq2, b2, mid_view=None):
         return None
     b1, b2 = _as_operand(b1), _as_operand(b2)
     d1, d2, out_shape = _pair_descriptors(eq1, a, b1, eq2, b2, mid_view)
-    key = (id(d1), id(d2))
-    hit = _pair_cache.get(key)
-    info = hit[2] if hit is not None and hit[0] is d1 and hit[1] is d2 else None
-    if info is None:
+    info = _pair_cache.find((d1, d2))
+    if info is _MISS:
         q = N.ArtnStepInfo()
         rc = N.lib().artn_contract2_query(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(q))
         if rc == -2:
@@ -576,7 +598,7 @@ def contract2(eq1, a, b1, eq2, b2, mid_view=None):
         else:
             N.check(rc)
             info = {name: getattr(q, name) for name, _ in N.ArtnStepInfo._fields_}
-        _pair_cache[key] = (d1, d2, info)
+        _pair_cache.keep((d1, d2), info)
     if info is False:
         return None
     out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
@@ -813,7 +835,7 @@ def _cut_chain(scheme, members, shapes, dtype, skip):
 
 
 _plan_cache = _Bounded(64)
-_schedule_cache = _Bounded(64)
+_schedule_cache = _IdMemo(64)    # scheme -> its chain / fusion schedule
 
 
 class _Op:
@@ -1415,7 +1437,7 @@ def tensor_contraction(tensors, scheme, accumulate_into=None):
 # ----------------------------------------------------------------------------------------
 # sparse-state executor
 # ----------------------------------------------------------------------------------------
-_index_cache = _Bounded(4096)
+_index_cache = _IdMemo(4096)    # (index tensor; device, rows of the operand) -> device copy
 # Out-of-range bookkeeping of the gather kernels is per THREAD (like `precision` and the deferred check of the slice
 # loop): a thread reads and clears only the flags its own launches may have set.
 _flag_state = threading.local()
@@ -1445,10 +1467,10 @@ def _device_index(idx, device, src_rows=None):
     from, with the reference's semantics (`tensors[i][idx]`, contraction.py:149-150, :177-178,
     :187): an index outside [-src_rows, src_rows) raises (the reference dies with IndexError there,
     contraction.py:192-195), a negative one counts from the end."""
-    key = (id(idx), str(device), src_rows)
-    hit = _index_cache.get(key)
-    if hit is not None and hit[0] is idx:
-        return hit[1]
+    extra = (str(device), src_rows)
+    dev = _index_cache.find((idx,), extra)
+    if dev is not _MISS:
+        return dev
     host = torch.as_tensor(idx, dtype=torch.int64).reshape(-1).cpu()
     if src_rows is not None and host.numel():
         lo, hi = int(host.min()), int(host.max())
@@ -1457,9 +1479,7 @@ def _device_index(idx, device, src_rows=None):
                                "(IndexError in the reference, contraction.py:192-195)")
         if lo < 0:
             host = torch.where(host < 0, host + src_rows, host)
-    dev = host.to(device).contiguous()
-    _index_cache[key] = (idx, dev)
-    return dev
+    return _index_cache.keep((idx,), host.to(device).contiguous(), extra)
 
 
 def _flag(device):
@@ -1488,7 +1508,7 @@ def check_gather_flag(what="gather"):
                            "(the reference raises IndexError, contraction.py:192-195)")
 
 
-_single_row_cache = _Bounded(4096)   # id(index tensor) -> (index tensor, its one entry)
+_single_row_cache = _IdMemo(4096)   # index tensor of one entry -> that entry
 
 
 def _single_row(idx, t):
@@ -1505,13 +1525,9 @@ def _single_row_of_shape(idx, shape, itemsize):
     rows = shape[0]
     # the value is read ONCE per index tensor (a device-resident index would cost a host synchronisation per step and per
     # slice here, and int() of it is illegal during HIP-graph capture): cached like _is_identity / _device_index
-    key = id(idx)
-    hit = _single_row_cache.get(key)
-    if hit is not None and hit[0] is idx:
-        v = hit[1]
-    else:
-        v = int(idx.reshape(-1)[0])
-        _single_row_cache[key] = (idx, v)
+    v = _single_row_cache.find((idx,))
+    if v is _MISS:
+        v = _single_row_cache.keep((idx,), int(idx.reshape(-1)[0]))
     if v < -rows or v >= rows:
         raise RuntimeError(f"row index out of range: {v} for {rows} rows")
     # (a row of one element would be an 8-byte view: the tiled kernels want 16-byte aligned operands)
@@ -1523,20 +1539,18 @@ def _single_row_of_shape(idx, shape, itemsize):
     return v % rows
 
 
-_identity_cache = _Bounded(4096)
+_identity_cache = _IdMemo(4096)   # index tensor -> its length if it is 0, 1, ..., n - 1, else -1
 
 
 def _is_identity(idx, rows):
     """True when `idx` is 0, 1, ..., rows-1: the gather would copy the tensor onto itself (every
     row select of a single-bitstring scheme is of this kind; checked once per index tensor)."""
-    key = id(idx)
-    hit = _identity_cache.get(key)
-    if hit is None or hit[0] is not idx:
+    ident = _identity_cache.find((idx,))
+    if ident is _MISS:
         flat = torch.as_tensor(idx, dtype=torch.int64).reshape(-1).cpu()
         n = flat.numel()
-        ident = n if bool(torch.equal(flat, torch.arange(n, dtype=torch.int64))) else -1
-        hit = _identity_cache[key] = (idx, ident)
-    return hit[1] == rows
+        ident = _identity_cache.keep((idx,), n if bool(torch.equal(flat, torch.arange(n, dtype=torch.int64))) else -1)
+    return ident == rows
 
 
 def contract_gathered(eq, a, rows_a, b, rows_b, out=None, label=None, _validate=True):
@@ -1662,7 +1676,7 @@ def _fusable_kind(step):
 
 LAZY_SELECT_MIN_NUMEL = 1 << 24   # a row select of a tensor at least this big is deferred to its consumer (_RowsOf)
 _lazy_state = threading.local()    # .on: set by tensor_contraction_sparse around its step loop (never under scientific_notation)
-_compose_cache = _Bounded(1024)   # (id(select), id(rows)) -> (select, rows, select[rows])
+_compose_cache = _IdMemo(1024)   # (select, rows) -> select[rows]
 
 
 class _RowsOf:
@@ -1689,16 +1703,15 @@ def rows_of(t):
 
 def _composed(sel, rows):
     """sel[rows] as a CPU int64 tensor, cached per (select, rows) pair: the scheme's index tensors live as long as the scheme."""
-    key = (id(sel), id(rows))
-    hit = _compose_cache.get(key)
-    if hit is None or hit[0] is not sel or hit[1] is not rows:
+    got = _compose_cache.find((sel, rows))
+    if got is _MISS:
         s_ = torch.as_tensor(sel, dtype=torch.int64).reshape(-1)
         r_ = torch.as_tensor(rows, dtype=torch.int64).reshape(-1)
         if r_.numel() and (int(r_.min()) < -len(s_) or int(r_.max()) >= len(s_)):
             raise RuntimeError(f"row index out of range: indices span [{int(r_.min())}, {int(r_.max())}] but the operand has {len(s_)} rows "
                                "(IndexError in the reference, contraction.py:192-195)")
-        hit = _compose_cache[key] = (sel, rows, s_[r_])
-    return hit[2]
+        got = _compose_cache.keep((sel, rows), s_[r_])
+    return got
 
 
 def _sparse_step(tensors, step):
@@ -1776,7 +1789,7 @@ def _sparse_step(tensors, step):
         tensors[j] = []
 
 
-_sparse_prog_cache = _Bounded(64)   # id(scheme) -> (scheme, shape signature, program or None, hoisted step indices)
+_sparse_prog_cache = _IdMemo(64)   # scheme -> (shape signature, program or None, hoisted step indices)
 _NO_HOIST = frozenset()
 
 
@@ -1794,12 +1807,12 @@ def _sparse_program(scheme, tensors):
     if dtype not in _DTYPES or not on_gpu:
         return None, _NO_HOIST
     sig = tuple(shapes.items())
-    hit = _sparse_prog_cache.get(id(scheme))
-    if hit is None or hit[0] is not scheme or hit[1] != sig or not _same_steps(hit[4], scheme):
+    hit = _sparse_prog_cache.find((scheme,), schemes=(scheme,))
+    if hit is _MISS or hit[0] != sig:
         prog, main = _plan_small_program(scheme, shapes, dtype)
         hoisted = frozenset(range(len(scheme))) - frozenset(main) if prog is not None else _NO_HOIST
-        hit = _sparse_prog_cache[id(scheme)] = (scheme, sig, prog, hoisted, tuple(scheme))
-    return hit[2], hit[3]
+        hit = _sparse_prog_cache.keep((scheme,), (sig, prog, hoisted), schemes=(scheme,))
+    return hit[1], hit[2]
 
 
 _defer = threading.local()   # .flag_check: the slice loop reads the gather flag once, after its last slice
@@ -1821,10 +1834,10 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
     if len(contraction_scheme) == 0:
         raise RuntimeError("empty contraction scheme")
     scheme = contraction_scheme
-    key = id(scheme)
-    hit = _schedule_cache.get(key)
-    if hit is None or hit[0] is not scheme or not _same_steps(hit[2], scheme):
-        hit = _schedule_cache[key] = (scheme, chain_schedule(scheme) if _chain_plan_on() else fusion_schedule(scheme), tuple(scheme))
+    schedule = _schedule_cache.find((scheme,), (_chain_plan_on(),), (scheme,))
+    if schedule is _MISS:
+        schedule = _schedule_cache.keep((scheme,), chain_schedule(scheme) if _chain_plan_on() else fusion_schedule(scheme),
+                                        (_chain_plan_on(),), (scheme,))
     factor = None
     last = scheme[-1][0][0]
 
@@ -1860,7 +1873,7 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
                 tensors[j] = []
     _lazy_state.on = not _os_environ.get("ARTN_NO_LAZY_SELECT")
     try:
-        _run_sparse_main(tensors, scheme, hit[1], hoisted, one)
+        _run_sparse_main(tensors, scheme, schedule, hoisted, one)
     finally:
         _lazy_state.on = False
     if isinstance(tensors[last], _RowsOf):
@@ -1935,7 +1948,7 @@ def _plain_form(step, a_shape, b_shape, itemsize):
 
 
 _chain_trace = None             # optional hook: called with the prices and the cut of every planned chain
-_chain_cache = _Bounded(1024)   # (id(scheme), first member, shape of the chain's tensor, ...) -> (scheme, groups)
+_chain_cache = _IdMemo(1024)   # (scheme; first member, count, shape of the chain's tensor, ...) -> groups
 CHAIN_BW, CHAIN_FLOPS = 5.0e12, 120e12   # what a tile-structured pass / the fp32 matrix pipe sustain: the cost model
 CHAIN_PAIR_BYTES = 1.35
 CHAIN_SPILL_FACTOR = 2.5
@@ -1956,27 +1969,23 @@ def _plan_chain(tensors, scheme, members):
     a = tensors[first[0][0]]
     if not isinstance(a, torch.Tensor) or not a.is_cuda or a.dtype not in _DTYPES:
         return [(members[0],)]
-    key = (id(scheme), members[0], len(members), tuple(a.shape), a.dtype, precision.current())
-    hit = _chain_cache.get(key)
-    # (the entry holds the scheme, so its id cannot be reused, and the member steps as they were: a scheme list edited in
-    #  place between two calls must not replay a stale cut -- _same_steps)
-    if hit is not None and hit[0] is scheme and len(hit[2]) == len(members) and all(scheme[n] is st for n, st in zip(members, hit[2])):
-        return hit[1]
+    extra = (members[0], len(members), tuple(a.shape), a.dtype, precision.current())
+    groups = _chain_cache.find((scheme,), extra, (scheme,))
+    if groups is not _MISS:
+        return groups
     b_shapes = [tuple(tensors[scheme[n][0][1]].shape) if hasattr(tensors[scheme[n][0][1]], "shape") else None for n in members]
-    groups = _cut_sparse_chain(scheme, members, tuple(a.shape), b_shapes, a.dtype)
-    _chain_cache[key] = (scheme, groups, tuple(scheme[n] for n in members))
-    return groups
+    return _chain_cache.keep((scheme,), _cut_sparse_chain(scheme, members, tuple(a.shape), b_shapes, a.dtype), extra, (scheme,))
 
 
-_left_cache = _Bounded(64)
+_left_cache = _IdMemo(64)
 
 
 def _left_pairs(scheme):
     """the candidate pairs of fusion_schedule (pairs from the left: the cut of rounds 1-4) as a set of (n, m)"""
-    hit = _left_cache.get(id(scheme))
-    if hit is None or hit[0] is not scheme or not _same_steps(hit[2], scheme):
-        hit = _left_cache[id(scheme)] = (scheme, frozenset((e[1], e[2]) for e in fusion_schedule(scheme) if e[0] == "pair"), tuple(scheme))
-    return hit[1]
+    pairs = _left_cache.find((scheme,), schemes=(scheme,))
+    if pairs is _MISS:
+        pairs = _left_cache.keep((scheme,), frozenset((e[1], e[2]) for e in fusion_schedule(scheme) if e[0] == "pair"), schemes=(scheme,))
+    return pairs
 
 
 def _cut_sparse_chain(scheme, members, a_shape, b_shapes, dtype):

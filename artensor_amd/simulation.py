@@ -719,7 +719,7 @@ def partition_output(scheme, leaf_shapes, n_fix):
     return new_scheme, selects, fixed_dims
 
 
-_partition_cache = _C._Bounded(64)   # (id(scheme), n_fix, leaf shapes) -> (scheme, partitioned scheme, selects, fixed dims)
+_partition_cache = _C._IdMemo(64)   # (scheme; n_fix, leaf shapes) -> (partitioned scheme, selects, fixed dims)
 
 
 def partitioned_contraction(tensors, scheme, n_fix, part, device="cuda", dtype=torch.complex64):
@@ -728,11 +728,11 @@ def partitioned_contraction(tensors, scheme, n_fix, part, device="cuda", dtype=t
     (slab, fixed_dims, values); slab has the result's remaining dims in order."""
     items = list(tensors.items()) if isinstance(tensors, dict) else list(enumerate(tensors))
     shapes = {k: tuple(t.shape) for k, t in items}
-    key = (id(scheme), n_fix, tuple(sorted(shapes.items(), key=lambda kv: repr(kv[0]))))
-    hit = _partition_cache.get(key)
-    if hit is None or hit[0] is not scheme or not _C._same_steps(hit[4], scheme):
-        hit = _partition_cache[key] = (scheme,) + tuple(partition_output(scheme, shapes, n_fix)) + (tuple(scheme),)
-    _, new_scheme, selects, fixed_dims, _ = hit
+    extra = (n_fix, tuple(sorted(shapes.items(), key=lambda kv: repr(kv[0]))))
+    hit = _partition_cache.find((scheme,), extra, (scheme,))
+    if hit is _C._MISS:
+        hit = _partition_cache.keep((scheme,), tuple(partition_output(scheme, shapes, n_fix)), extra, (scheme,))
+    new_scheme, selects, fixed_dims = hit
     values = slice_assignments(n_fix, part)
     per_leaf = {}
     for (leaf, dim), v in zip(selects, values):

@@ -131,3 +131,28 @@ def test_stage1_reruns_counts_only_the_outer_labels_of_the_second_step():
     assert four["stage1_reruns"] == 4
     grow = info([(3, 7), (3, 3)])      # seven new labels in the FIRST step: re-reads of A, no repeated stage
     assert grow["a_rereads"] == 8 and grow["stage1_reruns"] == 1
+
+
+def test_identity_memo_holds_its_objects_and_sees_edited_scheme_lists():
+    """contraction._IdMemo: the one place where the host-side memos decide whether an entry is still the caller's --
+    identity of the key objects (held by the entry, so an id cannot be recycled) and, for scheme lists, the same step
+    objects in the same order (the reference re-reads the list on every call, contraction.py:66)."""
+    memo = C._IdMemo(8)
+    a, b = [1, 2], [1, 2]                       # equal, not identical
+    assert memo.find((a,)) is C._MISS
+    assert memo.keep((a,), "A") == "A" and memo.find((a,)) == "A" and memo.find((b,)) is C._MISS
+    assert memo.find((a,), extra=("cuda:0", 4)) is C._MISS
+    memo.keep((a, b), "AB", extra=(7,))
+    assert memo.find((a, b), (7,)) == "AB" and memo.find((b, a), (7,)) is C._MISS
+    scheme = [((0, 1), "ab,bc->ac"), ((0, 2), "ac,cd->ad")]
+    memo.keep((scheme,), "plan", schemes=(scheme,))
+    assert memo.find((scheme,), schemes=(scheme,)) == "plan"
+    scheme.append(((0, 3), "ad,de->ae"))        # edited in place: same list object, other steps
+    assert memo.find((scheme,), schemes=(scheme,)) is C._MISS
+    scheme.pop()
+    assert memo.find((scheme,), schemes=(scheme,)) == "plan"
+    scheme[0] = tuple([(0, 1), "ab,bc->ac"])    # an equal but different step object (built at run time): treated as an edit
+    assert memo.find((scheme,), schemes=(scheme,)) is C._MISS
+    for q in range(20):                          # bounded: forgets everything rather than grow
+        memo.keep(([q],), q)
+    assert len(memo) <= 8
