@@ -256,3 +256,18 @@ def test_gray_ordered_shard_is_lazy():
     assert h == list(h)
     with pytest.raises(IndexError):
         h[5]
+
+
+@pytest.mark.parametrize("n,world", [(1024, 3), (4096, 8), (100, 7), (8, 8), (5, 8)])
+def test_gray_ordered_shards_partition_the_slices(n, world):
+    """Every slice belongs to exactly one rank's Gray-ordered shard (what the N-rank slice loop sums, reference
+    simulation.py:107-114 sharded), and inside a power-of-two shard consecutive slices differ in ONE sliced bond."""
+    shards = [A.rank_slices(n, r, world, gray=True) for r in range(world)]
+    flat = [s for sh in shards for s in sh]
+    assert sorted(flat) == list(range(n)) and sum(len(sh) for sh in shards) == n
+    for r, sh in enumerate(shards):
+        count = len(sh)
+        if count and count & (count - 1) == 0 and world & (world - 1) == 0:
+            vals = list(sh)
+            for x, y in zip(vals, vals[1:]):
+                assert bin(x ^ y).count("1") == 1, (r, x, y)
