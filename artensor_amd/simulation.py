@@ -42,7 +42,8 @@ class _GraySlices:
     """rank + world_size * g for g = t ^ (t >> 1), t = 0, 1, ... (values g >= count skipped): the Gray-ordered shard of
     rank_slices as a LAZY sequence -- a plan with 41 sliced bonds has 2^41 slices, and a list of a rank's share does not fit any
     host (a diagnostic that built one took its machine down in round 5).  Iteration, len(), integer indices and slices
-    (a slice is a list: prefixes and the checkpoint loop's pieces are what callers take) cost what they touch."""
+    (a slice is a list: prefixes and the checkpoint loop's pieces are what callers take) cost what they touch: an integer
+    index is O(log^2 count) for any count (a rank/select over the reflected Gray sequence, `_below`), never a walk from 0."""
     __slots__ = ("rank", "world", "count", "span")
 
     def __init__(self, rank, world_size, count):
@@ -55,19 +56,60 @@ class _GraySlices:
     def __len__(self):
         return self.count
 
+    def _below(self, n, T, c, rev=False):
+        """How many of the first T entries of the n-bit reflected Gray sequence (reversed: rev) are < c.  The sequence is
+        0.G(n-1) followed by 1.reverse(G(n-1)), so one of the two halves is always whole or absent: O(n)."""
+        total = 0
+        while True:
+            if T <= 0 or c <= 0:
+                return total
+            size = 1 << n
+            if c >= size:
+                return total + min(T, size)
+            if T >= size:
+                return total + c
+            half = size >> 1
+            # first half of the (possibly reversed) sequence: non-reversed -> values G(n-1) below `half`;
+            # reversed -> values half + G(n-1) (the reverse of the reversed upper half)
+            if not rev:
+                if T <= half:
+                    n, c = n - 1, min(c, half)
+                    continue
+                total += min(c, half)                       # the whole lower half
+                if c <= half:
+                    return total
+                n, T, c, rev = n - 1, T - half, c - half, True
+            else:
+                if T <= half:
+                    if c <= half:
+                        return total
+                    n, c, rev = n - 1, c - half, False
+                    continue
+                total += max(0, c - half)                   # the whole upper half (values half .. size-1)
+                n, T, c = n - 1, T - half, min(c, half)
+
+    def _t_of(self, pos):
+        """the counter value t whose Gray code is the shard's entry number `pos` (O(log^2): a binary search over _below)"""
+        if self.count == self.span:
+            return pos
+        n = self.span.bit_length() - 1
+        lo, hi = 0, self.span            # smallest T with _below(T) == pos + 1; t = T - 1
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if self._below(n, mid, self.count) >= pos + 1:
+                hi = mid
+            else:
+                lo = mid + 1
+        return lo - 1
+
     def _from(self, start):
         """the values from position `start` on"""
-        if self.count == self.span:       # a power of two: position p holds Gray(p)
-            for t in range(start, self.span):
-                yield self.rank + self.world * (t ^ (t >> 1))
+        if start >= self.count:
             return
-        seen = 0
-        for t in range(self.span):
+        for t in range(self._t_of(start), self.span):
             g = t ^ (t >> 1)
             if g < self.count:
-                if seen >= start:
-                    yield self.rank + self.world * g
-                seen += 1
+                yield self.rank + self.world * g
 
     def __iter__(self):
         return self._from(0)
@@ -90,7 +132,8 @@ class _GraySlices:
             idx += self.count
         if not 0 <= idx < self.count:
             raise IndexError("slice position out of range")
-        return next(self._from(idx))
+        t = self._t_of(idx)
+        return self.rank + self.world * (t ^ (t >> 1))
 
     def __eq__(self, other):
         try:
@@ -488,6 +531,19 @@ def _checkpoint_path(prefix, rank, world):
     return f"{prefix}.rank{rank}of{world}.pt"
 
 
+def _slices_array(my_slices):
+    """the shard's slice numbers as one int64 array (8 bytes per slice instead of a list of Python ints)"""
+    if isinstance(my_slices, np.ndarray) and my_slices.dtype == np.int64:
+        return my_slices
+    return np.fromiter((int(x) for x in my_slices), dtype=np.int64, count=len(my_slices))
+
+
+def _checkpoint_head(my_slices, done):
+    """the last (up to) eight slices a checkpoint covers: O(1) per save, whatever `done` is"""
+    done = int(done)
+    return [int(x) for x in my_slices[max(0, done - 8):done]]
+
+
 def run_digest(runner, my_slices):
     """What a checkpoint must match besides the plan: the VALUES of the leaves (same circuit structure, other gate
     parameters: same plan fingerprint, different sums), their dtype, the accumulator's shape and dtype, and the whole
@@ -501,7 +557,7 @@ def run_digest(runner, my_slices):
             h.update(repr((str(t.dtype), tuple(t.shape))).encode())
             h.update(np.ascontiguousarray(torch.view_as_real(t).cpu().numpy() if t.is_complex() else t.cpu().numpy()).tobytes())
     h.update(repr((str(runner.collect.dtype), tuple(runner.collect.shape))).encode())
-    h.update(np.asarray([int(x) for x in my_slices], dtype=np.int64).tobytes())
+    h.update(_slices_array(my_slices).tobytes())
     return h.hexdigest()
 
 
@@ -517,7 +573,7 @@ def load_checkpoint(path, fingerprint, my_slices, digest=None, collect=None):
     if ck.get("fingerprint") != fingerprint:
         raise RuntimeError(f"{path} was written for another plan (scheme / sliced bonds / output order differ): not resumed")
     done = int(ck["done"])
-    if ck.get("n_slices") != len(my_slices) or ck.get("head") != [int(x) for x in my_slices[:done][-8:]]:
+    if ck.get("n_slices") != len(my_slices) or ck.get("head") != _checkpoint_head(my_slices, done):
         raise RuntimeError(f"{path} was written for another shard of the slices: not resumed")
     if digest is not None and ck.get("digest") != digest:
         raise RuntimeError(f"{path} was written for other leaf tensors, another dtype, output shape or slice list: not resumed")
@@ -533,7 +589,7 @@ def save_checkpoint(path, fingerprint, my_slices, done, collect, digest=None):
     import os
     tmp = path + ".tmp"
     torch.save({"fingerprint": fingerprint, "n_slices": len(my_slices), "done": int(done), "digest": digest,
-                "head": [int(x) for x in my_slices[:done][-8:]], "partial": collect.detach().cpu()}, tmp)
+                "head": _checkpoint_head(my_slices, done), "partial": collect.detach().cpu()}, tmp)
     os.replace(tmp, path)
 
 
@@ -600,21 +656,32 @@ def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce
         _check_same_plan(runner, permute_dims, group)
     if slices is None:
         slices = rank_slices(2 ** runner.n_bonds, rank, world, gray=runner.reuse_small)
+    guarded = distributed and reduce is not None
     if checkpoint is None:
-        collect = runner.run(slices)
+        # (a slice that raises on ONE rank must not leave the others waiting in the reduction: every rank reports first)
+        err, collect = None, None
+        try:
+            collect = runner.run(slices)
+        except Exception as e:
+            if not guarded:
+                raise
+            err = e
+        if guarded:
+            _all_ranks_ok(err, group, "the slice loop")
     else:   # resumable: the shard in pieces of `checkpoint_every` slices, the partial sum saved after each
-        if len(slices) > (1 << 26):
-            raise RuntimeError(f"checkpointing keeps the shard's slice list ({len(slices)} slices): pass `slices=` pieces of at most 2^26")
-        slices = [int(x) for x in slices]
         fp = plan_fingerprint(runner.scheme, runner.slicing_indices, permute_dims)
         path = _checkpoint_path(checkpoint, rank, world)
         err, done, partial, dg = None, 0, None, None
         try:
+            # (inside the guarded block: shards differ by one slice, so ONE rank may be the only one over the limit)
+            if len(slices) > (1 << 26):
+                raise RuntimeError(f"checkpointing keeps the shard's slice list ({len(slices)} slices): pass `slices=` pieces of at most 2^26")
+            slices = np.fromiter((int(x) for x in slices), dtype=np.int64, count=len(slices))
             dg = run_digest(runner, slices)
             done, partial = load_checkpoint(path, fp, slices, dg, runner.collect)
         except Exception as e:   # (reported to every rank below: nobody enters the reduction alone)
             err = e
-        if distributed and reduce is not None:
+        if guarded:
             _all_ranks_ok(err, group, "loading the checkpoint")
         elif err is not None:
             raise err
@@ -623,12 +690,12 @@ def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce
         every = max(1, int(checkpoint_every))
         try:
             while done < len(slices):
-                runner.run(slices[done:done + every])
+                runner.run(slices[done:done + every].tolist())
                 done = min(done + every, len(slices))
                 save_checkpoint(path, fp, slices, done, runner.collect, dg)
         except Exception as e:
             err = e
-        if distributed and reduce is not None:
+        if guarded:
             _all_ranks_ok(err, group, "the slice loop")
         elif err is not None:
             raise err
@@ -638,7 +705,8 @@ def _shard_and_reduce(runner, permute_dims=None, group=None, slices=None, reduce
         if reduce == "all":
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         else:
-            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
+            # (torch wants the GLOBAL rank of the destination: rank 0 of a sub-group is not global rank 0)
+            dist.reduce(buf, dst=dist.get_global_rank(group, 0) if group is not None else 0, op=dist.ReduceOp.SUM, group=group)
     if permute_dims is not None and len(permute_dims) > 0:
         collect = collect.permute(tuple(permute_dims))
     return collect

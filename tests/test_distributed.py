@@ -289,3 +289,80 @@ def test_checkpoint_and_resume_of_the_slice_loop(tmp_path, monkeypatch):
     perm[0], perm[1] = perm[1], perm[0]
     with pytest.raises(RuntimeError, match="slice list"):
         S._shard_and_reduce(runner(), reduce=None, slices=perm, checkpoint=prefix, checkpoint_every=10)
+
+
+# ---------------------------------------------------------------------------------------------
+# world sizes 3 and 4: a shard count that is not a power of two, a sub-group that does not
+# contain global rank 0, and one rank raising in the middle of its slice loop
+# ---------------------------------------------------------------------------------------------
+def _worker_wide(rank, world, port, name, mode, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = load_case(os.path.join(GOLDEN, name + ".npz"))
+        want = case.arrays["final"]
+        sparse = case.meta.get("pattern") == "sparse"
+        from artensor_amd import simulation as S
+        execute = _oracle_execute(sparse)
+        if mode == "raise" and rank == world - 1:
+            calls = [0]
+            inner = execute
+
+            def execute(tensors, scheme):   # the last rank's SECOND slice fails
+                calls[0] += 1
+                if calls[0] == 2:
+                    raise ValueError("slice went wrong on purpose")
+                return inner(tensors, scheme)
+        runner = S.SliceRunner._with_seams(case.tensors, case.scheme, case.slicing_indices, want.shape, sparse,
+                                           torch.complex64, "cpu", execute, _cpu_add)
+        group = None
+        if mode == "subgroup":      # every rank creates the group (a collective); only its members use it
+            group = dist.new_group(ranks=list(range(1, world)))
+            if rank == 0:
+                return
+        try:
+            out = S._shard_and_reduce(runner, group=group, reduce="root" if mode == "subgroup" else "all")
+            np.save(os.path.join(out_dir, f"{mode}_{rank}.npy"), out.numpy())
+        except Exception as e:
+            with open(os.path.join(out_dir, f"{mode}_{rank}.txt"), "w") as f:
+                f.write(f"{type(e).__name__}: {e}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_three_and_four_ranks_shard_the_slices(tmp_path, world):
+    """64 slices over 3 ranks (22 + 21 + 21: shards whose count is not a power of two) and over 4."""
+    name = "rand_D2_closed_sliced"
+    port = _free_port()
+    mp.spawn(_worker_wide, args=(world, port, name, "all", str(tmp_path)), nprocs=world, join=True)
+    want = load_case(os.path.join(GOLDEN, name + ".npz")).arrays["final"]
+    for r in range(world):
+        got = np.load(tmp_path / f"all_{r}.npy")
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
+def test_a_sub_group_without_global_rank_0_reduces_to_its_own_root(tmp_path):
+    """reduce="root" inside a group made of global ranks 1 and 2: the sum lands on global rank 1 (group rank 0).  torch's
+    dist.reduce takes a GLOBAL destination rank; with dst=0 this raised (rank 0 is not in the group)."""
+    name = "rand_D2_closed_sliced"
+    port = _free_port()
+    mp.spawn(_worker_wide, args=(3, port, name, "subgroup", str(tmp_path)), nprocs=3, join=True)
+    want = load_case(os.path.join(GOLDEN, name + ".npz")).arrays["final"]
+    assert not (tmp_path / "subgroup_1.txt").exists(), open(tmp_path / "subgroup_1.txt").read()
+    root = np.load(tmp_path / "subgroup_1.npy")
+    other = np.load(tmp_path / "subgroup_2.npy")
+    assert np.abs(root - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.abs(other - want).max() > 1e-3 * np.abs(want).max()     # keeps its partial sum
+
+
+def test_a_slice_that_raises_on_one_rank_raises_on_every_rank(tmp_path):
+    """No checkpoint: rank 2's second slice raises.  Ranks 0 and 1 must not be left waiting in the all_reduce
+    (mp.spawn would hang until pytest's timeout); every rank raises, the failing one its own exception."""
+    port = _free_port()
+    mp.spawn(_worker_wide, args=(3, port, "rand_D2_closed_sliced", "raise", str(tmp_path)), nprocs=3, join=True)
+    msgs = [open(tmp_path / f"raise_{r}.txt").read() for r in range(3)]
+    assert msgs[2].startswith("ValueError: slice went wrong on purpose")
+    for r in (0, 1):
+        assert "the slice loop failed on rank 2" in msgs[r] and "on purpose" in msgs[r]

@@ -256,6 +256,18 @@ def test_gray_ordered_shard_is_lazy():
     assert h == list(h)
     with pytest.raises(IndexError):
         h[5]
+    # an integer index or a late start never walks the shard from its first slice: a shard of
+    # 2^41 - 12345 slices answers positions 10^11 and len - 1 at once, and agrees with the walk where the walk is cheap
+    big = A.rank_slices(8 * (2 ** 38 - 12345) + 3, 3, 8, gray=True)
+    assert len(big) == 2 ** 38 - 12345
+    t0 = __import__("time").time()
+    far = [big[10 ** 11], big[len(big) - 1]] + big[10 ** 11:10 ** 11 + 3]
+    assert __import__("time").time() - t0 < 1.0 and far[0] == far[2] and len(set(far)) == 4
+    for count in (5, 6, 7, 100, 257, 1000, 4097):
+        sh = A.rank_slices(count * 3, 1, 3, gray=True)
+        walk = list(sh)
+        assert len(walk) == count and [sh[i] for i in range(count)] == walk
+        assert sh[count // 2:count // 2 + 9] == walk[count // 2:count // 2 + 9]
 
 
 @pytest.mark.parametrize("n,world", [(1024, 3), (4096, 8), (100, 7), (8, 8), (5, 8)])
