@@ -325,6 +325,16 @@ def _big_k_outer_extents(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype
         outer.append(x)
         tiles *= e
         k_total //= e
+    # The split step carries `outer` as batch labels (in A, B and the result): the planner has its own limits for those
+    # (ARTN_XG_MAXH batch labels, 20 labels per side) -- a split the extent GEMM declines would run the whole contraction on
+    # the strided kernel instead.  Ask for the split descriptor and give labels back until the answer is the extent GEMM.
+    bs = tuple(b_stride if b_stride is not None else _dense_strides(tuple(b_shape)))
+    while outer:
+        mid = tuple(outer) + tuple(lo)
+        ds, _ = _descriptor(tuple(la), tuple(lb), mid, tuple(a_shape), tuple(a_stride), tuple(b_shape), bs, dtype)
+        if _step_info_cached(ds)["kernel"] == N.KERNEL_XGEMM:
+            break
+        outer.pop()
     return outer or None
 
 
@@ -1224,7 +1234,8 @@ def _own_layouts(scheme, main_idx, shapes, dtype):
                         order), then the free labels of the other operand (in its order, fastest)
     -- consecutive rows of the extent GEMM's 128-row tiles are then consecutive in the first operand's free labels
     AND in the result (1 KiB contiguous per tile column), whatever the planner's `list(set)` said.  The last step
-    keeps the scheme's order.  Returns the scheme itself or a rewritten copy (label-tuple equations)."""
+    keeps the scheme's order, and so does every step none of whose labels has an odd extent (a mixed network's
+    power-of-two steps stay what the bit kernels' planner was tuned on).  Returns the scheme itself or a rewritten copy (label-tuple equations)."""
     if dtype not in _DTYPES or not main_idx or _os_environ.get("ARTN_OWN_LAYOUTS", "1") in ("0",):
         return scheme
     if all(e & (e - 1) == 0 for sh in shapes.values() for e in sh):
@@ -1247,7 +1258,10 @@ def _own_layouts(scheme, main_idx, shapes, dtype):
             ext.update(zip(la_act, shapes[i]))
         if j in shapes:
             ext.update(zip(lb_act, shapes[j]))
-        if n == last or len(set(lo)) != len(lo):
+        pow2_step = all(e & (e - 1) == 0 for e in ext.values())
+        if n == last or len(set(lo)) != len(lo) or pow2_step:
+            # (a step whose labels are all powers of two runs on the bit kernels: its pair eligibility and its plan are
+            #  tuned to the reference's orders -- only its operands' ACTUAL orders are passed on)
             lo_act = tuple(lo)
         else:
             in_a, in_b = set(la), set(lb)
@@ -1337,7 +1351,8 @@ def tensor_contraction(tensors, scheme, accumulate_into=None):
         shape_key.append(t.shape)
     if first is None or dtype not in _DTYPES:
         raise RuntimeError("tensor_contraction needs complex64 or complex128 GPU tensors")
-    key = (id(scheme), dtype, precision.current(), tuple(shape_key), _HAS_PAIR_QUERY(), bool(_os_environ.get("ARTN_NO_FUSE")), _chain_plan_on())
+    key = (id(scheme), dtype, precision.current(), tuple(shape_key), _HAS_PAIR_QUERY(), bool(_os_environ.get("ARTN_NO_FUSE")), _chain_plan_on(),
+           _os_environ.get("ARTN_OWN_LAYOUTS", "1"))
     hit = _plan_cache.get(key)
     if hit is None or hit[0] is not scheme or hit[3] is not su[2]:   # (su[2]: the step snapshot just verified above)
         shapes = {k: tuple(tensors[k].shape) for k in su[1] if (k in tensors if is_dict else isinstance(k, int) and 0 <= k < n_list)}

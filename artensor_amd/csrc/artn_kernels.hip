@@ -1013,8 +1013,13 @@ struct StageRun {
 #pragma unroll
     for (int s = 0; s < U3; ++s) {
       const float xs = buf[s].x + buf[s].y;
-      // (re + im of the small operand is one v_add per MFMA triple: cheaper than 16-32 more fragment registers)
-      const float ws = W0[BASE + s] + W1[BASE + s];
+      // (re + im of the small operand is one v_add per MFMA triple: cheaper than 16-32 more fragment registers.  For the
+      //  6-bit stage hipcc hoisted all 32 sums out of the TILE loop -- they are loop-invariant -- into 32 registers, and under
+      //  that pressure its scheduler sank every operand read next to its first use: ds_read, s_waitcnt lgkmcnt(0), MFMA,
+      //  one exposed LDS round trip per triple (found in the ISA in round 6).  A volatile asm is not hoisted.)
+      float ws;
+      if constexpr (KB == 6) asm volatile("v_add_f32 %0, %1, %2" : "=v"(ws) : "v"(W0[BASE + s]), "v"(W1[BASE + s]));
+      else ws = W0[BASE + s] + W1[BASE + s];
 #ifdef ARTN_ABLATE_MFMA
       asm volatile("" ::"v"(buf[s].x), "v"(buf[s].y), "v"(xs), "v"(W0[BASE + s]), "v"(W1[BASE + s]), "v"(ws));
 #else
@@ -1231,6 +1236,18 @@ __device__ __forceinline__ void run_stage(const StageConst<KB> &L, float (&W0)[1
 
 #include "artn_wide_kernel.h"
 
+// s_setprio takes an immediate: a run-time level goes through a scalar switch (the priority experiments of round 6:
+// ArtnBitsPlan::stage_prio >= 0x100 packs one level per phase -- bits 0-1 stage 1, 2-3 stage 2, 4-5 the copy phases,
+// bit 6: only the workgroup in the odd wave slots raises its stages)
+__device__ __forceinline__ void set_prio_rt(int v) {
+  switch (v & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
 // KB2 == 0: single stage.  BIGK: 7 or 8 contracted bits (KB1 = 6 of them in the chain).
 // NP: 0 = fp32 MFMA chains; 3 / 1 = split-bf16 chains (stages with >= 3 contracted bits).
 // GATHER: row indices on one outer axis (artn_contract_gather; single stage, fp32 chains).
@@ -1369,10 +1386,15 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
   // issue priority of ONE of the two (the one whose waves sit in the odd wave slots) during
   // its MFMA stages only breaks the symmetry: its chains never wait, the other workgroup's
   // chains fill the pipe while it copies, and the pair locks into alternation (offset 0.48).
-  const bool stage_prio = (P.stage_prio == 1 || P.stage_prio == 3) && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1); // HW_ID.wave_id bit 0
+  // (mode 4, development builds: EVERY workgroup raises its stages and leaves its copy phases at 0 -- a workgroup in a stage
+  //  starves its partner's copy phase, which is what holds tools/probes/tri_probe.hip in anti-phase)
+  const bool stage_prio = ((P.stage_prio == 1 || P.stage_prio == 3) && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) || P.stage_prio == 4; // HW_ID.wave_id bit 0
   // experiment (ARTN_STAGE_PRIO=2/3): the COPY phases of every workgroup run at raised priority instead, so their few
   // instructions never queue behind the co-resident workgroup's MFMA stream (3: on top of the asymmetric stage priority)
-  const bool copy_prio = P.stage_prio >= 2;
+  const bool copy_prio = P.stage_prio == 2 || P.stage_prio == 3;
+  const bool prio_rt = P.stage_prio >= 0x100;
+  const bool prio_mine = !((P.stage_prio >> 6) & 1) || (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1);
+  const int prio_s1 = prio_mine ? P.stage_prio & 3 : 0, prio_s2 = prio_mine ? (P.stage_prio >> 2) & 3 : 0, prio_cp = (P.stage_prio >> 4) & 3;
   STAMP_DECL
   bool half_pending = false;
   for (long tile = t0; tile < n_tiles; tile += G) {
@@ -1422,6 +1444,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
 
     // ---- stage 1: R0 -> R1, fused stage 2: R1 -> R0
     if (stage_prio) __builtin_amdgcn_s_setprio(2);
+    if (prio_rt) set_prio_rt(prio_s1);
     if constexpr (N3 == 1) {
       WideStage<KBN> sn{LN, WN0, WN1, WN2, R0, R1, -1, 0, 0};
       WideNoFill nf;
@@ -1440,6 +1463,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     __syncthreads();
     unsigned outr = R1;
     if (KB2 > 0) {
+      if (prio_rt) set_prio_rt(prio_s2);
       STAMP(6);
       if constexpr (N3 == 2) {
         WideStage<KBN> sn{LN, WN0, WN1, WN2, R1, R0, -1, 0, 0};
@@ -1456,6 +1480,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (BIGK ? 1 : 2)) void artn_k_bits(c
     STAMP(6); // barriers after the stages
     PHASE_MARK(2);
     if (copy_prio) __builtin_amdgcn_s_setprio(3);
+    if (prio_rt) set_prio_rt(prio_cp);
 
     unsigned lo_in = in_lane, lo_out = out_lane, t16 = tid16, t16o = tid16_out;
     OPAQUE_V(lo_in);
@@ -2958,9 +2983,11 @@ static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, 
     if (g.nb != 1) return hipErrorInvalidValue;
     if (g.trans) {
       auto kern = artn_k_xgemm<1, true, 8>;
+      if (hipError_t e = ensure_lds<artn_k_xgemm<1, true, 8>>(lds); e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);
     } else {
       auto kern = artn_k_xgemm<1, false, 8>;
+      if (hipError_t e = ensure_lds<artn_k_xgemm<1, false, 8>>(lds); e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);
     }
     return hipGetLastError();

@@ -283,7 +283,10 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_TILE_TARGET")) x.tile_target = std::min(ARTN_TILE_BITS_MAX, std::max(9, atoi(e)));
     if (const char *e = getenv("ARTN_RUN_MAX")) x.run_max = std::min(6, std::max(1, atoi(e)));
     if (const char *e = getenv("ARTN_SWIZZLE")) x.swizzle = atoi(e) != 0;
-    if (const char *e = getenv("ARTN_STAGE_PRIO")) x.stage_prio = std::min(3, std::max(0, atoi(e)));
+    if (const char *e = getenv("ARTN_STAGE_PRIO")) {
+      const int v = (int)strtol(e, nullptr, 0);   // (>= 0x100: one level per phase, see set_prio_rt in artn_kernels.hip)
+      x.stage_prio = v >= 0x100 ? (v & 0x17f) : std::min(4, std::max(0, v));
+    }
     if (const char *e = getenv("ARTN_NT")) x.nt = atoi(e) != 0;
     if (const char *e = getenv("ARTN_GEMM")) x.gemm = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_GEMM_3M")) x.gemm_3m = atoi(e) != 0;
@@ -1568,7 +1571,8 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   x.k_groups = x.k.total / x.k.L0;
   const int64_t chunks = x.k_groups * x.cpg;
   if (chunks >= lim) { p.why_generic = "extent GEMM: too many chunks per tile"; return false; }
-  x.flush_chunks = chunks > ARTN_XG_FLUSH / x.kc ? ARTN_XG_FLUSH / x.kc : 0;
+  // (complex128: f64 accumulators need no periodic flush -- the interval exists to bound fp32 rounding growth)
+  x.flush_chunks = (!c128 && chunks > ARTN_XG_FLUSH / x.kc) ? ARTN_XG_FLUSH / x.kc : 0;
   x.tiles_m = (x.m.total + ARTN_XG_TM - 1) / ARTN_XG_TM;
   x.tiles_n = (x.n.total + 32 * x.nb - 1) / (32 * x.nb);
   x.n_tiles = x.tiles_m * x.tiles_n * hprod;

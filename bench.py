@@ -714,6 +714,10 @@ def compact_line(full):
          "err_loose": sig(vt.get("hip_loose", cfg.get("err_rel_to_max_abs_or_rms")), 3),
          "err_strict": sig(vt.get("hip_strict", cfg.get("rel_err_strict_over_1e-3rms")), 3),
          "ref_c64_loose": sig(vt.get("reference_c64_loose"), 3), "ref_c64_strict": sig(vt.get("reference_c64_strict"), 3),
+         # the interpretation of north_star's "<= 1e-5 relative" this line's `check` applies: loose =
+         # |d| <= tol_loose * max(|amp|, rms) per amplitude; strict = max relative error over |amp| >= 1e-3 rms within
+         # tol_strict_x times the reference's own complex64-vs-complex128 figure (ref_c64_strict)
+         "tol_loose": vt.get("tol_loose", LOOSE_TOL), "tol_strict_x_ref": STRICT_FACTOR if vt else None,
          "err_vs": "c128 truth" if vt else "reference c64", "n12_gpu_us": sig(cfg.get("n12_gpu_us")),
          "ms_unprofiled": sig(cfg.get("ms_per_step_unprofiled"), 6)}
     if cfg.get("failed_workloads"):

@@ -116,6 +116,27 @@ for sc in (30, 12, 9):
           selects=sum(len(s) == 5 and len(s[2][0]) == 1 and len(s[2][1]) == 0 for s in r[0]))
 
 
+# the n30 m14 tree with Google's 10 000 bitstrings (BASELINE configs[2], SURVEY 8a row A4: the reference's compiler needs
+# 10-40 s for it): the first live equality above 1 500 rows, on the circuit and batch the bench leg runs
+import make_golden as MG  # noqa: E402  (same directory: the n30 .qsim conversion and the amplitude file reader)
+t0 = time.time()
+g_bits, _ = MG.read_google(10000)
+n30 = R.TensorNetworkSimulation.from_circuit_file(MG.n30_qsim(), g_bits)
+n30.prepare_contraction(sc_target=30, **PLAN)
+t_plan = time.time() - t0
+t0 = time.time()
+r = R.contraction_scheme_sparse(deepcopy(n30.ctree), g_bits, sc_target=30)
+t_ref = time.time() - t0
+t0 = time.time()
+m = A.contraction_scheme_sparse(deepcopy(n30.ctree), g_bits, sc_target=30)
+t_mine = time.time() - t0
+check("contraction_scheme_sparse(n30 m14 tree, Google's 10 000 bitstrings) == reference",
+      same_sparse_scheme(m[0], r[0]) and list(m[1]) == list(r[1]) and list(m[2]) == list(r[2]),
+      steps=len(r[0]), five_tuples=sum(len(s) == 5 for s in r[0]), chunked=sum(len(s[2][0]) > 1 for s in r[0]),
+      rows=len(r[2]), seconds_reference=round(t_ref, 1), seconds_here=round(t_mine, 2), seconds_planning=round(t_plan, 1))
+del n30, r, m
+
+
 def slicing_ok(sim):
     """True when the reference's slice loop is well defined for this plan: no tensor
     carries two sliced bonds in ascending dim order, and no sliced bond sits on a leaf whose leading

@@ -35,6 +35,7 @@ CASES = {   # key in c128_truth_gpu.npz -> (fixture, sparse executor, sliced)
     "n30_sparse10000_final": ("n30_sparse10000.npz", True, False),
     "n30_dense_at_google": ("n30_dense.npz", False, False),
     "n53_m20_batch_slice0": ("n53_m20_batch.npz", True, True),
+    "n53_m20_bigbatch_slice0": ("n53_m20_bigbatch.npz", True, True),   # round 6: 65 536 amplitudes
 }
 
 

@@ -91,6 +91,7 @@ CASES = [
     ("n53_m14_sliced", lambda dt: slice0("n53_m14_sliced", True, dt)),
     ("n53_m20_sliced", lambda dt: slice0("n53_m20_sliced", True, dt)),
     ("n53_m20_batch", lambda dt: slice0("n53_m20_batch", True, dt)),
+    ("n53_m20_bigbatch", lambda dt: slice0("n53_m20_bigbatch", True, dt)),   # round 6: 65 536 amplitudes
     ("rand_D2_nv260_sliced", lambda dt: slice0("rand_D2_nv260_sliced", False, dt)),
     ("rand_D4_nv100", lambda dt: slice0("rand_D4_nv100", False, dt)),
 ]
@@ -101,7 +102,8 @@ REFERENCE_C64 = {
     "n30_dense_block_sums": ("n30_dense", "block_sums"),
     "n30_sparse10000_final": ("n30_sparse10000", "final"), "n30_sparse100_final": ("n30_sparse100", "final"),
     "n53_m14_sliced_slice0": ("n53_m14_sliced", "slice0"), "n53_m20_sliced_slice0": ("n53_m20_sliced", "slice0"),
-    "n53_m20_batch_slice0": ("n53_m20_batch", "slice0"), "rand_D2_nv260_sliced_slice0": ("rand_D2_nv260_sliced", "slice0"),
+    "n53_m20_batch_slice0": ("n53_m20_batch", "slice0"), "n53_m20_bigbatch_slice0": ("n53_m20_bigbatch", "slice0"),
+    "rand_D2_nv260_sliced_slice0": ("rand_D2_nv260_sliced", "slice0"),
     "rand_D4_nv100_slice0": ("rand_D4_nv100", "slice0"),
 }
 

@@ -834,6 +834,47 @@ def case_random_bench_nonpow2():
               res128.reshape(-1), f"{dt:.0f} s / {dt128:.0f} s", flush=True)
 
 
+def case_random_bench_nonpow2_open():
+    """The OPEN twins of case_random_bench_nonpow2 (round 6): the closed benchmark fixtures pin ONE
+    complex scalar each, so a layout slip that cancels in the final dot product would pass.  Same graphs, seeds and
+    planner budget, with dangling bonds on the first tensors (tests/golden/make_golden.py::_rand_tn):
+      * D = 3, 112 vertices, 6 open bonds: 3^6 = 729 amplitudes;
+      * D = 6, 64 vertices, 4 open bonds: 6^4 = 1 296 amplitudes.
+    `final` is the reference executor's complex64 result in the order of the scheme's output bonds, `exact128` the
+    same executor on complex128 leaves (the truth the 1e-5 contract is checked against)."""
+    for nv0, D, n_open, stem in [(112, 3, 6, "rand_D3_open6"), (64, 6, 4, "rand_D6_open4")]:
+        # (open bonds raise the space complexity: the largest graph of the family that the planner leaves UNSLICED at
+        #  sc_target 30 -- 8 GiB of complex64, 16 of complex128 on this 64 GB host; the reference's slice loop is defined
+        #  for bond dimension 2 only)
+        for nv in range(nv0, 8, -4):
+            tensors, tensor_bonds, bond_dims = _rand_tn(nv, D, 0, n_open)
+            order, slicing_bonds, ctree = find_order(
+                deepcopy(tensor_bonds), deepcopy(bond_dims), [], 0, 1, sc_target=30,
+                trials=4, iters=5, betas=np.linspace(3.0, 21.0, 61), start_seed=0, slicing_repeat=1)
+            print(stem, "nv", nv, "sliced bonds", len(slicing_bonds), "sc", float(ctree.tree_complexity()[1]), flush=True)
+            if len(slicing_bonds) == 0:
+                break
+        name = f"{stem}_nv{nv}"
+        scheme, output_bonds = contraction_scheme(deepcopy(ctree))
+        assert len(output_bonds) == n_open, (name, output_bonds)
+        tc, sc = ctree.tree_complexity()[:2]
+        t0 = time.time()
+        res = tensor_contraction(dict(tensors), scheme)
+        dt = time.time() - t0
+        t0 = time.time()
+        res128 = tensor_contraction({i: t.to(torch.complex128) for i, t in tensors.items()}, scheme)
+        dt128 = time.time() - t0
+        assert tuple(res.shape) == (D,) * n_open
+        meta = dict(D=D, nv=nv, n_open=n_open, sc_target=30, log10_tc=float(tc), sc=float(sc), bond_dim=D,
+                    output_bonds=[int(b) for b in output_bonds], n_slicing=0, reference_cpu_seconds=dt,
+                    reference_cpu_seconds_c128=dt128, graph="networkx.random_regular_graph(3, nv, seed=0)")
+        save_case(os.path.join(HERE, name + ".npz"), tensors, scheme, meta,
+                  arrays=dict(final=res.numpy().copy(), exact128=res128.numpy().copy()))
+        err = (res.to(torch.complex128) - res128).abs().max() / res128.abs().max()
+        print(name, "steps", len(scheme), "log10 tc", float(tc), "sc", float(sc), "amplitudes", res.numel(),
+              "c64 vs c128", err.item(), f"{dt:.0f} s / {dt128:.0f} s", flush=True)
+
+
 def case_gates():
     """Gate lists (array + bond labels per gate, in circuit order) of the n12 and n30 circuits as
     the reference's TensorNetworkCircuit builds them (circuit.py:100-130): the input of
@@ -851,6 +892,7 @@ CASES = {
     "gates": case_gates,
     "random_bench": case_random_bench,
     "random_bench_nonpow2": case_random_bench_nonpow2,
+    "random_bench_nonpow2_open": case_random_bench_nonpow2_open,
     "n53_plan": case_n53_plan,
     "n53_slice0": case_n53_slice0,
     "n53m20_plan": lambda: case_n53_plan("m20"),

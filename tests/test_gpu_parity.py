@@ -45,8 +45,9 @@ def rel(got, want):
 
 
 def amp_rel(got, want, rms=None):
-    """max over amplitudes of |got - want| / max(|want|, rms)."""
-    got, want = np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)
+    """max over amplitudes of |got - want| / max(|want|, rms).  (In float64: the open bond-dimension-6 network's
+    amplitudes are ~1e-26, whose squares underflow float32 -- the rms came out 0 and the metric became the strict one.)"""
+    got, want = np.asarray(got, dtype=np.complex128).reshape(-1), np.asarray(want, dtype=np.complex128).reshape(-1)
     if rms is None:
         rms = np.sqrt(np.mean(np.abs(want) ** 2))
     return (np.abs(got - want) / np.maximum(np.abs(want), rms)).max()
@@ -54,7 +55,7 @@ def amp_rel(got, want, rms=None):
 
 def amp_strict(got, want):
     """SURVEY 8c's contract: max over amplitudes with |want| >= 1e-3 rms of |got - want| / |want|."""
-    got, want = np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)
+    got, want = np.asarray(got, dtype=np.complex128).reshape(-1), np.asarray(want, dtype=np.complex128).reshape(-1)
     rms = np.sqrt(np.mean(np.abs(want) ** 2))
     sel = np.abs(want) >= 1e-3 * rms
     return float((np.abs(got - want)[sel] / np.abs(want)[sel]).max())
@@ -86,7 +87,8 @@ def c128_spread():
 _truth = None
 
 
-_EXACT128 = {"rand_D3_nv112_slice0": "rand_D3_nv112.npz", "rand_D6_nv64_slice0": "rand_D6_nv64.npz"}
+_EXACT128 = {"rand_D3_nv112_slice0": "rand_D3_nv112.npz", "rand_D6_nv64_slice0": "rand_D6_nv64.npz",
+             "rand_D3_open6_nv96_final": "rand_D3_open6_nv96.npz", "rand_D6_open4_nv60_final": "rand_D6_open4_nv60.npz"}
 
 
 def gpu_truth(key):
@@ -1012,6 +1014,33 @@ def test_random_networks_whose_bond_dimension_is_not_a_power_of_two(name):
         del os.environ["ARTN_OWN_LAYOUTS"]
         C._plan_cache.clear()
     assert amp_rel(plain, got) <= 1e-5
+
+
+@pytest.mark.parametrize("name,n_amp", [("rand_D3_open6_nv96", 3 ** 6), ("rand_D6_open4_nv60", 6 ** 4)])
+def test_open_random_networks_whose_bond_dimension_is_not_a_power_of_two(name, n_amp):
+    """The OPEN twins of the benchmark-scale fixtures above (round 6; tests/golden/make_golden.py
+    random_bench_nonpow2_open): 3^6 = 729 and 6^4 = 1 296 output amplitudes instead of one closing dot product, so a
+    layout slip in any extent step shows -- every amplitude through assert_contract against the reference executor's
+    complex64 result and its complex128 run, in the scheme's own output order; then the same in complex128 (1e-11)."""
+    case = load_case(os.path.join(GOLDEN, name + ".npz"))
+    want = case.arrays["final"]
+    assert want.size == n_amp and want.ndim == case.meta["n_open"]
+    got = A.tensor_contraction(case.fresh_tensors(device=DEV), case.scheme)
+    assert tuple(got.shape) == tuple(want.shape)
+    assert_contract(got.cpu().numpy(), want, name + "_final")
+    got128 = A.tensor_contraction(case.fresh_tensors(dtype=torch.complex128, device=DEV), case.scheme).cpu().numpy()
+    t = case.arrays["exact128"]
+    assert np.abs(got128 - t).max() <= 1e-11 * np.abs(t).max()
+    # the reference's label orders for the intermediates (no private layouts): the same amplitudes in the same places
+    from artensor_amd import contraction as C
+    os.environ["ARTN_OWN_LAYOUTS"] = "0"
+    try:
+        C._plan_cache.clear()
+        plain = A.tensor_contraction(case.fresh_tensors(device=DEV), list(case.scheme)).cpu().numpy()
+    finally:
+        del os.environ["ARTN_OWN_LAYOUTS"]
+        C._plan_cache.clear()
+    assert amp_rel(plain.reshape(-1), got.cpu().numpy().reshape(-1)) <= 1e-5
 
 
 @pytest.mark.parametrize("n_slabs", [2, 4, 8])

@@ -75,7 +75,7 @@ def test_sparse_sliced_loop():
 
 
 @pytest.mark.parametrize("name", ["rand_D2_closed", "rand_D3_open", "rand_D4_closed",
-                                  "rand_D2_open_sliced", "rand_D2_closed_sliced"])
+                                  "rand_D2_open_sliced", "rand_D2_closed_sliced", "rand_D6_open4_nv60"])
 def test_random_networks(name):
     case = load_case(os.path.join(GOLDEN, name + ".npz"))
     want = case.arrays["final"]

@@ -41,7 +41,7 @@ __device__ __forceinline__ void stage(unsigned a_base, unsigned w_base, const v2
   auto fetch = [&](int s0, int buf) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      a[buf][u] = ldr8((a_base + (unsigned)((s0 + u) * 2 * 128 * 8)) & (REGION - 1));   // k = 2 s (+ lane half): 128 columns per k
+      a[buf][u] = ldr8((a_base & ~(REGION - 1)) | ((a_base + (unsigned)((s0 + u) * 2 * 128 * 8)) & (REGION - 1)));   // k = 2 s (+ lane half): 128 columns per k
       if (WLDS) w[buf][u] = ldr8(w_base + (unsigned)((s0 + u) * 512));
       else w[buf][u] = wreg[s0 + u];
     }
@@ -78,8 +78,17 @@ __device__ __forceinline__ long gaddr(long t, int c, int rs) {
   return (t >> (st - rb)) * (rows << st) + ((t & ((1L << (st - rb)) - 1)) << rb) + (long)(c >> (rb - 4)) * ((1L << st) + g_skew) + (c & ((1 << (rb - 4)) - 1)) * 16;
 }
 __device__ unsigned long long g_marks[1024 * 10];
+// (round 6: random operands.  On all-zero data the chip holds 2.38 GHz where the real kernel, on real data, holds 1.84 --
+//  MI355X_MICROARCH.md "DVFS give-back" -- and the probe looked 25 % faster than it is.)
+__global__ void fill_random(float *p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned s = (unsigned)i * 2654435761u + 12345u;
+    s = s * 1664525u + 1013904223u;
+    p[i] = ((int)(s >> 9) - (1 << 22)) * (1.0f / (1 << 22));
+  }
+}
 #define MARK(i) do { if (marks && iter == 20 && tid == 0) g_marks[blockIdx.x * 10 + (i)] = wall_clock64(); } while (0)
-template <int L1, int L2, int WPC, bool WLDS, bool MFMA, bool COPY>
+template <int L1, int L2, int WPC, bool WLDS, bool MFMA, bool COPY, bool TWOREG = false, int PRIO = 0>
 __global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char *__restrict__ C, long n_tiles, int rs_in, int rs_out, int marks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -89,9 +98,9 @@ __global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char
     for (unsigned o = tid * 8; o < 16384u + 4096u; o += 256 * 8) ldw8(W1_OFF + o, v2f{1.0f / 64, 0.5f / 64});
   } else {
 #pragma unroll
-    for (int s = 0; s < L1; ++s) wreg1[s] = v2f{1.0f / 64 + s * 1e-6f, 0.5f / 64};
+    for (int s = 0; s < L1; ++s) { unsigned q = (unsigned)(lane * 131 + s * 7919 + 1) * 2654435761u; wreg1[s] = v2f{((int)(q >> 9) - (1 << 22)) * (1.0f / (1 << 26)), ((int)((q * 1664525u) >> 9) - (1 << 22)) * (1.0f / (1 << 26))}; }
 #pragma unroll
-    for (int s = 0; s < L2; ++s) wreg2[s] = v2f{1.0f / 64 + s * 1e-6f, 0.5f / 64};
+    for (int s = 0; s < L2; ++s) { unsigned q = (unsigned)(lane * 137 + s * 7907 + 5) * 2654435761u; wreg2[s] = v2f{((int)(q >> 9) - (1 << 22)) * (1.0f / (1 << 26)), ((int)((q * 1664525u) >> 9) - (1 << 22)) * (1.0f / (1 << 26))}; }
   }
   const unsigned a_lane = (unsigned)(((lane >> 5) * 128 + wave * 32 + (lane & 31)) * 8); // column = wave * 32 + lane & 31, k parity = lane >> 5
   const unsigned w_lane = (unsigned)lane * 8u;
@@ -113,6 +122,25 @@ __global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char
   for (; t < n_tiles; t += G, ++iter) {
     float hold[32];
     MARK(0);
+    if constexpr (TWOREG) {
+      // artn_k_bits' structure (round 6): two regions, a stage scatters its result into the OTHER region right after its
+      // chain (no barrier between chain and scatter), four barriers per tile
+      if (PRIO == 2 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) __builtin_amdgcn_s_setprio(2);
+      stage<L1, WLDS, MFMA>(a_lane, W1_OFF + w_lane, wreg1, hold);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ldw8(32768u + ((sc_lane + (unsigned)e * 1024u) & (REGION - 1)), v2f{hold[2 * e], hold[2 * e + 1]});
+      MARK(1);
+      __syncthreads();
+      MARK(2);
+      stage<L2, WLDS, MFMA>(32768u + a_lane, W2_OFF + w_lane, wreg2, hold);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ldw8((sc_lane + (unsigned)e * 1024u) & (REGION - 1), v2f{hold[2 * e], hold[2 * e + 1]});
+      if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+      MARK(3);
+      __syncthreads();
+      MARK(4);
+      if (PRIO >= 1) __builtin_amdgcn_s_setprio(3);
+    } else {
     stage<L1, WLDS, MFMA>(a_lane, W1_OFF + w_lane, wreg1, hold);
     MARK(1);
     __syncthreads();                       // every wave has read the tile: results go over it
@@ -127,6 +155,7 @@ __global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char
     for (int e = 0; e < 16; ++e) ldw8((sc_lane + (unsigned)e * 1024u) & (REGION - 1), v2f{hold[2 * e], hold[2 * e + 1]});
     __syncthreads();
     MARK(4);
+    }
     if (COPY) {
       f32x4 x[8];
 #pragma unroll
@@ -145,6 +174,7 @@ __global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char
     } else if (hold[0] == 12345.f) {
       C[tid] = 1;
     }
+    if (TWOREG && PRIO >= 1) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     MARK(7);
     if (marks && iter == 21 && tid == 0) g_marks[blockIdx.x * 10 + 8] = wall_clock64();
@@ -192,6 +222,9 @@ static void run_all(const char *a, char *c, long n_tiles, hipEvent_t e0, hipEven
   timeit("fragments in LDS, 3 workgroups per CU", tri<L1, L2, 3, true, true, true>, 3, LDS_MIN);
   timeit("fragments in LDS, 2 workgroups per CU (LDS padded)", tri<L1, L2, 3, true, true, true>, 2, 70 * 1024);
   timeit("fragments in registers, 2 per CU", tri<L1, L2, 2, false, true, true>, 2, LDS_MIN);
+  timeit("  ... two regions, scatter after the chain, 4 barriers", tri<L1, L2, 2, false, true, true, true, 0>, 2, 65536 + 4096);
+  timeit("  ... and s_setprio 3 in the copy phases", tri<L1, L2, 2, false, true, true, true, 1>, 2, 65536 + 4096);
+  timeit("  ... and s_setprio 2 in the odd workgroup's stages", tri<L1, L2, 2, false, true, true, true, 2>, 2, 65536 + 4096);
   timeit("fragments in registers, ONE per CU (one wave per SIMD)", tri<L1, L2, 2, false, true, true>, 1, LDS_MIN);
   timeit("fragments in registers, ONE per CU, no global traffic", tri<L1, L2, 2, false, true, false>, 1, LDS_MIN);
   timeit("fragments in registers, 2 per CU, no global traffic", tri<L1, L2, 2, false, true, false>, 2, LDS_MIN);
@@ -212,7 +245,9 @@ int main(int argc, char **argv) {
   char *a, *c;
   CK(hipMalloc(&a, n_tiles * 32768L + 512L * skew + (1L << 30)));
   CK(hipMalloc(&c, n_tiles * 32768L + 512L * skew + (1L << 30)));
-  CK(hipMemset(a, 0, n_tiles * 32768L));
+  if (getenv("TRI_ZERO")) CK(hipMemset(a, 0, n_tiles * 32768L));
+  else hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (float *)a, n_tiles * 8192L);
+  CK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
