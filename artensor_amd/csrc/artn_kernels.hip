@@ -1001,7 +1001,10 @@ struct StageRun {
   // the next one -- is read under the MFMAs of the current one.  (6 contracted bits: units of 2, which is what lets
   // the fused 6+4 instantiation fit the register file without spilling a prefetched chunk -- the spill made the
   // load-issue phase wait for HBM; 6 MFMAs = 384 cycles still cover an LDS read)
-  static constexpr int U3 = KB == 6 ? 2 : 8;
+#ifndef ARTN_U3_6
+#define ARTN_U3_6 2
+#endif
+  static constexpr int U3 = KB == 6 ? ARTN_U3_6 : 8;
   static constexpr int NU3 = S / U3 > 0 ? S / U3 : 1;
   template <int BASE>
   __device__ __forceinline__ void load_u3(v2f_t (&buf)[U3], unsigned li) const {
@@ -1018,7 +1021,7 @@ struct StageRun {
       //  that pressure its scheduler sank every operand read next to its first use: ds_read, s_waitcnt lgkmcnt(0), MFMA,
       //  one exposed LDS round trip per triple (found in the ISA in round 6).  A volatile asm is not hoisted.)
       float ws;
-      if constexpr (KB == 6) asm volatile("v_add_f32 %0, %1, %2" : "=v"(ws) : "v"(W0[BASE + s]), "v"(W1[BASE + s]));
+      if constexpr (KB == 6) asm volatile("v_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(ws) : "v"(W0[BASE + s]), "v"(W1[BASE + s]));
       else ws = W0[BASE + s] + W1[BASE + s];
 #ifdef ARTN_ABLATE_MFMA
       asm volatile("" ::"v"(buf[s].x), "v"(buf[s].y), "v"(xs), "v"(W0[BASE + s]), "v"(W1[BASE + s]), "v"(ws));

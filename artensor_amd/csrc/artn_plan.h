@@ -1469,8 +1469,11 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
     else { p.why_generic = "extent GEMM: label summed out of a single operand"; return false; }
     if (e >= (int64_t(1) << 31)) { p.why_generic = "extent GEMM: extent beyond 2^31"; return false; }
   }
-  const int64_t lim = int64_t(1) << 31; // element offsets are 32-bit in the kernel
-  if (spanA >= lim || spanB >= lim || spanC >= lim) { p.why_generic = "extent GEMM: a tensor of 2^31 elements or more"; return false; }
+  const int64_t lim = int64_t(1) << 31; // flattened indices, tiles and chunks are 31-bit in the kernel
+  // element offsets are UNSIGNED 32-bit in the kernel (tables, decode, sums; widened before the scaling by the element size):
+  // a tensor may span up to 2^32 elements -- 32 GiB of complex64, e.g. 3^20 = 2^31.7 -- (round 6: the limit used to be 2^31)
+  const int64_t span_lim = int64_t(1) << 32;
+  if (spanA >= span_lim || spanB >= span_lim || spanC >= span_lim) { p.why_generic = "extent GEMM: a tensor of 2^32 elements or more"; return false; }
   auto prod = [](const std::vector<Lab> &v) { int64_t t = 1; for (auto &l : v) t *= l.e; return t; };
   if (min_tiles > 1 && work < (double)(int64_t(1) << 24)) { p.why_generic = "extent GEMM: too little work for a tiled launch"; return false; }
   // the first operand supplies the 128-row tiles: it is the one with more free values

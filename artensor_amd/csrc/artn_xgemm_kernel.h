@@ -229,18 +229,42 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
     OPAQUE_V(t);
     const bool part = kvalid_next < KC; // (uniform: the last chunk of a group)
     const int kv = kvalid_next;
+    // (round 6: the zero padding is a UNIFORM branch -- as `part && k >= kv` selects inside one body hipcc emitted four
+    //  v_cndmask per element for EVERY chunk, ~45 vector instructions next to the 48 MFMAs of a chunk, although only one
+    //  chunk in cpg is partial: SQ_INSTS_VALU per MFMA 5.2 -> see profiles/r06_xgemm_pmc.md)
+    if (!part) {
+      if (amode == 0) {
+        const unsigned d = buf + ((t >> 7) * PA + (t & 127u)) * 8u;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) lds_write8(d + (unsigned)u * (2u * PA * 8u), va[u]);
+      } else {
+        const unsigned d = buf + ((t & (KC - 1u)) * PA + (t >> KCL)) * 8u;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) lds_write8(d + 8u * RSTEP * u, va[u]);
+      }
+      if (bmode == 0) {
+        const unsigned d = buf + A_BYTES + ((t >> 5) * PB + (t & 31u)) * 8u;
+#pragma unroll
+        for (int u = 0; u < NBL; ++u) lds_write8(d + (unsigned)(u / NB) * (8u * PB * 8u) + (unsigned)(u % NB) * 256u, vb[u]);
+      } else {
+        const unsigned d = buf + A_BYTES + ((t & (KC - 1u)) * PB + (t >> KCL)) * 8u;
+#pragma unroll
+        for (int u = 0; u < NBL; ++u) lds_write8(d + 8u * RSTEP * u, vb[u]);
+      }
+      return;
+    }
     if (amode == 0) {
       const unsigned d = buf + ((t >> 7) * PA + (t & 127u)) * 8u;
       const int kh = (int)(t >> 7);
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         v2f_t v = va[u];
-        if (part && kh + 2 * u >= kv) v = v2f_t{0.f, 0.f};
+        if (kh + 2 * u >= kv) v = v2f_t{0.f, 0.f};
         lds_write8(d + (unsigned)u * (2u * PA * 8u), v);
       }
     } else {
       const unsigned d = buf + ((t & (KC - 1u)) * PA + (t >> KCL)) * 8u;
-      const bool z = part && (int)(t & (KC - 1u)) >= kv;
+      const bool z = (int)(t & (KC - 1u)) >= kv;
 #pragma unroll
       for (int u = 0; u < NA; ++u) lds_write8(d + 8u * RSTEP * u, z ? v2f_t{0.f, 0.f} : va[u]);
     }
@@ -250,12 +274,12 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
 #pragma unroll
       for (int u = 0; u < NBL; ++u) {
         v2f_t v = vb[u];
-        if (part && kh + 8 * (u / NB) >= kv) v = v2f_t{0.f, 0.f};
+        if (kh + 8 * (u / NB) >= kv) v = v2f_t{0.f, 0.f};
         lds_write8(d + (unsigned)(u / NB) * (8u * PB * 8u) + (unsigned)(u % NB) * 256u, v);
       }
     } else {
       const unsigned d = buf + A_BYTES + ((t & (KC - 1u)) * PB + (t >> KCL)) * 8u;
-      const bool z = part && (int)(t & (KC - 1u)) >= kv;
+      const bool z = (int)(t & (KC - 1u)) >= kv;
 #pragma unroll
       for (int u = 0; u < NBL; ++u) lds_write8(d + 8u * RSTEP * u, z ? v2f_t{0.f, 0.f} : vb[u]);
     }

