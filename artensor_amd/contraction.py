@@ -1656,6 +1656,68 @@ def gather_rows(t, idx, _validate=True):
     return out
 
 
+_pair_rows_cache = _IdMemo(1024)   # (rows of the first operand, rows of the second; source row counts) -> distinct rows + pair index
+ROW_PAIRS_MIN = 256          # index pairs from which the distinct-row form is considered
+ROW_PAIRS_REUSE = 4          # ... when each operand's distinct rows are used at least this many times on average
+ROW_PAIRS_WASTE = 2.0        # ... and the full (distinct x distinct) product computes at most this many times the pairs asked for
+
+
+def _row_pairs(rows_a, rows_b, src_rows_a, src_rows_b):
+    """(distinct rows of a, distinct rows of b, index of pair p in the distinct x distinct grid) for two index lists of equal
+    length, or None when the pairs do not re-use rows enough.  Host side, once per pair of index tensors (cached): the
+    reference's indexing semantics as in _device_index (negative counts from the end, out of range raises)."""
+    extra = (src_rows_a, src_rows_b)
+    got = _pair_rows_cache.find((rows_a, rows_b), extra)
+    if got is not _MISS:
+        return got
+    res = None
+    ha = torch.as_tensor(rows_a, dtype=torch.int64).reshape(-1).cpu()
+    hb = torch.as_tensor(rows_b, dtype=torch.int64).reshape(-1).cpu()
+    n = ha.numel()
+    if n == hb.numel() and n >= ROW_PAIRS_MIN:
+        for h, rows in ((ha, src_rows_a), (hb, src_rows_b)):
+            if int(h.min()) < -rows or int(h.max()) >= rows:
+                raise RuntimeError(f"row index out of range: indices span [{int(h.min())}, {int(h.max())}] but the operand has {rows} rows "
+                                   "(IndexError in the reference, contraction.py:192-195)")
+        ha = torch.where(ha < 0, ha + src_rows_a, ha)
+        hb = torch.where(hb < 0, hb + src_rows_b, hb)
+        ua, inva = torch.unique(ha, return_inverse=True)
+        ub, invb = torch.unique(hb, return_inverse=True)
+        if (ua.numel() * ROW_PAIRS_REUSE <= n and ub.numel() * ROW_PAIRS_REUSE <= n
+                and ua.numel() * ub.numel() <= ROW_PAIRS_WASTE * n):
+            res = (ua, ub, inva * ub.numel() + invb)
+    return _pair_rows_cache.keep((rows_a, rows_b), res, extra)
+
+
+def contract_row_pairs(eq, a, rows_a, b, rows_b, out=None):
+    """einsum(eq, a[rows_a], b[rows_b]) -- the batched product over index PAIRS of the sparse executor's chunk loop and gathered
+    step (reference contraction.py:149-156, :177-179) -- when the pairs re-use few distinct rows: ONE unbatched contraction of
+    the distinct rows of `a` with the distinct rows of `b` (a plain GEMM on the bit kernels) followed by a row gather of the
+    pairs asked for.  The n53 m20 big-batch slice (65 536 bitstrings) asks for 15 344 pairs of 512 x 32 distinct rows, over 2^10
+    contracted values: as a batched product with a 4 x 16 block per pair it ran on the extent GEMM at 1.5 TFLOP/s (128-row
+    tiles with 4 valid rows; 2 x 5.4 ms of a 76 ms slice in the reduced-precision mode), as one 2 048 x 512 x 1 024 GEMM plus a
+    gather of 64-element rows it is a fraction of a millisecond.  Same products, same sums (fp32 summation order differs).
+    Returns None when the pairs do not re-use rows (the caller gathers inside the kernel or materialises the gathers)."""
+    la, lb, lo = _parse(eq) if isinstance(eq, str) else (tuple(eq[0]), tuple(eq[1]), tuple(eq[2]))
+    if (rows_a is None or rows_b is None or not la or not lb or not lo or la[0] != lo[0] or lb[0] != lo[0]
+            or la[0] in la[1:] or lb[0] in lb[1:] or lo[0] in lo[1:]
+            or a.dtype != b.dtype or a.dtype not in _DTYPES or a.dim() != len(la) or b.dim() != len(lb)):
+        return None
+    pairs = _row_pairs(rows_a, rows_b, a.shape[0], b.shape[0])
+    if pairs is None:
+        return None
+    ua, ub, grid = pairs
+    au = gather_rows(a, ua)                 # (the identity returns `a` itself)
+    bu = gather_rows(b, ub)
+    ra, rb = ("row pairs", 0), ("row pairs", 1)   # two private labels in place of the shared batch label
+    full = contract(((ra,) + la[1:], (rb,) + lb[1:], (ra, rb) + lo[1:]), au, bu)
+    res = gather_rows(full.reshape((ua.numel() * ub.numel(),) + tuple(full.shape[2:])), grid)
+    if out is not None:
+        out.copy_(res.reshape(out.shape))
+        return out
+    return res
+
+
 def _normalize_inplace(t):
     """t /= t.abs().max(); returns the device scalar abs-max (reference contraction.py:197-199)."""
     if t.dtype not in _DTYPES:
@@ -1757,8 +1819,11 @@ def _sparse_step(tensors, step):
                 ext.update(zip(lb, (rows[k],) + tuple(src_j.shape[1:])))
                 first = torch.empty((sum(rows),) + tuple(ext[x] for x in lo[1:]), dtype=src_i.dtype, device=src_i.device)
             dst = first[r0:r0 + rows[k]]
-            # rows gathered inside the contraction kernel; two gathers + contraction otherwise
-            if contract_gathered(eq, src_i, rows_i[k], src_j, batch_j[k], out=dst) is None:
+            # pairs that re-use few distinct rows: one plain GEMM of the distinct rows + a gather of the pairs; else rows
+            # gathered inside the contraction kernel; two gathers + contraction otherwise
+            if _row_pairs_on() and contract_row_pairs(eq, src_i, rows_i[k], src_j, batch_j[k], out=dst) is not None:
+                pass
+            elif contract_gathered(eq, src_i, rows_i[k], src_j, batch_j[k], out=dst) is None:
                 contract(eq, gather_rows(src_i, rows_i[k]), gather_rows(src_j, batch_j[k]), out=dst)
             r0 += rows[k]
         if step[3]:
@@ -1779,6 +1844,9 @@ def _sparse_step(tensors, step):
             ri, rj = _single_row(rows_i0, tensors[i]), _single_row(batch_j[0], tensors[j])
             if ri is not None and rj is not None:
                 fused = contract(eq, tensors[i][ri:ri + 1], tensors[j][rj:rj + 1])
+        if (fused is None and not plain and _row_pairs_on() and isinstance(tensors[i], torch.Tensor)
+                and isinstance(tensors[j], torch.Tensor)):
+            fused = contract_row_pairs(eq, tensors[i], rows_i0, tensors[j], batch_j[0])
         if fused is None and not plain and isinstance(tensors[i], torch.Tensor) and tensors[i].numel() >= (1 << 20):
             fused = contract_gathered(eq, tensors[i], rows_i0, tensors[j], batch_j[0])
         if fused is None:
@@ -1898,6 +1966,10 @@ def tensor_contraction_sparse(tensors, contraction_scheme, scientific_notation=F
     if _flags_used() and not getattr(_defer, "flag_check", False):
         check_gather_flag("tensor_contraction_sparse")
     return tensors[last]
+
+
+def _row_pairs_on():
+    return _os_environ.get("ARTN_ROW_PAIRS", "1") not in ("0",)
 
 
 def _chain_plan_on():
