@@ -22,6 +22,12 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/n53m2
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY \
   --kernel-trace --output-format csv -d $OUT/n53m20b_bf16_pmc -- python3 bench.py --workload n53m20b --precision bf16 --slices 1 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/n53m20b_bf16_pmc.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/n53m20b_bf16_clk -- python3 bench.py --workload n53m20b --precision bf16 --slices 1 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/n53m20b_bf16_clk.log 2>&1
+# round 6: BASELINE configs[4] at 65 536 bitstrings in the reduced-precision mode: kernel table + matrix-core counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/n53m20bb_bf16 -- python3 bench.py --workload n53m20bb --precision bf16 --slices 2 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/n53m20bb_bf16.log 2>&1
+grep -h '^{' $OUT/n53m20bb_bf16.log | tail -1 > $OUT/n53m20bb_bf16.json
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY \
+  --kernel-trace --output-format csv -d $OUT/n53m20bb_bf16_pmc -- python3 bench.py --workload n53m20bb --precision bf16 --slices 1 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/n53m20bb_bf16_pmc.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/n53m20bb_bf16_clk -- python3 bench.py --workload n53m20bb --precision bf16 --slices 1 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/n53m20bb_bf16_clk.log 2>&1
 # the headline scheme in complex128 (artn_k_bits128 pairs + artn_k_gemm128): kernel statistics and matrix-core counters
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/n30_c128 -- python3 tools/trace_c128.py 3 > $OUT/n30_c128.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY \

@@ -8,7 +8,7 @@ md = [f"# rocprofv3 kernel statistics of the secondary workloads, round {R}", ""
       f"`tools/profile_workloads.sh {R}` on one MI355X: `rocprofv3 --kernel-trace --stats` around",
       "`bench.py --workload W --slices 4 --steps 2 --warmup 1` (13 slices incl. warm-up and check) and around",
       "`tools/trace_sparse.py` (3 runs of the n30 sparse fixtures) and `tools/trace_c128.py` (3 runs of the n30 dense fixture in complex128).", ""]
-for w in ("n53", "n53m20", "n53m20b", "n53m20b_bf16", "n53m20bb", "rand2", "rand4", "rand3", "rand6", "n30_sparse10000", "n30_sparse100", "n30_c128"):
+for w in ("n53", "n53m20", "n53m20b", "n53m20b_bf16", "n53m20bb", "n53m20bb_bf16", "rand2", "rand4", "rand3", "rand6", "n30_sparse10000", "n30_sparse100", "n30_c128"):
     fs = sorted(glob.glob(f"{root}/{w}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
     if not fs:
         continue
@@ -54,10 +54,13 @@ if pm:
                f"* SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: {sum(d.get('SQ_LDS_BANK_CONFLICT', 0) for d in sb) / max(sum(d.get('SQ_LDS_IDX_ACTIVE', 0) for d in sb), 1):.3f}",
                f"* SQ_WAIT_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}",
                f"* SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_INST_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}", ""]
-# the same for the packed-operand GEMM of the reduced-precision mode
-pm = glob.glob(f"{root}/n53m20b_bf16_pmc/**/*_counter_collection.csv", recursive=True)
-ck = glob.glob(f"{root}/n53m20b_bf16_clk/**/*_counter_collection.csv", recursive=True)
-if pm:
+# the same for the packed-operand GEMM of the reduced-precision mode (1 024 bitstrings; round 6: and 65 536)
+for leg, flop, what in (("n53m20b_bf16", 1.407e14, "n53 m20 big-batch slice (15 contracted bits"),
+                        ("n53m20bb_bf16", 3.518e13, "n53 m20 big-batch slice of 65 536 bitstrings (13 contracted bits")):
+    pm = glob.glob(f"{root}/{leg}_pmc/**/*_counter_collection.csv", recursive=True)
+    ck = glob.glob(f"{root}/{leg}_clk/**/*_counter_collection.csv", recursive=True)
+    if not pm:
+        continue
     def load2(f):
         per = collections.OrderedDict()
         for r in csv.DictReader(open(f)):
@@ -75,8 +78,8 @@ if pm:
     if sb:
         dur = sum(d["t1"] - d["t0"] for d in sb) * 1e-9
         mf = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for d in sb)
-        md += ["## artn_k_pgemm on the n53 m20 big-batch slice (15 contracted bits, bf16 operands packed once, LDS-DMA): PMC counters", "",
-               f"* launches counted: {len(sb)}, {dur / len(sb) * 1e3:.1f} ms each (1.407e14 real FLOP: {1.407e14 / (dur / len(sb)) / 1e12:.0f} TFLOP/s)",
+        md += [f"## artn_k_pgemm on the {what}, bf16 operands packed once, LDS-DMA): PMC counters", "",
+               f"* launches counted: {len(sb)}, {dur / len(sb) * 1e3:.1f} ms each ({flop:.3e} real FLOP: {flop / (dur / len(sb)) / 1e12:.0f} TFLOP/s)",
                f"* SQ_VALU_MFMA_BUSY_CYCLES / (duration x 1024 SIMDs x clock): {mf / (dur * 1024 * (clk or 2.1e9)):.3f} (clock {clk / 1e9:.2f} GHz from GRBM_GUI_ACTIVE)",
                f"* SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: {sum(d.get('SQ_LDS_BANK_CONFLICT', 0) for d in sb) / max(sum(d.get('SQ_LDS_IDX_ACTIVE', 0) for d in sb), 1):.3f}",
                f"* SQ_WAIT_ANY / SQ_WAVE_CYCLES: {sum(d.get('SQ_WAIT_ANY', 0) for d in sb) / sum(d.get('SQ_WAVE_CYCLES', 1) for d in sb):.3f}",
