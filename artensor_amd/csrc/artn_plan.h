@@ -1570,29 +1570,6 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
 #if defined(ARTN_DEV_SWITCHES) && defined(ARTN_DEV_XGPC)
   if (const char *e = getenv("ARTN_XG_PC")) x.pc = (atoi(e) != 0 && x.kc == ARTN_XG_KC && !c128) ? 1 : 0;
 #endif
-  // 16-byte loads of two neighbouring elements (bond dimension 6, 10, 12 ...: half the load instructions, half the address
-  // arithmetic and half the cache-line look-ups of the copy).  Needs the pair to be ADJACENT in memory and 16-byte aligned:
-  // the label the copy lanes start with is the operand's fastest one (stride 1), its extent is even -- pairs never straddle
-  // its end; tiles, chunks and groups are even -- and every other stride of the operand is even (the base pointers are
-  // 16-byte aligned wherever a tiled plan is allowed at all).
-  x.pairs = 0;
-  if (!c128 && x.kc == ARTN_XG_KC) {
-    auto others_even = [&](int which, const Lab *skip) {
-      for (auto *v : {&M, &N, &K, &H})
-        for (auto &l : *v) {
-          if (&l == skip) continue;
-          const bool has = which == 0 ? (v != &N) : (v != &M);
-          const int64_t st = which == 0 ? l.sA : l.sB;
-          if (has && (st & 1)) return false;
-        }
-      return true;
-    };
-    if (x.amode == 0 && !M.empty() && M[0].sA == 1 && (M[0].e & 1) == 0 && others_even(0, &M[0])) x.pairs |= 1;
-    if (x.bmode == 1 && !K.empty() && K[0].sB == 1 && (K[0].e & 1) == 0 && others_even(1, &K[0])) x.pairs |= 2;
-  }
-#ifdef ARTN_DEV_SWITCHES
-  if (const char *e = getenv("ARTN_XG_PAIRS")) x.pairs &= atoi(e);
-#endif
   x.cpg = (x.k.L0 + x.kc - 1) / x.kc;
   x.k_groups = x.k.total / x.k.L0;
   const int64_t chunks = x.k_groups * x.cpg;

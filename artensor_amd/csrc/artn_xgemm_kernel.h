@@ -183,18 +183,6 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
 #endif
   };
 
-  auto ld16 = [&](const char *base, unsigned off) {
-#ifdef XG_ABLATE_MEM
-    f32x4 v;
-    asm volatile("" : "=v"(v) : "s"(base), "v"(off));
-    return v;
-#else
-    return *reinterpret_cast<const f32x4 *>(base + ((unsigned long)off << 3));
-#endif
-  };
-  // (pairs: ArtnXGemmPlan::pairs -- chunks of 16 only; the slot maps of the pair forms are in issue() and fill())
-  const bool apair = KC == 16 && (P.pairs & 1) && amode == 0, bpair = KC == 16 && (P.pairs & 2) && bmode == 1;
-
   auto issue = [&](const XgTile &T, unsigned rs, unsigned cs, bool first_of_tile) {
     if (first_of_tile) { iq = 0; ig = 0; gA = 0; gB = 0; }
     else if (++iq == cpg) {
@@ -210,17 +198,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
     const unsigned ttr = TT + rs * 1024u, ttc = TT + 2048u + cs * 1024u;
     unsigned t = (unsigned)tid;
     OPAQUE_V(t); // (nothing derived from the thread id is hoisted out of the chunk loop: the accumulators need the registers)
-    if (apair) { // rows 2 rp, 2 rp + 1 of one contracted value in ONE 16-byte load: rp = t & 63, kk = (t >> 6) + 4 u  (u < NA / 2)
-      // (the pair starts one element before its odd row: a row pair past the end is clamped to the last VALID pair that way)
-      const unsigned base = T.hA + gA + lds_read4(ttr + 4u * (2u * (t & 63u) + 1u)) - 1u;
-      const unsigned ka = T_KA + 4u * (kbase + (t >> 6));
-#pragma unroll
-      for (int u = 0; u < NA / 2; ++u) {
-        const f32x4 q = ld16(Ac, base + lds_read4(ka + 16u * u));
-        va[2 * u] = v2f_t{q[0], q[1]};
-        va[2 * u + 1] = v2f_t{q[2], q[3]};
-      }
-    } else if (amode == 0) {
+    if (amode == 0) {
       const unsigned base = T.hA + gA + lds_read4(ttr + 4u * (t & 127u));
       const unsigned ka = T_KA + 4u * (kbase + (t >> 7));
 #pragma unroll
@@ -239,15 +217,6 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
       for (int b = 0; b < NB; ++b) cv[b] = lds_read4(cb + 128u * b);
 #pragma unroll
       for (int u = 0; u < NBL; ++u) vb[u] = ld(Bc, (u / NB ? k1 : k0) + cv[u % NB]);
-    } else if (bpair) { // contracted values 2 kp, 2 kp + 1 of one column in ONE 16-byte load: kp = t & 7, col = (t >> 3) + 32 u  (u < NBL / 2)
-      const unsigned base = T.hB + gB + lds_read4(T_KB + 4u * (kbase + 2u * (t & (KC / 2 - 1u)) + 1u)) - 1u;
-      const unsigned cb = ttc + 4u * (t >> (KCL - 1));
-#pragma unroll
-      for (int u = 0; u < NBL / 2; ++u) {
-        const f32x4 q = ld16(Bc, base + lds_read4(cb + 4u * 2u * RSTEP * u));
-        vb[2 * u] = v2f_t{q[0], q[1]};
-        vb[2 * u + 1] = v2f_t{q[2], q[3]};
-      }
     } else {
       const unsigned base = T.hB + gB + lds_read4(T_KB + 4u * (kbase + (t & (KC - 1u))));
       const unsigned cb = ttc + 4u * (t >> KCL);
@@ -264,12 +233,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
     //  v_cndmask per element for EVERY chunk, ~45 vector instructions next to the 48 MFMAs of a chunk, although only one
     //  chunk in cpg is partial: SQ_INSTS_VALU per MFMA 5.2 -> see profiles/r06_xgemm_pmc.md)
     if (!part) {
-      if (apair) {
-        const unsigned d = buf + ((t >> 6) * PA + 2u * (t & 63u)) * 8u;   // (16-byte aligned: PA * 8 = 65 * 16)
-#pragma unroll
-        for (int u = 0; u < NA / 2; ++u)
-          lds_write16(d + (unsigned)u * (4u * PA * 8u), f32x4{va[2 * u].x, va[2 * u].y, va[2 * u + 1].x, va[2 * u + 1].y});
-      } else if (amode == 0) {
+      if (amode == 0) {
         const unsigned d = buf + ((t >> 7) * PA + (t & 127u)) * 8u;
 #pragma unroll
         for (int u = 0; u < NA; ++u) lds_write8(d + (unsigned)u * (2u * PA * 8u), va[u]);
@@ -282,13 +246,6 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
         const unsigned d = buf + A_BYTES + ((t >> 5) * PB + (t & 31u)) * 8u;
 #pragma unroll
         for (int u = 0; u < NBL; ++u) lds_write8(d + (unsigned)(u / NB) * (8u * PB * 8u) + (unsigned)(u % NB) * 256u, vb[u]);
-      } else if (bpair) {
-        const unsigned d = buf + A_BYTES + (2u * (t & (KC / 2 - 1u)) * PB + (t >> (KCL - 1))) * 8u;
-#pragma unroll
-        for (int u = 0; u < NBL / 2; ++u) {
-          lds_write8(d + 8u * 2u * RSTEP * u, vb[2 * u]);
-          lds_write8(d + 8u * 2u * RSTEP * u + PB * 8u, vb[2 * u + 1]);
-        }
       } else {
         const unsigned d = buf + A_BYTES + ((t & (KC - 1u)) * PB + (t >> KCL)) * 8u;
 #pragma unroll
@@ -296,16 +253,7 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
       }
       return;
     }
-    if (apair) {
-      const unsigned d = buf + ((t >> 6) * PA + 2u * (t & 63u)) * 8u;
-      const int kh = (int)(t >> 6);
-#pragma unroll
-      for (int u = 0; u < NA / 2; ++u) {
-        f32x4 v = f32x4{va[2 * u].x, va[2 * u].y, va[2 * u + 1].x, va[2 * u + 1].y};
-        if (kh + 4 * u >= kv) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        lds_write16(d + (unsigned)u * (4u * PA * 8u), v);
-      }
-    } else if (amode == 0) {
+    if (amode == 0) {
       const unsigned d = buf + ((t >> 7) * PA + (t & 127u)) * 8u;
       const int kh = (int)(t >> 7);
 #pragma unroll
@@ -328,14 +276,6 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, (KC == 8 ? 4 : 2)) void artn_k_xge
         v2f_t v = vb[u];
         if (kh + 8 * (u / NB) >= kv) v = v2f_t{0.f, 0.f};
         lds_write8(d + (unsigned)(u / NB) * (8u * PB * 8u) + (unsigned)(u % NB) * 256u, v);
-      }
-    } else if (bpair) {   // (kv is even: a pair is valid or padding as a whole)
-      const unsigned d = buf + A_BYTES + (2u * (t & (KC / 2 - 1u)) * PB + (t >> (KCL - 1))) * 8u;
-      const bool z = (int)(2u * (t & (KC / 2 - 1u))) >= kv;
-#pragma unroll
-      for (int u = 0; u < NBL / 2; ++u) {
-        lds_write8(d + 8u * 2u * RSTEP * u, z ? v2f_t{0.f, 0.f} : vb[2 * u]);
-        lds_write8(d + 8u * 2u * RSTEP * u + PB * 8u, z ? v2f_t{0.f, 0.f} : vb[2 * u + 1]);
       }
     } else {
       const unsigned d = buf + A_BYTES + ((t & (KC - 1u)) * PB + (t >> KCL)) * 8u;

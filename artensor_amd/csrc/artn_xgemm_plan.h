@@ -52,11 +52,7 @@ struct ArtnXGemmPlan {
   int32_t prio;                // 1: the workgroup in the odd wave slots runs its MFMA loops at s_setprio 1
   int32_t kc;                  // contracted values per chunk: 16, or 8 (few contracted values, nb = 1: four workgroups per CU)
   int32_t pc;                  // 1: artn_k_xgemm_pc -- one 8-wave workgroup per CU, four consumer and four producer waves (kc = 16)
-  int32_t c128;                // 1: complex128 operands -- artn_k_xgemm128 (16-byte elements, kc = 8, nb = 1, f64 MFMA)
-  int32_t pairs;               // 16-byte loads of TWO neighbouring elements (round 6; complex64, kc = 16): bit 0 -- the first operand, copy
-                               // lanes along m (amode 0), rows 2r and 2r + 1 adjacent in memory (its fastest label is the innermost label of m, of
-                               // even extent, every other stride even); bit 1 -- the second operand, copy lanes along k (bmode 1), contracted
-                               // values 2q and 2q + 1 adjacent (its fastest label is the innermost contracted label, even extent, other strides even)
+  int32_t c128, pad_;          // 1: complex128 operands -- artn_k_xgemm128 (16-byte elements, kc = 8, nb = 1, f64 MFMA)
   int64_t k_groups;            // k.total / k.L0
   int64_t tiles_m, tiles_n, n_tiles; // n_tiles = tiles_m * tiles_n * prod(h_ext); tile index = (h, tile of m, tile of n), n fastest
 };

@@ -836,43 +836,22 @@ static void run_xgemm(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C)
       const int kvalid = (int)std::min<uint32_t>(K0 - kbase, KC);
       for (auto &x : imgA) x = cf(-777.f, -777.f);
       for (auto &x : imgB) x = cf(-777.f, -777.f);
-      // (round 6) pair forms -- ArtnXGemmPlan::pairs, chunks of 16: ONE 16-byte load of two elements that the planner says are
-      // adjacent in memory; the emulator reads element `off` and element `off + 1` exactly as the kernel does, so a planner
-      // that pairs what is not adjacent shows as wrong results
-      const bool apair = KC == 16 && (P.pairs & 1) && P.amode == 0, bpair = KC == 16 && (P.pairs & 2) && P.bmode == 1;
-      auto ktab = [&](const std::vector<uint32_t> &t, uint32_t k) { return t[k >= K0 ? K0 - 1 : k]; };   // (the padded k tables)
       for (int tid = 0; tid < 256; ++tid) {
-        if (apair) {
-          for (int u = 0; u < TM * KC / 512; ++u) {
-            const int rp = tid & 63, kk = (tid >> 6) + 4 * u;
-            const uint32_t off = hA + gA + rowA[2 * rp + 1] - 1u + ktab(kA, kbase + (uint32_t)kk);
-            const bool z = kk >= kvalid;
-            imgA[(size_t)kk * PA + 2 * rp] = z ? cf(0.f, 0.f) : A[off];
-            imgA[(size_t)kk * PA + 2 * rp + 1] = z ? cf(0.f, 0.f) : A[off + 1u];
-          }
-        } else {
-          for (int u = 0; u < TM * KC / 256; ++u) {
-            int row, kk;
-            if (P.amode) { kk = tid & (KC - 1); row = (tid >> KCL) + RSTEP * u; } else { row = tid & (TM - 1); kk = (tid >> 7) + 2 * u; }
-            const cf v = A[(uint32_t)(hA + gA + rowA[row] + ktab(kA, kbase + (uint32_t)kk))];
-            imgA[(size_t)kk * PA + row] = kk >= kvalid ? cf(0.f, 0.f) : v;
-          }
+        for (int u = 0; u < TM * KC / 256; ++u) {
+          int row, kk;
+          if (P.amode) { kk = tid & (KC - 1); row = (tid >> KCL) + RSTEP * u; } else { row = tid & (TM - 1); kk = (tid >> 7) + 2 * u; }
+          uint32_t kc = kbase + (uint32_t)kk;
+          if (kc >= K0) kc = K0 - 1;
+          const cf v = A[(uint32_t)(hA + gA + rowA[row] + kA[kc])];
+          imgA[(size_t)kk * PA + row] = kk >= kvalid ? cf(0.f, 0.f) : v;
         }
-        if (bpair) {
-          for (int u = 0; u < TN * KC / 512; ++u) {
-            const int kp = tid & 7, col = (tid >> 3) + 32 * u;
-            const uint32_t off = hB + gB + ktab(kB, kbase + 2u * (uint32_t)kp + 1u) - 1u + colB[col];
-            const bool z = 2 * kp >= kvalid;
-            imgB[(size_t)(2 * kp) * PB + col] = z ? cf(0.f, 0.f) : B[off];
-            imgB[(size_t)(2 * kp + 1) * PB + col] = z ? cf(0.f, 0.f) : B[off + 1u];
-          }
-        } else {
-          for (int u = 0; u < TN * KC / 256; ++u) {
-            int col, kk;
-            if (P.bmode) { kk = tid & (KC - 1); col = (tid >> KCL) + RSTEP * u; } else { col = (tid & 31) + 32 * (u % NB); kk = (tid >> 5) + 8 * (u / NB); }
-            const cf v = B[(uint32_t)(hB + gB + colB[col] + ktab(kB, kbase + (uint32_t)kk))];
-            imgB[(size_t)kk * PB + col] = kk >= kvalid ? cf(0.f, 0.f) : v;
-          }
+        for (int u = 0; u < TN * KC / 256; ++u) {
+          int col, kk;
+          if (P.bmode) { kk = tid & (KC - 1); col = (tid >> KCL) + RSTEP * u; } else { col = (tid & 31) + 32 * (u % NB); kk = (tid >> 5) + 8 * (u / NB); }
+          uint32_t kc = kbase + (uint32_t)kk;
+          if (kc >= K0) kc = K0 - 1;
+          const cf v = B[(uint32_t)(hB + gB + colB[col] + kB[kc])];
+          imgB[(size_t)kk * PB + col] = kk >= kvalid ? cf(0.f, 0.f) : v;
         }
       }
       const int trips = (kvalid + 3) >> 2;
@@ -1039,21 +1018,9 @@ extern "C" int artn_emulate_xgemm(const ArtnStepDesc *d, const void *A, const vo
   memset(&p.info, 0, sizeof(p.info));
   if (!artn::make_xgemm(d, p, 256, 1)) return ARTN_E_UNSUPPORTED;
   if (info) *info = p.info;
-  if (modes) { modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; modes[6] = p.xg.kc; modes[7] = p.xg.pairs; }
+  if (modes) { modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; modes[6] = p.xg.kc; }
   if (p.xg.c128) run_xgemm128(p.xg, (const cd *)A, (const cd *)B, (cd *)C);
   else run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
-  return 0;
-}
-
-// planner only: the modes of the extent GEMM's plan for a step (no data touched; benchmark-size descriptors)
-extern "C" int artn_xgemm_plan_modes(const ArtnStepDesc *d, int32_t *modes) {
-  ArtnPlan p;
-  std::string err;
-  int rc = artn::validate(d, err);
-  if (rc) return rc;
-  memset(&p.info, 0, sizeof(p.info));
-  if (!artn::make_xgemm(d, p, 256, 1)) return ARTN_E_UNSUPPORTED;
-  modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; modes[6] = p.xg.kc; modes[7] = p.xg.pairs;
   return 0;
 }
 

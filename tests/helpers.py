@@ -420,7 +420,7 @@ def emulate_xgemm(eq, a, b):
     d, out_shape = C._descriptor(la, lb, lo, tuple(ta.shape), tuple(ta.stride()), tuple(tb.shape), tuple(tb.stride()), ta.dtype)
     out = np.full(out_shape, np.nan + 0j, dtype=a.dtype)
     info = N.ArtnStepInfo()
-    modes = (ctypes.c_int32 * 8)()
+    modes = (ctypes.c_int32 * 7)()
     emu = emulator()
     emu.artn_emulate_xgemm.restype = ctypes.c_int
     # (strided views: the emulator takes the base pointer of the view, like the kernel)
@@ -429,5 +429,5 @@ def emulate_xgemm(eq, a, b):
     if rc == -2:
         return None, None, None
     assert rc == 0, rc
-    names = ("amode", "bmode", "trans", "swapped", "nb", "flush_chunks", "kc", "pairs")
+    names = ("amode", "bmode", "trans", "swapped", "nb", "flush_chunks", "kc")
     return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}, dict(zip(names, modes))

@@ -79,45 +79,6 @@ def test_all_modes_are_covered():
     assert seen["nb"] == {1, 2, 3}
 
 
-def test_sixteen_byte_pair_loads_for_even_innermost_extents():
-    """Round 6 (ArtnXGemmPlan::pairs): an operand whose fastest label is the label its copy lanes start with, of EVEN extent, with
-    every other stride even, is copied two neighbouring elements per 16-byte load -- bit 0: the first operand along m, bit 1:
-    the second operand along k.  The replay reads element `off` and `off + 1` as the kernel does.  Shapes of the
-    bond-dimension-6 network's two big GEMMs (m innermost in A, a contracted label innermost in B), partial tiles and a
-    partial last chunk per group included; odd extents, odd strides and the small-chunk plan keep the single loads."""
-    rng = np.random.default_rng(60)
-    # A [k1, m1, k0, m0] with m0 fastest; B [n0, k1, k0] ... with k0 fastest: pairs on both sides
-    eq = (("k1", "m1", "k0", "m0"), ("n0", "k1", "n1", "k0"), ("n1", "n0", "m1", "m0"))
-    a, b = crandn(rng, (6, 30, 6, 6)), crandn(rng, (6, 6, 7, 6))
-    info, modes = check(eq, a, b)
-    assert modes["kc"] == 16 and modes["pairs"] == 3 and modes["amode"] == 0 and modes["bmode"] == 1, modes
-    # a long group (k0 x k1 = 10 x 6 = 60 = 3 chunks + 12: the partial chunk of a pair form) and rows past the end (M = 6 * 35 = 210)
-    eq = (("m1", "k1", "k0", "m0"), ("n0", "k1", "k0"), ("n0", "m1", "m0"))
-    a, b = crandn(rng, (35, 6, 10, 6)), crandn(rng, (40, 6, 10))
-    info, modes = check(eq, a, b)
-    assert modes["pairs"] == 3, modes
-    # only the first operand qualifies (B's fastest label is a free one: bmode 0)
-    eq = (("k0", "m1", "m0"), ("k0", "n0"), ("m1", "n0", "m0"))
-    a, b = crandn(rng, (36, 40, 4)), crandn(rng, (36, 33))
-    info, modes = check(eq, a, b)
-    assert modes["pairs"] == 1 and modes["bmode"] == 0, modes
-    # batch label, both pairs
-    eq = (("h", "m1", "k1", "k0", "m0"), ("h", "n0", "k1", "k0"), ("h", "n0", "m1", "m0"))
-    a, b = crandn(rng, (3, 70, 4, 12, 2)), crandn(rng, (3, 20, 4, 12))
-    info, modes = check(eq, a, b)
-    assert modes["pairs"] == 3, modes
-    # NOT taken: an odd innermost extent; an even one behind an odd stride of another label (a strided view)
-    eq = (("m1", "k0", "m0"), ("n0", "k0"), ("n0", "m1", "m0"))
-    info, modes = check(eq, crandn(rng, (50, 9, 3)), crandn(rng, (20, 9)))
-    assert modes["pairs"] == 0, modes
-    big = crandn(rng, (50, 6, 7))
-    info, modes = check((("m1", "k0", "m0"), ("n0", "k0"), ("n0", "m1", "m0")), big[:, :, :6], crandn(rng, (20, 6)))
-    assert (modes["pairs"] & 1) == 0, modes        # m0 has extent 6 and stride 1, but k0's stride in the view is 7
-    # few contracted values, one column block: chunks of 8, single loads
-    info, modes = check((("m1", "k0", "m0"), ("n0", "k0"), ("n0", "m1", "m0")), crandn(rng, (64, 6, 6)), crandn(rng, (12, 6)))
-    assert modes["kc"] == 8 and modes["pairs"] == 0, modes
-
-
 def test_long_contraction_flushes_partial_sums():
     """More than 4096 contracted values: the partial sums go through C (read-add-write); one group is not a multiple of 16."""
     rng = np.random.default_rng(7)
