@@ -10,7 +10,7 @@ all: $(LIB)
 # minute and a half instead of four
 SRCS := $(CSRC)/artn_kernels.hip $(CSRC)/artn_gemm_kernel.h $(CSRC)/artn_gemm128_kernel.h $(CSRC)/artn_pgemm_kernel.h $(CSRC)/artn_xgemm128_kernel.h \
         $(CSRC)/artn_bits128_kernel.h $(CSRC)/artn_bits3_kernel.h $(CSRC)/artn_wide_kernel.h $(CSRC)/artn_plan.h \
-        $(CSRC)/artn_xgemm_plan.h $(CSRC)/artn_xgemm_kernel.h $(CSRC)/artn_xgemm_pc_kernel.h include/artn.h
+        $(CSRC)/artn_xgemm_plan.h $(CSRC)/artn_xgemm_kernel.h $(CSRC)/artn_xrow_kernel.h $(CSRC)/artn_xgemm_pc_kernel.h include/artn.h
 OBJDIR := build/obj
 # The product library carries what the default planner can select.  `make dev` (DEV=1) adds the development-only pieces:
 # every ARTN_* planner switch of the A/B measurements in DESIGN.md (-DARTN_DEV_SWITCHES), three-step fusion (artn_k_bits3 /

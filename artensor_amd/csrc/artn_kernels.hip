@@ -1825,6 +1825,7 @@ __global__ __launch_bounds__(2 * ARTN_WG_THREADS, 1) void artn_k_alt(const float
 #include "artn_pgemm_kernel.h"
 #include "artn_xgemm_kernel.h"
 #include "artn_xgemm128_kernel.h"
+#include "artn_xrow_kernel.h"
 #ifdef ARTN_DEV_XGPC
 #include "artn_xgemm_pc_kernel.h"
 #endif
@@ -2951,6 +2952,20 @@ static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, 
   float2 *c = (float2 *)C;
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
   const size_t lds = (size_t)p.info.lds_bytes;
+  if (g.rowmode) { // the row-streaming form: the small operand in registers (1..8 MFMA steps of four contracted values, 1 or 2 column blocks)
+#define ARTN_XROW_LAUNCH(SV)                                                                         \
+  case SV:                                                                                           \
+    if (artn_xrow_nbk(g.n.total) == 1) hipLaunchKernelGGL((artn_k_xrow<SV, 1>), grid, block, lds, st, a, b, c, g); \
+    else hipLaunchKernelGGL((artn_k_xrow<SV, 2>), grid, block, lds, st, a, b, c, g);                   \
+    break;
+    switch (artn_xrow_steps(g.k.total)) {
+      ARTN_XROW_LAUNCH(1) ARTN_XROW_LAUNCH(2) ARTN_XROW_LAUNCH(3) ARTN_XROW_LAUNCH(4)
+      ARTN_XROW_LAUNCH(5) ARTN_XROW_LAUNCH(6) ARTN_XROW_LAUNCH(7) ARTN_XROW_LAUNCH(8)
+      default: return hipErrorInvalidValue;
+    }
+#undef ARTN_XROW_LAUNCH
+    return hipGetLastError();
+  }
 #define ARTN_XGEMM_LAUNCH(NBV, TRV)                                                                  \
   {                                                                                                  \
     auto kern = artn_k_xgemm<NBV, TRV>;                                                              \

@@ -225,6 +225,7 @@ struct Tuning {
                       // phases at raised priority (with 3M stages +1 % on n30, A/B in one session: 57.7 -> 57.1 ms; 2: copy only)
   int split = 0;      // complex64 chains: 0 fp32 MFMA, 3 fp32-grade split-bf16 MFMA
   int nt = 1;         // non-temporal loads of A tiles that are read once
+  int xrow = 1;       // the row-streaming form of the extent GEMM (artn_k_xrow; ARTN_XROW=0: artn_k_xgemm for those steps too)
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
   int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
   int gemm_tall = 1;  // GEMM kernel, fp32, 32 x 32 tiles: chunks of 2^6 contracted values
@@ -278,6 +279,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_WIDE")) x.wide = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("ARTN_WIDE_MIN_TILES")) x.wide_min_tiles = atoi(e);
     if (const char *e = getenv("ARTN_XGEMM")) x.xgemm = atoi(e) != 0;
+    if (const char *e = getenv("ARTN_XROW")) x.xrow = atoi(e);
 #ifdef ARTN_DEV_SWITCHES
     if (const char *e = getenv("ARTN_WG_PER_CU")) x.wg_per_cu = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_TILE_TARGET")) x.tile_target = std::min(ARTN_TILE_BITS_MAX, std::max(9, atoi(e)));
@@ -1580,6 +1582,20 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   x.tiles_n = (x.n.total + 32 * x.nb - 1) / (32 * x.nb);
   x.n_tiles = x.tiles_m * x.tiles_n * hprod;
   if (x.n_tiles >= lim) { p.why_generic = "extent GEMM: too many tiles"; return false; }
+  // the row-streaming form (artn_k_xrow): a handful of contracted values into a handful of columns on very many rows, the lanes
+  // of a store along rows; buffer instructions with 32-bit byte offsets: tensors below 4 GiB
+  {
+    const int64_t span_first = x.swapped ? spanB : spanA, row_lim = (int64_t(1) << 29) - 2;
+    const int64_t l2 = x.m.total / ((int64_t)x.m.L0 * x.m.L1);
+    // (measured on the bond-dimension-3 network, gpurun_out/s_r6s: 9 -> 9 on 3^16 rows 2.34 -> 2.02 ms, 27 -> 27 on 3^13 rows
+    //  0.38 -> 0.22 ms, but 27 -> 27 on 3^15 rows 1.70 -> 2.10 ms -- 84 MFMAs per 16 rows at four waves per SIMD no longer hide
+    //  under the loads: blocks of more than 16 x 16 stay with artn_k_xgemm from 2^22 rows on; ARTN_XROW=2: wherever it fits)
+    const bool pays = (x.k.total <= 16 && x.n.total <= 16) || x.m.total < (int64_t(1) << 22) || tuning().xrow == 2;
+    x.rowmode = (!c128 && x.n_h == 0 && x.trans == 0 && x.k.total <= ARTN_XROW_MAX && x.n.total <= ARTN_XROW_MAX &&
+                 x.m.total >= ARTN_XROW_MIN_ROWS && l2 <= ARTN_XROW_L2_MAX && span_first <= row_lim && spanC <= row_lim && tuning().xrow && pays) ? 1 : 0;
+    x.row_bytes_a = x.rowmode ? (uint32_t)(8 * span_first) : 0;
+    x.row_bytes_c = x.rowmode ? (uint32_t)(8 * spanC) : 0;
+  }
   p.kernel = ARTN_KERNEL_XGEMM;
   ArtnStepInfo &I = p.info;
   I.kernel = ARTN_KERNEL_XGEMM;
@@ -1590,6 +1606,14 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   I.n_tiles = x.n_tiles;
   I.grid = (int32_t)std::min<int64_t>(x.n_tiles, (int64_t)n_cu * (c128 ? 2 : (x.pc ? 1 : (x.kc == 8 ? 4 : 2))));
   I.a_rereads = x.tiles_n;
+  if (x.rowmode) { // 16-row blocks dealt round-robin to the waves of n_cu x (waves per SIMD the instantiation's registers allow) workgroups
+    const int S = artn_xrow_steps(x.k.total), NBK = artn_xrow_nbk(x.n.total);
+    I.m_tile_bits = 4;
+    I.lds_bytes = artn_xrow_lds_bytes(x.m.total / ((int64_t)x.m.L0 * x.m.L1));
+    I.n_tiles = (x.m.total + 15) / 16;
+    I.grid = (int32_t)std::min<int64_t>((I.n_tiles + 3) / 4, (int64_t)n_cu * artn_xrow_waves(S, NBK));
+    I.a_rereads = 1;
+  }
   return true;
 }
 

@@ -24,6 +24,9 @@
 #define ARTN_XG_LEVEL 256 /* entries of one level table */
 #define ARTN_XG_KTAB (ARTN_XG_LEVEL + ARTN_XG_KC) /* the k tables are padded by one chunk: no clamping in the copy loop */
 #define ARTN_XG_FLUSH 4096 /* contracted values per fp32 partial sum (as ARTN_GEMM_FLUSH_LOG2) */
+#define ARTN_XROW_MAX 32      /* artn_k_xrow: contracted values, and columns, of the small operand */
+#define ARTN_XROW_MIN_ROWS (1 << 15)
+#define ARTN_XROW_L2_MAX 4096 /* entries of the third level of its row-offset tables (what the two 256-entry levels leave of the row index) */
 
 // One flattened index: labels innermost first, each with its extent and its element stride in the two tensors that
 // carry it (m: A and C; n: B and C; k: A and B).
@@ -52,7 +55,10 @@ struct ArtnXGemmPlan {
   int32_t prio;                // 1: the workgroup in the odd wave slots runs its MFMA loops at s_setprio 1
   int32_t kc;                  // contracted values per chunk: 16, or 8 (few contracted values, nb = 1: four workgroups per CU)
   int32_t pc;                  // 1: artn_k_xgemm_pc -- one 8-wave workgroup per CU, four consumer and four producer waves (kc = 16)
-  int32_t c128, pad_;          // 1: complex128 operands -- artn_k_xgemm128 (16-byte elements, kc = 8, nb = 1, f64 MFMA)
+  int32_t c128;                // 1: complex128 operands -- artn_k_xgemm128 (16-byte elements, kc = 8, nb = 1, f64 MFMA)
+  int32_t rowmode;             // 1 (round 6): artn_k_xrow -- the row-streaming form (artn_xrow_kernel.h): at most 32 contracted values and 32
+                               //    columns, the small operand in registers, rows straight into the MFMA operand registers, no LDS staging
+  uint32_t row_bytes_a, row_bytes_c; // rowmode: bytes spanned by the kernel's first operand and by the result (buffer range checks)
   int64_t k_groups;            // k.total / k.L0
   int64_t tiles_m, tiles_n, n_tiles; // n_tiles = tiles_m * tiles_n * prod(h_ext); tile index = (h, tile of m, tile of n), n fastest
 };
@@ -67,6 +73,20 @@ static inline int artn_xg_lds_bytes(int nb, int kc) { return 2 * artn_xg_stage_b
 // complex128 (artn_k_xgemm128): 16-byte elements, chunks of 8 contracted values, nb = 1
 static inline int artn_xg128_lds_bytes(int nb) { return 2 * 8 * (artn_xg_pitch_a() + artn_xg_pitch_b(nb)) * 16 + artn_xg_level_bytes() + 2 * artn_xg_tiletab_bytes(); }
 static inline int artn_xg_pc_lds_bytes(int nb) { return 2 * artn_xg_stage_bytes(nb, ARTN_XG_KC) + artn_xg_level_bytes() + 8 * 1024; } // four row + four column table sets
+
+// artn_k_xrow: MFMA steps of four contracted values, column blocks of 16, prefetch distance in 16-row blocks, waves per SIMD
+// -- kernel, launcher, planner, emulator
+static inline constexpr int artn_xrow_steps(int64_t k_total) { return (int)((k_total + 3) / 4); }
+static inline constexpr int artn_xrow_nbk(int64_t n_total) { return n_total <= 16 ? 1 : 2; }
+#ifdef ARTN_XROW_DEEP /* development builds: two blocks ahead for the largest fragments too */
+static inline constexpr int artn_xrow_depth(int S) { return S <= 2 ? 4 : (S <= 4 ? 3 : 2); }
+#else
+static inline constexpr int artn_xrow_depth(int S) { return S <= 2 ? 4 : (S <= 4 ? 3 : (S <= 6 ? 2 : 1)); }
+#endif
+static inline constexpr int artn_xrow_waves(int S, int NBK) { // (what hipcc's register counts of the sixteen instantiations allow: 48 ... 125)
+  return NBK == 1 ? (S <= 2 ? 8 : (S <= 3 ? 6 : (S <= 6 ? 5 : 6))) : (S <= 1 ? 6 : (S <= 2 ? 5 : 4));
+}
+static inline int artn_xrow_lds_bytes(int64_t L2) { return 4096 + 8 * (int)L2; } // three levels of (A, C) byte offsets of a row
 
 // Mixed-radix decode of `idx` over labels [first, first + count) of a side: the two element offsets.
 #if defined(__HIPCC__)
@@ -85,6 +105,26 @@ ARTN_XG_HD void artn_xg_decode(const ArtnXSide &S, int first, int count, uint32_
   }
   o0 = a;
   o1 = b;
+}
+
+// artn_k_xrow: a row's position in the three levels of the row index (level 0 fastest) and its advance by a fixed stride
+// without a division: `d` is the stride's own position (d.i0 < L0, d.i1 < L1); i2 is left to grow past its level (rows past the
+// end: the kernel clamps the table read and stores nothing).
+struct ArtnXRowPos { uint32_t i0, i1, i2; };
+ARTN_XG_HD void artn_xrow_place(uint32_t m, uint32_t L0, uint32_t L1, ArtnXRowPos &p) {
+  const uint32_t q0 = m / L0;
+  p.i0 = m - q0 * L0;
+  p.i2 = q0 / L1;
+  p.i1 = q0 - p.i2 * L1;
+}
+ARTN_XG_HD void artn_xrow_advance(ArtnXRowPos &p, const ArtnXRowPos &d, uint32_t L0, uint32_t L1) {
+  p.i0 += d.i0;
+  uint32_t c = p.i0 >= L0 ? 1u : 0u;
+  p.i0 -= c ? L0 : 0u;
+  p.i1 += d.i1 + c;
+  c = p.i1 >= L1 ? 1u : 0u;
+  p.i1 -= c ? L1 : 0u;
+  p.i2 += d.i2 + c;
 }
 
 #endif

@@ -894,6 +894,72 @@ static void run_xgemm(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C)
   }
 }
 
+// ---- artn_k_xrow (artn_xrow_kernel.h): the row-streaming form, replayed lane by lane -- the wave's contiguous range of 16-row
+// blocks, the lane's row (clamped past the end: loads the last row, stores nothing), the small operand's fragments (zero
+// outside its extents), the three products of every v_mfma_f32_16x16x4_f32 step summed over its four contracted values in
+// order, accumulator register r of lane (j, g) <-> column 16 blk + 4 g + r of row 16 b + j, the predicated stores.
+static void run_xrow(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C, int grid) {
+  // artn_k_xrow wave by wave: three levels of (A, C) BYTE offsets, the launch's round-robin deal of 16-row blocks with the XCD
+  // swizzle, positions advanced by artn_xrow_advance (the kernel's own function), buffer range checks (offset 0xffffffff: dropped)
+  const cf *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
+  const uint32_t Mtot = (uint32_t)P.m.total, Ktot = (uint32_t)P.k.total, Ntot = (uint32_t)P.n.total;
+  const int S = artn_xrow_steps(P.k.total), NBK = artn_xrow_nbk(P.n.total), D = artn_xrow_depth(S);
+  if (S < 1 || S > 8 || (int)Ntot > 16 * NBK) abort();
+  const uint32_t L0 = (uint32_t)P.m.L0, L1 = (uint32_t)P.m.L1, L2 = Mtot / (L0 * L1);
+  if ((uint64_t)L0 * L1 * L2 != Mtot || L2 > ARTN_XROW_L2_MAX) abort();
+  std::vector<uint32_t> t0(2 * 256), t1(2 * 256), t2(2 * (size_t)L2);
+  for (uint32_t i = 0; i < L0; ++i) { uint32_t a, c; artn_xg_decode(P.m, 0, P.m.n0, i, a, c); t0[2 * i] = a << 3; t0[2 * i + 1] = c << 3; }
+  for (uint32_t i = 0; i < L1; ++i) { uint32_t a, c; artn_xg_decode(P.m, P.m.n0, P.m.n1, i, a, c); t1[2 * i] = a << 3; t1[2 * i + 1] = c << 3; }
+  for (uint32_t i = 0; i < L2; ++i) { uint32_t a, c; artn_xg_decode(P.m, P.m.n0 + P.m.n1, P.m.n_lab - P.m.n0 - P.m.n1, i, a, c); t2[2 * i] = a << 3; t2[2 * i + 1] = c << 3; }
+  const uint32_t n_blocks = (Mtot + 15) >> 4, per_it = 4u * (uint32_t)grid;
+  const uint32_t n_it = ((n_blocks + per_it - 1) / per_it + (uint32_t)D) / (uint32_t)(D + 1) * (uint32_t)(D + 1);
+  auto loadA = [&](uint32_t off) -> cf { return off > P.row_bytes_a - 8u ? cf(0.f, 0.f) : A[off >> 3]; };
+  for (uint32_t blockIdx = 0; blockIdx < (uint32_t)grid; ++blockIdx)
+    for (uint32_t wave = 0; wave < 4; ++wave)
+      for (int lane = 0; lane < 64; ++lane) {
+        const uint32_t j = (uint32_t)lane & 15, g = (uint32_t)lane >> 4;
+        const uint32_t wg = (uint32_t)grid % 8u == 0u ? (blockIdx % 8u) * ((uint32_t)grid / 8u) + blockIdx / 8u : blockIdx;
+        uint32_t m = 16u * (4u * wg + wave) + j;
+        ArtnXRowPos pos, step;
+        artn_xrow_place(m < Mtot ? m : Mtot - 1u, L0, L1, pos);
+        artn_xrow_place(16u * per_it, L0, L1, step);
+        for (uint32_t it = 0; it < n_it + (uint32_t)D; ++it) { // (the kernel issues D blocks' loads past its last multiply)
+          const uint32_t i2 = pos.i2 < L2 ? pos.i2 : L2 - 1u;
+          if (pos.i0 >= L0 || pos.i1 >= L1) abort();
+          const uint32_t ra = t0[2 * pos.i0] + t1[2 * pos.i1] + t2[2 * i2];
+          uint32_t rc = t0[2 * pos.i0 + 1] + t1[2 * pos.i1 + 1] + t2[2 * i2 + 1];
+          if (m >= Mtot) rc = 0xffffffffu;
+          else { // the tables and the carries agree with the plain decode of the row
+            uint32_t ea, ec;
+            artn_xg_decode(P.m, 0, P.m.n_lab, m, ea, ec);
+            if ((ea << 3) != ra || (ec << 3) != rc) abort();
+          }
+          if (it < n_it)
+            for (int blk = 0; blk < NBK; ++blk)
+              for (int r = 0; r < 4; ++r) {
+                const uint32_t n = 16u * (uint32_t)blk + 4 * g + (uint32_t)r;
+                uint32_t nB, nC;
+                artn_xg_decode(P.n, 0, P.n.n_lab, n < Ntot ? n : 0, nB, nC);
+                float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                for (uint32_t k = 0; k < 4u * (uint32_t)S; ++k) {
+                  uint32_t kA, kB;
+                  artn_xg_decode(P.k, 0, P.k.n_lab, k < Ktot ? k : Ktot - 1, kA, kB);
+                  const cf w = (k < Ktot && n < Ntot) ? B[nB + kB] : cf(0.f, 0.f);
+                  const cf x = loadA(ra + (kA << 3));
+                  s1 += w.real() * x.real();
+                  s2 += w.imag() * x.imag();
+                  s3 += (w.real() + w.imag()) * (x.real() + x.imag());
+                }
+                const uint32_t off = (rc != 0xffffffffu && n < Ntot) ? rc + (nC << 3) : 0xffffffffu;
+                if (off <= P.row_bytes_c - 8u) C[off >> 3] = cf(s1 - s2, s3 - s1 - s2);
+                else if (off != 0xffffffffu) abort(); // (a row and column that exist lie inside the result)
+              }
+          m += 16u * per_it;
+          artn_xrow_advance(pos, step, L0, L1);
+        }
+      }
+}
+
 // artn_k_xgemm128: the same walk with 16-byte elements, chunks of 8, and the lane / accumulator map of v_mfma_f64_16x16x4_f64
 // (wave w: rows 32 w + 16 a + j, a = 0, 1; blocks b of 8 complex columns; lane (j, g): W row 2 n_in + ro with j = 2 n_in + ro,
 // contracted value 2 s + (g >> 1), component p = g & 1; accumulator register r: component g & 1 of column (g >> 1) + 2 r).
@@ -1019,7 +1085,9 @@ extern "C" int artn_emulate_xgemm(const ArtnStepDesc *d, const void *A, const vo
   if (!artn::make_xgemm(d, p, 256, 1)) return ARTN_E_UNSUPPORTED;
   if (info) *info = p.info;
   if (modes) { modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; modes[6] = p.xg.kc; }
+  if (modes) modes[7] = p.xg.rowmode;
   if (p.xg.c128) run_xgemm128(p.xg, (const cd *)A, (const cd *)B, (cd *)C);
+  else if (p.xg.rowmode) run_xrow(p.xg, (const cf *)A, (const cf *)B, (cf *)C, p.info.grid);
   else run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
   return 0;
 }

@@ -71,7 +71,8 @@ def emulator():
             os.path.join(ROOT, "artensor_amd", "csrc", "artn_gemm128_kernel.h"),
             os.path.join(ROOT, "artensor_amd", "csrc", "artn_pgemm_kernel.h"),
             os.path.join(ROOT, "artensor_amd", "csrc", "artn_xgemm_plan.h"),
-            os.path.join(ROOT, "artensor_amd", "csrc", "artn_xgemm_kernel.h")]
+            os.path.join(ROOT, "artensor_amd", "csrc", "artn_xgemm_kernel.h"),
+            os.path.join(ROOT, "artensor_amd", "csrc", "artn_xrow_kernel.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "artensor_amd", "csrc"), src, "-o", so])
@@ -420,7 +421,7 @@ def emulate_xgemm(eq, a, b):
     d, out_shape = C._descriptor(la, lb, lo, tuple(ta.shape), tuple(ta.stride()), tuple(tb.shape), tuple(tb.stride()), ta.dtype)
     out = np.full(out_shape, np.nan + 0j, dtype=a.dtype)
     info = N.ArtnStepInfo()
-    modes = (ctypes.c_int32 * 7)()
+    modes = (ctypes.c_int32 * 8)()
     emu = emulator()
     emu.artn_emulate_xgemm.restype = ctypes.c_int
     # (strided views: the emulator takes the base pointer of the view, like the kernel)
@@ -429,5 +430,5 @@ def emulate_xgemm(eq, a, b):
     if rc == -2:
         return None, None, None
     assert rc == 0, rc
-    names = ("amode", "bmode", "trans", "swapped", "nb", "flush_chunks", "kc")
+    names = ("amode", "bmode", "trans", "swapped", "nb", "flush_chunks", "kc", "rowmode")
     return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}, dict(zip(names, modes))

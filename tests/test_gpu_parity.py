@@ -884,6 +884,38 @@ def _einsum128_labels(eq, a, b):
                      a.astype(np.complex128), b.astype(np.complex128))
 
 
+def test_row_streaming_form_of_the_extent_gemm():
+    """artn_k_xrow (round 6): a handful of contracted values into a handful of columns on 2^15+ rows -- every count of MFMA
+    steps (1..8 x four contracted values), one and two column blocks, rows that end inside a block, the contracted labels
+    inside / outside the row labels of the operand -- against complex128 einsums; and ARTN_XROW=0 plans no such launch."""
+    rng = np.random.default_rng(2026)
+    cases = 0
+    for kk, nn in ((1, 3), (3, 3), (5, 16), (9, 9), (12, 5), (16, 27), (17, 2), (21, 32), (24, 7), (27, 27), (29, 17), (32, 32)):
+        for form in range(2):
+            rows = max(int(rng.integers(1 << 15, 3 << 15)), (1 << 21) // (kk * nn) + 1000)   # (8 x rows x kk x nn >= 2^24: a tiled launch)
+            m0 = int(rng.integers(180, 250))   # (the third level of the row-offset tables takes up to 4 096 values)
+            m1 = -(-rows // m0)
+            if form == 0:   # contracted label slowest in the operand: rows contiguous
+                eq, sa, sb = (("k", "m1", "m0"), ("n", "k"), ("n", "m1", "m0")), (kk, m1, m0), (nn, kk)
+            else:           # contracted label fastest: neighbouring rows kk elements apart
+                eq, sa, sb = (("m1", "m0", "k"), ("k", "n"), ("n", "m1", "m0")), (m1, m0, kk), (kk, nn)
+            info = A.step_info(eq, sa, sb)
+            assert info["kernel"] == KERNEL_XGEMM and info["m_tile_bits"] == 4, (kk, nn, form, info)   # 16-row blocks: the row-streaming form
+            a, b = crandn(rng, sa), crandn(rng, sb)
+            got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
+            want = _einsum128_labels(eq, a, b)
+            assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (kk, nn, form)
+            cases += 1
+    assert cases == 24
+    # bond dimension 3 with the contracted labels between the row labels, all three levels of the row-offset tables in use
+    eq = (tuple("abcdKefgLhijk"), ("x", "K", "L", "y"), ("y", "x") + tuple("abcdefghijk"))
+    a, b = crandn(rng, (3,) * 13), crandn(rng, (3,) * 4)
+    assert A.step_info(eq, a.shape, b.shape)["m_tile_bits"] == 4
+    got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
+    want = _einsum128_labels(eq, a, b)
+    assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max()
+
+
 def test_non_power_of_two_extents_on_the_matrix_cores():
     """artn_k_xgemm (round 5): steps whose labels have extents that are not powers of two -- bond dimension 3, 5, 6, 7:
     the reference's einsum (contraction.py:70) takes any bond_dims (tensor_network.py:4-30) -- against complex128 einsums:

@@ -79,6 +79,49 @@ def test_all_modes_are_covered():
     assert seen["nb"] == {1, 2, 3}
 
 
+def test_row_streaming_form_for_small_blocks_on_many_rows():
+    """Round 6 (artn_k_xrow, ArtnXGemmPlan::rowmode): at most 32 contracted values into at most 32 columns on 2^15+ rows, lanes
+    along rows in the first operand and the result, no batch label -- the small operand in registers, rows straight into the
+    MFMA operand registers, 16-row blocks dealt round-robin to the waves, three levels of row-offset tables, buffer loads and
+    stores.  The 9 x 9 and 27 x 27 blocks of the bond-dimension-3 network (rows past the end, an odd count of contracted
+    values), all three table levels in use, a mixed-extent step; declined: a batch label, a result whose fastest label is a
+    column, few rows, more than 4 096 values left for the third level."""
+    rng = np.random.default_rng(70)
+    # 9 contracted values, 9 columns, 3^10 - style rows (label order as the network's: row labels fastest in A and C)
+    eq = (("k1", "m2", "k0", "m1", "m0"), ("n0", "k1", "k0", "n1"), ("n1", "n0", "m2", "m1", "m0"))
+    a, b = crandn(rng, (3, 150, 3, 27, 9)), crandn(rng, (3, 3, 3, 3))
+    info, modes = check(eq, a, b)
+    assert modes["rowmode"] == 1 and info["n_tiles"] == -(-150 * 27 * 9 // 16), (modes, info["n_tiles"])
+    # eleven row labels of extent 3 (243 x 243 x 3 rows: every level of the tables carries), 9 -> 9 with the contracted labels inside
+    eq = (tuple("abcdKefgLhijk"), ("x", "K", "L", "y"), ("y", "x") + tuple("abcdefghijk"))
+    info, modes = check(eq, crandn(rng, (3,) * 13), crandn(rng, (3,) * 4))
+    assert modes["rowmode"] == 1 and info["lds_bytes"] == 4096 + 8 * 3, (modes, info)
+    # 27 -> 27: 7 MFMA steps of four contracted values in registers (the last one holds three), two column blocks, 36 000 rows
+    eq = (("k0", "m1", "m0"), ("k0", "n0"), ("n0", "m1", "m0"))
+    a, b = crandn(rng, (27, 1125, 32)), crandn(rng, (27, 27))
+    info, modes = check(eq, a, b)
+    assert modes["rowmode"] == 1, modes
+    # mixed extents, 5 x 6 = 30 contracted values, 7 columns, a row count that is not a multiple of 32
+    eq = (("k1", "m1", "k0", "m0"), ("k0", "n0", "k1"), ("n0", "m1", "m0"))
+    a, b = crandn(rng, (5, 4001, 6, 9)), crandn(rng, (6, 7, 5))
+    info, modes = check(eq, a, b)
+    assert modes["rowmode"] == 1, modes
+    # NOT taken: the result's fastest label is a column (lanes of a store would not run along rows) ...
+    eq = (("k0", "m1", "m0"), ("k0", "n0"), ("m1", "m0", "n0"))
+    info, modes = check(eq, crandn(rng, (9, 1200, 30)), crandn(rng, (9, 9)))
+    assert modes["rowmode"] == 0, modes
+    # ... a batch label; too few rows; more than 32 columns
+    info, modes = check((("h", "k0", "m1", "m0"), ("h", "k0", "n0"), ("h", "n0", "m1", "m0")), crandn(rng, (2, 9, 1200, 30)), crandn(rng, (2, 9, 9)))
+    assert modes["rowmode"] == 0, modes
+    info, modes = check((("k0", "m1", "m0"), ("k0", "n0"), ("n0", "m1", "m0")), crandn(rng, (9, 100, 30)), crandn(rng, (9, 9)))
+    assert modes["rowmode"] == 0, modes
+    info, modes = check((("k0", "m1", "m0"), ("k0", "n0"), ("n0", "m1", "m0")), crandn(rng, (9, 1200, 30)), crandn(rng, (9, 33)))
+    assert modes["rowmode"] == 0, modes
+    # ... a row index that leaves more than 4 096 values to the third level of the offset tables (2 x 5 000 above one level of 7)
+    info, modes = check((("k0", "m2", "m1", "m0"), ("k0", "n0"), ("n0", "m2", "m1", "m0")), crandn(rng, (3, 2, 5000, 7)), crandn(rng, (3, 3)))
+    assert modes["rowmode"] == 0, modes
+
+
 def test_long_contraction_flushes_partial_sums():
     """More than 4096 contracted values: the partial sums go through C (read-add-write); one group is not a multiple of 16."""
     rng = np.random.default_rng(7)
@@ -125,7 +168,12 @@ def test_planner_sends_non_power_of_two_steps_to_the_extent_gemm():
     la = tuple(range(20))
     lo = tuple(20 if x == 3 else (21 if x == 11 else x) for x in la)
     big = step_info((la, (3, 11, 20, 21), lo), (3,) * 20, (3,) * 4)
+    # (9 contracted values into 9 columns on 3^18 rows; NOT the row-streaming form, whose buffer offsets are 32-bit BYTES)
     assert big["kernel"] == KERNEL_XGEMM and big["n_tiles"] == -(-3 ** 18 // 128), big
+    la = tuple(range(18))
+    lo = (18, 19) + tuple(x for x in la if x not in (3, 11))
+    rows = step_info((la, (3, 11, 18, 19), lo), (3,) * 18, (3,) * 4)   # the benchmark network's own size: 3.1 GB tensors
+    assert rows["kernel"] == KERNEL_XGEMM and rows["n_tiles"] == -(-3 ** 16 // 16), rows
     la = tuple(range(21))
     lo = tuple(30 if x == 3 else (31 if x == 11 else x) for x in la)
     huge = step_info((la, (3, 11, 30, 31), lo), (3,) * 21, (3,) * 4)
