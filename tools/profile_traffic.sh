@@ -9,7 +9,7 @@ R=${1:-r05}
 OUT=gpurun_out/traffic_$R
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-for spec in n30:3 n30_sparse10000:2 n53:5 n53m20b:1 n53m20b_bf16:1 n53m20bb:1 n53m20bb_bf16:1 n53m20:3 rand2:5 rand4:3 rand3:3 rand6:3 n30_c128:2 n30_sliced3:8; do
+for spec in ${LEGS:-n30:3 n30_sparse10000:2 n53:5 n53m20b:1 n53m20b_bf16:1 n53m20bb:1 n53m20bb_bf16:1 n53m20:3 rand2:5 rand4:3 rand3:3 rand6:3 n30_c128:2 n30_sliced3:8}; do
   leg=${spec%%:*}; units=${spec##*:}
   mkdir -p $OUT/$leg
   echo $units > $OUT/$leg/units

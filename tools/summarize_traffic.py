@@ -24,6 +24,8 @@ def family(name):
         return "pgemm"         # packing passes + the packed GEMM: one artn_contract_ws call
     if "artn_k_xgemm" in name:
         return "xgemm"         # the extent-based GEMM (non power-of-two extents)
+    if "artn_k_xrow" in name:
+        return "xrow"          # ... its row-streaming form (round 6)
     if "artn_k_gemm" in name:
         return "gemm"          # artn_k_gemm, artn_k_gemm_deep, artn_k_gemm128
     if "artn_k_program" in name:
