@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 #include "artn_plan.h"
 
@@ -2945,6 +2946,27 @@ static hipError_t launch_xgemm128(const ArtnPlan &p, const void *A, const void *
   }
   return hipGetLastError();
 }
+// chunks of 16 contracted values: one of the six (blocks per tile, operand roles) instantiations
+static hipError_t launch_xgemm16(const ArtnXGemmPlan &g, int n_wg, size_t lds, const float2 *a, const float2 *b, float2 *c, hipStream_t st) {
+  dim3 grid(n_wg), block(ARTN_WG_THREADS);
+#define ARTN_XGEMM_LAUNCH(NBV, TRV)                                                                  \
+  {                                                                                                  \
+    auto kern = artn_k_xgemm<NBV, TRV>;                                                              \
+    if (hipError_t e = ensure_lds<artn_k_xgemm<NBV, TRV>>(lds); e != hipSuccess) return e;           \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
+    return hipGetLastError();                                                                        \
+  }
+  switch (g.nb * 2 + (g.trans ? 1 : 0)) {
+    case 2: ARTN_XGEMM_LAUNCH(1, false)
+    case 3: ARTN_XGEMM_LAUNCH(1, true)
+    case 4: ARTN_XGEMM_LAUNCH(2, false)
+    case 5: ARTN_XGEMM_LAUNCH(2, true)
+    case 6: ARTN_XGEMM_LAUNCH(3, false)
+    case 7: ARTN_XGEMM_LAUNCH(3, true)
+  }
+#undef ARTN_XGEMM_LAUNCH
+  return hipErrorInvalidValue;
+}
 static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, void *C, hipStream_t st) {
   const ArtnXGemmPlan &g = p.xg;
   if (g.c128) return launch_xgemm128(p, A, B, C, st);
@@ -2965,13 +2987,6 @@ static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, 
     }
 #undef ARTN_XROW_LAUNCH
     return hipGetLastError();
-  }
-#define ARTN_XGEMM_LAUNCH(NBV, TRV)                                                                  \
-  {                                                                                                  \
-    auto kern = artn_k_xgemm<NBV, TRV>;                                                              \
-    if (hipError_t e = ensure_lds<artn_k_xgemm<NBV, TRV>>(lds); e != hipSuccess) return e;           \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, a, b, c, g);                                      \
-    return hipGetLastError();                                                                        \
   }
 #ifdef ARTN_DEV_XGPC
   if (g.pc) { // one 8-wave workgroup per CU: four consumer waves (MFMAs, epilogue), four producer waves (tables, loads, LDS fills)
@@ -3010,16 +3025,12 @@ static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, 
     }
     return hipGetLastError();
   }
-  switch (g.nb * 2 + (g.trans ? 1 : 0)) {
-    case 2: ARTN_XGEMM_LAUNCH(1, false)
-    case 3: ARTN_XGEMM_LAUNCH(1, true)
-    case 4: ARTN_XGEMM_LAUNCH(2, false)
-    case 5: ARTN_XGEMM_LAUNCH(2, true)
-    case 6: ARTN_XGEMM_LAUNCH(3, false)
-    case 7: ARTN_XGEMM_LAUNCH(3, true)
+  if (hipError_t e = launch_xgemm16(g, p.info.grid, lds, a, b, c, st); e != hipSuccess) return e;
+  if (g.tail_nb) { // the columns behind the full column tiles: a second launch of the instantiation they need (artn_xg_tail_plan)
+    const ArtnXGemmPlan t = artn_xg_tail_plan(g);
+    return launch_xgemm16(t, g.tail_grid, (size_t)g.tail_lds, a, b, c, st);
   }
-#undef ARTN_XGEMM_LAUNCH
-  return hipErrorInvalidValue;
+  return hipSuccess;
 }
 
 static hipError_t launch_gemm(const ArtnPlan &p, const void *A, const void *B, void *C, hipStream_t st) {

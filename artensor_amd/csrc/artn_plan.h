@@ -225,6 +225,7 @@ struct Tuning {
                       // phases at raised priority (with 3M stages +1 % on n30, A/B in one session: 57.7 -> 57.1 ms; 2: copy only)
   int split = 0;      // complex64 chains: 0 fp32 MFMA, 3 fp32-grade split-bf16 MFMA
   int nt = 1;         // non-temporal loads of A tiles that are read once
+  int xg_tail = 1;    // extent GEMM: the columns behind the full column tiles as a second, narrower launch (ARTN_XG_TAIL=0: one padded launch)
   int xrow = 1;       // the row-streaming form of the extent GEMM (artn_k_xrow; ARTN_XROW=0: artn_k_xgemm for those steps too)
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
   int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
@@ -280,6 +281,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_WIDE_MIN_TILES")) x.wide_min_tiles = atoi(e);
     if (const char *e = getenv("ARTN_XGEMM")) x.xgemm = atoi(e) != 0;
     if (const char *e = getenv("ARTN_XROW")) x.xrow = atoi(e);
+    if (const char *e = getenv("ARTN_XG_TAIL")) x.xg_tail = atoi(e) != 0;
 #ifdef ARTN_DEV_SWITCHES
     if (const char *e = getenv("ARTN_WG_PER_CU")) x.wg_per_cu = std::max(1, atoi(e));
     if (const char *e = getenv("ARTN_TILE_TARGET")) x.tile_target = std::min(ARTN_TILE_BITS_MAX, std::max(9, atoi(e)));
@@ -1547,14 +1549,32 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
     x.h_sA[i] = H[i].sA; x.h_sB[i] = H[i].sB; x.h_sC[i] = H[i].sC;
     hprod *= H[i].e;
   }
-  // 32-column blocks per tile: the count that wastes the fewest columns (ties: the wider tile), a single block weighted down --
-  // one block per wave is 3 MFMAs per pair of LDS reads and per barrier share: 73 against 108 TFLOP/s on long contractions
-  // (216 columns: 7 tiles of 32 waste 4 %, 4 tiles of 64 waste 16 % and are still faster)
-  double best = -1;
-  for (int nb = c128 ? 1 : 3; nb >= 1; --nb) { // (complex128: one block -- two need 128 accumulator registers and spill)
-    const int64_t tn = 32 * nb, tiles = (x.n.total + tn - 1) / tn;
-    const double eff = (double)x.n.total / (double)(tiles * tn) * (nb == 1 ? 0.75 : 1.0);
-    if (eff > best + 1e-9) { best = eff; x.nb = nb; }
+  // 32-column blocks per tile (1..3).  A tile costs a fixed part -- staging 128 rows of the first operand, tables, barriers --
+  // plus its blocks' MFMAs: time ~ tiles x a + blocks x b with a = 0.95 b (from the measured 73 / 96 / 108 TFLOP/s of one / two /
+  // three blocks per tile on long contractions).  Round 6: columns that do not fill a last tile run as a SECOND launch with
+  // just the blocks they need (tail_nb, artn_xg_tail_plan) -- 216 columns are 2 tiles of 3 blocks + 1 tile of 1 (7 blocks in 3
+  // tiles; was 4 tiles of 2 blocks, 8 in 4: the width that wasted the fewest columns), 243 columns 2 x 3 + 1 x 2 (was 4 x 2).
+  // Ties go to the narrower tile.  (ARTN_XG_TAIL=0: one launch, the last tile padded, as before.)
+  const int64_t blocks_n = (x.n.total + 31) / 32;
+  auto pick_nb = [&](bool tail) {
+    double best = 0;
+    int pick = 1;
+    for (int nb = 1; nb <= (c128 ? 1 : 3) && nb <= blocks_n; ++nb) { // (complex128: one block -- two need 128 accumulator registers and spill)
+      const int64_t tiles = (blocks_n + nb - 1) / nb;
+      const double cost = 0.95 * (double)tiles + (double)(tail ? blocks_n : tiles * nb);
+      if (nb == 1 || cost < best - 1e-9) { best = cost; pick = nb; }
+    }
+    return pick;
+  };
+  x.nb = pick_nb(false);
+  bool with_tail = false;
+  if (tuning().xg_tail && !c128) {
+    // (two launches are two tails: a step of 244 tiles -- one round of the 512 resident workgroups -- went from 0.26 to 0.49 ms as
+    //  122 + 61 tiles; the split is for launches of many rounds: 8 760 tiles 7.2 -> 6.9 ms, 49 824 tiles 3.06 -> 2.88 ms)
+    const int nb_t = pick_nb(true);
+    const int64_t full_cols = blocks_n / nb_t;
+    const int64_t tiles_main = ((x.m.total + ARTN_XG_TM - 1) / ARTN_XG_TM) * full_cols * hprod;
+    if (blocks_n % nb_t != 0 && full_cols >= 1 && tiles_main >= (int64_t)8 * n_cu) { x.nb = nb_t; with_tail = true; }
   }
 #ifdef ARTN_DEV_SWITCHES
   if (const char *e = getenv("ARTN_XG_NB")) { const int v = atoi(e); if (v >= 1 && v <= 3) x.nb = v; }
@@ -1580,6 +1600,12 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   x.flush_chunks = (!c128 && chunks > ARTN_XG_FLUSH / x.kc) ? ARTN_XG_FLUSH / x.kc : 0;
   x.tiles_m = (x.m.total + ARTN_XG_TM - 1) / ARTN_XG_TM;
   x.tiles_n = (x.n.total + 32 * x.nb - 1) / (32 * x.nb);
+  x.col0 = 0;
+  x.tail_nb = 0;
+  if (with_tail && !x.pc) { // the last column tile would be narrower: its own launch
+    x.tail_nb = (int32_t)(blocks_n % x.nb);
+    x.tiles_n -= 1;
+  }
   x.n_tiles = x.tiles_m * x.tiles_n * hprod;
   if (x.n_tiles >= lim) { p.why_generic = "extent GEMM: too many tiles"; return false; }
   // the row-streaming form (artn_k_xrow): a handful of contracted values into a handful of columns on very many rows, the lanes
@@ -1606,6 +1632,13 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   I.n_tiles = x.n_tiles;
   I.grid = (int32_t)std::min<int64_t>(x.n_tiles, (int64_t)n_cu * (c128 ? 2 : (x.pc ? 1 : (x.kc == 8 ? 4 : 2))));
   I.a_rereads = x.tiles_n;
+  if (x.tail_nb) { // (the tail launch: chunks as in the main one, two workgroups per CU)
+    const int64_t tail_tiles = x.tiles_m * hprod;
+    x.tail_grid = (int32_t)std::min<int64_t>(tail_tiles, (int64_t)n_cu * 2);
+    x.tail_lds = artn_xg_lds_bytes(x.tail_nb, x.kc);
+    I.n_tiles += tail_tiles;
+    I.a_rereads += 1;
+  }
   if (x.rowmode) { // 16-row blocks dealt round-robin to the waves of n_cu x (waves per SIMD the instantiation's registers allow) workgroups
     const int S = artn_xrow_steps(x.k.total), NBK = artn_xrow_nbk(x.n.total);
     I.m_tile_bits = 4;

@@ -33,7 +33,7 @@ __device__ __forceinline__ XgTile xg_tile(const ArtnXGemmPlan &P, unsigned hm, u
   unsigned hh = hm / tsm;
   const unsigned tm = hm - hh * tsm;
   T.m0 = tm * ARTN_XG_TM;
-  T.n0 = tn * 32u * (unsigned)P.nb;
+  T.n0 = (unsigned)P.col0 + tn * 32u * (unsigned)P.nb; // (col0: the tail launch of a step whose last column tile is narrower)
   unsigned a = 0, b = 0, c = 0;
   for (int i = 0; i < P.n_h; ++i) {
     const unsigned e = (unsigned)P.h_ext[i], q = hh / e, d = hh - q * e;

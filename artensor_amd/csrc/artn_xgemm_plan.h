@@ -59,6 +59,11 @@ struct ArtnXGemmPlan {
   int32_t rowmode;             // 1 (round 6): artn_k_xrow -- the row-streaming form (artn_xrow_kernel.h): at most 32 contracted values and 32
                                //    columns, the small operand in registers, rows straight into the MFMA operand registers, no LDS staging
   uint32_t row_bytes_a, row_bytes_c; // rowmode: bytes spanned by the kernel's first operand and by the result (buffer range checks)
+  int32_t col0;                // first column of this launch (0; the tail launch: 32 nb tiles_n of the main one)
+  int32_t tail_nb;             // > 0 (round 6): the columns behind the tiles_n FULL column tiles -- fewer than nb blocks of 32 -- run as a
+                               //    second launch of the instantiation with tail_nb blocks per tile (artn_xg_tail_plan), so that a narrow last
+                               //    tile does not multiply blocks that hold no column (216 columns: 2 tiles of 96 + 1 of 32, was 4 of 64)
+  int32_t tail_grid, tail_lds; // workgroups and LDS bytes of that launch
   int64_t k_groups;            // k.total / k.L0
   int64_t tiles_m, tiles_n, n_tiles; // n_tiles = tiles_m * tiles_n * prod(h_ext); tile index = (h, tile of m, tile of n), n fastest
 };
@@ -87,6 +92,18 @@ static inline constexpr int artn_xrow_waves(int S, int NBK) { // (what hipcc's r
   return NBK == 1 ? (S <= 2 ? 8 : (S <= 3 ? 6 : (S <= 6 ? 5 : 6))) : (S <= 1 ? 6 : (S <= 2 ? 5 : 4));
 }
 static inline int artn_xrow_lds_bytes(int64_t L2) { return 4096 + 8 * (int)L2; } // three levels of (A, C) byte offsets of a row
+
+// The tail launch of a plan with tail_nb > 0: the same step restricted to the columns behind the full tiles, one column tile wide.
+static inline ArtnXGemmPlan artn_xg_tail_plan(const ArtnXGemmPlan &P) {
+  ArtnXGemmPlan T = P;
+  T.col0 = (int32_t)(P.tiles_n * 32 * P.nb);
+  T.nb = P.tail_nb;
+  T.n_tiles = P.n_tiles / P.tiles_n; // tiles_m x batch values
+  T.tiles_n = 1;
+  T.tail_nb = 0;
+  T.tail_grid = T.tail_lds = 0;
+  return T;
+}
 
 // Mixed-radix decode of `idx` over labels [first, first + count) of a side: the two element offsets.
 #if defined(__HIPCC__)

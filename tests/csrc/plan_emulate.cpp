@@ -802,7 +802,7 @@ static void run_xgemm(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C)
   for (int64_t tile = 0; tile < P.n_tiles; ++tile) {
     const uint32_t tu = (uint32_t)tile, r = tu / (uint32_t)P.tiles_n, tn = tu - r * (uint32_t)P.tiles_n;
     uint32_t hh = r / (uint32_t)P.tiles_m;
-    const uint32_t tm = r - hh * (uint32_t)P.tiles_m, m0 = tm * TM, n0 = tn * TN;
+    const uint32_t tm = r - hh * (uint32_t)P.tiles_m, m0 = tm * TM, n0 = (uint32_t)P.col0 + tn * TN;
     uint32_t hA = 0, hB = 0, hC = 0;
     for (int i = 0; i < P.n_h; ++i) {
       const uint32_t e = (uint32_t)P.h_ext[i], q = hh / e, d = hh - q * e;
@@ -1082,13 +1082,17 @@ extern "C" int artn_emulate_xgemm(const ArtnStepDesc *d, const void *A, const vo
   int rc = artn::validate(d, err);
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
-  if (!artn::make_xgemm(d, p, 256, 1)) return ARTN_E_UNSUPPORTED;
+  if (!artn::make_xgemm(d, p, (modes && modes[8] > 0) ? modes[8] : 256, 1)) return ARTN_E_UNSUPPORTED; // (modes[8] on entry: the CU count to plan for)
   if (info) *info = p.info;
   if (modes) { modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; modes[6] = p.xg.kc; }
   if (modes) modes[7] = p.xg.rowmode;
   if (p.xg.c128) run_xgemm128(p.xg, (const cd *)A, (const cd *)B, (cd *)C);
   else if (p.xg.rowmode) run_xrow(p.xg, (const cf *)A, (const cf *)B, (cf *)C, p.info.grid);
-  else run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
+  else {
+    run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
+    if (p.xg.tail_nb) run_xgemm(artn_xg_tail_plan(p.xg), (const cf *)A, (const cf *)B, (cf *)C); // (the launcher's second launch)
+  }
+  if (modes) modes[8] = p.xg.tail_nb;
   return 0;
 }
 
@@ -1122,8 +1126,13 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
   if (d->dtype != ARTN_C64 && !(d->dtype == ARTN_C64_BF16 && p.kernel == ARTN_KERNEL_GEMM_MFMA)) return ARTN_E_UNSUPPORTED;
   if (p.kernel == ARTN_KERNEL_BITS_MFMA) run_bits(p.bits, (const cf *)A, (const cf *)B, nullptr, (cf *)C);
   else if (p.kernel == ARTN_KERNEL_GEMM_MFMA) run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);
-  else if (p.kernel == ARTN_KERNEL_XGEMM) run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
-  else run_generic(p.gen, (const cf *)A, (const cf *)B, (cf *)C);
+  else if (p.kernel == ARTN_KERNEL_XGEMM) {
+    if (p.xg.rowmode) run_xrow(p.xg, (const cf *)A, (const cf *)B, (cf *)C, p.info.grid);
+    else {
+      run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
+      if (p.xg.tail_nb) run_xgemm(artn_xg_tail_plan(p.xg), (const cf *)A, (const cf *)B, (cf *)C);
+    }
+  } else run_generic(p.gen, (const cf *)A, (const cf *)B, (cf *)C);
   return 0;
 }
 

@@ -408,10 +408,11 @@ def emulate_program(prog, leaves):
     return ws, stats
 
 
-def emulate_xgemm(eq, a, b):
+def emulate_xgemm(eq, a, b, n_cu=None):
     """One step through the CPU replay of the extent-based GEMM (artn_k_xgemm; plan forced); returns (result, planner
-    info, modes) -- modes = dict(amode, bmode, trans, swapped, nb, flush_chunks) -- or (None, None, None) when
-    make_xgemm declines.  `eq`: an einsum string or a triple of label tuples; a / b may be strided views."""
+    info, modes) -- modes = dict(amode, bmode, trans, swapped, nb, flush_chunks, ...) -- or (None, None, None) when
+    make_xgemm declines.  `eq`: an einsum string or a triple of label tuples; a / b may be strided views; `n_cu`: the CU
+    count the plan is made for (256; a test-size step is a many-round launch on a one-CU device)."""
     import torch
     from artensor_amd import contraction as C
     from artensor_amd import _native as N
@@ -421,7 +422,8 @@ def emulate_xgemm(eq, a, b):
     d, out_shape = C._descriptor(la, lb, lo, tuple(ta.shape), tuple(ta.stride()), tuple(tb.shape), tuple(tb.stride()), ta.dtype)
     out = np.full(out_shape, np.nan + 0j, dtype=a.dtype)
     info = N.ArtnStepInfo()
-    modes = (ctypes.c_int32 * 8)()
+    modes = (ctypes.c_int32 * 9)()
+    modes[8] = int(n_cu or 0)
     emu = emulator()
     emu.artn_emulate_xgemm.restype = ctypes.c_int
     # (strided views: the emulator takes the base pointer of the view, like the kernel)
@@ -430,5 +432,5 @@ def emulate_xgemm(eq, a, b):
     if rc == -2:
         return None, None, None
     assert rc == 0, rc
-    names = ("amode", "bmode", "trans", "swapped", "nb", "flush_chunks", "kc", "rowmode")
+    names = ("amode", "bmode", "trans", "swapped", "nb", "flush_chunks", "kc", "rowmode", "tail_nb")
     return out, {name: getattr(info, name) for name, _ in N.ArtnStepInfo._fields_}, dict(zip(names, modes))

@@ -884,6 +884,27 @@ def _einsum128_labels(eq, a, b):
                      a.astype(np.complex128), b.astype(np.complex128))
 
 
+def test_extent_gemm_with_a_narrower_launch_for_the_last_columns():
+    """Round 6 (ArtnXGemmPlan::tail_nb): on launches of many rounds the columns behind the full column tiles run as a second
+    launch of a narrower instantiation -- 243 columns = 2 tiles of 96 + 1 of 64, 216 = 2 x 96 + 1 x 32 -- both operand roles;
+    ARTN_XG_TAIL is read when the library loads, so the one-launch plan is the other tests' business (small steps)."""
+    rng = np.random.default_rng(606)
+    for cols, eq_out in (((3, 3, 3, 3, 3), ("n4", "n3", "n2", "n1", "n0", "m1", "m0")),      # rows fastest in the result
+                         ((6, 6, 6), ("m1", "m0", "n2", "n1", "n0"))):                          # columns fastest (roles swapped)
+        nl = tuple(f"n{i}" for i in reversed(range(len(cols))))
+        eq = (("m1", "k0", "m0"), nl[:1] + ("k0",) + nl[1:], eq_out)
+        sa, sb = (1100, 9, 250), cols[:1] + (9,) + cols[1:]
+        info = A.step_info(eq, sa, sb)
+        n_cols = int(np.prod(cols))
+        full = (n_cols // 32) // 3
+        assert info["kernel"] == KERNEL_XGEMM and info["a_rereads"] == full + 1, info                       # 2 full column tiles + the tail
+        assert info["n_tiles"] == -(-1100 * 250 // 128) * (full + 1), info
+        a, b = crandn(rng, sa), crandn(rng, sb)
+        got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
+        want = _einsum128_labels(eq, a, b)
+        assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), cols
+
+
 def test_row_streaming_form_of_the_extent_gemm():
     """artn_k_xrow (round 6): a handful of contracted values into a handful of columns on 2^15+ rows -- every count of MFMA
     steps (1..8 x four contracted values), one and two column blocks, rows that end inside a block, the contracted labels

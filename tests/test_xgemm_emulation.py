@@ -34,8 +34,8 @@ def einsum_labels(eq, a, b):
     return np.einsum(s, a.astype(np.complex128), b.astype(np.complex128))
 
 
-def check(eq, a, b, tol=2e-6):
-    got, info, modes = emulate_xgemm(eq, a, b)
+def check(eq, a, b, tol=2e-6, n_cu=None):
+    got, info, modes = emulate_xgemm(eq, a, b, n_cu=n_cu)
     assert got is not None, "make_xgemm declined"
     want = einsum_labels(eq, a, b)
     assert got.shape == want.shape
@@ -77,6 +77,33 @@ def test_all_modes_are_covered():
     seen["nb"].add(modes["nb"])
     assert seen["amode"] == {0, 1} and seen["bmode"] == {0, 1} and seen["trans"] == {0, 1} and seen["swapped"] == {0, 1}
     assert seen["nb"] == {1, 2, 3}
+
+
+def test_columns_behind_the_full_tiles_run_as_a_second_launch():
+    """Round 6 (ArtnXGemmPlan::tail_nb, artn_xg_tail_plan): 216 columns are two tiles of three 32-column blocks plus ONE block in a
+    second launch (7 blocks in 3 tiles; one launch needs 4 tiles of 2 = 8 blocks), 243 columns 2 x 3 + 2; both operand roles
+    (lanes of a store along rows / along columns), a batch label, partial sums through C; 192 columns need no tail."""
+    rng = np.random.default_rng(77)
+    # 6 x 6 x 6 columns, rows fastest in the result
+    eq = (("k0", "m1", "m0"), ("n2", "k0", "n1", "n0"), ("n2", "n1", "n0", "m1", "m0"))
+    info, modes = check(eq, crandn(rng, (11, 30, 13)), crandn(rng, (6, 11, 6, 6)))
+    assert (modes["nb"], modes["tail_nb"]) == (2, 0), modes   # 4 x 4 tiles on 256 CUs: one round -- one launch, as before
+    info, modes = check(eq, crandn(rng, (11, 30, 13)), crandn(rng, (6, 11, 6, 6)), n_cu=1)   # (8+ tiles per CU: many rounds)
+    assert (modes["nb"], modes["tail_nb"], modes["trans"]) == (3, 1, 0), modes
+    assert info["n_tiles"] == 4 * 2 + 4 and info["a_rereads"] == 3, info   # 390 rows: 4 row tiles x (2 full column tiles + the tail's 1)
+    # 3^5 columns, columns fastest in the result (the MFMA roles swapped), a batch label
+    eq = (("h", "m0", "k0", "k1"), ("k1", "h", "n0", "k0"), ("h", "m0", "n0"))
+    info, modes = check(eq, crandn(rng, (2, 300, 5, 7)), crandn(rng, (7, 2, 243, 5)), n_cu=1)
+    assert (modes["nb"], modes["tail_nb"], modes["trans"]) == (3, 2, 1), modes
+    # more than 4 096 contracted values: the partial sums of the tail launch go through C as well
+    eq = (("m0", "k0", "k1"), ("k1", "n0", "k0"), ("n0", "m0"))
+    info, modes = check(eq, crandn(rng, (1100, 81, 63)), crandn(rng, (63, 130, 81)), tol=5e-6, n_cu=1)
+    assert (modes["nb"], modes["tail_nb"], modes["swapped"]) == (3, 2, 0) and modes["flush_chunks"] > 0, modes   # (130 columns: 3 + 2 blocks; 9 row tiles x 1 full column tile)
+    # 192 = 2 x 96 columns: nothing behind the full tiles; 60 columns: one tile of two blocks
+    info, modes = check((("m", "k"), ("k", "n"), ("n", "m")), crandn(rng, (1200, 11)), crandn(rng, (11, 192)), n_cu=1)
+    assert (modes["nb"], modes["tail_nb"]) == (3, 0), modes
+    info, modes = check((("m", "k"), ("k", "n"), ("n", "m")), crandn(rng, (1200, 11)), crandn(rng, (11, 60)), n_cu=1)
+    assert (modes["nb"], modes["tail_nb"]) == (2, 0), modes
 
 
 def test_row_streaming_form_for_small_blocks_on_many_rows():
