@@ -63,6 +63,51 @@ def test_random_mixed_extents(seed):
     check(eq, crandn(rng, sa), crandn(rng, sb))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_steps_planned_for_a_one_cu_device(seed):
+    """The same random steps planned for ONE CU: a test-size step is then a launch of many rounds and the planner may cut the
+    last columns off into a second launch (tail_nb); the replay runs both launches."""
+    rng = np.random.default_rng(3000 + seed)
+    M = {f"m{i}": int(rng.choice([3, 5, 6])) for i in range(5)}           # 243 .. 7 776 rows
+    Nn = {f"n{i}": int(rng.choice([5, 6, 7])) for i in range(3)}          # 125 .. 343 columns: 4 .. 11 blocks of 32
+    K = {f"k{i}": int(rng.choice([3, 5])) for i in range(int(rng.integers(1, 3)))}
+    H = {"h0": 2} if seed % 3 == 0 else {}
+    ext = {**M, **Nn, **K, **H}
+    la, lb, lo = list(M) + list(K) + list(H), list(Nn) + list(K) + list(H), list(M) + list(Nn) + list(H)
+    for lst in (la, lb, lo):
+        rng.shuffle(lst)
+    info, modes = check((tuple(la), tuple(lb), tuple(lo)), crandn(rng, tuple(ext[x] for x in la)), crandn(rng, tuple(ext[x] for x in lb)), n_cu=1)
+    cols = min(int(np.prod(list(M.values()))), int(np.prod(list(Nn.values()))))
+    blocks = -(-cols // 32)
+    assert modes["nb"] == 3 and modes["tail_nb"] == blocks % 3, (modes, cols)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_row_streaming_steps(seed):
+    """Random steps of the row-streaming form: 2^15+ rows over 4-7 row labels, at most 32 contracted values and 32 columns over
+    one or two labels each, labels shuffled in both operands and in the result -- whose fastest label stays a row label."""
+    rng = np.random.default_rng(4000 + seed)
+    while True:
+        M = {f"m{i}": int(rng.choice([2, 3, 4, 5, 7, 9])) for i in range(int(rng.integers(4, 8)))}
+        rows = int(np.prod(list(M.values())))
+        if 1 << 15 <= rows <= 1 << 17:
+            break
+    def small(prefix):
+        while True:
+            d = {f"{prefix}{i}": int(rng.choice([2, 3, 4, 5, 6, 7])) for i in range(int(rng.integers(1, 3)))}
+            if int(np.prod(list(d.values()))) <= 32:
+                return d
+    K, Nn = small("k"), small("n")
+    ext = {**M, **K, **Nn}
+    la, lb, lo = list(M) + list(K), list(Nn) + list(K), list(M) + list(Nn)
+    for lst in (la, lb, lo):
+        rng.shuffle(lst)
+    last_m = max(i for i, x in enumerate(lo) if x in M)
+    lo[last_m], lo[-1] = lo[-1], lo[last_m]
+    info, modes = check((tuple(la), tuple(lb), tuple(lo)), crandn(rng, tuple(ext[x] for x in la)), crandn(rng, tuple(ext[x] for x in lb)))
+    assert modes["rowmode"] == 1, (modes, ext)
+
+
 def test_all_modes_are_covered():
     """amode / bmode / trans / swapped each take both values over a set of steps (otherwise a copy mode could rot)."""
     seen = {name: set() for name in ("amode", "bmode", "trans", "swapped", "nb")}
