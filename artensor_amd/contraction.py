@@ -233,6 +233,7 @@ SPLIT_K_MIN_TILES = 512   # the GEMM kernel loops over any number of contracted 
                           # contracted labels are turned into a batch label only to get this many tiles
 
 
+XGEMM_FEW_TILES = 256     # below this a step cannot even fill the CUs: contracted values are split off down to 32 per tile
 XGEMM_SPLIT_TILES = 4096  # the extent GEMM's persistent grid is 512 workgroups: eight rounds keep the last one's idle share under 6 %
 _ONE = object()  # operand id of the scalar 1 in a compiled sum-out op
 _ones = {}
@@ -305,7 +306,7 @@ def _big_k_outer_extents(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype
     every contracted value inside one workgroup): when the result has too few 128 x 96 tiles to fill the chip -- the
     closing steps of a bond-dimension-3 network contract 3^11 values into a 3^7 x 3^5 result: 36 tiles -- the
     slowest-varying contracted labels of A become a temporary batch label until SPLIT_K_MIN_TILES workgroups have
-    work, as long as a few hundred contracted values stay inside."""
+    work, as long as a few hundred contracted values stay inside (a few dozen while the step has fewer tiles than the chip CUs)."""
     if b_shape is None or dtype != torch.complex64:
         return None
     d, _ = _descriptor(tuple(la), tuple(lb), tuple(lo), tuple(a_shape), tuple(a_stride), tuple(b_shape),
@@ -320,7 +321,9 @@ def _big_k_outer_extents(la, lb, lo, a_shape, a_stride, b_shape, b_stride, dtype
     outer = []
     for _, x in sorted(ka, reverse=True):   # highest A stride first
         e = a_shape[la.index(x)]
-        if tiles >= XGEMM_SPLIT_TILES or k_total // e < 256:
+        # (fewer tiles than CUs: a chain of chunks at one workgroup per CU, 3 us per chunk of 16 values -- 6 tiles x 1 296 values
+        #  took 0.24 ms for 0.1 GFLOP in the bond-dimension-6 network: split down to a few dozen values per tile)
+        if tiles >= XGEMM_SPLIT_TILES or k_total // e < (256 if tiles >= XGEMM_FEW_TILES else 32):
             break
         outer.append(x)
         tiles *= e

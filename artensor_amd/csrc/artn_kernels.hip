@@ -2977,12 +2977,17 @@ static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, 
   if (g.rowmode) { // the row-streaming form: the small operand in registers (1..8 MFMA steps of four contracted values, 1 or 2 column blocks)
 #define ARTN_XROW_LAUNCH(SV)                                                                         \
   case SV:                                                                                           \
-    if (artn_xrow_nbk(g.n.total) == 1) hipLaunchKernelGGL((artn_k_xrow<SV, 1>), grid, block, lds, st, a, b, c, g); \
-    else hipLaunchKernelGGL((artn_k_xrow<SV, 2>), grid, block, lds, st, a, b, c, g);                   \
+    switch (artn_xrow_nbk(g.n.total)) {                                                              \
+      case 1: hipLaunchKernelGGL((artn_k_xrow<SV, 1>), grid, block, lds, st, a, b, c, g); break;     \
+      case 2: hipLaunchKernelGGL((artn_k_xrow<SV, 2>), grid, block, lds, st, a, b, c, g); break;     \
+      case 3: hipLaunchKernelGGL((artn_k_xrow<SV, 3>), grid, block, lds, st, a, b, c, g); break;     \
+      default: return hipErrorInvalidValue;                                                          \
+    }                                                                                                \
     break;
     switch (artn_xrow_steps(g.k.total)) {
       ARTN_XROW_LAUNCH(1) ARTN_XROW_LAUNCH(2) ARTN_XROW_LAUNCH(3) ARTN_XROW_LAUNCH(4)
       ARTN_XROW_LAUNCH(5) ARTN_XROW_LAUNCH(6) ARTN_XROW_LAUNCH(7) ARTN_XROW_LAUNCH(8)
+      ARTN_XROW_LAUNCH(9) ARTN_XROW_LAUNCH(10) ARTN_XROW_LAUNCH(11) ARTN_XROW_LAUNCH(12)
       default: return hipErrorInvalidValue;
     }
 #undef ARTN_XROW_LAUNCH

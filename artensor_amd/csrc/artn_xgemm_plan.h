@@ -24,7 +24,7 @@
 #define ARTN_XG_LEVEL 256 /* entries of one level table */
 #define ARTN_XG_KTAB (ARTN_XG_LEVEL + ARTN_XG_KC) /* the k tables are padded by one chunk: no clamping in the copy loop */
 #define ARTN_XG_FLUSH 4096 /* contracted values per fp32 partial sum (as ARTN_GEMM_FLUSH_LOG2) */
-#define ARTN_XROW_MAX 32      /* artn_k_xrow: contracted values, and columns, of the small operand */
+#define ARTN_XROW_MAX 48      /* artn_k_xrow: contracted values, and columns, of the small operand */
 #define ARTN_XROW_MIN_ROWS (1 << 15)
 #define ARTN_XROW_L2_MAX 4096 /* entries of the third level of its row-offset tables (what the two 256-entry levels leave of the row index) */
 
@@ -56,7 +56,7 @@ struct ArtnXGemmPlan {
   int32_t kc;                  // contracted values per chunk: 16, or 8 (few contracted values, nb = 1: four workgroups per CU)
   int32_t pc;                  // 1: artn_k_xgemm_pc -- one 8-wave workgroup per CU, four consumer and four producer waves (kc = 16)
   int32_t c128;                // 1: complex128 operands -- artn_k_xgemm128 (16-byte elements, kc = 8, nb = 1, f64 MFMA)
-  int32_t rowmode;             // 1 (round 6): artn_k_xrow -- the row-streaming form (artn_xrow_kernel.h): at most 32 contracted values and 32
+  int32_t rowmode;             // 1 (round 6): artn_k_xrow -- the row-streaming form (artn_xrow_kernel.h): at most 48 contracted values and 48
                                //    columns, the small operand in registers, rows straight into the MFMA operand registers, no LDS staging
   uint32_t row_bytes_a, row_bytes_c; // rowmode: bytes spanned by the kernel's first operand and by the result (buffer range checks)
   int32_t col0;                // first column of this launch (0; the tail launch: 32 nb tiles_n of the main one)
@@ -82,14 +82,16 @@ static inline int artn_xg_pc_lds_bytes(int nb) { return 2 * artn_xg_stage_bytes(
 // artn_k_xrow: MFMA steps of four contracted values, column blocks of 16, prefetch distance in 16-row blocks, waves per SIMD
 // -- kernel, launcher, planner, emulator
 static inline constexpr int artn_xrow_steps(int64_t k_total) { return (int)((k_total + 3) / 4); }
-static inline constexpr int artn_xrow_nbk(int64_t n_total) { return n_total <= 16 ? 1 : 2; }
+static inline constexpr int artn_xrow_nbk(int64_t n_total) { return (int)((n_total + 15) / 16); }
 #ifdef ARTN_XROW_DEEP /* development builds: two blocks ahead for the largest fragments too */
-static inline constexpr int artn_xrow_depth(int S) { return S <= 2 ? 4 : (S <= 4 ? 3 : 2); }
+static inline constexpr int artn_xrow_depth(int S) { return S <= 2 ? 4 : (S <= 4 ? 3 : (S <= 8 ? 2 : 1)); }
 #else
 static inline constexpr int artn_xrow_depth(int S) { return S <= 2 ? 4 : (S <= 4 ? 3 : (S <= 6 ? 2 : 1)); }
 #endif
-static inline constexpr int artn_xrow_waves(int S, int NBK) { // (what hipcc's register counts of the sixteen instantiations allow: 48 ... 125)
-  return NBK == 1 ? (S <= 2 ? 8 : (S <= 3 ? 6 : (S <= 6 ? 5 : 6))) : (S <= 1 ? 6 : (S <= 2 ? 5 : 4));
+static inline constexpr int artn_xrow_waves(int S, int NBK) { // (what hipcc's register counts of the 36 instantiations allow: 48 ... 210)
+  return NBK == 1 ? (S <= 2 ? 8 : (S <= 3 ? 6 : (S <= 6 ? 5 : (S <= 8 ? 6 : (S <= 9 ? 5 : 4)))))
+       : NBK == 2 ? (S <= 1 ? 6 : (S <= 2 ? 5 : (S <= 8 ? 4 : 3)))
+                  : (S <= 1 ? 6 : (S <= 3 ? 4 : (S <= 8 ? 3 : 2)));
 }
 static inline int artn_xrow_lds_bytes(int64_t L2) { return 4096 + 8 * (int)L2; } // three levels of (A, C) byte offsets of a row
 

@@ -5,7 +5,7 @@
 // bond-dimension-3 benchmark network (reference torch.einsum at /root/reference/artensor/contraction.py:70).  artn_k_xgemm runs
 // them at 2.3-3.6 TB/s: its cost there is per TILE (row tables, a mixed-radix decode, two barriers per chunk of 8 contracted
 // values, 18 vector + 13 scalar instructions per MFMA: profiles/r06_xgemm_pmc.md).  Here
-//   * the small operand (at most 32 contracted values x 32 columns) lives in REGISTERS for the whole kernel, as MFMA fragments;
+//   * the small operand (at most 48 contracted values x 48 columns) lives in REGISTERS for the whole kernel, as MFMA fragments;
 //   * the rows are cut into blocks of 16, dealt round-robin to the waves of the launch (block b -> wave b mod #waves: at any time
 //     the launch works on ONE window of consecutive rows -- a few MB of the operand and of every column of the result);
 //   * per block every lane loads its row's contracted values STRAIGHT into the MFMA operand registers
@@ -20,8 +20,8 @@
 //   * 3M arithmetic as in artn_k_xgemm (T1 = A_re B_re, T2 = A_im B_im, T3 = (A_re + A_im)(B_re + B_im));
 //   * the result leaves from the accumulators: register r of lane (j, g) is column 4 g + r (+ 16 per column block) of row 16 b + j.
 // Taken by make_xgemm (ArtnXGemmPlan::rowmode) for complex64 steps without batch labels whose contracted and free-B indices are
-// at most 32 values each, whose result's fastest label is a free label of the first operand, on 2^15+ rows, tensors below 4 GiB.
-// S: MFMA steps (four contracted values each) held in registers, 1..8; NBK: column blocks of 16 (1, 2); prefetch distance and
+// at most 48 values each, whose result's fastest label is a free label of the first operand, on 2^15+ rows, tensors below 4 GiB.
+// S: MFMA steps (four contracted values each) held in registers, 1..12; NBK: column blocks of 16 (1..3); prefetch distance and
 // waves per SIMD: artn_xrow_depth / artn_xrow_waves (artn_xgemm_plan.h).
 
 template <int S, int NBK>

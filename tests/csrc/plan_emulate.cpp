@@ -904,7 +904,7 @@ static void run_xrow(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C, 
   const cf *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
   const uint32_t Mtot = (uint32_t)P.m.total, Ktot = (uint32_t)P.k.total, Ntot = (uint32_t)P.n.total;
   const int S = artn_xrow_steps(P.k.total), NBK = artn_xrow_nbk(P.n.total), D = artn_xrow_depth(S);
-  if (S < 1 || S > 8 || (int)Ntot > 16 * NBK) abort();
+  if (S < 1 || S > 12 || NBK > 3 || (int)Ntot > 16 * NBK) abort();
   const uint32_t L0 = (uint32_t)P.m.L0, L1 = (uint32_t)P.m.L1, L2 = Mtot / (L0 * L1);
   if ((uint64_t)L0 * L1 * L2 != Mtot || L2 > ARTN_XROW_L2_MAX) abort();
   std::vector<uint32_t> t0(2 * 256), t1(2 * 256), t2(2 * (size_t)L2);

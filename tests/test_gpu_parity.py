@@ -907,11 +907,12 @@ def test_extent_gemm_with_a_narrower_launch_for_the_last_columns():
 
 def test_row_streaming_form_of_the_extent_gemm():
     """artn_k_xrow (round 6): a handful of contracted values into a handful of columns on 2^15+ rows -- every count of MFMA
-    steps (1..8 x four contracted values), one and two column blocks, rows that end inside a block, the contracted labels
+    steps (1..12 x four contracted values), one to three column blocks, rows that end inside a block, the contracted labels
     inside / outside the row labels of the operand -- against complex128 einsums; and ARTN_XROW=0 plans no such launch."""
     rng = np.random.default_rng(2026)
     cases = 0
-    for kk, nn in ((1, 3), (3, 3), (5, 16), (9, 9), (12, 5), (16, 27), (17, 2), (21, 32), (24, 7), (27, 27), (29, 17), (32, 32)):
+    for kk, nn in ((1, 3), (3, 3), (5, 16), (9, 9), (12, 5), (16, 27), (17, 2), (21, 32), (24, 7), (27, 27), (29, 17), (32, 32),
+                   (36, 36), (33, 9), (40, 48), (45, 20), (48, 33), (7, 41)):
         for form in range(2):
             rows = max(int(rng.integers(1 << 15, 3 << 15)), (1 << 21) // (kk * nn) + 1000)   # (8 x rows x kk x nn >= 2^24: a tiled launch)
             m0 = int(rng.integers(180, 250))   # (the third level of the row-offset tables takes up to 4 096 values)
@@ -927,7 +928,7 @@ def test_row_streaming_form_of_the_extent_gemm():
             want = _einsum128_labels(eq, a, b)
             assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (kk, nn, form)
             cases += 1
-    assert cases == 24
+    assert cases == 36
     # bond dimension 3 with the contracted labels between the row labels, all three levels of the row-offset tables in use
     eq = (tuple("abcdKefgLhijk"), ("x", "K", "L", "y"), ("y", "x") + tuple("abcdefghijk"))
     a, b = crandn(rng, (3,) * 13), crandn(rng, (3,) * 4)

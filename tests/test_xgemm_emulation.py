@@ -84,7 +84,7 @@ def test_random_steps_planned_for_a_one_cu_device(seed):
 
 @pytest.mark.parametrize("seed", range(10))
 def test_random_row_streaming_steps(seed):
-    """Random steps of the row-streaming form: 2^15+ rows over 4-7 row labels, at most 32 contracted values and 32 columns over
+    """Random steps of the row-streaming form: 2^15+ rows over 4-7 row labels, at most 48 contracted values and 48 columns over
     one or two labels each, labels shuffled in both operands and in the result -- whose fastest label stays a row label."""
     rng = np.random.default_rng(4000 + seed)
     while True:
@@ -95,7 +95,7 @@ def test_random_row_streaming_steps(seed):
     def small(prefix):
         while True:
             d = {f"{prefix}{i}": int(rng.choice([2, 3, 4, 5, 6, 7])) for i in range(int(rng.integers(1, 3)))}
-            if int(np.prod(list(d.values()))) <= 32:
+            if int(np.prod(list(d.values()))) <= 48:
                 return d
     K, Nn = small("k"), small("n")
     ext = {**M, **K, **Nn}
@@ -152,7 +152,7 @@ def test_columns_behind_the_full_tiles_run_as_a_second_launch():
 
 
 def test_row_streaming_form_for_small_blocks_on_many_rows():
-    """Round 6 (artn_k_xrow, ArtnXGemmPlan::rowmode): at most 32 contracted values into at most 32 columns on 2^15+ rows, lanes
+    """Round 6 (artn_k_xrow, ArtnXGemmPlan::rowmode): at most 48 contracted values into at most 48 columns on 2^15+ rows, lanes
     along rows in the first operand and the result, no batch label -- the small operand in registers, rows straight into the
     MFMA operand registers, 16-row blocks dealt round-robin to the waves, three levels of row-offset tables, buffer loads and
     stores.  The 9 x 9 and 27 x 27 blocks of the bond-dimension-3 network (rows past the end, an odd count of contracted
@@ -182,13 +182,19 @@ def test_row_streaming_form_for_small_blocks_on_many_rows():
     eq = (("k0", "m1", "m0"), ("k0", "n0"), ("m1", "m0", "n0"))
     info, modes = check(eq, crandn(rng, (9, 1200, 30)), crandn(rng, (9, 9)))
     assert modes["rowmode"] == 0, modes
-    # ... a batch label; too few rows; more than 32 columns
+    # ... a batch label; too few rows; more than 48 columns
     info, modes = check((("h", "k0", "m1", "m0"), ("h", "k0", "n0"), ("h", "n0", "m1", "m0")), crandn(rng, (2, 9, 1200, 30)), crandn(rng, (2, 9, 9)))
     assert modes["rowmode"] == 0, modes
     info, modes = check((("k0", "m1", "m0"), ("k0", "n0"), ("n0", "m1", "m0")), crandn(rng, (9, 100, 30)), crandn(rng, (9, 9)))
     assert modes["rowmode"] == 0, modes
-    info, modes = check((("k0", "m1", "m0"), ("k0", "n0"), ("n0", "m1", "m0")), crandn(rng, (9, 1200, 30)), crandn(rng, (9, 33)))
+    info, modes = check((("k0", "m1", "m0"), ("k0", "n0"), ("n0", "m1", "m0")), crandn(rng, (9, 1200, 30)), crandn(rng, (9, 49)))
     assert modes["rowmode"] == 0, modes
+    # 36 -> 36 (bond dimension 6: two labels each): nine MFMA steps, three column blocks; 48 contracted values into 40 columns
+    eq = (("k1", "m1", "k0", "m0"), ("n1", "k0", "n0", "k1"), ("n1", "n0", "m1", "m0"))
+    info, modes = check(eq, crandn(rng, (6, 1100, 6, 31)), crandn(rng, (6, 6, 6, 6)))
+    assert modes["rowmode"] == 1, modes
+    info, modes = check((("m1", "m0", "k0"), ("k0", "n0"), ("n0", "m1", "m0")), crandn(rng, (1100, 31, 48)), crandn(rng, (48, 40)))
+    assert modes["rowmode"] == 1, modes
     # ... a row index that leaves more than 4 096 values to the third level of the offset tables (2 x 5 000 above one level of 7)
     info, modes = check((("k0", "m2", "m1", "m0"), ("k0", "n0"), ("n0", "m2", "m1", "m0")), crandn(rng, (3, 2, 5000, 7)), crandn(rng, (3, 3)))
     assert modes["rowmode"] == 0, modes
