@@ -229,10 +229,11 @@ def _as_operand(t):
 
 
 MAX_TILE_K_BITS = 8   # contracted bits one LDS tile of the state-streaming kernel can hold
-SPLIT_K_MIN_TILES = 512   # the GEMM kernel loops over any number of contracted bits inside a workgroup;
-                          # contracted labels are turned into a batch label only to get this many tiles
+SPLIT_K_MIN_TILES = int(__import__("os").environ.get("ARTN_SPLIT_K_MIN_TILES", "512"))   # the GEMM kernel loops over any number of
+                          # contracted bits inside a workgroup; contracted labels are turned into a batch label only to get this many tiles
 
 
+SPLIT_K_FEW_TILES = int(__import__("os").environ.get("ARTN_SPLIT_K_FEW_TILES", "4096"))   # ... this many when the unsplit step has fewer tiles than CUs
 XGEMM_FEW_TILES = 256     # below this a step cannot even fill the CUs: contracted values are split off down to 32 per tile
 XGEMM_SPLIT_TILES = 4096  # the extent GEMM's persistent grid is 512 workgroups: eight rounds keep the last one's idle share under 6 %
 _ONE = object()  # operand id of the scalar 1 in a compiled sum-out op
@@ -286,8 +287,17 @@ def _big_k_outer(la, lb, lo, a_shape, a_stride=None, b_shape=None, b_stride=None
         if info["kernel"] == N.KERNEL_GEMM_MFMA:
             want = 0   # bits to split off for parallelism
             tiles = max(1, info["n_tiles"])
+            # (a step that cannot fill the CUs even once is one long chain per workgroup: 64 tiles x 2^16 contracted values of the
+            #  D = 4 network ran at 44 TFLOP/s split into 256 x 2^14 -- such steps are split on, up to SPLIT_K_FEW_TILES ...
             while (tiles << want) < SPLIT_K_MIN_TILES and bits - want > 6:
                 want += 1
+            if tiles < XGEMM_FEW_TILES:
+                # ... unless its operands stream from HBM for longer than a tile's chain of chunks takes anyway (1.5 us per chunk of
+                # 32 contracted values, measured): the closing steps of n53 m20 -- 1 024 results of 2^25-term sums, 17 GB -- lost
+                # 13 % with 2 048 tiles of 2^14 values instead of 512 of 2^16
+                stream_us = info.get("bytes", 0.0) / 5.0e12 * 1e6
+                while (tiles << want) < SPLIT_K_FEW_TILES and bits - want > 6 and 1.5 * (1 << max(0, bits - want - 5)) > stream_us:
+                    want += 1
             if want == 0:
                 return None
             keep = bits - want

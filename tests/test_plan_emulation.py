@@ -417,6 +417,25 @@ def test_planner_routes_big_contractions_to_the_gemm_kernel():
     lo = la[:5] + lb[21:]
     outer = _big_k_outer(la, lb, lo, (2,) * 26, None, (2,) * 26)
     assert outer is not None and 1 <= len(outer) <= 10
+    # round 6: a step that cannot fill the CUs even once is a chain of chunks per workgroup -- 16 tiles x 2^16 contracted values
+    # between operands of 2^26 / 2^24 elements (0.7 GB: 0.13 ms of streaming) is split down to 2^11 values per tile; the same
+    # shape between two operands of 2^30 elements streams for longer than its chains take and keeps the 512-tile target
+    la = tuple(f"m{x}" for x in range(8)) + tuple(f"h{x}" for x in range(2)) + tuple(f"k{x}" for x in range(16))
+    lb = tuple(f"k{x}" for x in range(16)) + tuple(f"h{x}" for x in range(2)) + tuple(f"n{x}" for x in range(6))
+    lo = tuple(f"h{x}" for x in range(2)) + la[:8] + lb[18:]
+    outer = _big_k_outer(la, lb, lo, (2,) * 26, None, (2,) * 24)
+    assert outer is not None and len(outer) == 5, outer
+    import artensor_amd.contraction as _C
+    few, _C.SPLIT_K_FEW_TILES = _C.SPLIT_K_FEW_TILES, 0   # (the 512-tile target alone: 2^14 values per tile)
+    try:
+        assert len(_big_k_outer(la, lb, lo, (2,) * 26, None, (2,) * 24)) == 2
+    finally:
+        _C.SPLIT_K_FEW_TILES = few
+    la = tuple(f"m{x}" for x in range(5)) + tuple(f"k{x}" for x in range(25))
+    lb = tuple(f"k{x}" for x in range(25)) + tuple(f"n{x}" for x in range(5))
+    lo = la[:5] + lb[25:]
+    outer = _big_k_outer(la, lb, lo, (2,) * 30, None, (2,) * 30)
+    assert outer is not None and len(outer) == 9, outer   # (1 tile -> 512 tiles of 2^16 values)
     # small second operand, 5 contracted bits: stays on the state-streaming kernel
     info = step_info("ABCDEFGHIJKLMNOPQRST,DHKOSwxyz->ABCEFGIJLMNPQRTwxyz", (2,) * 20, (2,) * 9)
     assert info["kernel"] == KERNEL_BITS
