@@ -60,8 +60,9 @@ for leg_dir in sorted(glob.glob(os.path.join(SRC, "*"))):
     if not os.path.isdir(leg_dir):
         continue
     units = int(open(os.path.join(leg_dir, "units")).read())
-    f = glob.glob(os.path.join(leg_dir, "fetch", "**", "*counter_collection.csv"), recursive=True)
-    w = glob.glob(os.path.join(leg_dir, "write", "**", "*counter_collection.csv"), recursive=True)
+    # (gpurun MERGES a call's files into gpurun_out/: an earlier run of the same tag leaves its files behind -- newest first)
+    f = sorted(glob.glob(os.path.join(leg_dir, "fetch", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+    w = sorted(glob.glob(os.path.join(leg_dir, "write", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if not f or not w:
         print("missing counters for", leg)
         continue
