@@ -5,7 +5,9 @@ out = sys.argv[1]
 for sub in ("a", "b", "c"):
     files = glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True)
     if not files:
-        print(sub, "no counters:", open(os.path.join(out, sub + ".log")).read()[-600:])
+        log = os.path.join(out, sub + ".log")
+        if os.path.exists(log):   # (pass "c" is optional)
+            print(sub, "no counters:", open(log).read()[-600:])
         continue
     per = collections.OrderedDict()
     for r in csv.DictReader(open(files[0])):
