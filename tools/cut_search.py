@@ -21,9 +21,10 @@ def spy(scheme, members, a_shape, b_shapes, dtype):
 C._cut_sparse_chain = spy
 SPARSE = "bitstrings_sorted" in case.meta
 ROWS = len(case.meta["bitstrings_sorted"]) if SPARSE else 1
+OUT_SHAPE = tuple(int(x) for x in os.environ["OUT_SHAPE"].split(",")) if os.environ.get("OUT_SHAPE") else (ROWS,)   # (open dense fixtures: OUT_SHAPE=2,2,...)
 def time_slices(n=6):
     C._chain_cache.clear()
-    r = A.SliceRunner(leaves, case.scheme, case.slicing_indices, (ROWS,), sparse=SPARSE, device="cuda")
+    r = A.SliceRunner(leaves, case.scheme, case.slicing_indices, OUT_SHAPE, sparse=SPARSE, device="cuda")
     order = A.rank_slices(2 ** len(case.slicing_indices), 0, 8, gray=True)
     r.run(order[:2]); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
