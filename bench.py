@@ -166,7 +166,10 @@ def roofline_of(ks, gpu_ms, launches_div=1, f64_peak=None, leg=None, units=1):
     traffic, ratio, tnote = None, None, None
     tj, tnote = traffic_record()
     if tj is not None and leg is not None:
-        fam = (tj.get("workloads", {}).get(leg) or {}).get(FAMILY_KEYS.get(kid, str(kid)))
+        legs = tj.get("workloads", {}).get(leg) or {}
+        fam = legs.get(FAMILY_KEYS.get(kid, str(kid)))
+        if fam and kid == 5 and legs.get("xrow"):   # (planner id 5 covers artn_k_xgemm and its row-streaming form artn_k_xrow)
+            fam = dict(fam, hbm_bytes_per_unit=fam["hbm_bytes_per_unit"] + legs["xrow"]["hbm_bytes_per_unit"])
         if fam:   # bytes per contraction (slice) of this family / its contract calls per contraction
             traffic = fam["hbm_bytes_per_unit"] / (d["launches"] / launches_div / units)
             ratio = traffic / alg_per_launch if alg_per_launch else None
