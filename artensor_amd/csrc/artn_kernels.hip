@@ -2974,6 +2974,21 @@ static hipError_t launch_xgemm(const ArtnPlan &p, const void *A, const void *B, 
   float2 *c = (float2 *)C;
   dim3 grid(p.info.grid), block(ARTN_WG_THREADS);
   const size_t lds = (size_t)p.info.lds_bytes;
+  if (g.rowmode == 2) { // the row-streaming form with a lane per row (64-row superblocks)
+#define ARTN_XROW64_LAUNCH(SV)                                                                       \
+  case SV:                                                                                           \
+    if (artn_xrow_nbk(g.n.total) == 1) hipLaunchKernelGGL((artn_k_xrow64<SV, 1>), grid, block, lds, st, a, b, c, g); \
+    else hipLaunchKernelGGL((artn_k_xrow64<SV, 2>), grid, block, lds, st, a, b, c, g);                 \
+    break;
+    if (artn_xrow_nbk(g.n.total) > 2) return hipErrorInvalidValue;
+    switch (artn_xrow_steps(g.k.total)) {
+      ARTN_XROW64_LAUNCH(1) ARTN_XROW64_LAUNCH(2) ARTN_XROW64_LAUNCH(3) ARTN_XROW64_LAUNCH(4)
+      ARTN_XROW64_LAUNCH(5) ARTN_XROW64_LAUNCH(6) ARTN_XROW64_LAUNCH(7) ARTN_XROW64_LAUNCH(8)
+      default: return hipErrorInvalidValue;
+    }
+#undef ARTN_XROW64_LAUNCH
+    return hipGetLastError();
+  }
   if (g.rowmode) { // the row-streaming form: the small operand in registers (1..8 MFMA steps of four contracted values, 1 or 2 column blocks)
 #define ARTN_XROW_LAUNCH(SV)                                                                         \
   case SV:                                                                                           \

@@ -226,6 +226,7 @@ struct Tuning {
   int split = 0;      // complex64 chains: 0 fp32 MFMA, 3 fp32-grade split-bf16 MFMA
   int nt = 1;         // non-temporal loads of A tiles that are read once
   int xg_tail = 1;    // extent GEMM: the columns behind the full column tiles as a second, narrower launch (ARTN_XG_TAIL=0: one padded launch)
+  int xrow64 = 1;     // ... its 64-row shape (artn_k_xrow64; ARTN_XROW64=0: the 16-row shape only)
   int xrow = 1;       // the row-streaming form of the extent GEMM (artn_k_xrow; ARTN_XROW=0: artn_k_xgemm for those steps too)
   int gemm = 1;       // two-operand LDS GEMM: 0 never, 1 for 7+ contracted bits or a big second operand, 2 whenever it fits
   int gemm_3m = 1;    // GEMM kernel, fp32, tiles with 32+ columns: three real products per complex product
@@ -281,6 +282,7 @@ static inline Tuning &tuning() {
     if (const char *e = getenv("ARTN_WIDE_MIN_TILES")) x.wide_min_tiles = atoi(e);
     if (const char *e = getenv("ARTN_XGEMM")) x.xgemm = atoi(e) != 0;
     if (const char *e = getenv("ARTN_XROW")) x.xrow = atoi(e);
+    if (const char *e = getenv("ARTN_XROW64")) x.xrow64 = atoi(e) != 0;
     if (const char *e = getenv("ARTN_XG_TAIL")) x.xg_tail = atoi(e) != 0;
 #ifdef ARTN_DEV_SWITCHES
     if (const char *e = getenv("ARTN_WG_PER_CU")) x.wg_per_cu = std::max(1, atoi(e));
@@ -1449,6 +1451,18 @@ static inline bool make_pgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, bool
 // dimension 3, 5, 6 ... (reference tensor_network.py:4-30 accepts any bond_dims; the einsum at contraction.py:70
 // has no such restriction).
 // ----------------------------------------------------------------------------------------
+// launch geometry of the row-streaming forms (ArtnXGemmPlan::rowmode 1: 16-row blocks, 2: 64-row superblocks), dealt round-robin to
+// the waves of n_cu x (waves per SIMD the instantiation's registers allow) workgroups
+static inline void xrow_fill_info(const ArtnXGemmPlan &x, ArtnStepInfo &I, int n_cu) {
+  const int S = artn_xrow_steps(x.k.total), NBK = artn_xrow_nbk(x.n.total);
+  const int rows = x.rowmode == 2 ? 64 : 16;
+  I.m_tile_bits = x.rowmode == 2 ? 6 : 4;
+  I.lds_bytes = artn_xrow_lds_bytes(x.m.total / ((int64_t)x.m.L0 * x.m.L1));
+  I.n_tiles = (x.m.total + rows - 1) / rows;
+  I.grid = (int32_t)std::min<int64_t>((I.n_tiles + 3) / 4, (int64_t)n_cu * (x.rowmode == 2 ? artn_xrow64_waves(S, NBK) : artn_xrow_waves(S, NBK)));
+  I.a_rereads = 1;
+}
+
 static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int64_t min_tiles) {
   const bool c128 = d->dtype == ARTN_C128; // (artn_k_xgemm128: the same plan with 16-byte elements, chunks of 8, one or two column blocks)
   ArtnXGemmPlan &x = p.xg;
@@ -1617,8 +1631,12 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
     //  0.38 -> 0.22 ms, but 27 -> 27 on 3^15 rows 1.70 -> 2.10 ms -- 84 MFMAs per 16 rows at four waves per SIMD no longer hide
     //  under the loads: blocks of more than 16 x 16 stay with artn_k_xgemm from 2^22 rows on; ARTN_XROW=2: wherever it fits)
     const bool pays = (x.k.total <= 16 && x.n.total <= 16) || x.m.total < (int64_t(1) << 22) || tuning().xrow == 2;
-    x.rowmode = (!c128 && x.n_h == 0 && x.trans == 0 && x.k.total <= ARTN_XROW_MAX && x.n.total <= ARTN_XROW_MAX &&
-                 x.m.total >= ARTN_XROW_MIN_ROWS && l2 <= ARTN_XROW_L2_MAX && span_first <= row_lim && spanC <= row_lim && tuning().xrow && pays) ? 1 : 0;
+    const bool fits = !c128 && x.n_h == 0 && x.trans == 0 && x.k.total <= ARTN_XROW_MAX && x.n.total <= ARTN_XROW_MAX &&
+                      x.m.total >= ARTN_XROW_MIN_ROWS && l2 <= ARTN_XROW_L2_MAX && span_first <= row_lim && spanC <= row_lim && tuning().xrow;
+    // rowmode 2 (artn_k_xrow64): a lane per row, 64-row superblocks -- up to 32 contracted values and 32 columns; 4.5-4.9 TB/s on the
+    // steps above (tools/probes/xrow64_probe.hip), so it is taken wherever it fits, the 16-row shape (rowmode 1) where that pays
+    const bool wide = fits && tuning().xrow64 && artn_xrow_steps(x.k.total) <= 8 && artn_xrow_nbk(x.n.total) <= 2;
+    x.rowmode = wide ? 2 : ((fits && pays) ? 1 : 0);
     x.row_bytes_a = x.rowmode ? (uint32_t)(8 * span_first) : 0;
     x.row_bytes_c = x.rowmode ? (uint32_t)(8 * spanC) : 0;
   }
@@ -1639,14 +1657,7 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
     I.n_tiles += tail_tiles;
     I.a_rereads += 1;
   }
-  if (x.rowmode) { // 16-row blocks dealt round-robin to the waves of n_cu x (waves per SIMD the instantiation's registers allow) workgroups
-    const int S = artn_xrow_steps(x.k.total), NBK = artn_xrow_nbk(x.n.total);
-    I.m_tile_bits = 4;
-    I.lds_bytes = artn_xrow_lds_bytes(x.m.total / ((int64_t)x.m.L0 * x.m.L1));
-    I.n_tiles = (x.m.total + 15) / 16;
-    I.grid = (int32_t)std::min<int64_t>((I.n_tiles + 3) / 4, (int64_t)n_cu * artn_xrow_waves(S, NBK));
-    I.a_rereads = 1;
-  }
+  if (x.rowmode) xrow_fill_info(x, I, n_cu);
   return true;
 }
 

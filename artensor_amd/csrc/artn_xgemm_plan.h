@@ -56,7 +56,7 @@ struct ArtnXGemmPlan {
   int32_t kc;                  // contracted values per chunk: 16, or 8 (few contracted values, nb = 1: four workgroups per CU)
   int32_t pc;                  // 1: artn_k_xgemm_pc -- one 8-wave workgroup per CU, four consumer and four producer waves (kc = 16)
   int32_t c128;                // 1: complex128 operands -- artn_k_xgemm128 (16-byte elements, kc = 8, nb = 1, f64 MFMA)
-  int32_t rowmode;             // 1 (round 6): artn_k_xrow -- the row-streaming form (artn_xrow_kernel.h): at most 48 contracted values and 48
+  int32_t rowmode;             // 1 (round 6): artn_k_xrow, 2: artn_k_xrow64 (a lane per row) -- the row-streaming form (artn_xrow_kernel.h): at most 48 contracted values and 48
                                //    columns, the small operand in registers, rows straight into the MFMA operand registers, no LDS staging
   uint32_t row_bytes_a, row_bytes_c; // rowmode: bytes spanned by the kernel's first operand and by the result (buffer range checks)
   int32_t col0;                // first column of this launch (0; the tail launch: 32 nb tiles_n of the main one)
@@ -93,7 +93,11 @@ static inline constexpr int artn_xrow_waves(int S, int NBK) { // (what hipcc's r
        : NBK == 2 ? (S <= 1 ? 6 : (S <= 2 ? 5 : (S <= 8 ? 4 : 3)))
                   : (S <= 1 ? 6 : (S <= 3 ? 4 : (S <= 8 ? 3 : 2)));
 }
-static inline int artn_xrow_lds_bytes(int64_t L2) { return 4096 + 8 * (int)L2; } // three levels of (A, C) byte offsets of a row
+static inline int artn_xrow_lds_bytes(int64_t L2) { return 4096 + 8 * (int)L2 + 4 * 48; } // three levels of (A, C) byte offsets of a row (+ artn_k_xrow64: one per column)
+// artn_k_xrow64 (rowmode 2: a lane per row, 64-row superblocks): S <= 8, NBK <= 2; waves per SIMD by hipcc's register counts
+static inline constexpr int artn_xrow64_waves(int S, int NBK) {
+  return NBK == 1 ? (S <= 1 ? 6 : (S <= 4 ? 4 : (S <= 7 ? 3 : 2))) : (S <= 1 ? 4 : (S <= 7 ? 2 : 1));
+}
 
 // The tail launch of a plan with tail_nb > 0: the same step restricted to the columns behind the full tiles, one column tile wide.
 static inline ArtnXGemmPlan artn_xg_tail_plan(const ArtnXGemmPlan &P) {

@@ -960,6 +960,130 @@ static void run_xrow(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C, 
       }
 }
 
+// artn_k_xrow64 lane by lane: a wave = 64 rows, the register butterflies (v_permlane16_swap: odd 16-lane groups of the first
+// register <-> even groups of the second; v_permlane32_swap: upper half of the first <-> lower half of the second) and the lane
+// map of v_mfma_f32_16x16x4_f32 (A operand: lane (i, kk) = row i, contracted kk; B operand: lane (n, kk); D: lane (n, g), register
+// r = row 4 g + r), positions through the kernel's own artn_xrow_place / artn_xrow_advance, buffer range checks.
+static void xrow_bfly(float *a0, float *a1, float *a2, float *a3) {
+  auto swap16 = [](float *a, float *b) { for (int q = 0; q < 2; ++q) for (int l = 0; l < 16; ++l) std::swap(a[32 * q + 16 + l], b[32 * q + l]); };
+  auto swap32 = [](float *a, float *b) { for (int l = 0; l < 32; ++l) std::swap(a[32 + l], b[l]); };
+  swap16(a0, a1); swap16(a2, a3); swap32(a0, a2); swap32(a1, a3);
+}
+static void xrow_mfma(const float *a, const float *b, float (*d)[4]) { // d[lane][r] += sum_kk a[(4 g + r) + 16 kk] b[n + 16 kk]
+  for (int l = 0; l < 64; ++l)
+    for (int r = 0; r < 4; ++r) {
+      const int n = l & 15, i = 4 * (l >> 4) + r;
+      float s = d[l][r];
+      for (int kk = 0; kk < 4; ++kk) s += a[i + 16 * kk] * b[n + 16 * kk];
+      d[l][r] = s;
+    }
+}
+static void run_xrow64(const ArtnXGemmPlan &P, const cf *A0, const cf *B0, cf *C, int grid) {
+  const cf *A = P.swapped ? B0 : A0, *B = P.swapped ? A0 : B0;
+  const uint32_t Mtot = (uint32_t)P.m.total, Ktot = (uint32_t)P.k.total, Ntot = (uint32_t)P.n.total;
+  const int S = artn_xrow_steps(P.k.total), NBK = artn_xrow_nbk(P.n.total);
+  if (S < 1 || S > 8 || NBK > 2) abort();
+  const uint32_t L0 = (uint32_t)P.m.L0, L1 = (uint32_t)P.m.L1, L2 = Mtot / (L0 * L1);
+  if ((uint64_t)L0 * L1 * L2 != Mtot || L2 > ARTN_XROW_L2_MAX) abort();
+  std::vector<uint32_t> t0(2 * 256), t1(2 * 256), t2(2 * (size_t)L2), tcol(16 * NBK), ka(4 * S);
+  for (uint32_t i = 0; i < L0; ++i) { uint32_t a, c; artn_xg_decode(P.m, 0, P.m.n0, i, a, c); t0[2 * i] = a << 3; t0[2 * i + 1] = c << 3; }
+  for (uint32_t i = 0; i < L1; ++i) { uint32_t a, c; artn_xg_decode(P.m, P.m.n0, P.m.n1, i, a, c); t1[2 * i] = a << 3; t1[2 * i + 1] = c << 3; }
+  for (uint32_t i = 0; i < L2; ++i) { uint32_t a, c; artn_xg_decode(P.m, P.m.n0 + P.m.n1, P.m.n_lab - P.m.n0 - P.m.n1, i, a, c); t2[2 * i] = a << 3; t2[2 * i + 1] = c << 3; }
+  for (uint32_t n = 0; n < 16u * NBK; ++n) { uint32_t b, c; artn_xg_decode(P.n, 0, P.n.n_lab, n < Ntot ? n : 0, b, c); tcol[n] = c << 3; }
+  for (uint32_t k = 0; k < 4u * S; ++k) { uint32_t a, b; artn_xg_decode(P.k, 0, P.k.n_lab, k < Ktot ? k : Ktot - 1, a, b); ka[k] = a << 3; }
+  // fragments of the small operand, per lane
+  std::vector<float> wr((size_t)NBK * S * 64), wi((size_t)NBK * S * 64), ws((size_t)NBK * S * 64);
+  for (int blk = 0; blk < NBK; ++blk)
+    for (int s = 0; s < S; ++s)
+      for (int l = 0; l < 64; ++l) {
+        const uint32_t n = 16u * blk + (l & 15), k = 4u * s + (l >> 4);
+        uint32_t kA, kB, nB, nC;
+        artn_xg_decode(P.k, 0, P.k.n_lab, k < Ktot ? k : Ktot - 1, kA, kB);
+        artn_xg_decode(P.n, 0, P.n.n_lab, n < Ntot ? n : 0, nB, nC);
+        const cf w = (k < Ktot && n < Ntot) ? B[nB + kB] : cf(0.f, 0.f);
+        const size_t o = ((size_t)blk * S + s) * 64 + l;
+        wr[o] = w.real(); wi[o] = w.imag(); ws[o] = w.real() + w.imag();
+      }
+  const uint32_t n_sb = (Mtot + 63) >> 6, per_it = 4u * (uint32_t)grid, n_it = (n_sb + per_it - 1) / per_it;
+  auto loadA = [&](uint32_t voff, uint32_t soff) -> cf { return voff > P.row_bytes_a - 8u ? cf(0.f, 0.f) : A[((uint64_t)voff + soff) >> 3]; };
+  std::vector<float> xr((size_t)S * 4 * 64), xi((size_t)S * 4 * 64);
+  for (uint32_t blockIdx = 0; blockIdx < (uint32_t)grid; ++blockIdx)
+    for (uint32_t wave = 0; wave < 4; ++wave) {
+      const uint32_t wg = (uint32_t)grid % 8u == 0u ? (blockIdx % 8u) * ((uint32_t)grid / 8u) + blockIdx / 8u : blockIdx;
+      uint32_t m[64], ra[64], rc[64];
+      ArtnXRowPos pos[64], step;
+      artn_xrow_place(64u * per_it, L0, L1, step);
+      auto offsets = [&]() {
+        for (int l = 0; l < 64; ++l) {
+          const uint32_t i2 = pos[l].i2 < L2 ? pos[l].i2 : L2 - 1u;
+          if (pos[l].i0 >= L0 || pos[l].i1 >= L1) abort();
+          const uint32_t a = t0[2 * pos[l].i0] + t1[2 * pos[l].i1] + t2[2 * i2], c = t0[2 * pos[l].i0 + 1] + t1[2 * pos[l].i1 + 1] + t2[2 * i2 + 1];
+          if (m[l] < Mtot) { // the tables and the carries agree with the plain decode of the row
+            uint32_t ea, ec;
+            artn_xg_decode(P.m, 0, P.m.n_lab, m[l], ea, ec);
+            if ((ea << 3) != a || (ec << 3) != c) abort();
+          }
+          ra[l] = m[l] < Mtot ? a : 0xffffffffu;
+          rc[l] = m[l] < Mtot ? c : 0xffffffffu;
+        }
+      };
+      auto issue = [&](int s) {
+        for (int gg = 0; gg < 4; ++gg)
+          for (int l = 0; l < 64; ++l) {
+            const cf v = loadA(4u * s + gg < Ktot ? ra[l] : 0xffffffffu, ka[4 * s + gg]);
+            xr[((size_t)s * 4 + gg) * 64 + l] = v.real();
+            xi[((size_t)s * 4 + gg) * 64 + l] = v.imag();
+          }
+      };
+      for (int l = 0; l < 64; ++l) { m[l] = 64u * (4u * wg + wave) + (uint32_t)l; artn_xrow_place(m[l] < Mtot ? m[l] : Mtot - 1u, L0, L1, pos[l]); }
+      offsets();
+      for (int s = 0; s < S; ++s) issue(s);
+      for (uint32_t it = 0; it < n_it; ++it) {
+        uint32_t rc_cur[64];
+        for (int l = 0; l < 64; ++l) { rc_cur[l] = rc[l]; m[l] += 64u * per_it; artn_xrow_advance(pos[l], step, L0, L1); }
+        offsets();
+        std::vector<float> acc((size_t)3 * 4 * NBK * 64 * 4, 0.f); // product, block q, column block, lane, register
+        auto T = [&](int t, int q, int blk) { return reinterpret_cast<float (*)[4]>(&acc[((((size_t)t * 4 + q) * NBK + blk) * 64) * 4]); };
+        for (int s = 0; s < S; ++s) {
+          float *X = &xr[(size_t)s * 4 * 64], *Y = &xi[(size_t)s * 4 * 64];
+          xrow_bfly(X, X + 64, X + 128, X + 192);
+          xrow_bfly(Y, Y + 64, Y + 128, Y + 192);
+          for (int q = 0; q < 4; ++q) {
+            float xs[64];
+            for (int l = 0; l < 64; ++l) xs[l] = X[64 * q + l] + Y[64 * q + l];
+            for (int blk = 0; blk < NBK; ++blk) {
+              const size_t o = ((size_t)blk * S + s) * 64;
+              xrow_mfma(&wr[o], X + 64 * q, T(0, q, blk));
+              xrow_mfma(&wi[o], Y + 64 * q, T(1, q, blk));
+              xrow_mfma(&ws[o], xs, T(2, q, blk));
+            }
+          }
+          issue(s);
+        }
+        for (int blk = 0; blk < NBK; ++blk)
+          for (int r = 0; r < 4; ++r) {
+            float re[4][64], im[4][64];
+            for (int q = 0; q < 4; ++q)
+              for (int l = 0; l < 64; ++l) {
+                const float a = T(0, q, blk)[l][r], b = T(1, q, blk)[l][r], c = T(2, q, blk)[l][r];
+                re[q][l] = a - b;
+                im[q][l] = c - a - b;
+              }
+            xrow_bfly(re[0], re[1], re[2], re[3]);
+            xrow_bfly(im[0], im[1], im[2], im[3]);
+            for (int gg = 0; gg < 4; ++gg) {
+              const uint32_t n = 16u * blk + 4u * gg + (uint32_t)r;
+              for (int l = 0; l < 64; ++l) {
+                const uint32_t voff = n < Ntot ? rc_cur[l] : 0xffffffffu;
+                if (voff > P.row_bytes_c - 8u) { if (voff != 0xffffffffu) abort(); continue; }
+                C[((uint64_t)voff + tcol[n]) >> 3] = cf(re[gg][l], im[gg][l]);
+              }
+            }
+          }
+      }
+    }
+}
+
 // artn_k_xgemm128: the same walk with 16-byte elements, chunks of 8, and the lane / accumulator map of v_mfma_f64_16x16x4_f64
 // (wave w: rows 32 w + 16 a + j, a = 0, 1; blocks b of 8 complex columns; lane (j, g): W row 2 n_in + ro with j = 2 n_in + ro,
 // contracted value 2 s + (g >> 1), component p = g & 1; accumulator register r: component g & 1 of column (g >> 1) + 2 r).
@@ -1083,10 +1207,15 @@ extern "C" int artn_emulate_xgemm(const ArtnStepDesc *d, const void *A, const vo
   if (rc) return rc;
   memset(&p.info, 0, sizeof(p.info));
   if (!artn::make_xgemm(d, p, (modes && modes[8] > 0) ? modes[8] : 256, 1)) return ARTN_E_UNSUPPORTED; // (modes[8] on entry: the CU count to plan for)
+  if (modes && modes[7] == 1 && p.xg.rowmode == 2) { // (modes[7] = 1 on entry: the 16-row shape where the planner takes the 64-row one)
+    p.xg.rowmode = 1;
+    artn::xrow_fill_info(p.xg, p.info, (modes[8] > 0) ? modes[8] : 256);
+  }
   if (info) *info = p.info;
   if (modes) { modes[0] = p.xg.amode; modes[1] = p.xg.bmode; modes[2] = p.xg.trans; modes[3] = p.xg.swapped; modes[4] = p.xg.nb; modes[5] = p.xg.flush_chunks; modes[6] = p.xg.kc; }
   if (modes) modes[7] = p.xg.rowmode;
   if (p.xg.c128) run_xgemm128(p.xg, (const cd *)A, (const cd *)B, (cd *)C);
+  else if (p.xg.rowmode == 2) run_xrow64(p.xg, (const cf *)A, (const cf *)B, (cf *)C, p.info.grid);
   else if (p.xg.rowmode) run_xrow(p.xg, (const cf *)A, (const cf *)B, (cf *)C, p.info.grid);
   else {
     run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
@@ -1127,7 +1256,8 @@ extern "C" int artn_emulate(const ArtnStepDesc *d, const void *A, const void *B,
   if (p.kernel == ARTN_KERNEL_BITS_MFMA) run_bits(p.bits, (const cf *)A, (const cf *)B, nullptr, (cf *)C);
   else if (p.kernel == ARTN_KERNEL_GEMM_MFMA) run_gemm(p.gemm, (const cf *)A, (const cf *)B, (cf *)C);
   else if (p.kernel == ARTN_KERNEL_XGEMM) {
-    if (p.xg.rowmode) run_xrow(p.xg, (const cf *)A, (const cf *)B, (cf *)C, p.info.grid);
+    if (p.xg.rowmode == 2) run_xrow64(p.xg, (const cf *)A, (const cf *)B, (cf *)C, p.info.grid);
+    else if (p.xg.rowmode) run_xrow(p.xg, (const cf *)A, (const cf *)B, (cf *)C, p.info.grid);
     else {
       run_xgemm(p.xg, (const cf *)A, (const cf *)B, (cf *)C);
       if (p.xg.tail_nb) run_xgemm(artn_xg_tail_plan(p.xg), (const cf *)A, (const cf *)B, (cf *)C);

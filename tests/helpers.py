@@ -408,7 +408,7 @@ def emulate_program(prog, leaves):
     return ws, stats
 
 
-def emulate_xgemm(eq, a, b, n_cu=None):
+def emulate_xgemm(eq, a, b, n_cu=None, rows16=False):
     """One step through the CPU replay of the extent-based GEMM (artn_k_xgemm; plan forced); returns (result, planner
     info, modes) -- modes = dict(amode, bmode, trans, swapped, nb, flush_chunks, ...) -- or (None, None, None) when
     make_xgemm declines.  `eq`: an einsum string or a triple of label tuples; a / b may be strided views; `n_cu`: the CU
@@ -424,6 +424,7 @@ def emulate_xgemm(eq, a, b, n_cu=None):
     info = N.ArtnStepInfo()
     modes = (ctypes.c_int32 * 9)()
     modes[8] = int(n_cu or 0)
+    modes[7] = 1 if rows16 else 0   # (the 16-row shape of the row-streaming form where the planner would take the 64-row one)
     emu = emulator()
     emu.artn_emulate_xgemm.restype = ctypes.c_int
     # (strided views: the emulator takes the base pointer of the view, like the kernel)

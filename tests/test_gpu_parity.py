@@ -906,7 +906,7 @@ def test_extent_gemm_with_a_narrower_launch_for_the_last_columns():
 
 
 def test_row_streaming_form_of_the_extent_gemm():
-    """artn_k_xrow (round 6): a handful of contracted values into a handful of columns on 2^15+ rows -- every count of MFMA
+    """artn_k_xrow / artn_k_xrow64 (round 6): a handful of contracted values into a handful of columns on 2^15+ rows -- every count of MFMA
     steps (1..12 x four contracted values), one to three column blocks, rows that end inside a block, the contracted labels
     inside / outside the row labels of the operand -- against complex128 einsums; and ARTN_XROW=0 plans no such launch."""
     rng = np.random.default_rng(2026)
@@ -922,7 +922,7 @@ def test_row_streaming_form_of_the_extent_gemm():
             else:           # contracted label fastest: neighbouring rows kk elements apart
                 eq, sa, sb = (("m1", "m0", "k"), ("k", "n"), ("n", "m1", "m0")), (m1, m0, kk), (kk, nn)
             info = A.step_info(eq, sa, sb)
-            assert info["kernel"] == KERNEL_XGEMM and info["m_tile_bits"] == 4, (kk, nn, form, info)   # 16-row blocks: the row-streaming form
+            assert info["kernel"] == KERNEL_XGEMM and info["m_tile_bits"] == (6 if kk <= 32 and nn <= 32 else 4), (kk, nn, form, info)   # 64-row superblocks (a lane per row) up to 32 x 32, 16-row blocks beyond
             a, b = crandn(rng, sa), crandn(rng, sb)
             got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
             want = _einsum128_labels(eq, a, b)
@@ -932,7 +932,7 @@ def test_row_streaming_form_of_the_extent_gemm():
     # bond dimension 3 with the contracted labels between the row labels, all three levels of the row-offset tables in use
     eq = (tuple("abcdKefgLhijk"), ("x", "K", "L", "y"), ("y", "x") + tuple("abcdefghijk"))
     a, b = crandn(rng, (3,) * 13), crandn(rng, (3,) * 4)
-    assert A.step_info(eq, a.shape, b.shape)["m_tile_bits"] == 4
+    assert A.step_info(eq, a.shape, b.shape)["m_tile_bits"] == 6
     got = A.contract(eq, gpu(a), gpu(b)).cpu().numpy()
     want = _einsum128_labels(eq, a, b)
     assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max()
@@ -1895,6 +1895,17 @@ def test_randomised_steps_with_extents_that_are_not_powers_of_two():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")   # (small random steps on the strided kernel warn by design)
         assert mod.main(120, seed=12) == 0
+
+
+def test_randomised_row_streaming_steps_in_the_16_row_shape():
+    """ARTN_XROW64=0 (read when the library loads: a process of its own): the steps the planner gives to artn_k_xrow64 run on the
+    16-row instantiations of artn_k_xrow instead -- 90 random cases of tools/stress_extents.py, a third of them row-streaming shapes."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ARTN_XROW64="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_extents.py"), "90", "7"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "'xrow')" in r.stdout and "xrow64" not in r.stdout, r.stdout[-600:]
 
 
 def test_gemm_kernel_strided_operands_and_split_k():

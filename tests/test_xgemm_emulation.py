@@ -34,8 +34,8 @@ def einsum_labels(eq, a, b):
     return np.einsum(s, a.astype(np.complex128), b.astype(np.complex128))
 
 
-def check(eq, a, b, tol=2e-6, n_cu=None):
-    got, info, modes = emulate_xgemm(eq, a, b, n_cu=n_cu)
+def check(eq, a, b, tol=2e-6, n_cu=None, rows16=False):
+    got, info, modes = emulate_xgemm(eq, a, b, n_cu=n_cu, rows16=rows16)
     assert got is not None, "make_xgemm declined"
     want = einsum_labels(eq, a, b)
     assert got.shape == want.shape
@@ -104,8 +104,13 @@ def test_random_row_streaming_steps(seed):
         rng.shuffle(lst)
     last_m = max(i for i, x in enumerate(lo) if x in M)
     lo[last_m], lo[-1] = lo[-1], lo[last_m]
-    info, modes = check((tuple(la), tuple(lb), tuple(lo)), crandn(rng, tuple(ext[x] for x in la)), crandn(rng, tuple(ext[x] for x in lb)))
-    assert modes["rowmode"] == 1, (modes, ext)
+    a, b = crandn(rng, tuple(ext[x] for x in la)), crandn(rng, tuple(ext[x] for x in lb))
+    info, modes = check((tuple(la), tuple(lb), tuple(lo)), a, b)
+    small = int(np.prod(list(K.values()))) <= 32 and int(np.prod(list(Nn.values()))) <= 32
+    assert modes["rowmode"] == (2 if small else 1), (modes, ext)   # a lane per row (artn_k_xrow64) up to 32 x 32, 16-row blocks beyond
+    if small:
+        info, modes = check((tuple(la), tuple(lb), tuple(lo)), a, b, rows16=True)
+        assert modes["rowmode"] == 1, (modes, ext)
 
 
 def test_all_modes_are_covered():
@@ -154,8 +159,8 @@ def test_columns_behind_the_full_tiles_run_as_a_second_launch():
 def test_row_streaming_form_for_small_blocks_on_many_rows():
     """Round 6 (artn_k_xrow, ArtnXGemmPlan::rowmode): at most 48 contracted values into at most 48 columns on 2^15+ rows, lanes
     along rows in the first operand and the result, no batch label -- the small operand in registers, rows straight into the
-    MFMA operand registers, 16-row blocks dealt round-robin to the waves, three levels of row-offset tables, buffer loads and
-    stores.  The 9 x 9 and 27 x 27 blocks of the bond-dimension-3 network (rows past the end, an odd count of contracted
+    MFMA operand registers, 16-row blocks (rowmode 1) or 64-row superblocks with a lane per row and register butterflies (rowmode 2,
+    artn_k_xrow64: up to 32 x 32) dealt round-robin to the waves, three levels of row-offset tables, buffer loads and stores.  The 9 x 9 and 27 x 27 blocks of the bond-dimension-3 network (rows past the end, an odd count of contracted
     values), all three table levels in use, a mixed-extent step; declined: a batch label, a result whose fastest label is a
     column, few rows, more than 4 096 values left for the third level."""
     rng = np.random.default_rng(70)
@@ -163,20 +168,28 @@ def test_row_streaming_form_for_small_blocks_on_many_rows():
     eq = (("k1", "m2", "k0", "m1", "m0"), ("n0", "k1", "k0", "n1"), ("n1", "n0", "m2", "m1", "m0"))
     a, b = crandn(rng, (3, 150, 3, 27, 9)), crandn(rng, (3, 3, 3, 3))
     info, modes = check(eq, a, b)
-    assert modes["rowmode"] == 1 and info["n_tiles"] == -(-150 * 27 * 9 // 16), (modes, info["n_tiles"])
+    assert modes["rowmode"] == 2 and info["n_tiles"] == -(-150 * 27 * 9 // 64), (modes, info["n_tiles"])   # 64-row superblocks: a lane per row
+    info, modes = check(eq, a, b, rows16=True)
+    assert modes["rowmode"] == 1 and info["n_tiles"] == -(-150 * 27 * 9 // 16), (modes, info["n_tiles"])   # the 16-row shape of the same step
     # eleven row labels of extent 3 (243 x 243 x 3 rows: every level of the tables carries), 9 -> 9 with the contracted labels inside
     eq = (tuple("abcdKefgLhijk"), ("x", "K", "L", "y"), ("y", "x") + tuple("abcdefghijk"))
     info, modes = check(eq, crandn(rng, (3,) * 13), crandn(rng, (3,) * 4))
-    assert modes["rowmode"] == 1 and info["lds_bytes"] == 4096 + 8 * 3, (modes, info)
+    assert modes["rowmode"] == 2 and info["lds_bytes"] == 4096 + 8 * 3 + 192, (modes, info)
+    info, modes = check(eq, crandn(rng, (3,) * 13), crandn(rng, (3,) * 4), rows16=True)
+    assert modes["rowmode"] == 1, modes
     # 27 -> 27: 7 MFMA steps of four contracted values in registers (the last one holds three), two column blocks, 36 000 rows
     eq = (("k0", "m1", "m0"), ("k0", "n0"), ("n0", "m1", "m0"))
     a, b = crandn(rng, (27, 1125, 32)), crandn(rng, (27, 27))
     info, modes = check(eq, a, b)
+    assert modes["rowmode"] == 2, modes
+    info, modes = check(eq, a, b, rows16=True)
     assert modes["rowmode"] == 1, modes
     # mixed extents, 5 x 6 = 30 contracted values, 7 columns, a row count that is not a multiple of 32
     eq = (("k1", "m1", "k0", "m0"), ("k0", "n0", "k1"), ("n0", "m1", "m0"))
     a, b = crandn(rng, (5, 4001, 6, 9)), crandn(rng, (6, 7, 5))
     info, modes = check(eq, a, b)
+    assert modes["rowmode"] == 2, modes
+    info, modes = check(eq, a, b, rows16=True)
     assert modes["rowmode"] == 1, modes
     # NOT taken: the result's fastest label is a column (lanes of a store would not run along rows) ...
     eq = (("k0", "m1", "m0"), ("k0", "n0"), ("m1", "m0", "n0"))
@@ -251,7 +264,7 @@ def test_planner_sends_non_power_of_two_steps_to_the_extent_gemm():
     la = tuple(range(18))
     lo = (18, 19) + tuple(x for x in la if x not in (3, 11))
     rows = step_info((la, (3, 11, 18, 19), lo), (3,) * 18, (3,) * 4)   # the benchmark network's own size: 3.1 GB tensors
-    assert rows["kernel"] == KERNEL_XGEMM and rows["n_tiles"] == -(-3 ** 16 // 16), rows
+    assert rows["kernel"] == KERNEL_XGEMM and rows["n_tiles"] == -(-3 ** 16 // 64) and rows["m_tile_bits"] == 6, rows   # (64-row superblocks)
     la = tuple(range(21))
     lo = tuple(30 if x == 3 else (31 if x == 11 else x) for x in la)
     huge = step_info((la, (3, 11, 30, 31), lo), (3,) * 21, (3,) * 4)

@@ -61,8 +61,8 @@ def main(cases=300, seed=0):
         if rows_ < cols_:
             rows_, cols_ = cols_, rows_
         hp = int(np.prod(list(H.values()))) if H else 1
-        if info["kernel"] == 5 and info["m_tile_bits"] == 4:
-            path = "xrow"
+        if info["kernel"] == 5 and info["m_tile_bits"] in (4, 6):
+            path = "xrow" if info["m_tile_bits"] == 4 else "xrow64"
         elif info["kernel"] == 5:   # (the planner's rule for the second launch, restated: 4+ column blocks, not a multiple of 3, 8+ main tiles per CU)
             blocks, rt = -(-cols_ // 32), -(-rows_ // 128) * hp
             path = "xgemm+tail" if blocks >= 4 and blocks % 3 and rt * (blocks // 3) >= 2048 else "xgemm"
