@@ -93,10 +93,10 @@ static inline constexpr int artn_xrow_waves(int S, int NBK) { // (what hipcc's r
        : NBK == 2 ? (S <= 1 ? 6 : (S <= 2 ? 5 : (S <= 8 ? 4 : 3)))
                   : (S <= 1 ? 6 : (S <= 3 ? 4 : (S <= 8 ? 3 : 2)));
 }
-static inline int artn_xrow_lds_bytes(int64_t L2) { return 4096 + 8 * (int)L2 + 4 * 48; } // three levels of (A, C) byte offsets of a row (+ artn_k_xrow64: one per column)
+static inline int artn_xrow_lds_bytes(int64_t L2) { return 4096 + 8 * (int)L2; } // three levels of (A, C) byte offsets of a row
 // artn_k_xrow64 (rowmode 2: a lane per row, 64-row superblocks): S <= 8, NBK <= 2; waves per SIMD by hipcc's register counts
 static inline constexpr int artn_xrow64_waves(int S, int NBK) {
-  return NBK == 1 ? (S <= 1 ? 6 : (S <= 4 ? 4 : (S <= 7 ? 3 : 2))) : (S <= 1 ? 4 : (S <= 7 ? 2 : 1));
+  return NBK == 1 ? (S <= 3 ? 4 : (S <= 7 ? 3 : 2)) : (S <= 1 ? 4 : (S <= 7 ? 2 : 1));
 }
 
 // The tail launch of a plan with tail_nb > 0: the same step restricted to the columns behind the full tiles, one column tile wide.

@@ -189,7 +189,6 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, artn_xrow64_waves(S, NBK)) void ar
   const unsigned j = (unsigned)(lane & 15), g = (unsigned)(lane >> 4);
   const unsigned Mtot = (unsigned)P.m.total, Ktot = (unsigned)P.k.total, Ntot = (unsigned)P.n.total;
   const unsigned L0 = (unsigned)P.m.L0, L1 = (unsigned)P.m.L1, L2 = Mtot / (L0 * L1);
-  const unsigned TCOL = T2 + 8u * L2; // C byte offset of every column (16 NBK entries)
   if (tid < P.m.L0) {
     unsigned o0, o1;
     artn_xg_decode(P.m, 0, P.m.n0, (unsigned)tid, o0, o1);
@@ -207,11 +206,6 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, artn_xrow64_waves(S, NBK)) void ar
     artn_xg_decode(P.m, P.m.n0 + P.m.n1, P.m.n_lab - P.m.n0 - P.m.n1, i, o0, o1);
     lds_write4(T2 + 8u * i, o0 << 3);
     lds_write4(T2 + 8u * i + 4u, o1 << 3);
-  }
-  if (tid < 16 * NBK) {
-    unsigned nB, nC;
-    artn_xg_decode(P.n, 0, P.n.n_lab, (unsigned)tid < Ntot ? (unsigned)tid : 0u, nB, nC);
-    lds_write4(TCOL + 4u * tid, nC << 3);
   }
   // ---- the small operand as MFMA fragments (lane (j, g): column 16 blk + j, contracted value 4 s + g) and the contracted
   //      values' byte offsets in the first operand: uniform, one scalar register each
@@ -239,6 +233,15 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, artn_xrow64_waves(S, NBK)) void ar
       artn_xg_decode(P.k, 0, P.k.n_lab, ku < Ktot ? ku : Ktot - 1u, uA, uB);
       ka[4 * s + gg] = __builtin_amdgcn_readfirstlane(uA << 3);
     }
+  }
+  // ... and the columns' byte offsets in the result: uniform too (from an LDS table every store waited ~100 cycles for its entry:
+  // eight lgkmcnt waits per superblock next to 1 150 cycles of MFMAs; past the scalar registers hipcc keeps them in VGPR lanes)
+  unsigned cn[16 * NBK];
+#pragma unroll
+  for (int n = 0; n < 16 * NBK; ++n) {
+    unsigned nB, nC;
+    artn_xg_decode(P.n, 0, P.n.n_lab, (unsigned)n < Ntot ? (unsigned)n : 0u, nB, nC);
+    cn[n] = __builtin_amdgcn_readfirstlane(nC << 3);
   }
   __syncthreads(); // tables are in LDS (the only barrier of the kernel)
 
@@ -315,10 +318,9 @@ __global__ __launch_bounds__(ARTN_WG_THREADS, artn_xrow64_waves(S, NBK)) void ar
         xrow_butterfly(im[0], im[1], im[2], im[3]);
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
-          const unsigned n = 16u * blk + 4u * gg + (unsigned)r;
-          const unsigned cn = __builtin_amdgcn_readfirstlane(lds_read4(TCOL + 4u * n));
+          const int n = 16 * blk + 4 * gg + r;
           const v2f_t val = {re[gg], im[gg]};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, val), rC, (int)(n < Ntot ? rc_cur : 0xffffffffu), (int)cn, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, val), rC, (int)((unsigned)n < Ntot ? rc_cur : 0xffffffffu), (int)cn[n], 0);
         }
       }
     __builtin_amdgcn_sched_barrier(0);

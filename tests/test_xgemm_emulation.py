@@ -174,7 +174,7 @@ def test_row_streaming_form_for_small_blocks_on_many_rows():
     # eleven row labels of extent 3 (243 x 243 x 3 rows: every level of the tables carries), 9 -> 9 with the contracted labels inside
     eq = (tuple("abcdKefgLhijk"), ("x", "K", "L", "y"), ("y", "x") + tuple("abcdefghijk"))
     info, modes = check(eq, crandn(rng, (3,) * 13), crandn(rng, (3,) * 4))
-    assert modes["rowmode"] == 2 and info["lds_bytes"] == 4096 + 8 * 3 + 192, (modes, info)
+    assert modes["rowmode"] == 2 and info["lds_bytes"] == 4096 + 8 * 3, (modes, info)
     info, modes = check(eq, crandn(rng, (3,) * 13), crandn(rng, (3,) * 4), rows16=True)
     assert modes["rowmode"] == 1, modes
     # 27 -> 27: 7 MFMA steps of four contracted values in registers (the last one holds three), two column blocks, 36 000 rows
