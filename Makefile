@@ -74,7 +74,11 @@ ablate: $(SRCS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -DARTN_ABLATE_MEM -DARTN_ABLATE_MFMA -Iinclude -I$(CSRC) $< -o tools/libartn_hip_nomem_nomfma.so
 
 # stand-alone HBM copy probes (tile-structured persistent copies; diagnostics only)
-probes: tools/bw_probe tools/bw_probe2
+probes: tools/bw_probe tools/bw_probe2 tools/probes/plane_probe tools/probes/xrow64_probe
+tools/probes/plane_probe: tools/probes/plane_probe.hip
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) $< -o $@
+tools/probes/xrow64_probe: tools/probes/xrow64_probe.hip
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) $< -o $@
 tools/bw_probe: tools/bw_probe.hip
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) $< -o $@
 tools/bw_probe2: tools/bw_probe2.hip
@@ -87,7 +91,7 @@ tools/bw_probe2: tools/bw_probe2.hip
 ASAN_RT := $(firstword $(wildcard /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so))
 ASAN_DIR := build/asan
 ASAN_FLAGS := -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared-libsan -fPIC -Iinclude -I$(CSRC)
-ASAN_LOG ?= profiles/r05_asan.log
+ASAN_LOG ?= profiles/r06_asan.log
 asan: $(SRCS) tests/csrc/plan_emulate.cpp
 	@mkdir -p $(ASAN_DIR)
 	$(HIPCC) $(ASAN_FLAGS) --offload-host-only -c $(CSRC)/artn_kernels.hip -o $(ASAN_DIR)/host.o
