@@ -1627,9 +1627,9 @@ static inline bool make_xgemm(const ArtnStepDesc *d, ArtnPlan &p, int n_cu, int6
   {
     const int64_t span_first = x.swapped ? spanB : spanA, row_lim = (int64_t(1) << 29) - 2;
     const int64_t l2 = x.m.total / ((int64_t)x.m.L0 * x.m.L1);
-    // (measured on the bond-dimension-3 network, gpurun_out/s_r6s: 9 -> 9 on 3^16 rows 2.34 -> 2.02 ms, 27 -> 27 on 3^13 rows
-    //  0.38 -> 0.22 ms, but 27 -> 27 on 3^15 rows 1.70 -> 2.10 ms -- 84 MFMAs per 16 rows at four waves per SIMD no longer hide
-    //  under the loads: blocks of more than 16 x 16 stay with artn_k_xgemm from 2^22 rows on; ARTN_XROW=2: wherever it fits)
+    // (the 16-row shape, measured on the bond-dimension-3 network, gpurun_out/s_r6t: 9 -> 9 on 3^16 rows 2.30 -> 1.70 ms, 27 -> 27 on
+    //  3^13 rows 0.38 -> 0.22 ms, but 27 -> 27 on 3^15 rows only ties, 1.76-1.79 against 1.74-1.77 ms -- 84 MFMAs per 16 rows at
+    //  four waves per SIMD: blocks of more than 16 x 16 stay with artn_k_xgemm from 2^22 rows on; ARTN_XROW=2: wherever it fits)
     const bool pays = (x.k.total <= 16 && x.n.total <= 16) || x.m.total < (int64_t(1) << 22) || tuning().xrow == 2;
     const bool fits = !c128 && x.n_h == 0 && x.trans == 0 && x.k.total <= ARTN_XROW_MAX && x.n.total <= ARTN_XROW_MAX &&
                       x.m.total >= ARTN_XROW_MIN_ROWS && l2 <= ARTN_XROW_L2_MAX && span_first <= row_lim && spanC <= row_lim && tuning().xrow;

@@ -61,7 +61,7 @@ def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
     for name in ("artn_kernels.hip", "artn_gemm_kernel.h", "artn_gemm128_kernel.h", "artn_bits128_kernel.h", "artn_bits3_kernel.h",
-                 "artn_wide_kernel.h", "artn_pgemm_kernel.h", "artn_plan.h", "artn_xgemm_kernel.h", "artn_xgemm128_kernel.h", "artn_xgemm_plan.h"):
+                 "artn_wide_kernel.h", "artn_pgemm_kernel.h", "artn_plan.h", "artn_xgemm_kernel.h", "artn_xgemm128_kernel.h", "artn_xgemm_plan.h", "artn_xrow_kernel.h"):
         with open(os.path.join(ROOT, "artensor_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
